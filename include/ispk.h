@@ -1,0 +1,148 @@
+/* ispk.h — C ABI of libispk.so: the MI355X (gfx950) kernels behind the isp-tts acoustic-model forward path.
+ *
+ * The reference (ilya16/isp-tts) has no FFI layer: its operator surface is Python nn.Modules plus one
+ * numba-compiled function.  This header is the boundary a drop-in binds instead (ctypes stub: INTEGRATION.md);
+ * every entry point names the reference interface it replaces (paths relative to the reference's `tts/`).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch/HIP types except the opaque stream handle.
+ *   - All pointers are DEVICE pointers (caller-allocated, e.g. tensor.data_ptr()); row-major; strides in ELEMENTS.
+ *   - No allocation, no ownership transfer, no host synchronisation: launches are asynchronous on `stream`
+ *     (NULL = the legacy default stream) and are graph-capturable.
+ *   - Return value: 0 ok; < 0 argument error (ISPK_E_*), message via ispk_last_error_string() (thread-local);
+ *     > 0 a hipError_t from the launch.
+ *   - Thread-safe and re-entrant: no mutable global state.
+ *   - `lengths` are int64 on device, as the reference's collator produces them (data/collator.py:36,45).
+ *   - `row_mask` is a byte per row (torch.bool storage): nonzero = valid.
+ */
+#ifndef ISPK_H
+#define ISPK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* ispk_stream_t; /* == hipStream_t */
+
+#define ISPK_ABI_VERSION 1
+
+#define ISPK_E_NULL (-1)        /* required pointer is NULL */
+#define ISPK_E_SHAPE (-2)       /* size out of the supported range */
+#define ISPK_E_ALIGN (-3)       /* pointer / stride alignment */
+#define ISPK_E_UNSUPPORTED (-4) /* combination not implemented */
+
+int32_t ispk_abi_version(void);
+const char* ispk_last_error_string(void);
+/* Fills name[cap] with the device's gcnArchName; returns CU count (>0) or a negative/hip error. */
+int32_t ispk_device_info(char* name, int32_t cap);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Monotonic Alignment Search.
+ * Replaces: modules/aligner/mas.py:29-35 `b_mas` (numba CPU) and modules/aligner/cuda_mas.py:11-46 `cuda_b_mas`
+ * (numba CUDA), as dispatched by models/acoustic/modules/alignment.py:291-331.
+ *   logits    [B][M_max][L_max] fp32, element strides (stride_b, stride_m, 1); NOT modified
+ *   text_len  [B] int64 (reference `in_lens`),  1 <= text_len[b] <= L_max <= 512
+ *   mel_len   [B] int64 (reference `out_lens`), 1 <= mel_len[b]  <= M_max <= 4096
+ *   attn_hard [B][M_max][L_max] int16, contiguous: one-hot rows, zero outside (mel_len, text_len)  (fully written)
+ *   dur       [B][L_max] int64 or NULL: column sums of attn_hard (alignment.py:275 `attn_hard.sum(dim=1)`)
+ *   path      [B][M_max] int16 or NULL: chosen text index per mel row, -1 for rows >= mel_len
+ * One wavefront runs the DP of one utterance; ties go to the diagonal predecessor exactly as mas.py:17.
+ */
+int32_t ispk_mas_f32(const float* logits, const int64_t* text_len, const int64_t* mel_len, int16_t* attn_hard,
+                     int64_t* dur, int16_t* path, int32_t B, int32_t M_max, int32_t L_max, int64_t stride_b,
+                     int64_t stride_m, ispk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * LayerNorm / AdaptiveLayerNorm (+ row mask).
+ * Replaces: modules/transformer/normalization.py:20-27 (LayerNorm) and :37-61 (AdaptiveLayerNorm), plus the
+ * `out * mask` of transformer.py:101-102 / :205-206 when row_mask is given.
+ *   y[r][:] = mask[r] * ( scale * ((x[r][:] - mean) / sqrt(var + eps)) + shift ),   biased variance
+ *   plain   : scale = gamma[D], shift = beta[D]                       (ada_scale == NULL)
+ *   adaptive: scale = ada_scale[b][D], shift = ada_shift[b][D], b = r / rows_per_batch, row stride ada_stride
+ *             (ada_stride = 0 broadcasts one condition row over the whole batch: the [1,1,C] case of :57)
+ * D must be a multiple of 64 and <= 1024.  x_f32 in, y in the named dtype.
+ */
+int32_t ispk_layernorm_f32(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* ada_scale,
+                           const float* ada_shift, int64_t ada_stride, int32_t rows_per_batch,
+                           const uint8_t* row_mask, float* y, int64_t ldy, int32_t rows, int32_t D, float eps,
+                           ispk_stream_t stream);
+int32_t ispk_layernorm_f32_bf16(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                const float* ada_scale, const float* ada_shift, int64_t ada_stride,
+                                int32_t rows_per_batch, const uint8_t* row_mask, uint16_t* y, int64_t ldy, int32_t rows,
+                                int32_t D, float eps, ispk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Linear layers on MFMA:  C[i][j] = epilogue( sum_k A[i][k] * W[j][k] ),  A [M][K], W [N][K] (nn.Linear layout).
+ * Replaces: nn.Linear call sites attention.py:105,111,168 (to_q / to_kv / to_out), feedforward.py:33-36
+ * (Linear -> GELU(erf) -> Linear), transformer.py:170 (project_emb), model.py:167-168 (to_mel + transpose + mask),
+ * and the residual / mask arithmetic of transformer.py:91,105,110 and attention.py:172 through `flags`.
+ *
+ *   v = acc (+ bias)                      bias indexed by column j, or by row i with ISPK_EP_BIAS_ROW
+ *   v = gelu_erf(v) | silu(v)             ISPK_EP_GELU | ISPK_EP_SILU
+ *   v = mask * v                          ISPK_EP_MASK_ACC   (mask BEFORE the residual add: attention.py:172)
+ *   v = v + resid[i][j]                   resid != NULL (same indexing as C, leading stride ldr)
+ *   v = mask * v                          ISPK_EP_MASK_OUT   (mask AFTER the residual add: transformer.py:110)
+ *   mask indexed by row i, or by column j with ISPK_EP_MASK_COL
+ *   store: C[i*ldc + j], or with cols_per_batch > 0:  C[(j / cpb) * batch_stride + i*ldc + (j % cpb)]
+ *          (to_mel: A = weight [80][384], "W" = activations [B*M][384], cpb = M, ldc = M, batch_stride = 80*M
+ *           -> mel[B][80][M] written with consecutive lanes along the mel-frame axis)
+ *
+ * Requirements: K % 8 == 0; lda, ldw % 4 == 0 (fp32) / % 8 (bf16); A, W 16-byte aligned.
+ * _f32      : fp32 in, v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate), fp32 out.
+ * _bf16     : bf16 in, v_mfma_f32_32x32x16_bf16 (fp32 accumulate), epilogue in fp32; C/resid dtype per flags.
+ */
+#define ISPK_EP_GELU 1u
+#define ISPK_EP_SILU 2u
+#define ISPK_EP_MASK_ACC 4u
+#define ISPK_EP_MASK_OUT 8u
+#define ISPK_EP_BIAS_ROW 16u
+#define ISPK_EP_MASK_COL 32u
+#define ISPK_EP_OUT_BF16 64u   /* _bf16 entry only: C is bf16 (default fp32) */
+#define ISPK_EP_RESID_BF16 128u /* _bf16 entry only: resid is bf16 (default fp32) */
+
+int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, const float* bias,
+                      const float* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N, int32_t K,
+                      uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);
+int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
+                       const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N,
+                       int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);
+
+/* Small / odd-shaped Linear (any K, N): one thread per output, fp32 FMA chain in k order.
+ * Replaces the tiny nn.Linear sites: embeddings.py:149-153 (time MLP 65->32->32), normalization.py:43-51 (AdaLN
+ * condition projections 32->D), temporal_adaptor.py:43,98 (linear_layer D->3), transformer.py:170 with
+ * emb_dim 2 / the 3 flow channels of the 387-wide predictor input.
+ *   out[i][j] = act( sum_k a[i][k]*w[j][k] + bias[j] ) + resid[i][j];  act: 0 none, ISPK_EP_GELU, ISPK_EP_SILU */
+int32_t ispk_linear_small_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,
+                              const float* resid, int64_t ldr, float* out, int64_t ldo, int32_t M, int32_t N, int32_t K,
+                              uint32_t act, ispk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * ALiBi-biased multi-query attention (one shared K/V head, head_dim 64).
+ * Replaces: modules/transformer/attend.py:49-122 (`Attend.efficient_attn`: SDPA with a materialised
+ * [B,H,N,N] fp32 bias) together with the bias construction of embeddings.py:51-72 and the key-mask assembly of
+ * attention.py:128-152.  Nothing of size N*N touches HBM here.
+ *   out[b][i][h*64 + d] = sum_j softmax_j( q[b][i][h]·k[b][j] / 8 - slopes[h] * |i - j| ) * v[b][j][d],
+ *   j restricted to j < key_len[b] (masked keys get weight exactly 0, as the reference's min/2 fill does)
+ *   q   [B][N][H*64] leading stride ldq;  k, v [B][N][64] leading stride ldkv (k and v may alias one
+ *   [B][N][128] `to_kv` buffer: k = kv, v = kv + 64);  out [B][N][H*64] leading stride ldo
+ *   slopes [H] fp32 = exp(learned_logslopes) (embeddings.py:81-82);  key_len [B] int64 or NULL (= N)
+ *   1 <= H <= 8.  Rows i >= key_len[b] are computed like the reference (finite values; zeroed later by the
+ *   caller's row mask, attention.py:172).
+ */
+int32_t ispk_alibi_mqa_attn_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                const float* slopes, const int64_t* key_len, float* out, int64_t ldo, int32_t B,
+                                int32_t N, int32_t H, ispk_stream_t stream);
+int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v, int64_t ldkv,
+                                 const float* slopes, const int64_t* key_len, uint16_t* out, int64_t ldo, int32_t B,
+                                 int32_t N, int32_t H, ispk_stream_t stream);
+
+/* fp32 -> bf16 conversion (round-to-nearest-even) of a [rows][cols] matrix; used to stage weights/activations. */
+int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int32_t rows, int32_t cols,
+                           ispk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISPK_H */

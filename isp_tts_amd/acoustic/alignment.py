@@ -1,0 +1,156 @@
+"""Aligner: ConvAttention front-end + MAS (tts/models/acoustic/modules/alignment.py of the reference).
+
+Scope: the MAS binarisation is the hand-written kernel (`ispk_mas_f32`); the convolutional front-end that
+PRODUCES the MAS input (conv k5 + GELU + masked instance norm, QKᵀ, log-softmax + diagonal prior) is row f1 "next" and
+runs here as stock PyTorch-ROCm ops with the reference's exact order of operations (Appendix A items 8-9).
+"""
+from __future__ import annotations
+
+from collections.abc import Sequence
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from ..modules.aligner import mas_device
+from ..modules.constructor import Constructor
+from ..utils import get_mask_from_lengths, max_dtype_value, min_dtype_value
+
+
+def batch_diagonal_prior(text_lengths: Tensor, mel_lengths: Tensor, gamma: float = 0.1, threshold: float = 1e-4,
+                         max_text: Optional[int] = None, max_mel: Optional[int] = None) -> Tensor:
+    """alignment.py:18-37: exp(-(t/T - m/M)^2 / 2 gamma^2), zero outside the lengths, rows normalised (+1e-5), values
+    under 1e-4 zeroed.  [B, M, T] fp32."""
+    dev = text_lengths.device
+    max_text = int(text_lengths.max().item()) if max_text is None else max_text
+    max_mel = int(mel_lengths.max().item()) if max_mel is None else max_mel
+    gt = torch.arange(max_text, dtype=torch.float32, device=dev).view(1, -1) / text_lengths.view(-1, 1)
+    gm = torch.arange(max_mel, dtype=torch.float32, device=dev).view(1, -1) / mel_lengths.view(-1, 1)
+    grid = gt.unsqueeze(1) - gm.unsqueeze(2)
+    prior = torch.exp(-grid ** 2 / (2 * gamma ** 2))
+    prior = prior * get_mask_from_lengths(text_lengths, max_text)[:, None, :]
+    prior = prior * get_mask_from_lengths(mel_lengths, max_mel)[:, :, None]
+    prior = prior / (prior.sum(dim=-1, keepdim=True) + 1e-5)
+    return prior.masked_fill(prior < threshold, 0.0)
+
+
+class MaskedInstanceNorm1d(nn.Module):
+    """modules/normalization.py:160-208 (`_masked_norm`, instance): statistics over valid positions only (biased
+    variance, eps 1e-5), every position normalised, affine.  Parameter names weight / bias like nn.InstanceNorm1d."""
+
+    def __init__(self, num_features: int, eps: float = 1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x: Tensor, mask: Tensor) -> Tensor:
+        m = mask.to(x.dtype)
+        n = m.sum(dim=2, keepdim=True)
+        mx = m * x
+        mean = mx.sum(dim=2, keepdim=True) / n
+        var = (((mx - mean) * m) ** 2).sum(dim=2, keepdim=True) / n
+        out = (x - mean) / (var + self.eps).sqrt()
+        return out * self.weight.view(1, -1, 1) + self.bias.view(1, -1, 1)
+
+
+class ConvBlock1D(nn.Module):
+    """alignment.py:40-83: x*mask -> Conv1d (no bias when normalised) -> activation -> masked norm -> dropout(eval: id)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 1, activation: str = "relu",
+                 normalization: Optional[str] = "batch", bias: bool = True):
+        super().__init__()
+        if normalization not in (None, "instance"):
+            raise NotImplementedError("only instance normalisation (the recipes' choice) is built")
+        if activation not in ("gelu", "linear"):
+            raise NotImplementedError("only gelu / linear activations (the recipes' choice) are built")
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, padding=(kernel_size - 1) // 2,
+                              bias=bias and normalization is None)
+        self.gelu = activation == "gelu"
+        self.norm = MaskedInstanceNorm1d(out_channels) if normalization is not None else None
+
+    def forward(self, x: Tensor, input_mask: Tensor, output_mask: Tensor) -> Tensor:
+        y = self.conv(x * input_mask)
+        if self.gelu:
+            y = F.gelu(y)
+        if self.norm is not None:
+            y = self.norm(y, output_mask)
+        return y
+
+
+class ConvAttention(nn.Module, Constructor):
+    def __init__(self, mel_dim: int, text_dim: int = 512, attention_dim: int = 80, key_kernel_size: int = 3,
+                 query_kernel_size=(3, 3), dropout: float = 0.0, normalization: Optional[str] = "instance",
+                 activation: str = "relu", attention_prior: bool = True):
+        super().__init__()
+        self.mel_dim, self.text_dim = mel_dim, text_dim
+        self.scale = attention_dim ** -0.5
+        if isinstance(query_kernel_size, int):
+            query_kernel_size = [query_kernel_size] * 2
+        self.key_proj = nn.ModuleList([
+            ConvBlock1D(text_dim, text_dim * 2, key_kernel_size, activation, normalization, bias=False),
+            ConvBlock1D(text_dim * 2, attention_dim, 1, "linear", None, bias=False)])
+        self.query_proj = nn.ModuleList([
+            ConvBlock1D(mel_dim, mel_dim * 2, query_kernel_size[0], activation, normalization, bias=False),
+            ConvBlock1D(mel_dim * 2, mel_dim, query_kernel_size[1], activation, normalization, bias=False),
+            ConvBlock1D(mel_dim, attention_dim, 1, "linear", None, bias=False)])
+        self.attention_prior = attention_prior
+
+    def forward(self, queries: Tensor, keys: Tensor, query_len: Tensor, key_len: Tensor):
+        """alignment.py:159-208.  queries [B, mel_dim, M], keys [B, text_dim, L] -> (attn_soft, attn_logits) [B,M,L]."""
+        max_q, max_k = queries.shape[2], keys.shape[2]
+        key_mask = get_mask_from_lengths(key_len, max_k).unsqueeze(1)
+        query_mask = get_mask_from_lengths(query_len, max_q).unsqueeze(1)
+        mask = query_mask.transpose(1, 2) & key_mask
+        k = keys
+        for conv in self.key_proj:
+            k = conv(k, key_mask, key_mask)
+        q = queries
+        for conv in self.query_proj:
+            q = conv(q, query_mask, query_mask)
+        attn = torch.matmul(q.transpose(1, 2), k) * self.scale
+        attn = torch.clamp(attn, max=max_dtype_value(attn))
+        if self.attention_prior:
+            prior = batch_diagonal_prior(key_len, query_len, max_text=max_k, max_mel=max_q)
+            attn = F.log_softmax(attn, dim=2, dtype=torch.float32) + torch.log(prior + 1e-6)
+        attn_logits = attn.clone()
+        attn = attn.masked_fill(~mask[:, :1], min_dtype_value(attn))
+        attn = F.softmax(attn, dim=2, dtype=torch.float32) * mask
+        return attn, attn_logits
+
+
+class AlignerOutput(NamedTuple):
+    attn_soft: Tensor
+    attn_logits: Tensor
+    attn_hard: Tensor
+    attn_hard_duration: Tensor
+
+
+class Aligner(nn.Module, Constructor):
+    def __init__(self, mel_dim: int, text_dim: int = 512, attention_dim: int = 80, key_kernel_size: int = 3,
+                 query_kernel_size=(3, 3), dropout: float = 0.0, normalization: Optional[str] = "instance",
+                 activation: str = "relu", attention_prior: bool = True):
+        super().__init__()
+        self.attention = ConvAttention(mel_dim=mel_dim, text_dim=text_dim, attention_dim=attention_dim,
+                                       key_kernel_size=key_kernel_size, query_kernel_size=query_kernel_size,
+                                       dropout=dropout, normalization=normalization, activation=activation,
+                                       attention_prior=attention_prior)
+
+    def forward(self, mel: Tensor, enc_text: Tensor, mel_len: Tensor, text_len: Tensor) -> AlignerOutput:
+        """alignment.py:259-289.  The duration fix-up of :278-282 (sum of durations != mel_len, possible only when
+        text_len > mel_len) is applied unconditionally on the device: adding `mel_len - sum` (zero otherwise) to column
+        0 gives the same result without the host round-trip of the reference's `torch.all(...)` check."""
+        attn_soft, attn_logits = self.attention(mel, enc_text, mel_len, text_len)
+        attn_hard, dur = self.binarize_attention_parallel(attn_logits, text_len, mel_len, return_duration=True)
+        dur[:, 0] += mel_len - dur.sum(dim=1)
+        return AlignerOutput(attn_soft=attn_soft, attn_logits=attn_logits, attn_hard=attn_hard, attn_hard_duration=dur)
+
+    @torch.no_grad()
+    def binarize_attention_parallel(self, attn_logits: Tensor, text_len: Tensor, mel_len: Tensor,
+                                    return_duration: bool = False):
+        """alignment.py:291-331: replaces both the numba-CPU and the numba-CUDA branch by the wavefront MAS kernel.
+        Returns the int16 one-hot [B,M,L] on the logits' device (and the int64 column sums when asked)."""
+        hard, dur, _ = mas_device(attn_logits.detach(), text_len, mel_len, want_dur=return_duration)
+        return (hard, dur) if return_duration else hard

@@ -1,0 +1,123 @@
+"""`AcousticModel`: forward / infer orchestration (tts/models/acoustic/model.py:60-238 of the reference).
+
+Same constructor config, parameter names (`state_dict` keys) and call signatures.  What runs where:
+  * encoder / decoder / adaptor transformer stacks, `to_mel`, MAS  -> hand-written gfx950 kernels (libispk.so);
+  * token embedding lookup, the aligner's conv front-end, the adaptor's small tensor algebra -> PyTorch-ROCm ops
+    ("next");
+all on the current stream, with no host synchronisation inside `forward` when `max_*` lengths are given by shapes.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import runtime
+from ..modules.constructor import Constructor
+from ..modules.transformer import Transformer
+from ..utils import get_mask_from_lengths
+from .alignment import Aligner, AlignerOutput
+from .temporal_adaptor import FlowTemporalAdaptor, TemporalAdaptorOutput
+
+
+class AcousticModelOutput(NamedTuple):
+    mel: Tensor
+    adaptor_output: TemporalAdaptorOutput
+    aligner_output: AlignerOutput
+    loss: Optional[Tensor] = None
+    losses: Optional[dict] = None
+
+
+class AcousticModel(nn.Module, Constructor):
+    def __init__(self, encoding_map: dict, mel_dim: int, text_dim: int = 384, encoder=None, decoder=None,
+                 temporal_adaptor=None, aligner=None, num_speakers: Optional[int] = 0, pitch_mean=None, pitch_std=None):
+        super().__init__()
+        if num_speakers:
+            raise NotImplementedError("multi-speaker models are outside the built scope (recipes: num_speakers null; "
+                                      "the reference's own forward is broken for them, model.py:146)")
+        self.encoding_map = dict(encoding_map)
+        self.mel_dim, self.text_dim = mel_dim, text_dim
+        self.text_embedding = nn.Embedding(len(encoding_map), text_dim, padding_idx=0)
+        self.encoder = Transformer.init(encoder, emb_dim=text_dim)
+        enc_dim = self.encoder.dim
+        self.aligner = Aligner.init(aligner, mel_dim=mel_dim, text_dim=enc_dim)
+        self.speaker_embedding = None
+        self.temporal_adaptor = FlowTemporalAdaptor.init(temporal_adaptor, encoder_dim=enc_dim)
+        self.decoder = Transformer.init(decoder, emb_dim=enc_dim)
+        self.to_mel = nn.Linear(self.decoder.dim, mel_dim)
+        self.register_buffer("pitch_mean", torch.tensor(float(pitch_mean or 0.)))
+        self.register_buffer("pitch_std", torch.tensor(float(pitch_std or 1.)))
+        self.compute_dtype = torch.float32
+        self._cache: dict = {}
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        """fp32 (parity path: exact-fp32 MFMA) or bf16 (throughput path: bf16 operands, fp32 accumulation,
+        fp32 residual stream / LayerNorm / softmax statistics).  Applies to the encoder and decoder stacks."""
+        self.encoder.set_compute_dtype(dtype)
+        self.decoder.set_compute_dtype(dtype)
+        self.compute_dtype = dtype
+        return self
+
+    def _to_mel(self, dec_out: Tensor, dec_mask: Optional[Tensor]) -> Tensor:
+        return runtime.to_mel(dec_out, self.to_mel.weight, self.to_mel.bias, dec_mask)
+
+    @torch.no_grad()
+    def forward(self, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Optional[Tensor] = None,
+                energy: Optional[Tensor] = None, speaker: Optional[Tensor] = None, sigma: float = 0., steps: int = 1, *,
+                flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None) -> AcousticModelOutput:
+        """model.py:116-174.  text int64 [B,L], mel fp32 [B,80,M], pitch/energy fp32 [B,M], lengths int64 [B]
+        (collator.py:36-55).  Padded shapes define the masks' widths (max length = L / M, as collated batches have)."""
+        token_emb = self.text_embedding(text)
+        enc_mask = get_mask_from_lengths(text_len, text.shape[1])
+        enc_out = self.encoder(token_emb, mask=enc_mask, key_len=text_len).out
+        aligner_output = self.aligner(mel=mel, enc_text=enc_out.transpose(1, 2).detach(), mel_len=mel_len,
+                                      text_len=text_len)
+        adaptor_output = self.temporal_adaptor(
+            enc_out=enc_out, enc_mask=enc_mask, max_dec_len=mel.size(2),
+            duration_target=aligner_output.attn_hard_duration, alignment=aligner_output.attn_soft,
+            pitch_target_dense=pitch, energy_target_dense=energy, noise=flow_noise, time_steps=flow_time)
+        dec_len = adaptor_output.dec_lengths
+        dec_mask = get_mask_from_lengths(dec_len, adaptor_output.enc_out.shape[1])
+        dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, key_len=dec_len).out
+        mel_out = self._to_mel(dec_out, dec_mask)
+        return AcousticModelOutput(mel=mel_out, adaptor_output=adaptor_output, aligner_output=aligner_output)
+
+    @torch.no_grad()
+    def infer(self, input_sequence: Tensor, text_lengths: Optional[Tensor] = None,
+              duration_target: Optional[Tensor] = None, duration_factor: float = 1.0,
+              pitch_target: Optional[Tensor] = None, pitch_factor: float = 1.0, pitch_delta: float = 0.,
+              pitch_normalize: bool = False, energy_target: Optional[Tensor] = None, steps: int = 4,
+              speaker: Optional[Tensor] = None, *, flow_noise: Optional[Tensor] = None,
+              max_dec_len: Optional[int] = None):
+        """model.py:177-238: masks only for batch > 1 (:191-201, :228)."""
+        batch_infer = input_sequence.shape[0] > 1
+        token_emb = self.text_embedding(input_sequence)
+        enc_mask = None
+        if batch_infer:
+            if text_lengths is None:
+                text_lengths = torch.full((input_sequence.shape[0],), input_sequence.shape[1], dtype=torch.int64,
+                                          device=input_sequence.device)
+            enc_mask = get_mask_from_lengths(text_lengths, input_sequence.shape[1])
+        enc_out = self.encoder(token_emb, mask=enc_mask).out
+        if pitch_normalize:
+            if pitch_target is not None:
+                pitch_target = (pitch_target - self.pitch_mean) / self.pitch_std
+            pitch_delta = pitch_delta / self.pitch_std
+        adaptor_output = self.temporal_adaptor.infer(
+            enc_out=enc_out, enc_mask=enc_mask, duration_target=duration_target, pitch_target=pitch_target,
+            energy_target=energy_target, duration_factor=duration_factor, pitch_factor=pitch_factor,
+            pitch_delta=pitch_delta, steps=steps, noise=flow_noise, max_dec_len=max_dec_len)
+        dec_mask = None
+        if batch_infer:
+            dec_mask = get_mask_from_lengths(adaptor_output.dec_lengths, adaptor_output.enc_out.shape[1])
+        dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask).out
+        return self._to_mel(dec_out, dec_mask), adaptor_output
+
+    def prepare_inputs(self, inputs: dict) -> dict:
+        """model.py:244-259 (collator field names -> forward kwargs)."""
+        return {"text": inputs["text_vector"], "text_len": inputs["text_vector_len"], "mel": inputs["mel"],
+                "mel_len": inputs["mel_len"], "pitch": inputs["pitch"], "energy": inputs["energy"],
+                "speaker": inputs.get("speaker")}

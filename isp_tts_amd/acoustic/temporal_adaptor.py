@@ -1,0 +1,242 @@
+"""Flow-matching temporal adaptor (tts/models/acoustic/modules/temporal_adaptor.py of the reference).
+
+The transformer stacks (predictor: dim 256 x 3 with AdaptiveLayerNorm; embedding: dim 256 x 1) run on the HIP
+kernels through `Transformer`.  The small tensor algebra around them (soft averaging, soft length regulation,
+soft-path generation: SURVEY row f3 "next") is stock PyTorch-ROCm with the reference's order of operations.
+
+The flow noise is an explicit, optional input (`noise`, `time_steps`) so that parity runs can feed host-generated
+draws; when omitted it is drawn like the reference (randn_like then rand, temporal_adaptor.py:113-115; randn :148).
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch import Tensor
+
+from .. import runtime
+from ..modules.constructor import Constructor
+from ..modules.transformer import Transformer, TimePositionalEmbedding
+from ..utils import get_float_mask_from_lengths, get_mask_3d, masked_mean
+
+
+class TransformerTemporalModule(nn.Module, Constructor):
+    """temporal_adaptor.py:26-59: Transformer(emb_dim=input_dim) -> Linear(with bias) -> * mask."""
+
+    def __init__(self, input_dim: int = 256, output_dim: int = 256, transformer=None, detach_inputs: bool = False):
+        super().__init__()
+        self.transformer = Transformer.init(transformer, emb_dim=input_dim)
+        self.linear_layer = nn.Linear(self.transformer.dim, output_dim, bias=True)
+        self.detach_inputs = detach_inputs
+
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+        m2 = mask[..., 0] if mask is not None else None
+        out = self.transformer(x, mask=m2).out
+        flags = runtime.EP_MASK_OUT if m2 is not None else 0
+        return runtime.gemm(out, self.linear_layer.weight, bias=self.linear_layer.bias, mask=m2, flags=flags)
+
+    def infer(self, x: Tensor, mask: Optional[Tensor] = None, steps: int = 4) -> Tensor:
+        return self.forward(x, mask)
+
+
+class FlowTransformerTemporalModule(nn.Module, Constructor):
+    """temporal_adaptor.py:72-170.  The predictor input is cat([x_t (3), cond (384)]) -> project_emb (387 -> 256).
+    That projection is split: the 384 condition channels go through ONE MFMA GEMM per call (they do not change between
+    Euler steps), the 3 flow channels are a K=3 update (`ispk_linear_small_f32` with the GEMM result as residual)."""
+
+    def __init__(self, input_dim: int = 256, output_dim: int = 256, transformer=None,
+                 time_embedding_dim: Optional[int] = None, sigma: float = 1e-5, detach_inputs: bool = False):
+        super().__init__()
+        time_embedding_dim = time_embedding_dim or input_dim
+        self.time_embedding = TimePositionalEmbedding(freq_dim=64, emb_dim=time_embedding_dim, with_steps=True)
+        self.transformer = Transformer.init(transformer, emb_dim=output_dim + input_dim, adaptive_norm=True,
+                                            condition_dim=time_embedding_dim)
+        self.linear_layer = nn.Linear(self.transformer.dim, output_dim, bias=True)
+        self.output_dim, self.sigma, self.detach_inputs = output_dim, sigma, detach_inputs
+        self._cache: dict = {}
+
+    def _cond_weight(self) -> Tensor:
+        w = self.transformer.project_emb.weight
+        key = (w.data_ptr(), w._version, w.device)
+        if self._cache.get("key") != key:
+            self._cache = {"key": key, "wc": w.detach()[:, self.output_dim:].contiguous()}
+        return self._cache["wc"]
+
+    def _project(self, x_t: Tensor, cond_proj: Tensor) -> Tensor:
+        w = self.transformer.project_emb.weight
+        return runtime.linear_small(x_t.contiguous(), w[:, :self.output_dim], None, resid=cond_proj)
+
+    def _cond_projection(self, cond: Tensor) -> Tensor:
+        return runtime.gemm(cond.float().contiguous(), self._cond_weight(), bias=self.transformer.project_emb.bias)
+
+    def forward(self, x: Tensor, targets: Tensor, mask: Optional[Tensor] = None, *, noise: Optional[Tensor] = None,
+                time_steps: Optional[Tensor] = None):
+        cond = x
+        if mask is None:
+            mask = torch.ones(x.shape[:2], dtype=torch.bool, device=x.device)
+        elif mask.ndim == 3:
+            mask = mask[..., 0]
+        x1 = targets.detach()
+        x0 = torch.randn_like(x1) if noise is None else noise.to(x1)
+        t = torch.rand((x1.shape[0],), dtype=x1.dtype, device=x1.device) if time_steps is None else time_steps.to(x1)
+        time_emb = self.time_embedding(t)
+        tt = t[:, None, None]
+        x_t = (1 - (1 - self.sigma) * tt) * x0 + tt * x1
+        flow = x1 - (1 - self.sigma) * x0
+        proj = self._project(x_t, self._cond_projection(cond))
+        out = self.transformer(None, mask=mask, adaptive_condition=time_emb, projected=proj).out
+        m3 = mask[..., None].expand(-1, -1, self.output_dim)
+        pred_flow = runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias) * m3
+        loss = masked_mean(F.mse_loss(pred_flow, flow, reduction="none"), m3)
+        return (x0 + pred_flow) * m3, {"flow_loss": loss}
+
+    def euler_grid(self, steps: int, step_factor: float, device) -> Tensor:
+        """temporal_adaptor.py:150-156 (steps=4, factor .75 -> [0, .3657, .6400, .8457, 1])."""
+        assert step_factor <= 1.
+        if step_factor == 1.:
+            return torch.linspace(0, 1, steps + 1, device=device)
+        ts = -torch.diff(torch.logspace(0, steps, steps + 1, base=step_factor, device=device))
+        ts = torch.cat([torch.zeros(1, device=device), ts])
+        return torch.cumsum(ts / ts.sum(), dim=0)
+
+    def infer(self, x: Tensor, mask: Optional[Tensor] = None, steps: int = 4, step_factor: float = 0.75, *,
+              noise: Optional[Tensor] = None) -> Tensor:
+        if mask is None:
+            mask = torch.ones(x.shape[:2], dtype=torch.bool, device=x.device)
+        elif mask.ndim == 3:
+            mask = mask.squeeze(-1)
+        x_t = (torch.randn(x.shape[0], x.shape[1], self.output_dim, device=x.device) if noise is None
+               else noise.to(device=x.device, dtype=torch.float32))
+        ts = self.euler_grid(steps, step_factor, x.device)
+        cond_proj = self._cond_projection(x)
+        key_len = mask.sum(dim=1)
+        for i in range(steps):
+            dt = ts[i + 1] - ts[i]
+            time_emb = self.time_embedding(ts[i].view(1, 1))
+            out = self.transformer(None, mask=mask, adaptive_condition=time_emb, projected=self._project(x_t, cond_proj),
+                                   key_len=key_len).out
+            x_t = x_t + runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias) * dt
+        return x_t * mask[..., None]
+
+
+class TemporalAdaptorOutput(NamedTuple):
+    enc_out: Tensor
+    log_duration: Optional[Tensor]
+    duration: Tensor
+    dec_lengths: Tensor
+    pitch: Optional[Tensor]
+    energy: Optional[Tensor]
+    pitch_target: Optional[Tensor]
+    energy_target: Optional[Tensor]
+    losses: Optional[dict] = None
+
+
+class LengthRegulator(nn.Module):
+    """temporal_adaptor.py:411-436, soft branch (the recipes' soft_duration): out = alignment @ x,
+    dec_lens = (sum(dur) + .5).long(), both cut to max_len."""
+
+    def forward(self, x: Tensor, durations: Tensor, max_len: Optional[int] = None, alignment: Optional[Tensor] = None):
+        if alignment is None:
+            raise NotImplementedError("hard (repeat) length regulation is unused by the recipes (soft_duration: true)")
+        dec_lens = (durations.sum(dim=1) + 0.5).long()
+        out = torch.bmm(alignment, x)
+        if max_len is not None:
+            out = out[:, :max_len]
+            dec_lens = torch.clamp_max(dec_lens, max_len)
+        return out, dec_lens
+
+
+class TemporalAverager(nn.Module):
+    """temporal_adaptor.py:439-449, soft branch: x[B,1,M] @ A[B,M,L] / (colsum(A) + 1e-5)."""
+
+    def forward(self, x: Tensor, durations: Tensor, alignment: Optional[Tensor] = None) -> Tensor:
+        if alignment is None:
+            raise NotImplementedError("hard averaging is unused by the recipes (soft_duration: true)")
+        return x @ alignment / (alignment.sum(dim=1, keepdim=True) + 1e-5)
+
+
+def generate_soft_path(duration: Tensor, mask: Tensor) -> Tensor:
+    """temporal_adaptor.py:468-478."""
+    b, t_x, t_y = mask.shape
+    cum = torch.cumsum(duration, 1).view(b * t_x)
+    path = get_float_mask_from_lengths(cum, t_y).to(mask.dtype).view(b, t_x, t_y)
+    path = path - F.pad(path, [0, 0, 1, 0, 0, 0])[:, :-1]
+    return path * mask
+
+
+class FlowTemporalAdaptor(nn.Module, Constructor):
+    def __init__(self, encoder_dim: int = 384, predictor=None, embedding=None, pitch: bool = True, energy: bool = True,
+                 soft_duration: bool = False):
+        super().__init__()
+        if not (pitch and energy and soft_duration):
+            raise NotImplementedError("built for the recipes' adaptor: pitch, energy and soft_duration all on")
+        self.length_regulator = LengthRegulator()
+        self.averager = TemporalAverager()
+        self.encoder_dim = encoder_dim
+        self.feature_dim = 3
+        self.pitch, self.energy, self.soft_duration = pitch, energy, soft_duration
+        self.pitch_idx, self.energy_idx = 1, 2
+        self.predictor = FlowTransformerTemporalModule.init(predictor, input_dim=encoder_dim, output_dim=self.feature_dim)
+        self.embedding = TransformerTemporalModule.init(embedding, input_dim=self.feature_dim - 1, output_dim=encoder_dim)
+
+    def _process_target(self, dense: Tensor, duration_target: Tensor, alignment: Tensor, enc_mask: Tensor) -> Tensor:
+        if dense.ndim == 2:
+            dense = dense[:, None]
+        return self.averager(dense, duration_target, alignment).transpose(1, 2) * enc_mask
+
+    def forward(self, enc_out: Tensor, enc_mask: Tensor, max_dec_len: int, duration_target: Optional[Tensor] = None,
+                alignment: Optional[Tensor] = None, pitch_target_dense: Optional[Tensor] = None,
+                energy_target_dense: Optional[Tensor] = None, *, noise: Optional[Tensor] = None,
+                time_steps: Optional[Tensor] = None) -> TemporalAdaptorOutput:
+        """temporal_adaptor.py:238-312 (teacher-forced: the decoder input uses the TARGET pitch/energy, :284,:292)."""
+        assert alignment is not None and duration_target is not None
+        assert pitch_target_dense is not None and energy_target_dense is not None
+        m3 = enc_mask[..., None]
+        pitch_target = self._process_target(pitch_target_dense, duration_target, alignment, m3)
+        energy_target = self._process_target(energy_target_dense, duration_target, alignment, m3)
+        targets = torch.cat([torch.log1p(duration_target)[..., None], pitch_target, energy_target], dim=-1)
+        pred, losses = self.predictor(enc_out, targets, m3, noise=noise, time_steps=time_steps)
+        log_duration_pred = pred[..., 0]
+        duration_pred = torch.clamp(torch.exp(log_duration_pred) - 1, min=0)
+        features = torch.cat([pitch_target, energy_target], dim=-1)
+        enc_out = enc_out + self.embedding(features, mask=m3)
+        enc_out, dec_lens = self.length_regulator(enc_out, duration_target, max_len=max_dec_len, alignment=alignment)
+        return TemporalAdaptorOutput(enc_out=enc_out, log_duration=log_duration_pred, duration=duration_pred,
+                                     dec_lengths=dec_lens, pitch=pred[..., 1], energy=pred[..., 2],
+                                     pitch_target=pitch_target.squeeze(-1), energy_target=energy_target.squeeze(-1),
+                                     losses=losses)
+
+    def infer(self, enc_out: Tensor, enc_mask: Optional[Tensor] = None, duration_target: Optional[Tensor] = None,
+              duration_factor: float = 1.0, pitch_target: Optional[Tensor] = None, pitch_factor: float = 1.0,
+              pitch_delta: float = 0., energy_target: Optional[Tensor] = None, energy_factor: float = 1.0,
+              energy_delta: float = 0., steps: int = 4, *, noise: Optional[Tensor] = None,
+              max_dec_len: Optional[int] = None) -> TemporalAdaptorOutput:
+        """temporal_adaptor.py:331-408.  Durations stay fractional (soft_duration, :355-356); the embedding transformer
+        gets NO mask even when batched (:384).  `max_dec_len` (optional) fixes the decoder length without reading
+        `dec_lens.max()` back to the host."""
+        m3 = enc_mask[..., None] if enc_mask is not None else None
+        pred = self.predictor.infer(enc_out, mask=m3, steps=steps, noise=noise)
+        if duration_target is None or bool((duration_target < 0).any()):
+            duration_pred = torch.clamp(duration_factor * (torch.exp(pred[..., 0]) - 1), min=0)
+            if duration_target is not None:
+                neg = duration_target < 0
+                duration_target = duration_target.float()
+                duration_target[neg] = duration_pred[neg]
+                duration_pred = duration_target
+        else:
+            duration_pred = duration_target
+        pitch = (pred[..., 1:2] if pitch_target is None else pitch_target.unsqueeze(-1)) * pitch_factor + pitch_delta
+        energy = (pred[..., 2:3] if energy_target is None else energy_target.unsqueeze(-1)) * energy_factor + energy_delta
+        enc_out = enc_out + self.embedding(torch.cat([pitch, energy], dim=-1))
+        b, l = enc_out.shape[:2]
+        enc_lens = torch.full((b,), l, device=enc_out.device) if enc_mask is None else enc_mask.sum(dim=1)
+        dec_lens = (duration_pred.sum(dim=1) + 0.5).long()
+        max_h = int(dec_lens.max().item()) if max_dec_len is None else max_dec_len
+        mask = get_mask_3d(enc_lens, dec_lens, l, max_h).float()
+        alignment = generate_soft_path(duration_pred, mask).transpose(1, 2)
+        enc_out, dec_lens = self.length_regulator(enc_out, duration_pred, alignment=alignment)
+        return TemporalAdaptorOutput(enc_out=enc_out, log_duration=None, duration=duration_pred, dec_lengths=dec_lens,
+                                     pitch=pitch.squeeze(-1), energy=energy.squeeze(-1), pitch_target=pitch_target,
+                                     energy_target=energy_target)

@@ -1,0 +1,22 @@
+// ABI bookkeeping: version, thread-local error string, device query.
+#include "common.h"
+
+char* ispk_err_buf() {
+    static thread_local char buf[256] = {0};
+    return buf;
+}
+
+extern "C" int32_t ispk_abi_version(void) { return ISPK_ABI_VERSION; }
+
+extern "C" const char* ispk_last_error_string(void) { return ispk_err_buf(); }
+
+extern "C" int32_t ispk_device_info(char* name, int32_t cap) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) ISPK_FAIL((int32_t)e, "hipGetDevice: %s", hipGetErrorString(e));
+    hipDeviceProp_t p;
+    e = hipGetDeviceProperties(&p, dev);
+    if (e != hipSuccess) ISPK_FAIL((int32_t)e, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (name && cap > 0) snprintf(name, (size_t)cap, "%s", p.gcnArchName);
+    return p.multiProcessorCount;
+}

@@ -1,0 +1,192 @@
+// ALiBi-biased multi-query attention for gfx950 — flash-style, nothing of size N x N ever touches HBM.
+//
+// Reference semantics: /root/reference/tts/modules/transformer/attend.py:49-122 (SDPA over a materialised
+// [B,H,N,N] fp32 bias = slopes[h] * -|i-j| with masked keys filled with min/2), embeddings.py:51-72,
+// attention.py:128-152.  One K/V head is shared by all H query heads (attend.py:63-67).
+//
+// Work decomposition: a workgroup owns one (batch item, 64-query tile) for ALL heads: 2*H waves, wave w handles head
+// w % H and the 32-query half w / H.  The K/V tile (64 keys x (64 + 64) fp32) is staged ONCE in LDS and consumed by
+// all 2*H waves — the MQA reuse the reference throws away by expanding K/V to H heads.
+//
+// fp32 path (v_mfma_f32_32x32x2_f32, exact fp32 products):
+//   * Sᵀ = K·Qᵀ (keys on the MFMA row axis, queries on the lane axis).  A lane then holds, for ITS query, 16 keys of
+//     the 32-key block in its accumulator registers, so the online-softmax row reductions are 16 in-register ops plus
+//     one cross-half exchange, and the exponentiated Pᵀ accumulator is ALREADY the B operand of the next product
+//     Oᵀ += Vᵀ·Pᵀ (register r of lane half h is key (r&3) + 8(r>>2) + 4h: the V row is simply read at that key).
+//     P never goes through LDS and is never transposed.
+//   * Q is held in registers (32 fp32 per lane: lane half h owns head dims 32h..32h+31), pre-scaled by 1/sqrt(64)
+//     (a power of two, so bitwise equal to scaling the product).
+//   * K rows are padded to 68 dwords so each ds_read_b128 lane group hits 16 distinct 4-bank slots.
+//   * bias -slope*|i-j| and the key-length mask are computed in registers; fully masked key blocks are skipped.
+#include "common.h"
+
+namespace {
+
+constexpr int kLdk = 68;   // padded K/V tile row (64 + 4 dwords)
+constexpr int kTileKeys = 64;
+
+__device__ __forceinline__ float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+
+__global__ __launch_bounds__(1024) void attn_f32_kernel(const float* __restrict__ q, int64_t ldq,
+                                                        const float* __restrict__ k, const float* __restrict__ v,
+                                                        int64_t ldkv, const float* __restrict__ slopes,
+                                                        const int64_t* __restrict__ key_len, float* __restrict__ out,
+                                                        int64_t ldo, int N, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);  // [2][64][kLdk]
+    float* Vs = Ks + 2 * kTileKeys * kLdk;           // [2][64][kLdk]
+
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int head = wave % H, qhalf = wave / H;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + qhalf * 32;
+    int klen = key_len ? (int)key_len[b] : N;
+    klen = klen < 1 ? 1 : (klen > N ? N : klen);
+    const float slope = slopes[head];
+    const float ninf = -__builtin_huge_valf();
+
+    // ---- Q fragment: lane (query l31, half h) holds Q[q][32h .. 32h+31] / 8
+    const int qi = q0 + l31;
+    const int qrow = qi < N ? qi : N - 1;
+    f32x4 qf[8];
+    {
+        const float* qp = q + ((int64_t)b * N + qrow) * ldq + head * 64 + h * 32;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            qf[c] = *reinterpret_cast<const f32x4*>(qp + c * 4);
+            qf[c] *= 0.125f;
+        }
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = ninf, l_run = 0.f;
+
+    const float* kb = k + (int64_t)b * N * ldkv;
+    const float* vb = v + (int64_t)b * N * ldkv;
+    const int ntiles = (klen + kTileKeys - 1) / kTileKeys;
+
+    auto stage = [&](int t, int buf) {
+        // 64 keys x 16 float4 for K and the same for V
+        for (int idx = tid; idx < kTileKeys * 32; idx += nthreads) {
+            const int isv = idx >> 10;  // 0: K, 1: V
+            const int rem = idx & 1023;
+            const int row = rem >> 4, c4 = (rem & 15) * 4;
+            const int key = t * kTileKeys + row;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (key < N) val = *reinterpret_cast<const float4*>((isv ? vb : kb) + (int64_t)key * ldkv + c4);
+            *reinterpret_cast<float4*>((isv ? Vs : Ks) + (buf * kTileKeys + row) * kLdk + c4) = val;
+        }
+    };
+
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+#pragma unroll 1
+        for (int kblk = 0; kblk < 2; ++kblk) {
+            const int key0 = t * kTileKeys + kblk * 32;
+            if (key0 >= klen) break;  // wave-uniform
+            // ---- Sᵀ[key][query] = sum_d K[key][d] * Q[query][d]
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const float* kp = Ks + (buf * kTileKeys + kblk * 32 + l31) * kLdk + h * 32;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kp + c * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s, 0, 0, 0);
+            }
+            // ---- bias, mask, online softmax (per query = per lane pair)
+            float smax = ninf;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int dist = key > qi ? key - qi : qi - key;
+                float val = s[r] - slope * (float)dist;
+                val = key < klen ? val : ninf;
+                s[r] = val;
+                smax = fmaxf(smax, val);
+            }
+            smax = xhalf_max(smax);
+            const float m_new = fmaxf(m_run, smax);
+            const float alpha = expf(m_run - m_new);  // first block: exp(-inf) = 0
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pexp = expf(s[r] - m_new);
+                s[r] = pexp;
+                psum += pexp;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+            // ---- Oᵀ[d][query] += sum_key V[key][d] * P[key][query]
+            const float* vp = Vs + (buf * kTileKeys + kblk * 32 + 4 * h) * kLdk + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float* vr = vp + ((r & 3) + 8 * (r >> 2)) * kLdk;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[0], s[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], s[r], o1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (query, half) holds d = dblk*32 + (r&3) + 8(r>>2) + 4h
+    const float inv = 1.0f / xhalf_sum(l_run);
+    if (qi < N) {
+        float* op = out + ((int64_t)b * N + qi) * ldo + head * 64 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 a, c;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a[e] = o0[4 * g + e] * inv;
+                c[e] = o1[4 * g + e] * inv;
+            }
+            *reinterpret_cast<f32x4*>(op + 8 * g) = a;
+            *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = c;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t ispk_alibi_mqa_attn_f32(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                           const float* slopes, const int64_t* key_len, float* out, int64_t ldo,
+                                           int32_t B, int32_t N, int32_t H, ispk_stream_t stream) {
+    ISPK_REQUIRE(q && k && v && slopes && out, ISPK_E_NULL, "attn: null pointer");
+    ISPK_REQUIRE(B >= 0 && N >= 1 && H >= 1 && H <= 8, ISPK_E_SHAPE, "attn: bad shape B=%d N=%d H=%d (H <= 8)", B, N, H);
+    ISPK_REQUIRE(B <= 65535, ISPK_E_SHAPE, "attn: B=%d exceeds the grid limit 65535", B);
+    ISPK_REQUIRE(ldq >= H * 64 && ldo >= H * 64 && ldkv >= 64, ISPK_E_SHAPE, "attn: leading strides too small");
+    ISPK_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0, ISPK_E_ALIGN, "attn: strides must be multiples of 4");
+    ISPK_REQUIRE(ispk_aligned(q, 16) && ispk_aligned(k, 16) && ispk_aligned(v, 16) && ispk_aligned(out, 16),
+                 ISPK_E_ALIGN, "attn: pointers must be 16-byte aligned");
+    if (B == 0) return 0;
+    constexpr size_t lds = (size_t)4 * kTileKeys * kLdk * sizeof(float);  // 69,632 B
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) ISPK_FAIL((int32_t)e, "attn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    dim3 grid((N + 63) / 64, B), block(2 * H * 64);
+    hipLaunchKernelGGL(attn_f32_kernel, grid, block, lds, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv,
+                       slopes, key_len, out, ldo, N, H);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v,
+                                            int64_t ldkv, const float* slopes, const int64_t* key_len, uint16_t* out,
+                                            int64_t ldo, int32_t B, int32_t N, int32_t H, ispk_stream_t stream) {
+    ISPK_FAIL(ISPK_E_UNSUPPORTED, "alibi_mqa_attn_bf16: not implemented in this build");
+}

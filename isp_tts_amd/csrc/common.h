@@ -1,0 +1,49 @@
+// Shared helpers for the gfx950 kernels of libispk.so (see include/ispk.h for the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ispk.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+
+// thread-local last-error text (set by ISPK_FAIL, read through ispk_last_error_string)
+char* ispk_err_buf();
+
+#define ISPK_FAIL(code, ...)                          \
+    do {                                              \
+        snprintf(ispk_err_buf(), 256, __VA_ARGS__);   \
+        return (code);                                \
+    } while (0)
+
+#define ISPK_REQUIRE(cond, code, ...) \
+    do {                              \
+        if (!(cond)) ISPK_FAIL(code, __VA_ARGS__); \
+    } while (0)
+
+static inline int32_t ispk_launch_status() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        snprintf(ispk_err_buf(), 256, "kernel launch failed: %s", hipGetErrorString(e));
+        return (int32_t)e;
+    }
+    return 0;
+}
+
+static inline bool ispk_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
+
+// bf16 <-> fp32 (round to nearest even; a plain cast keeps NaN a NaN on gfx950)
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+constexpr int kWave = 64;

@@ -1,0 +1,65 @@
+"""`FeedForward`: Linear -> GELU(erf) -> Linear (tts/modules/transformer/feedforward.py:20-40 of the reference).
+
+Two MFMA GEMMs; the exact-erf GELU (layers.py:29) is the first GEMM's epilogue, and the second GEMM's epilogue can
+carry the residual add and row mask of transformer.py:105,110.  Dropout is identity in eval (the forward path).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ... import runtime
+from ..constructor import Constructor, ModuleConfig
+
+_ACTS = {"gelu": runtime.EP_GELU, "swish": runtime.EP_SILU, "linear": 0}
+
+
+@dataclass
+class FeedForwardConfig(ModuleConfig):
+    dim: int = 384
+    inner_dim: int = 1536
+    dropout: float = 0.0
+    activation: str = "relu"
+    bias: bool = False
+    glu: bool = False
+
+
+class FeedForward(nn.Module, Constructor):
+    def __init__(self, dim: int = 384, inner_dim: int = 1536, dropout: float = 0.0, activation: str = "relu",
+                 bias: bool = False, glu: bool = False):
+        super().__init__()
+        if glu or activation not in _ACTS:
+            raise NotImplementedError(f"built for the recipes' feed-forward (gelu, no GLU); got activation="
+                                      f"{activation!r}, glu={glu}")
+        self.act_flag = _ACTS[activation]
+        self.dropout_p = dropout
+        # same container layout as the reference so the keys are net.0.weight / net.3.weight
+        self.net = nn.Sequential(nn.Linear(dim, inner_dim, bias=bias), nn.GELU() if activation == "gelu" else nn.Identity(),
+                                 nn.Dropout(dropout) if dropout > 0. else nn.Identity(),
+                                 nn.Linear(inner_dim, dim, bias=bias))
+        self.compute_dtype = torch.float32
+        self._cache: dict = {}
+
+    def _staged(self, dtype: torch.dtype):
+        ps = (self.net[0].weight, self.net[3].weight)
+        key = (dtype,) + tuple((p.data_ptr(), p._version, p.device) for p in ps)
+        if self._cache.get("key") != key:
+            self._cache = {"key": key, "w1": ps[0].detach().to(dtype).contiguous(),
+                           "w2": ps[1].detach().to(dtype).contiguous()}
+        return self._cache["w1"], self._cache["w2"]
+
+    def forward(self, x: Tensor, *, residual: Optional[Tensor] = None, mask: Optional[Tensor] = None) -> Tensor:
+        if self.training and self.dropout_p > 0:
+            raise NotImplementedError("feed-forward dropout (training) is outside the forward-path scope")
+        dt = self.compute_dtype
+        w1, w2 = self._staged(dt)
+        if x.dtype != dt:
+            x = runtime.cast_bf16(x) if dt == torch.bfloat16 else x.float()
+        hidden = runtime.gemm(x, w1, bias=self.net[0].bias, flags=self.act_flag)
+        flags = runtime.EP_MASK_OUT if mask is not None else 0
+        return runtime.gemm(hidden, w2, bias=self.net[3].bias, resid=residual, mask=mask, flags=flags,
+                            out_dtype=torch.float32)

@@ -1,0 +1,147 @@
+"""`TransformerLayer` / `Transformer` (tts/modules/transformer/transformer.py:37-211 of the reference).
+
+Pre-norm layer, as launched here (7 kernels, activations make one HBM round trip between them):
+    h  = LN/AdaLN(x)                                   ispk_layernorm
+    qkv = h · [Wq;Wkv]ᵀ                                ispk_gemm
+    o  = ALiBi-MQA(qkv)                                ispk_alibi_mqa_attn
+    x1 = x + mask * (o · Woᵀ)                          ispk_gemm, epilogue MASK_ACC + residual   (transformer.py:91)
+    h2 = mask * LN/AdaLN(x1)                           ispk_layernorm with row mask             (:97-102)
+    f  = gelu(h2 · W1ᵀ)                                ispk_gemm, epilogue GELU
+    y  = mask * (x1 + f · W2ᵀ)                         ispk_gemm, epilogue residual + MASK_OUT   (:105-110)
+The residual stream (x, x1, y) is always fp32; with compute_dtype = bf16 the GEMM/attention operands are bf16.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import NamedTuple, Optional, Union
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ... import runtime
+from ..constructor import Constructor, ModuleConfig
+from .attend import AttentionIntermediates
+from .attention import Attention, AttentionConfig, AttentionSharedIntermediates
+from .feedforward import FeedForward, FeedForwardConfig
+from .normalization import AdaptiveLayerNorm, LayerNorm
+
+
+class TransformerLayerIntermediates(NamedTuple):
+    attention: Optional[AttentionIntermediates] = None
+
+
+class TransformerLayerOutput(NamedTuple):
+    out: Tensor
+    intermediates: Optional[TransformerLayerIntermediates] = None
+    shared_intermediates: Optional[AttentionSharedIntermediates] = None
+
+
+@dataclass
+class TransformerLayerConfig(ModuleConfig):
+    dim: int = 384
+    attention: Union[AttentionConfig, dict] = field(default_factory=AttentionConfig)
+    feed_forward: Union[FeedForwardConfig, dict] = field(default_factory=FeedForwardConfig)
+    pre_norm: bool = True
+    adaptive_norm: bool = False
+    condition_dim: Optional[int] = None
+
+
+class TransformerLayer(nn.Module, Constructor):
+    def __init__(self, dim: int = 384, attention=None, feed_forward=None, pre_norm: bool = True,
+                 adaptive_norm: bool = False, condition_dim: Optional[int] = None):
+        super().__init__()
+        if not pre_norm:
+            raise NotImplementedError("post-norm layers are unused by the recipes and not built")
+        assert not adaptive_norm or condition_dim is not None
+        self.pre_norm, self.adaptive_norm = pre_norm, adaptive_norm
+        norm = (lambda: AdaptiveLayerNorm(dim, condition_dim=condition_dim)) if adaptive_norm else (lambda: LayerNorm(dim))
+        self.attention_norm = norm()
+        self.attention = Attention.init(attention if attention is not None else AttentionConfig(), dim=dim)
+        self.feed_forward_norm = norm()
+        self.feed_forward = FeedForward.init(feed_forward if feed_forward is not None else FeedForwardConfig(), dim=dim)
+
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
+                context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
+                adaptive_condition: Optional[Tensor] = None, cache: Optional[TransformerLayerIntermediates] = None,
+                shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None):
+        assert not self.adaptive_norm or adaptive_condition is not None, \
+            "`adaptive_condition` should be provided for AdaptiveLayerNorm"
+        if cache is not None:
+            raise NotImplementedError("KV caches are not on the acoustic-model forward path")
+        x = x.float().contiguous()
+        cdt = self.attention.compute_dtype
+        if mask is not None and key_len is None:
+            key_len = mask.sum(dim=1)
+        h = self.attention_norm(x, adaptive_condition, out_dtype=cdt)
+        x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
+                                           attention_mask=attention_mask, key_len=key_len, residual=x)
+        h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt)
+        y = self.feed_forward(h2, residual=x1, mask=mask)
+        return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
+                                      shared_intermediates=shared)
+
+
+class TransformerOutput(NamedTuple):
+    out: Tensor
+    intermediates: Optional[list] = None
+
+
+@dataclass
+class TransformerConfig(ModuleConfig):
+    dim: int = 384
+    depth: int = 6
+    transformer_layer: Union[TransformerLayerConfig, dict] = field(default_factory=TransformerLayerConfig)
+    emb_dim: Optional[int] = None
+    use_abs_pos_emb: bool = True
+    adaptive_norm: bool = False
+    condition_dim: Optional[int] = None
+
+
+class Transformer(nn.Module, Constructor):
+    def __init__(self, dim: int = 384, depth: int = 6, transformer_layer=None, emb_dim: Optional[int] = None,
+                 use_abs_pos_emb: bool = True, adaptive_norm: bool = False, condition_dim: Optional[int] = None):
+        super().__init__()
+        self.dim = dim
+        self.emb_dim = emb_dim = emb_dim or dim
+        self.adaptive_norm = adaptive_norm
+        layer_cfg = transformer_layer if transformer_layer is not None else TransformerLayerConfig()
+        self.layers = nn.ModuleList([
+            TransformerLayer.init(layer_cfg, dim=dim, adaptive_norm=adaptive_norm, condition_dim=condition_dim)
+            for _ in range(depth)])
+        if use_abs_pos_emb and self.layers[0].attention.rel_pos is None:
+            raise NotImplementedError("absolute sinusoidal position embeddings (no ALiBi) are unused by the recipes")
+        self.pos_emb = None
+        self.project_emb = nn.Linear(emb_dim, dim) if emb_dim != dim else nn.Identity()  # transformer.py:170
+        self.norm = nn.LayerNorm(dim)                                                      # transformer.py:172
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        for layer in self.layers:
+            layer.attention.compute_dtype = dtype
+            layer.feed_forward.compute_dtype = dtype
+        return self
+
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
+                context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
+                adaptive_condition: Optional[Tensor] = None, return_intermediates: bool = False, *,
+                key_len: Optional[Tensor] = None, projected: Optional[Tensor] = None):
+        """`projected` lets a caller that already holds project_emb(x) (e.g. the Euler loop, which re-projects only the
+        3 flow channels per step) skip the projection."""
+        if projected is not None:
+            out = projected
+        elif isinstance(self.project_emb, nn.Identity):
+            out = x.float()
+        else:
+            out = runtime.linear(x.float().contiguous(), self.project_emb.weight, self.project_emb.bias)
+        if mask is not None and key_len is None:
+            key_len = mask.sum(dim=1)
+        intermediates = []
+        for layer in self.layers:
+            res = layer(out, mask=mask, context=context, context_mask=context_mask, attention_mask=attention_mask,
+                        adaptive_condition=adaptive_condition, key_len=key_len)
+            out = res.out
+            if return_intermediates:
+                intermediates.append(res.intermediates)
+        out = runtime.layernorm(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps)
+        return TransformerOutput(out=out, intermediates=intermediates)

@@ -1,0 +1,256 @@
+"""ctypes binding of libispk.so (the C ABI declared in include/ispk.h) and thin tensor-level wrappers.
+
+PyTorch here is plumbing only: it owns device memory and the stream.  Every wrapper passes raw
+`data_ptr()`s and the CURRENT torch stream to the library, so launches are ordered with torch ops and are
+capturable in a HIP graph.  There is no CPU fallback anywhere: a missing library or a non-GPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libispk.so")
+
+EP_GELU, EP_SILU, EP_MASK_ACC, EP_MASK_OUT, EP_BIAS_ROW, EP_MASK_COL, EP_OUT_BF16, EP_RESID_BF16 = (
+    1, 2, 4, 8, 16, 32, 64, 128)
+
+_P, _I32, _I64, _U32, _F32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
+
+# name -> argtypes; must list EVERY symbol of include/ispk.h (tests/test_abi.py checks header == this table == .so)
+SIGNATURES = {
+    "ispk_abi_version": [],
+    "ispk_last_error_string": [],
+    "ispk_device_info": [ctypes.c_char_p, _I32],
+    "ispk_mas_f32": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I64, _P],
+    "ispk_layernorm_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _F32, _P],
+    "ispk_layernorm_f32_bf16": [_P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _F32, _P],
+    "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
+    "ispk_gemm_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
+    "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
+    "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
+    "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
+    "ispk_cast_f32_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
+}
+
+_lib = None
+
+
+class IspkError(RuntimeError):
+    pass
+
+
+def lib() -> ctypes.CDLL:
+    """Loads libispk.so.  Fails loudly when it has not been built (`python -m isp_tts_amd.build`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IspkError(f"{LIB_PATH} is missing: the HIP extension was not built "
+                            f"(run `python -m isp_tts_amd.build` or `__graft_entry__.build()`); there is no CPU fallback")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes = argtypes
+            fn.restype = ctypes.c_char_p if name == "ispk_last_error_string" else ctypes.c_int32
+        if handle.ispk_abi_version() != 1:
+            raise IspkError(f"libispk.so ABI version {handle.ispk_abi_version()} != 1")
+        _lib = handle
+    return _lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ispk_last_error_string()
+        raise IspkError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")
+
+
+def _dev(*tensors: Optional[Tensor]) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise IspkError("isp_tts_amd kernels need GPU tensors (got a CPU tensor); there is no CPU fallback")
+
+
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def device_info() -> tuple[str, int]:
+    buf = ctypes.create_string_buffer(256)
+    n = lib().ispk_device_info(buf, 256)
+    if n <= 0:
+        _check(n if n != 0 else -1, "ispk_device_info")
+    return buf.value.decode(), n
+
+
+def _rows2d(t: Tensor) -> Tensor:
+    """[..., D] -> [rows, D] view with unit inner stride (copies only when the layout requires it)."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    return t.reshape(-1, t.shape[-1])
+
+
+# ------------------------------------------------------------------------------------------------- MAS
+def mas(logits: Tensor, text_len: Tensor, mel_len: Tensor, want_dur: bool = True, want_path: bool = False):
+    """ispk_mas_f32.  logits fp32 [B,M,L] (unit stride on L), lengths int64 [B] on the same device.
+    Returns (attn_hard int16 [B,M,L], dur int64 [B,L] | None, path int16 [B,M] | None)."""
+    _dev(logits, text_len, mel_len)
+    assert logits.dtype == torch.float32 and logits.ndim == 3
+    if logits.stride(2) != 1:
+        logits = logits.contiguous()
+    B, M, L = logits.shape
+    text_len = text_len.to(torch.int64).contiguous()
+    mel_len = mel_len.to(torch.int64).contiguous()
+    hard = torch.empty((B, M, L), dtype=torch.int16, device=logits.device)
+    dur = torch.empty((B, L), dtype=torch.int64, device=logits.device) if want_dur else None
+    path = torch.empty((B, M), dtype=torch.int16, device=logits.device) if want_path else None
+    _check(lib().ispk_mas_f32(logits.data_ptr(), text_len.data_ptr(), mel_len.data_ptr(), hard.data_ptr(), _ptr(dur),
+                              _ptr(path), B, M, L, logits.stride(0), logits.stride(1), _stream()), "ispk_mas_f32")
+    return hard, dur, path
+
+
+# ------------------------------------------------------------------------------------------------- LayerNorm
+def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ada_scale: Optional[Tensor] = None,
+              ada_shift: Optional[Tensor] = None, rows_per_batch: int = 1, row_mask: Optional[Tensor] = None,
+              eps: float = 1e-5, out_dtype: torch.dtype = torch.float32) -> Tensor:
+    """ispk_layernorm_f32[_bf16].  x fp32 [..., D]; ada_* [Bc, D] with Bc == batch or 1 (broadcast)."""
+    _dev(x, gamma, beta, ada_scale, ada_shift, row_mask)
+    assert x.dtype == torch.float32
+    x2 = _rows2d(x)
+    rows, D = x2.shape
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    ada_stride = 0
+    if ada_scale is not None:
+        ada_scale = ada_scale.reshape(-1, D).contiguous()
+        ada_shift = ada_shift.reshape(-1, D).contiguous() if ada_shift is not None else None
+        ada_stride = D if ada_scale.shape[0] > 1 else 0
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).contiguous()
+        assert row_mask.dtype == torch.bool and row_mask.numel() == rows
+    fn = lib().ispk_layernorm_f32 if out_dtype == torch.float32 else lib().ispk_layernorm_f32_bf16
+    _check(fn(x2.data_ptr(), x2.stride(0), _ptr(gamma), _ptr(beta), _ptr(ada_scale), _ptr(ada_shift), ada_stride,
+              rows_per_batch, _ptr(row_mask), y.data_ptr(), D, rows, D, eps, _stream()), "ispk_layernorm")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------- GEMM
+def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
+         mask: Optional[Tensor] = None, flags: int = 0, out: Optional[Tensor] = None,
+         out_dtype: Optional[torch.dtype] = None) -> Tensor:
+    """C[..., N] = epilogue(a[..., K] @ w[N, K]^T)  (ispk_gemm_f32 / ispk_gemm_bf16 by a.dtype)."""
+    _dev(a, w, bias, resid, mask, out)
+    a2 = _rows2d(a)
+    M, K = a2.shape
+    N = w.shape[0]
+    assert w.shape[1] == K and w.stride(1) == 1 and a.dtype == w.dtype
+    bf16 = a.dtype == torch.bfloat16
+    if out_dtype is None:
+        out_dtype = torch.float32 if not bf16 else torch.bfloat16
+    if out is None:
+        out = torch.empty((*a.shape[:-1], N), dtype=out_dtype, device=a.device)
+    c2 = out.view(-1, N)
+    r2 = None
+    if resid is not None:
+        r2 = _rows2d(resid)
+        assert r2.shape == (M, N)
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+        assert mask.dtype == torch.bool
+    if bf16:
+        if out.dtype == torch.bfloat16:
+            flags |= EP_OUT_BF16
+        if r2 is not None and r2.dtype == torch.bfloat16:
+            flags |= EP_RESID_BF16
+        fn = lib().ispk_gemm_bf16
+    else:
+        assert out.dtype == torch.float32 and (r2 is None or r2.dtype == torch.float32)
+        fn = lib().ispk_gemm_f32
+    _check(fn(a2.data_ptr(), a2.stride(0), w.data_ptr(), w.stride(0), c2.data_ptr(), c2.stride(0), _ptr(bias), _ptr(r2),
+              r2.stride(0) if r2 is not None else 0, _ptr(mask), M, N, K, flags, 0, 0, _stream()), "ispk_gemm")
+    return out
+
+
+def to_mel(dec: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """mel[B, C, T] = mask[b,t] * (dec[B,T,D] @ weight[C,D]^T + bias[C])  — Linear + transpose + mask of
+    model.py:167-168 as ONE GEMM with swapped operands: lanes run along the mel-frame axis T, so the transposed
+    output is written with coalesced 128-B segments."""
+    _dev(dec, weight, bias, mask)
+    B, T, D = dec.shape
+    C = weight.shape[0]
+    x2 = _rows2d(dec)
+    out = torch.empty((B, C, T), dtype=torch.float32, device=dec.device)
+    flags = EP_BIAS_ROW | EP_MASK_COL
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+        flags |= EP_MASK_OUT
+    fn = lib().ispk_gemm_bf16 if dec.dtype == torch.bfloat16 else lib().ispk_gemm_f32
+    _check(fn(weight.data_ptr(), weight.stride(0), x2.data_ptr(), x2.stride(0), out.data_ptr(), T, _ptr(bias), None, 0,
+              _ptr(mask), C, B * T, D, flags, T, C * T, _stream()), "ispk_gemm(to_mel)")
+    return out
+
+
+def linear_small(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
+                 act: int = 0) -> Tensor:
+    """ispk_linear_small_f32: any K / N, fp32.  `w` may be a column slice of a wider weight (stride kept)."""
+    _dev(a, w, bias, resid)
+    assert a.dtype == torch.float32 and w.dtype == torch.float32 and w.stride(1) == 1
+    a2 = _rows2d(a)
+    M, K = a2.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    out = torch.empty((*a.shape[:-1], N), dtype=torch.float32, device=a.device)
+    r2 = _rows2d(resid) if resid is not None else None
+    _check(lib().ispk_linear_small_f32(a2.data_ptr(), a2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias), _ptr(r2),
+                                       r2.stride(0) if r2 is not None else 0, out.data_ptr(), N, M, N, K, act,
+                                       _stream()), "ispk_linear_small_f32")
+    return out
+
+
+def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = 0) -> Tensor:
+    """nn.Linear on the device: MFMA GEMM when the shape allows (K % 8 == 0, enough rows), else the small kernel."""
+    K = w.shape[1]
+    rows = a.numel() // K
+    if a.dtype == torch.float32 and (K % 8 != 0 or rows * w.shape[0] < 64 * 64 or w.stride(0) % 4 != 0
+                                     or w.data_ptr() % 16 != 0):
+        return linear_small(a, w, bias, None, act)
+    return gemm(a, w, bias=bias, flags=act)
+
+
+# ------------------------------------------------------------------------------------------------- attention
+def alibi_mqa_attention_raw(q: Tensor, ldq: int, k: Tensor, v: Tensor, ldkv: int, slopes: Tensor,
+                            key_len: Optional[Tensor], B: int, N: int, heads: int) -> Tensor:
+    """ispk_alibi_mqa_attn_*: q is any tensor whose storage holds [B][N][H*64] rows at leading stride ldq starting at
+    q.data_ptr(); k / v likewise [B][N][64] at stride ldkv.  Returns the merged heads [B, N, H*64]."""
+    _dev(q, k, v, slopes, key_len)
+    out = torch.empty((B, N, heads * 64), dtype=q.dtype, device=q.device)
+    if key_len is not None:
+        key_len = key_len.to(torch.int64).contiguous()
+    slopes = slopes.to(torch.float32).contiguous()
+    fn = lib().ispk_alibi_mqa_attn_f32 if q.dtype == torch.float32 else lib().ispk_alibi_mqa_attn_bf16
+    _check(fn(q.data_ptr(), ldq, k.data_ptr(), v.data_ptr(), ldkv, slopes.data_ptr(), _ptr(key_len), out.data_ptr(),
+              heads * 64, B, N, heads, _stream()), "ispk_alibi_mqa_attn")
+    return out
+
+
+def alibi_mqa_attention(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor]) -> Tensor:
+    """qkv [B, N, H*64 + 128] = [Q | K | V] (the fused to_q / to_kv projection) -> merged heads [B, N, H*64]."""
+    B, N, W = qkv.shape
+    assert W == heads * 64 + 128 and qkv.is_contiguous()
+    return alibi_mqa_attention_raw(qkv, W, qkv[..., heads * 64:], qkv[..., heads * 64 + 64:], W, slopes, key_len, B, N,
+                                   heads)
+
+
+def cast_bf16(x: Tensor) -> Tensor:
+    _dev(x)
+    x2 = _rows2d(x)
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    _check(lib().ispk_cast_f32_bf16(x2.data_ptr(), x2.stride(0), y.data_ptr(), x2.shape[1], x2.shape[0], x2.shape[1],
+                                    _stream()), "ispk_cast_f32_bf16")
+    return y

@@ -129,8 +129,9 @@ def make_state_dict(dims: AcousticDims = AcousticDims(), seed: int = SEED) -> di
         elif kind == "ada_w":
             t = _normal(name, shape, 0.1 / math.sqrt(shape[1]), seed=seed)
         elif kind == "logslopes":
-            base = torch.tensor(alibi_default_slopes(shape[0])).log().view(shape)
-            t = base + _normal(name, shape, 0.1, seed=seed)
+            # float64 libm then one rounding: identical on every host (fp32 vector log is not)
+            base = torch.tensor([math.log(v) for v in alibi_default_slopes(shape[0])], dtype=torch.float64)
+            t = (base.view(shape) + _normal(name, shape, 0.1, seed=seed).double()).float()
         else:
             raise KeyError(kind)
         sd[name] = t.contiguous()
@@ -164,7 +165,8 @@ def make_inputs(batch: int, text_max: int = 100, mel_max: int = 512, variable: b
     mel = torch.from_numpy((g.standard_normal((batch, dims.mel_dim, mel_max)) * 2.0 - 5.0).astype(np.float32))
     mel = mel.clamp_(min=math.log(1e-5))
     pitch = torch.from_numpy(g.standard_normal((batch, mel_max)).astype(np.float32))
-    energy = torch.log1p(torch.from_numpy(np.abs(g.standard_normal((batch, mel_max))).astype(np.float32)) * 5.0)
+    # float64 log1p rounded once to fp32 (host-independent, unlike torch's vectorised fp32 log1p)
+    energy = torch.from_numpy(np.log1p(np.abs(g.standard_normal((batch, mel_max))) * 5.0).astype(np.float32))
     tmask = torch.arange(text_max)[None] < text_len[:, None]
     mmask = torch.arange(mel_max)[None] < mel_len[:, None]
     text = text * tmask
@@ -180,17 +182,19 @@ def make_inputs(batch: int, text_max: int = 100, mel_max: int = 512, variable: b
 
 def make_mas_logits(batch: int, mel_max: int, text_max: int, variable: bool = False, kind: str = "realistic",
                     seed: int = SEED):
-    """Aligner-like MAS inputs: log_softmax(N(0,1)) + log(diagonal prior + 1e-6), or integer-valued
-    logits ("ties") that force the tie-breaking rule (ties -> diagonal, mas.py:17 of the reference)."""
+    """Aligner-like MAS inputs, built from IEEE-exact operations only (+, -, *, /, max) so that every host produces
+    the same bits: "realistic" = N(0,1) noise plus the log of the reference's diagonal prior
+    (-(t/T - m/M)^2 / (2 * 0.1^2), floored at log(1e-6) like `log(prior + 1e-6)`, alignment.py:196; per-row
+    normalisation constants are dropped because MAS is invariant to them); "ties" = small integers, which force the
+    tie-breaking rule (ties -> diagonal, mas.py:17 of the reference)."""
     g = _rng(f"mas/{batch}/{mel_max}/{text_max}/{int(variable)}/{kind}", seed)
     text_len, mel_len = make_lengths(batch, text_max, mel_max, variable, seed)
     if kind == "ties":
         x = torch.from_numpy(g.integers(-3, 1, size=(batch, mel_max, text_max)).astype(np.float32))
     else:
         z = torch.from_numpy(g.standard_normal((batch, mel_max, text_max)).astype(np.float32))
-        ti = torch.arange(text_max, dtype=torch.float32)[None, None, :] / text_len[:, None, None]
-        mi = torch.arange(mel_max, dtype=torch.float32)[None, :, None] / mel_len[:, None, None]
-        prior = torch.exp(-(ti - mi) ** 2 / (2 * 0.1 ** 2))
-        prior = prior / (prior.sum(-1, keepdim=True) + 1e-5)
-        x = torch.log_softmax(z, dim=-1) + torch.log(prior + 1e-6)
+        ti = torch.arange(text_max, dtype=torch.float32)[None, None, :] / text_len[:, None, None].float()
+        mi = torch.arange(mel_max, dtype=torch.float32)[None, :, None] / mel_len[:, None, None].float()
+        d = ti - mi
+        x = z + torch.clamp(-(d * d) * 50.0, min=-13.815511)
     return x.contiguous(), text_len, mel_len

@@ -1,0 +1,244 @@
+"""GPU parity of each HIP kernel against the oracle (oracle/), called through the C ABI (runtime -> libispk.so)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import crc, golden
+
+pytestmark = pytest.mark.gpu
+
+from isp_tts_amd import runtime, synth  # noqa: E402
+from oracle import acoustic_oracle as orc  # noqa: E402
+from oracle import mas_oracle  # noqa: E402
+
+DEV = "cuda"
+
+
+def _mas_gpu(x, tl, ml):
+    hard, dur, path = runtime.mas(x.to(DEV), tl.to(DEV), ml.to(DEV), want_dur=True, want_path=True)
+    torch.cuda.synchronize()
+    return hard.cpu().numpy(), dur.cpu().numpy(), path.cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------ MAS
+def test_mas_golden_vectors():
+    g = golden("mas.npz")
+    n_cases = sum(1 for k in g.files if k.endswith("_shape"))
+    assert n_cases >= 6
+    for i in range(n_cases):
+        B, M, L, var = (int(v) for v in g[f"case{i}_shape"])
+        kind = str(g[f"case{i}_kind"])
+        x, tl, ml = synth.make_mas_logits(B, M, L, bool(var), kind)
+        assert crc(x) == int(g[f"case{i}_logits_crc"]), "synthetic generator drifted from the fixtures"
+        hard, dur, path = _mas_gpu(x, tl, ml)
+        assert np.array_equal(path, g[f"case{i}_path"]), f"case {i}: MAS path differs from the reference"
+        assert np.array_equal(dur, g[f"case{i}_dur"].astype(np.int64))
+        ref_hard = np.zeros((B, M, L), np.int16)
+        bi, mi = np.nonzero(g[f"case{i}_path"] >= 0)
+        ref_hard[bi, mi, g[f"case{i}_path"][bi, mi]] = 1
+        assert np.array_equal(hard, ref_hard)
+
+
+@pytest.mark.parametrize("B,M,L,var,kind", [
+    (1, 1, 1, False, "realistic"), (3, 7, 1, False, "ties"), (2, 1, 9, False, "realistic"),   # degenerate shapes
+    (5, 33, 64, True, "ties"), (5, 130, 65, True, "realistic"), (7, 257, 129, True, "ties"),  # chunk boundaries
+    (4, 700, 300, True, "realistic"), (2, 1723, 300, True, "realistic"),                      # recipe maxima
+    (3, 90, 400, True, "realistic"), (2, 64, 512, False, "ties"),                             # n < m, max L
+    (64, 512, 100, False, "realistic"), (37, 512, 100, True, "realistic"),
+])
+def test_mas_matches_oracle(B, M, L, var, kind):
+    x, tl, ml = synth.make_mas_logits(B, M, L, var, kind)
+    hard, dur, path = _mas_gpu(x, tl, ml)
+    ref, ref_path = mas_oracle.b_mas(x.numpy(), tl.numpy(), ml.numpy(), return_path=True)
+    assert np.array_equal(path, ref_path)
+    assert np.array_equal(hard, ref)
+    assert np.array_equal(dur, ref.sum(axis=1))
+
+
+def test_mas_properties_full_size():
+    """BASELINE size (B=64, M=512, L=100) with strided input: structural invariants of any MAS result."""
+    B, M, L = 64, 512, 100
+    x, tl, ml = synth.make_mas_logits(B, M, L, True, "realistic")
+    big = torch.zeros(B, M, L + 28)
+    big[..., :L] = x
+    view = big.to(DEV)[..., :L]              # row stride 128, not contiguous
+    assert view.stride(1) == L + 28
+    hard, dur, path = runtime.mas(view, tl.to(DEV), ml.to(DEV), want_dur=True, want_path=True)
+    hard, dur, path = hard.cpu().numpy(), dur.cpu().numpy(), path.cpu().numpy()
+    for b in range(B):
+        n, m = int(ml[b]), int(tl[b])
+        p = path[b, :n]
+        assert p[-1] == m - 1 and (path[b, n:] == -1).all()
+        d = np.diff(p)
+        assert ((d == 0) | (d == 1)).all(), "path must be monotone with unit steps"
+        if n >= m:
+            assert p[0] == 0
+        assert hard[b].sum() == n and (hard[b, :n].sum(axis=1) == 1).all()
+        assert hard[b, n:].sum() == 0 and hard[b, :, m:].sum() == 0
+        assert dur[b].sum() == n
+    ref = mas_oracle.b_mas(x.numpy(), tl.numpy(), ml.numpy())
+    assert np.array_equal(hard, ref)
+
+
+def test_mas_does_not_mutate_input_and_b_mas_signature():
+    from isp_tts_amd.modules.aligner import b_mas
+    x, tl, ml = synth.make_mas_logits(4, 96, 23, True, "realistic")
+    xin = x.numpy().copy()
+    out = b_mas(xin, tl.numpy(), ml.numpy())
+    assert out.dtype == np.int16 and out.shape == xin.shape
+    assert np.array_equal(xin, x.numpy())
+    assert np.array_equal(out, mas_oracle.b_mas(x.numpy(), tl.numpy(), ml.numpy()))
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("D", [64, 256, 384, 1024])
+def test_layernorm_plain_adaptive_mask(D):
+    B, N = 3, 41
+    x = synth._normal(f"t/ln/x{D}", (B, N, D), 2.0, 0.5)
+    g, b = synth._normal("t/ln/g", (D,), 0.1, 1.0), synth._normal("t/ln/b", (D,), 0.1)
+    mask = torch.arange(N)[None] < torch.tensor([N, 17, 1])[:, None]
+    ref = F.layer_norm(x.double(), (D,), g.double(), b.double(), 1e-5)
+    out = runtime.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
+    assert (out.cpu().double() - ref).abs().max() < 2e-6
+    out = runtime.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), row_mask=mask.to(DEV))
+    assert (out.cpu().double() - ref * mask[..., None]).abs().max() < 2e-6
+    # adaptive: per-batch and broadcast conditions
+    sc, sh = synth._normal("t/ln/sc", (B, D), 0.3, 1.0), synth._normal("t/ln/sh", (B, D), 0.3)
+    nref = F.layer_norm(x.double(), (D,), None, None, 1e-5)
+    out = runtime.layernorm(x.to(DEV), None, None, sc.to(DEV), sh.to(DEV), rows_per_batch=N, row_mask=mask.to(DEV))
+    want = (sc.double()[:, None] * nref + sh.double()[:, None]) * mask[..., None]
+    assert (out.cpu().double() - want).abs().max() < 3e-6
+    out = runtime.layernorm(x.to(DEV), None, None, sc[:1].to(DEV), sh[:1].to(DEV), rows_per_batch=N)
+    want = sc.double()[:1, None] * nref + sh.double()[:1, None]
+    assert (out.cpu().double() - want).abs().max() < 3e-6
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+def _gemm_ref(a, w, bias=None, act=None, resid=None, mask=None, mask_acc=False, mask_out=False):
+    v = a.double() @ w.double().T
+    if bias is not None:
+        v = v + bias.double()
+    if act == "gelu":
+        v = F.gelu(v)
+    if act == "silu":
+        v = F.silu(v)
+    if mask_acc:
+        v = v * mask[..., None]
+    if resid is not None:
+        v = v + resid.double()
+    if mask_out:
+        v = v * mask[..., None]
+    return v
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (32768, 512, 384), (300, 1536, 384), (777, 384, 1536),
+                                   (64, 64, 8), (200, 384, 256), (130, 80, 384), (5, 3, 24)])
+def test_gemm_f32_shapes(M, N, K):
+    a = synth._normal(f"t/gemm/a{M}x{K}", (M, K))
+    w = synth._normal(f"t/gemm/w{N}x{K}", (N, K), K ** -0.5)
+    out = runtime.gemm(a.to(DEV), w.to(DEV)).cpu()
+    ref = _gemm_ref(a, w)
+    assert (out.double() - ref).abs().max() < 2e-5
+
+
+def test_gemm_f32_epilogues():
+    B, T, K, N = 3, 210, 384, 384
+    a = synth._normal("t/gemm/ea", (B, T, K))
+    w = synth._normal("t/gemm/ew", (N, K), K ** -0.5)
+    bias = synth._normal("t/gemm/eb", (N,))
+    resid = synth._normal("t/gemm/er", (B, T, N))
+    mask = torch.arange(T)[None] < torch.tensor([T, 100, 1])[:, None]
+    d = lambda t: t.to(DEV)  # noqa: E731
+    cases = [
+        (dict(bias=d(bias)), dict(bias=bias)),
+        (dict(bias=d(bias), flags=runtime.EP_GELU), dict(bias=bias, act="gelu")),
+        (dict(flags=runtime.EP_SILU), dict(act="silu")),
+        (dict(resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_ACC), dict(resid=resid, mask=mask, mask_acc=True)),
+        (dict(resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT), dict(resid=resid, mask=mask, mask_out=True)),
+        (dict(resid=d(resid)), dict(resid=resid)),
+    ]
+    for kw, rkw in cases:
+        out = runtime.gemm(d(a), d(w), **kw).cpu()
+        assert (out.double() - _gemm_ref(a, w, **rkw)).abs().max() < 2e-5, kw.keys()
+
+
+def test_gemm_strided_operands():
+    """A may be a column slice of a wider buffer (leading stride > K), like the K/V halves of the fused projection."""
+    a_full = synth._normal("t/gemm/sa", (500, 512))
+    w = synth._normal("t/gemm/sw", (384, 384), 384 ** -0.5)
+    ad = a_full.to(DEV)
+    out = runtime.gemm(ad[:, 128:], w.to(DEV)).cpu()
+    assert (out.double() - _gemm_ref(a_full[:, 128:], w)).abs().max() < 2e-5
+
+
+def test_to_mel_transposed_masked_store():
+    B, T, D, C = 3, 203, 384, 80
+    x = synth._normal("t/mel/x", (B, T, D))
+    w, b = synth._normal("t/mel/w", (C, D), D ** -0.5), synth._normal("t/mel/b", (C,))
+    mask = torch.arange(T)[None] < torch.tensor([T, 77, 5])[:, None]
+    ref = (x.double() @ w.double().T + b.double()).transpose(1, 2) * mask[:, None]
+    out = runtime.to_mel(x.to(DEV), w.to(DEV), b.to(DEV), mask.to(DEV)).cpu()
+    assert out.shape == (B, C, T) and (out.double() - ref).abs().max() < 2e-5
+    out = runtime.to_mel(x.to(DEV), w.to(DEV), b.to(DEV), None).cpu()
+    assert (out.double() - (x.double() @ w.double().T + b.double()).transpose(1, 2)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(7, 32, 65), (200, 256, 3), (200, 3, 256), (1, 256, 32), (200, 256, 2)])
+def test_linear_small(M, N, K):
+    a, w = synth._normal("t/ls/a", (M, K)), synth._normal("t/ls/w", (N, K))
+    bias, resid = synth._normal("t/ls/b", (N,)), synth._normal("t/ls/r", (M, N))
+    out = runtime.linear_small(a.to(DEV), w.to(DEV), bias.to(DEV), resid.to(DEV), act=runtime.EP_SILU).cpu()
+    ref = F.silu(a.double() @ w.double().T + bias.double()) + resid.double()
+    assert (out.double() - ref).abs().max() < 1e-5
+    wide = synth._normal("t/ls/wide", (N, K + 5))
+    out = runtime.linear_small(a.to(DEV), wide.to(DEV)[:, :K]).cpu()      # column slice of a wider weight
+    assert (out.double() - a.double() @ wide[:, :K].double().T).abs().max() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize("B,N,H,lens", [(2, 100, 6, [100, 73]), (2, 512, 6, [512, 390]), (3, 37, 4, [37, 1, 20]),
+                                        (2, 64, 6, None), (1, 129, 8, [65]), (2, 1000, 6, [1000, 333])])
+def test_attention_matches_reference_algorithm(B, N, H, lens):
+    """Kernel vs the oracle's `attend` (materialised bias + masked_fill(min/2) + SDPA, attend.py:49-122)."""
+    q = synth._normal(f"t/at/q{N}", (B, N, H * 64))
+    kv = synth._normal(f"t/at/kv{N}", (B, N, 128))
+    slopes = torch.tensor(synth.alibi_default_slopes(H)) * 1.1
+    mask = None if lens is None else torch.arange(N)[None] < torch.tensor(lens)[:, None]
+    bias = slopes.view(H, 1, 1) * orc.alibi_int_bias(N, N).float()
+    ref = orc.attend(q.view(B, N, H, 64).transpose(1, 2), kv[..., :64], kv[..., 64:],
+                     None if mask is None else mask[:, None, None, :], bias)
+    ref = ref.transpose(1, 2).reshape(B, N, H * 64)
+    qkv = torch.cat([q, kv], dim=-1).to(DEV)
+    key_len = None if lens is None else torch.tensor(lens, device=DEV)
+    out = runtime.alibi_mqa_attention(qkv, H, slopes.to(DEV), key_len).cpu()
+    assert (out - ref).abs().max() < 2e-5
+
+
+def test_attention_online_softmax_rescale_is_exercised():
+    """A key far down the sequence with a huge score forces the running max to jump in a late tile."""
+    B, N, H = 1, 256, 6
+    q = synth._normal("t/at/spike_q", (B, N, H * 64))
+    kv = synth._normal("t/at/spike_kv", (B, N, 128))
+    kv[0, 200, :64] = q[0, 10, :64] * 4.0          # key 200 aligns with query 10 / head 0
+    slopes = torch.full((H,), 0.01)
+    bias = slopes.view(H, 1, 1) * orc.alibi_int_bias(N, N).float()
+    ref = orc.attend(q.view(B, N, H, 64).transpose(1, 2), kv[..., :64], kv[..., 64:], None, bias)
+    ref = ref.transpose(1, 2).reshape(B, N, H * 64)
+    out = runtime.alibi_mqa_attention(torch.cat([q, kv], -1).to(DEV), H, slopes.to(DEV), None).cpu()
+    assert (out - ref).abs().max() < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ ABI errors
+def test_abi_argument_errors_are_reported():
+    lib = runtime.lib()
+    x = torch.zeros(8, 100, device=DEV)
+    with pytest.raises(runtime.IspkError, match="multiple of 64"):
+        runtime.layernorm(x, None, None)
+    with pytest.raises(runtime.IspkError, match="multiple of 8"):
+        runtime.gemm(torch.zeros(8, 100, device=DEV), torch.zeros(16, 100, device=DEV))
+    with pytest.raises(runtime.IspkError, match="GPU tensors"):
+        runtime.gemm(torch.zeros(8, 64), torch.zeros(16, 64))
+    assert lib.ispk_mas_f32(None, None, None, None, None, None, 1, 1, 1, 1, 1, None) == -1
+    name, cus = runtime.device_info()
+    assert "gfx950" in name and cus >= 128

@@ -1,0 +1,147 @@
+"""GPU parity of the module mirror (Attention, FeedForward, TransformerLayer, Transformer, AcousticModel.forward/infer)
+against the golden fixtures generated from the real reference, and against the oracle on other seeded inputs.
+
+Tolerances: BASELINE.json's bar is mel L-inf < 1e-4 (fp32); per-op outputs are held to 5e-5."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import crc, golden
+
+pytestmark = pytest.mark.gpu
+
+from isp_tts_amd import synth  # noqa: E402
+from oracle import acoustic_oracle as orc  # noqa: E402
+
+DEV = "cuda"
+OP_TOL = 5e-5
+MEL_TOL = 1e-4
+
+
+def _maxdiff(a, b):
+    a = a.detach().cpu() if isinstance(a, torch.Tensor) else torch.as_tensor(a)
+    b = b.detach().cpu() if isinstance(b, torch.Tensor) else torch.as_tensor(b)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return (a.double() - b.double()).abs().max().item()
+
+
+@pytest.mark.parametrize("tag,n", [("enc", 100), ("dec", 512)])
+def test_ops_against_reference_goldens(gpu_model, tag, n):
+    g = golden("ops.npz")
+    step = int(g[f"{tag}_row_step"])
+    lens = torch.tensor(g[f"{tag}_lens"])
+    x = synth._normal(f"golden/op/{tag}/x", (2, n, 384))
+    assert crc(x) == int(g[f"{tag}_x_crc"])
+    mask = (torch.arange(n)[None] < lens[:, None]).to(DEV)
+    xd = x.to(DEV)
+    stack = gpu_model.encoder if tag == "enc" else gpu_model.decoder
+    layer = stack.layers[0]
+    out, inter, shared = layer.attention(xd, mask=mask)
+    assert _maxdiff(out[:, ::step], g[f"{tag}_attention"]) < OP_TOL
+    assert inter.queries.shape == (2, 6, n, 64) and inter.keys.shape == (2, n, 64) and shared.rel_pos_bias is None
+    assert _maxdiff(layer.attention(xd)[0][:, ::step], g[f"{tag}_attention_nomask"]) < OP_TOL
+    assert _maxdiff(layer.feed_forward(xd)[:, ::step], g[f"{tag}_feed_forward"]) < OP_TOL
+    assert _maxdiff(layer(xd, mask=mask).out[:, ::step], g[f"{tag}_layer"]) < OP_TOL
+    assert _maxdiff(stack(xd, mask=mask).out[:, ::step], g[f"{tag}_transformer"]) < OP_TOL
+    assert _maxdiff(stack(xd).out[:, ::step], g[f"{tag}_transformer_nomask"]) < OP_TOL
+
+
+def test_adaptive_norm_stack_against_reference_goldens(gpu_model):
+    g = golden("ops.npz")
+    n, lens = 100, torch.tensor(g["ada_lens"])
+    x = synth._normal("golden/op/ada/x", (2, n, 387))
+    assert crc(x) == int(g["ada_x_crc"])
+    cond = synth._normal("golden/op/ada/cond", (2, 32)).to(DEV)
+    mask = (torch.arange(n)[None] < lens[:, None]).to(DEV)
+    tr = gpu_model.temporal_adaptor.predictor.transformer
+    assert _maxdiff(tr(x.to(DEV), mask=mask, adaptive_condition=cond).out, g["ada_transformer"]) < OP_TOL
+    x256 = synth._normal("golden/op/ada/x256", (2, n, 256)).to(DEV)
+    assert _maxdiff(tr.layers[0](x256, mask=mask, adaptive_condition=cond).out, g["ada_layer"]) < OP_TOL
+    cond3 = synth._normal("golden/op/ada/cond3", (1, 1, 32)).to(DEV)
+    assert _maxdiff(tr(x.to(DEV), mask=mask, adaptive_condition=cond3).out, g["ada_transformer_cond3"]) < OP_TOL
+
+
+def _forward_inputs():
+    inp = synth.make_inputs(2, 100, 512)
+    text_len, mel_len = torch.tensor([100, 73]), torch.tensor([512, 390])
+    tm = torch.arange(100)[None] < text_len[:, None]
+    mm = torch.arange(512)[None] < mel_len[:, None]
+    return dict(text=inp["text"] * tm, text_len=text_len, mel=inp["mel"] * mm[:, None], mel_len=mel_len,
+                pitch=inp["pitch"] * mm, energy=inp["energy"] * mm, flow_noise=inp["flow_x0"], flow_time=inp["flow_t"])
+
+
+def test_forward_against_reference_golden(gpu_model):
+    g = golden("forward.npz")
+    inp = _forward_inputs()
+    assert [crc(inp[k]) for k in ("text", "mel", "pitch", "energy")] == [int(v) for v in g["inputs_crc"]]
+    out = gpu_model(**{k: v.to(DEV) for k, v in inp.items()})
+    torch.cuda.synchronize()
+    assert out.mel.shape == (2, 80, 512)
+    d = _maxdiff(out.mel, g["mel"])
+    print(f"forward mel L-inf vs reference = {d:.3e}")
+    assert d < MEL_TOL
+    assert np.array_equal(out.adaptor_output.dec_lengths.cpu().numpy(), g["dec_lengths"])
+    assert _maxdiff(out.aligner_output.attn_logits, g["attn_logits"]) < 1e-3      # PyTorch-ROCm conv front-end
+    assert _maxdiff(out.aligner_output.attn_soft[:, ::8], g["attn_soft_rows"]) < 1e-4
+    assert _maxdiff(out.adaptor_output.log_duration, g["log_duration"]) < 1e-3
+    assert _maxdiff(out.adaptor_output.pitch, g["pitch"]) < 1e-3
+    assert _maxdiff(out.adaptor_output.pitch_target, g["pitch_target"]) < 1e-4
+    assert abs(float(out.adaptor_output.losses["flow_loss"]) - float(g["flow_loss"])) < 1e-3
+    # MAS on the reference's own pre-MAS logits is bit-exact (the end-to-end path may differ at near-ties because the
+    # front-end logits differ in the last bits, SURVEY 7 "MAS bit-exactness")
+    hard = gpu_model.aligner.binarize_attention_parallel(torch.from_numpy(g["attn_logits"]).to(DEV),
+                                                         inp["text_len"].to(DEV), inp["mel_len"].to(DEV))
+    path = g["path"]
+    ref_hard = np.zeros(hard.shape, np.int16)
+    bi, mi = np.nonzero(path >= 0)
+    ref_hard[bi, mi, path[bi, mi]] = 1
+    assert hard.dtype == torch.int16 and np.array_equal(hard.cpu().numpy(), ref_hard)
+    assert np.array_equal(out.aligner_output.attn_hard_duration.sum(1).cpu().numpy(), g["mel_len"])
+
+
+def test_infer_against_reference_golden(gpu_model):
+    g = golden("infer.npz")
+    inp = synth.make_inputs(2, 100, 512)
+    text_len = torch.tensor(g["b2_text_len"])
+    text = (inp["text"] * (torch.arange(100)[None] < text_len[:, None])).to(DEV)
+    dur = torch.from_numpy(g["b2_dur"]).to(DEV)
+    x_t = inp["flow_x0"].to(DEV)
+    mel, ao = gpu_model.infer(text, text_lengths=text_len.to(DEV), duration_target=dur, steps=4, flow_noise=x_t)
+    assert _maxdiff(mel, g["b2_mel"]) < MEL_TOL
+    assert _maxdiff(ao.pitch, g["b2_pitch"]) < MEL_TOL and _maxdiff(ao.energy, g["b2_energy"]) < MEL_TOL
+    assert np.array_equal(ao.dec_lengths.cpu().numpy(), g["b2_dec_lengths"])
+    # single utterance: no masks anywhere
+    mel1, ao1 = gpu_model.infer(text[:1], duration_target=dur[:1], steps=4, flow_noise=x_t[:1])
+    assert _maxdiff(mel1, g["b1_mel"]) < MEL_TOL
+    # predicted (fractional) durations
+    melp, aop = gpu_model.infer(text, text_lengths=text_len.to(DEV), steps=4, flow_noise=x_t)
+    assert _maxdiff(aop.duration, g["b2p_duration"]) < 1e-3
+    if np.array_equal(aop.dec_lengths.cpu().numpy(), g["b2p_dec_lengths"]):
+        assert _maxdiff(melp, g["b2p_mel"]) < 5e-4   # soft path is continuous in the (fp32-noisy) predicted durations
+
+
+def test_forward_matches_oracle_on_other_inputs(gpu_model, state_dict):
+    """Different seed, B=3 variable lengths (not in the fixtures): HIP path vs the oracle."""
+    inp = synth.make_inputs(3, 60, 200, variable=True, seed=7)
+    args = (inp["text"], inp["text_len"], inp["mel"], inp["mel_len"], inp["pitch"], inp["energy"])
+    ref = orc.acoustic_forward(state_dict, *args, inp["flow_x0"], inp["flow_t"])
+    out = gpu_model(*[a.to(DEV) for a in args], flow_noise=inp["flow_x0"].to(DEV), flow_time=inp["flow_t"].to(DEV))
+    assert _maxdiff(out.mel, ref.mel) < MEL_TOL
+    assert np.array_equal(out.adaptor_output.dec_lengths.cpu().numpy(), ref.adaptor.dec_lengths.numpy())
+
+
+def test_full_size_forward_properties(gpu_model):
+    """BASELINE headline size (B=64, L=100, M=512): padding invariance and batch independence."""
+    inp = synth.make_inputs(64, 100, 512, variable=True)
+    dev = {k: v.to(DEV) for k, v in inp.items()}
+    kw = dict(flow_noise=dev["flow_x0"], flow_time=dev["flow_t"])
+    out = gpu_model(dev["text"], dev["text_len"], dev["mel"], dev["mel_len"], dev["pitch"], dev["energy"], **kw)
+    assert out.mel.shape == (64, 80, 512) and torch.isfinite(out.mel).all()
+    mm = torch.arange(512, device=DEV)[None] < dev["mel_len"][:, None]
+    assert (out.mel * ~mm[:, None]).abs().max() == 0, "padded frames must be exactly zero"
+    assert torch.equal(out.aligner_output.attn_hard_duration.sum(1), dev["mel_len"])
+    # an utterance's mel does not depend on its batch neighbours
+    sub = slice(5, 9)
+    out4 = gpu_model(dev["text"][sub], dev["text_len"][sub], dev["mel"][sub], dev["mel_len"][sub], dev["pitch"][sub],
+                     dev["energy"][sub], flow_noise=dev["flow_x0"][sub], flow_time=dev["flow_t"][sub])
+    assert _maxdiff(out4.mel, out.mel[sub]) < 2e-5

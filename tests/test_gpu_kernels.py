@@ -186,12 +186,12 @@ def test_to_mel_transposed_masked_store():
 
 @pytest.mark.parametrize("M,N,K", [(7, 32, 65), (200, 256, 3), (200, 3, 256), (1, 256, 32), (200, 256, 2)])
 def test_linear_small(M, N, K):
-    a, w = synth._normal("t/ls/a", (M, K)), synth._normal("t/ls/w", (N, K))
+    a, w = synth._normal("t/ls/a", (M, K)), synth._normal("t/ls/w", (N, K), K ** -0.5)
     bias, resid = synth._normal("t/ls/b", (N,)), synth._normal("t/ls/r", (M, N))
     out = runtime.linear_small(a.to(DEV), w.to(DEV), bias.to(DEV), resid.to(DEV), act=runtime.EP_SILU).cpu()
     ref = F.silu(a.double() @ w.double().T + bias.double()) + resid.double()
     assert (out.double() - ref).abs().max() < 1e-5
-    wide = synth._normal("t/ls/wide", (N, K + 5))
+    wide = synth._normal("t/ls/wide", (N, K + 5), K ** -0.5)
     out = runtime.linear_small(a.to(DEV), wide.to(DEV)[:, :K]).cpu()      # column slice of a wider weight
     assert (out.double() - a.double() @ wide[:, :K].double().T).abs().max() < 1e-5
 
@@ -212,7 +212,17 @@ def test_attention_matches_reference_algorithm(B, N, H, lens):
     qkv = torch.cat([q, kv], dim=-1).to(DEV)
     key_len = None if lens is None else torch.tensor(lens, device=DEV)
     out = runtime.alibi_mqa_attention(qkv, H, slopes.to(DEV), key_len).cpu()
-    assert (out - ref).abs().max() < 2e-5
+    # float64 evaluation of the same formula: both fp32 implementations are judged against it.  The ALiBi bias reaches
+    # slope * N (550 at N=1000, where one fp32 ulp is 6e-5), so the achievable agreement scales with N.
+    qd = q.view(B, N, H, 64).transpose(1, 2).double()
+    sc = qd @ kv[..., :64].double().transpose(1, 2)[:, None] / 8.0 + bias.double()[None]
+    if mask is not None:
+        sc = sc.masked_fill(~mask[:, None, None, :], float("-inf"))
+    exact = (sc.softmax(-1) @ kv[..., 64:].double()[:, None]).transpose(1, 2).reshape(B, N, H * 64)
+    err_kernel, err_ref = (out.double() - exact).abs().max().item(), (ref.double() - exact).abs().max().item()
+    tol = 2e-5 * max(1.0, N / 256)
+    assert err_kernel < tol, (err_kernel, err_ref)
+    assert (out - ref).abs().max() < 2 * tol
 
 
 def test_attention_online_softmax_rescale_is_exercised():

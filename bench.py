@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: mel-frames/s of the acoustic-model forward path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the full `AcousticModel.forward` (encoder -> aligner front-end -> MAS -> temporal adaptor with
+one flow-matching evaluation -> decoder -> to_mel) over one batch of synthetic fixed-length utterances that is already
+resident in HBM: BASELINE config 3, B = 64 utterances x 100 phonemes x 512 mel frames PER GPU (weak scaling: each rank
+owns its own utterances — they are independent end to end — and the only exchange is one RCCL all-gather of the mel
+outputs per step, inside the timed region).  Synthetic weights and inputs (isp_tts_amd.synth); no work is skipped.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     the dominant kernel of the timed region (by summed HIP-event time on the launch stream): achieved
+                  algorithmic FLOP/s (or B/s) per launch vs the gfx950 peak; "kernels" lists every timed kernel;
+  "cpu_baseline": the oracle (CPU restatement of the reference algorithm, oracle/) timed on this host's cores on a
+                  bounded sample of the same workload (N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from isp_tts_amd import runtime, synth  # noqa: E402
+from isp_tts_amd.acoustic import AcousticModel  # noqa: E402
+from isp_tts_amd.config import AcousticDims  # noqa: E402
+
+# gfx950 peaks from /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters", dense, no sparsity)
+PEAK = {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3, "mfma_bf16_TFs": 2500.0}
+FLOP_PER_FRAME = 29.0e6  # full forward, SURVEY 8(d) / BASELINE.md section 4
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--text-len", type=int, default=100)
+    ap.add_argument("--mel-len", type=int, default=512)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (no roofline object)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, sd):
+    """Oracle forward (reference algorithm restated on PyTorch-CPU + C MAS) on a bounded sample: cpu_batch utterances
+    of the same shape, 1 warm-up + cpu_iters timed passes, median."""
+    from oracle import acoustic_oracle as orc
+    torch.set_num_threads(os.cpu_count() or 1)
+    inp = synth.make_inputs(args.cpu_batch, args.text_len, args.mel_len)
+    a = (inp["text"], inp["text_len"], inp["mel"], inp["mel_len"], inp["pitch"], inp["energy"], inp["flow_x0"],
+         inp["flow_t"])
+    orc.acoustic_forward(sd, *a)
+    ts = []
+    for _ in range(args.cpu_iters):
+        t0 = time.perf_counter()
+        orc.acoustic_forward(sd, *a)
+        ts.append(time.perf_counter() - t0)
+    med = sorted(ts)[len(ts) // 2]
+    return {"value": args.cpu_batch * args.mel_len / med, "unit": "mel-frames/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"oracle acoustic_forward fp32, B={args.cpu_batch} x L={args.text_len} x M={args.mel_len}, "
+                      f"1 warm-up + {args.cpu_iters} timed, median {med * 1e3:.0f} ms"}
+
+
+def roofline(prof_summary: dict, steps: int, dtype: str):
+    if not prof_summary:
+        return None
+    kernels = {}
+    for label, d in sorted(prof_summary.items(), key=lambda kv: -kv[1]["total_ms"]):
+        per_launch_flops = d["flops"] / d["launches"]
+        per_launch_bytes = d["bytes"] / d["launches"]
+        sec = d["avg_us"] * 1e-6
+        kernels[label] = {"launches_per_step": d["launches"] / steps, "avg_us": round(d["avg_us"], 2),
+                          "ms_per_step": round(d["total_ms"] / steps, 4),
+                          "TFLOPs": round(per_launch_flops / sec / 1e12, 2), "GBs": round(per_launch_bytes / sec / 1e9, 1)}
+    top = next(iter(kernels))
+    k = kernels[top]
+    if k["TFLOPs"] > 0:
+        peak = PEAK["mfma_bf16_TFs"] if "bf16" in top else PEAK["mfma_f32_TFs"]
+        rl = {"kernel": top, "bound": "mfma", "achieved": k["TFLOPs"], "peak": peak, "unit": "TFLOP/s",
+              "frac": round(k["TFLOPs"] / peak, 4), "traffic": None}
+    else:
+        rl = {"kernel": top, "bound": "hbm", "achieved": k["GBs"], "peak": PEAK["hbm_GBs"], "unit": "GB/s",
+              "frac": round(k["GBs"] / PEAK["hbm_GBs"], 4), "traffic": None}
+    rl["avg_us"] = k["avg_us"]
+    rl["kernels"] = kernels
+    return rl
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+
+    sd = synth.make_state_dict()
+    model = AcousticModel.init(AcousticDims().model_config()).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    model.set_compute_dtype(torch.float32 if args.dtype == "f32" else torch.bfloat16)
+
+    B, L, M = args.batch, args.text_len, args.mel_len
+    inp = synth.make_inputs(B, L, M, seed=synth.SEED + rank)           # each rank owns different utterances
+    d = {k: v.to(dev) for k, v in inp.items()}
+    gathered = torch.empty((world * B, 80, M), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        out = model(d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
+                    flow_noise=d["flow_x0"], flow_time=d["flow_t"])
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out.mel.contiguous())   # the one exchange: mel outputs over xGMI
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    prof = None
+    if not args.no_kernel_events and rank == 0:
+        prof = runtime.LaunchProfiler()
+        runtime.set_profiler(prof)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    runtime.set_profiler(None)
+    assert torch.isfinite(out.mel).all()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames = world * B * M * args.steps
+        value = frames / elapsed
+        name, cus = runtime.device_info()
+        line = {
+            "metric": "mel-frames/s (whole node), batch=64 x 512-frame utterances per GPU, full forward incl. MAS",
+            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: AcousticModel.forward (TextEncoder + Aligner/MAS + TemporalAdaptor "
+                                   "1 flow eval + MelDecoder + to_mel), fixed-length synthetic random-phoneme batch, "
+                                   "random-init weights of the recipe architecture (23.2 M params)",
+                       "batch_per_gpu": B, "global_batch": world * B, "text_len": L, "mel_len": M,
+                       "parallelism": f"dp{world} (utterances sharded, RCCL all-gather of mel)" if world > 1 else "single GPU",
+                       "device": name, "compute_units": cus},
+            "model_TFLOPs": round(value * FLOP_PER_FRAME / 1e12, 2),
+        }
+        if prof is not None:
+            line["roofline"] = roofline(prof.summary(), args.steps, args.dtype)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args, sd)
+            line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,6 +102,9 @@ int32_t ispk_layernorm_f32_bf16(const float* x, int64_t ldx, const float* gamma,
 #define ISPK_EP_OUT_BF16 64u   /* _bf16 entry only: C is bf16 (default fp32) */
 #define ISPK_EP_RESID_BF16 128u /* _bf16 entry only: resid is bf16 (default fp32) */
 
+/* Which block tile ispk_gemm_f32 will use for (M, N, K): TM*10 + TN, block = 64*TM x 64*TN (22 -> 128x128).  Lets a
+ * profiler label a launch with the kernel instance rocprof will report. */
+int32_t ispk_gemm_f32_tile(int32_t M, int32_t N, int32_t K);
 int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, const float* bias,
                       const float* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N, int32_t K,
                       uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);

@@ -180,6 +180,16 @@ int32_t check_common(const GemmParams& p, int elt) {
 
 }  // namespace
 
+// tile choice: the largest tile that still gives every one of the 256 CUs a workgroup.  Returns TM*10 + TN.
+extern "C" int32_t ispk_gemm_f32_tile(int32_t M, int32_t N, int32_t K) {
+    (void)K;
+    const int64_t wg128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+    const int64_t wg64x128 = (int64_t)((M + 63) / 64) * ((N + 127) / 128);
+    if (wg128 >= 256) return 22;
+    if (wg64x128 >= 256 || N > 64) return 12;
+    return 11;
+}
+
 extern "C" int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc,
                                  const float* bias, const float* resid, int64_t ldr, const uint8_t* mask, int32_t M,
                                  int32_t N, int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride,
@@ -190,11 +200,10 @@ extern "C" int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, in
                  "gemm_f32: bf16 output/residual flags belong to ispk_gemm_bf16");
     if (M == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    // tile choice: the largest tile that still gives every one of the 256 CUs a workgroup
-    const int64_t wg128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
-    const int64_t wg64x128 = (int64_t)((M + 63) / 64) * ((N + 127) / 128);
-    if (wg128 >= 256) return launch_f32<2, 2>(p, s);
-    if (wg64x128 >= 256 || N > 64) return launch_f32<1, 2>(p, s);
+    switch (ispk_gemm_f32_tile(M, N, K)) {
+        case 22: return launch_f32<2, 2>(p, s);
+        case 12: return launch_f32<1, 2>(p, s);
+    }
     return launch_f32<1, 1>(p, s);
 }
 

@@ -29,6 +29,7 @@ SIGNATURES = {
     "ispk_mas_f32": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I64, _I64, _P],
     "ispk_layernorm_f32": [_P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _F32, _P],
     "ispk_layernorm_f32_bf16": [_P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _F32, _P],
+    "ispk_gemm_f32_tile": [_I32, _I32, _I32],
     "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_gemm_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
@@ -60,6 +61,47 @@ def lib() -> ctypes.CDLL:
             raise IspkError(f"libispk.so ABI version {handle.ispk_abi_version()} != 1")
         _lib = handle
     return _lib
+
+
+class LaunchProfiler:
+    """Optional per-launch timing with HIP events on the launch stream (used by bench.py for the roofline object).
+    Each record: (kernel label, algorithmic FLOPs, algorithmic HBM bytes, start event, end event)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self) -> dict:
+        """label -> {launches, total_ms, avg_us, flops, bytes} (call after a device synchronise)."""
+        out: dict = {}
+        for label, flops, nbytes, e0, e1 in self.records:
+            d = out.setdefault(label, {"launches": 0, "total_ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            d["launches"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        for d in out.values():
+            d["avg_us"] = 1e3 * d["total_ms"] / d["launches"]
+        return out
+
+
+_profiler: Optional[LaunchProfiler] = None
+
+
+def set_profiler(p: Optional[LaunchProfiler]) -> None:
+    global _profiler
+    _profiler = p
+
+
+def _launch(label: str, flops: float, nbytes: float, fn, *args) -> None:
+    if _profiler is None:
+        _check(fn(*args), label)
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = fn(*args)
+    e1.record()
+    _check(rc, label)
+    _profiler.records.append((label, flops, nbytes, e0, e1))
 
 
 def _check(rc: int, what: str) -> None:
@@ -111,8 +153,9 @@ def mas(logits: Tensor, text_len: Tensor, mel_len: Tensor, want_dur: bool = True
     hard = torch.empty((B, M, L), dtype=torch.int16, device=logits.device)
     dur = torch.empty((B, L), dtype=torch.int64, device=logits.device) if want_dur else None
     path = torch.empty((B, M), dtype=torch.int16, device=logits.device) if want_path else None
-    _check(lib().ispk_mas_f32(logits.data_ptr(), text_len.data_ptr(), mel_len.data_ptr(), hard.data_ptr(), _ptr(dur),
-                              _ptr(path), B, M, L, logits.stride(0), logits.stride(1), _stream()), "ispk_mas_f32")
+    _launch(f"mas_kernel<{(L + 63) // 64}>", 0.0, 6.0 * B * M * L, lib().ispk_mas_f32, logits.data_ptr(),
+            text_len.data_ptr(), mel_len.data_ptr(), hard.data_ptr(), _ptr(dur), _ptr(path), B, M, L, logits.stride(0),
+            logits.stride(1), _stream())
     return hard, dur, path
 
 
@@ -135,8 +178,9 @@ def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ada_sc
         row_mask = row_mask.reshape(-1).contiguous()
         assert row_mask.dtype == torch.bool and row_mask.numel() == rows
     fn = lib().ispk_layernorm_f32 if out_dtype == torch.float32 else lib().ispk_layernorm_f32_bf16
-    _check(fn(x2.data_ptr(), x2.stride(0), _ptr(gamma), _ptr(beta), _ptr(ada_scale), _ptr(ada_shift), ada_stride,
-              rows_per_batch, _ptr(row_mask), y.data_ptr(), D, rows, D, eps, _stream()), "ispk_layernorm")
+    _launch(f"layernorm_kernel<{D // 64}>", 0.0, float(rows) * D * (4 + y.element_size()), fn, x2.data_ptr(),
+            x2.stride(0), _ptr(gamma), _ptr(beta), _ptr(ada_scale), _ptr(ada_shift), ada_stride, rows_per_batch,
+            _ptr(row_mask), y.data_ptr(), D, rows, D, eps, _stream())
     return y
 
 
@@ -172,9 +216,22 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Optional[Te
     else:
         assert out.dtype == torch.float32 and (r2 is None or r2.dtype == torch.float32)
         fn = lib().ispk_gemm_f32
-    _check(fn(a2.data_ptr(), a2.stride(0), w.data_ptr(), w.stride(0), c2.data_ptr(), c2.stride(0), _ptr(bias), _ptr(r2),
-              r2.stride(0) if r2 is not None else 0, _ptr(mask), M, N, K, flags, 0, 0, _stream()), "ispk_gemm")
+    _launch(_gemm_label(bf16, M, N, K), 2.0 * M * N * K, _gemm_bytes(a2, w, out, r2), fn, a2.data_ptr(), a2.stride(0),
+            w.data_ptr(), w.stride(0), c2.data_ptr(), c2.stride(0), _ptr(bias), _ptr(r2),
+            r2.stride(0) if r2 is not None else 0, _ptr(mask), M, N, K, flags, 0, 0, _stream())
     return out
+
+
+def _gemm_label(bf16: bool, M: int, N: int, K: int) -> str:
+    if bf16:
+        return "gemm_bf16_kernel"
+    t = lib().ispk_gemm_f32_tile(M, N, K)
+    return f"gemm_f32_kernel<{t // 10},{t % 10}>"
+
+
+def _gemm_bytes(a2: Tensor, w: Tensor, out: Tensor, r2: Optional[Tensor]) -> float:
+    n = a2.numel() * a2.element_size() + w.numel() * w.element_size() + out.numel() * out.element_size()
+    return float(n + (r2.numel() * r2.element_size() if r2 is not None else 0))
 
 
 def to_mel(dec: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor]) -> Tensor:
@@ -191,8 +248,9 @@ def to_mel(dec: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor]) ->
         mask = mask.reshape(-1).contiguous()
         flags |= EP_MASK_OUT
     fn = lib().ispk_gemm_bf16 if dec.dtype == torch.bfloat16 else lib().ispk_gemm_f32
-    _check(fn(weight.data_ptr(), weight.stride(0), x2.data_ptr(), x2.stride(0), out.data_ptr(), T, _ptr(bias), None, 0,
-              _ptr(mask), C, B * T, D, flags, T, C * T, _stream()), "ispk_gemm(to_mel)")
+    _launch(_gemm_label(dec.dtype == torch.bfloat16, C, B * T, D), 2.0 * C * B * T * D, _gemm_bytes(x2, weight, out, None),
+            fn, weight.data_ptr(), weight.stride(0), x2.data_ptr(), x2.stride(0), out.data_ptr(), T, _ptr(bias), None, 0,
+            _ptr(mask), C, B * T, D, flags, T, C * T, _stream())
     return out
 
 
@@ -207,9 +265,9 @@ def linear_small(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Opt
     assert w.shape[1] == K
     out = torch.empty((*a.shape[:-1], N), dtype=torch.float32, device=a.device)
     r2 = _rows2d(resid) if resid is not None else None
-    _check(lib().ispk_linear_small_f32(a2.data_ptr(), a2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias), _ptr(r2),
-                                       r2.stride(0) if r2 is not None else 0, out.data_ptr(), N, M, N, K, act,
-                                       _stream()), "ispk_linear_small_f32")
+    _launch("linear_small_kernel", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N), lib().ispk_linear_small_f32,
+            a2.data_ptr(), a2.stride(0), w.data_ptr(), w.stride(0), _ptr(bias), _ptr(r2),
+            r2.stride(0) if r2 is not None else 0, out.data_ptr(), N, M, N, K, act, _stream())
     return out
 
 
@@ -234,8 +292,10 @@ def alibi_mqa_attention_raw(q: Tensor, ldq: int, k: Tensor, v: Tensor, ldkv: int
         key_len = key_len.to(torch.int64).contiguous()
     slopes = slopes.to(torch.float32).contiguous()
     fn = lib().ispk_alibi_mqa_attn_f32 if q.dtype == torch.float32 else lib().ispk_alibi_mqa_attn_bf16
-    _check(fn(q.data_ptr(), ldq, k.data_ptr(), v.data_ptr(), ldkv, slopes.data_ptr(), _ptr(key_len), out.data_ptr(),
-              heads * 64, B, N, heads, _stream()), "ispk_alibi_mqa_attn")
+    es = q.element_size()
+    _launch("attn_f32_kernel" if es == 4 else "attn_bf16_kernel", 256.0 * B * N * N * heads,
+            float(B) * N * (2 * heads * 64 + 128) * es, fn, q.data_ptr(), ldq, k.data_ptr(), v.data_ptr(), ldkv,
+            slopes.data_ptr(), _ptr(key_len), out.data_ptr(), heads * 64, B, N, heads, _stream())
     return out
 
 
@@ -251,6 +311,6 @@ def cast_bf16(x: Tensor) -> Tensor:
     _dev(x)
     x2 = _rows2d(x)
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    _check(lib().ispk_cast_f32_bf16(x2.data_ptr(), x2.stride(0), y.data_ptr(), x2.shape[1], x2.shape[0], x2.shape[1],
-                                    _stream()), "ispk_cast_f32_bf16")
+    _launch("cast_bf16_kernel", 0.0, 6.0 * x2.numel(), lib().ispk_cast_f32_bf16, x2.data_ptr(), x2.stride(0),
+            y.data_ptr(), x2.shape[1], x2.shape[0], x2.shape[1], _stream())
     return y

@@ -51,16 +51,31 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=8, help="utterances in the CPU-baseline sample")
-    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-iters", type=int, default=5)
     return ap.parse_args()
+
+
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask, cgroup CPU quota, and the GPU box's per-GPU share (16)."""
+    if os.environ.get("ISPK_CPU_THREADS"):
+        return int(os.environ["ISPK_CPU_THREADS"])
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 16))
 
 
 def cpu_baseline(args, sd):
     """Oracle forward (reference algorithm restated on PyTorch-CPU + C MAS) on a bounded sample: cpu_batch utterances
     of the same shape, 1 warm-up + cpu_iters timed passes, median."""
     from oracle import acoustic_oracle as orc
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(host_cores())
+    os.environ["OMP_NUM_THREADS"] = str(host_cores())
     inp = synth.make_inputs(args.cpu_batch, args.text_len, args.mel_len)
     a = (inp["text"], inp["text_len"], inp["mel"], inp["mel_len"], inp["pitch"], inp["energy"], inp["flow_x0"],
          inp["flow_t"])

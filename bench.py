@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 from isp_tts_amd import runtime, synth  # noqa: E402
 from isp_tts_amd.acoustic import AcousticModel  # noqa: E402
 from isp_tts_amd.config import AcousticDims  # noqa: E402
+from isp_tts_amd.dist import all_gather_mel  # noqa: E402
 
 # gfx950 peaks from /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters", dense, no sparsity)
 PEAK = {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3, "mfma_bf16_TFs": 2500.0}
@@ -140,13 +141,12 @@ def main():
     B, L, M = args.batch, args.text_len, args.mel_len
     inp = synth.make_inputs(B, L, M, seed=synth.SEED + rank)           # each rank owns different utterances
     d = {k: v.to(dev) for k, v in inp.items()}
-    gathered = torch.empty((world * B, 80, M), dtype=torch.float32, device=dev) if world > 1 else None
 
     def step():
         out = model(d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
                     flow_noise=d["flow_x0"], flow_time=d["flow_t"])
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out.mel.contiguous())   # the one exchange: mel outputs over xGMI
+        if world > 1:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather)
+            all_gather_mel(out.mel, out.adaptor_output.dec_lengths, max_frames=M, max_batch=B)
         return out
 
     def fence():

@@ -55,9 +55,11 @@ class AcousticModel(nn.Module, Constructor):
 
     def set_compute_dtype(self, dtype: torch.dtype):
         """fp32 (parity path: exact-fp32 MFMA) or bf16 (throughput path: bf16 operands, fp32 accumulation,
-        fp32 residual stream / LayerNorm / softmax statistics).  Applies to the encoder and decoder stacks."""
+        fp32 residual stream / LayerNorm / softmax statistics).  Applies to all four transformer stacks."""
         self.encoder.set_compute_dtype(dtype)
         self.decoder.set_compute_dtype(dtype)
+        self.temporal_adaptor.predictor.transformer.set_compute_dtype(dtype)
+        self.temporal_adaptor.embedding.transformer.set_compute_dtype(dtype)
         self.compute_dtype = dtype
         return self
 

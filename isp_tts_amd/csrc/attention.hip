@@ -185,8 +185,185 @@ extern "C" int32_t ispk_alibi_mqa_attn_f32(const float* q, int64_t ldq, const fl
     return ispk_launch_status();
 }
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 path (v_mfma_f32_32x32x16_bf16, fp32 accumulate; softmax statistics, bias and mask in fp32).
+// Same decomposition and the same Sᵀ = K·Qᵀ trick.  What changes with the 16-deep MFMA:
+//   * Q: 4 fragments of 8 bf16 per lane (lane half h owns head dims 16ks + 8h .. +7);
+//   * the Pᵀ accumulator (fp32, register r = key (r&3) + 8(r>>2) + 4h) is packed pairwise to bf16 and used directly as
+//     the B operand of Oᵀ += Vᵀ·Pᵀ: registers 8s..8s+7 form k-step s, whose element j is key 16s + 8(j>>2) + 4h + (j&3)
+//     (guide §3 "An accumulator tile as the next MFMA's operand").  The A operand must present V in that same key order,
+//     so the V tile is staged TRANSPOSED in LDS (Vt[d][key]): a lane reads two 8-byte runs of 4 consecutive keys;
+//   * exp() runs as v_exp_f32 on log2-domain scores: s*log2(e)/8 - slope*log2(e)*|i-j| in one FMA.
+// Per 32x32 (key x query) block a wave issues 8 MFMAs (256 cycles) but ~16 exp + ~130 VALU ops, so this kernel is
+// VALU-bound, not MFMA-bound; 3 waves per SIMD overlap one wave's softmax with another's MFMAs.
+constexpr int kLdh = 72;  // padded row of the bf16 K / Vt tiles (64 + 8 elements = 144 B)
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+__global__ __launch_bounds__(1024) void attn_bf16_kernel(const uint16_t* __restrict__ q, int64_t ldq,
+                                                         const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                         int64_t ldkv, const float* __restrict__ slopes,
+                                                         const int64_t* __restrict__ key_len,
+                                                         uint16_t* __restrict__ out, int64_t ldo, int N, int H) {
+    __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * kTileKeys * kLdh];  // [2][key][d]
+    __shared__ __attribute__((aligned(16))) uint16_t Vt[2 * 64 * kLdh];         // [2][d][key]
+
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int head = wave % H, qhalf = wave / H;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + qhalf * 32;
+    int klen = key_len ? (int)key_len[b] : N;
+    klen = klen < 1 ? 1 : (klen > N ? N : klen);
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float slope2 = slopes[head] * kLog2e;
+    const float scale2 = 0.125f * kLog2e;
+    const float ninf = -__builtin_huge_valf();
+
+    const int qi = q0 + l31;
+    const int qrow = qi < N ? qi : N - 1;
+    bf16x8 qf[4];
+    {
+        const uint16_t* qp = q + ((int64_t)b * N + qrow) * ldq + head * 64 + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = ninf, l_run = 0.f;
+
+    const uint16_t* kb = k + (int64_t)b * N * ldkv;
+    const uint16_t* vb = v + (int64_t)b * N * ldkv;
+    const int ntiles = (klen + kTileKeys - 1) / kTileKeys;
+
+    auto stage = [&](int t, int buf) {
+        // K: 64 keys x 8 chunks of 8 bf16, row-major.  V: the same chunks, scattered transposed into Vt[d][key].
+        for (int idx = tid; idx < kTileKeys * 16; idx += nthreads) {
+            const int isv = idx >> 9;
+            const int rem = idx & 511;
+            const int row = rem >> 3, c8 = (rem & 7) * 8;
+            const int key = t * kTileKeys + row;
+            uint4 val = make_uint4(0u, 0u, 0u, 0u);
+            if (key < N) val = *reinterpret_cast<const uint4*>((isv ? vb : kb) + (int64_t)key * ldkv + c8);
+            if (!isv) {
+                *reinterpret_cast<uint4*>(Ks + (buf * kTileKeys + row) * kLdh + c8) = val;
+            } else {
+                uint16_t* dst = Vt + (buf * 64 + c8) * kLdh + row;
+                const uint32_t w[4] = {val.x, val.y, val.z, val.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dst[(2 * e) * kLdh] = (uint16_t)(w[e] & 0xffffu);
+                    dst[(2 * e + 1) * kLdh] = (uint16_t)(w[e] >> 16);
+                }
+            }
+        }
+    };
+
+    stage(0, 0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+#pragma unroll 1
+        for (int kblk = 0; kblk < 2; ++kblk) {
+            const int key0 = t * kTileKeys + kblk * 32;
+            if (key0 >= klen) break;  // wave-uniform
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+            const uint16_t* kp = Ks + (buf * kTileKeys + kblk * 32 + l31) * kLdh + h * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            float smax = ninf;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int dist = key > qi ? key - qi : qi - key;
+                float val = fmaf(s[r], scale2, -slope2 * (float)dist);
+                val = key < klen ? val : ninf;
+                s[r] = val;
+                smax = fmaxf(smax, val);
+            }
+            smax = xhalf_max(smax);
+            const float m_new = fmaxf(m_run, smax);
+            const float alpha = exp2f(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pexp = exp2f(s[r] - m_new);
+                s[r] = pexp;
+                psum += pexp;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+            // P -> bf16 B-operand fragments (k-step st = registers 8st .. 8st+7)
+            const uint16_t* vp = Vt + (buf * 64 + l31) * kLdh + kblk * 32 + 4 * h;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                union { uint32_t u[4]; bf16x8 f; } pf, va, vc;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
+                // A operand: Vt[d][key0 + 16st + 4h + 0..3] and [.. + 8 + 0..3]
+                const uint2 a_lo = *reinterpret_cast<const uint2*>(vp + 16 * st);
+                const uint2 a_hi = *reinterpret_cast<const uint2*>(vp + 16 * st + 8);
+                va.u[0] = a_lo.x; va.u[1] = a_lo.y; va.u[2] = a_hi.x; va.u[3] = a_hi.y;
+                const uint2 c_lo = *reinterpret_cast<const uint2*>(vp + 32 * kLdh + 16 * st);
+                const uint2 c_hi = *reinterpret_cast<const uint2*>(vp + 32 * kLdh + 16 * st + 8);
+                vc.u[0] = c_lo.x; vc.u[1] = c_lo.y; vc.u[2] = c_hi.x; vc.u[3] = c_hi.y;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.f, pf.f, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc.f, pf.f, o1, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const float inv = 1.0f / xhalf_sum(l_run);
+    if (qi < N) {
+        uint16_t* op = out + ((int64_t)b * N + qi) * ldo + head * 64 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 a, c;
+            a.x = pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+            a.y = pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            c.x = pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+            c.y = pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(op + 8 * g) = a;
+            *reinterpret_cast<uint2*>(op + 32 + 8 * g) = c;
+        }
+    }
+}
+
+}  // namespace
+
 extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v,
                                             int64_t ldkv, const float* slopes, const int64_t* key_len, uint16_t* out,
                                             int64_t ldo, int32_t B, int32_t N, int32_t H, ispk_stream_t stream) {
-    ISPK_FAIL(ISPK_E_UNSUPPORTED, "alibi_mqa_attn_bf16: not implemented in this build");
+    ISPK_REQUIRE(q && k && v && slopes && out, ISPK_E_NULL, "attn: null pointer");
+    ISPK_REQUIRE(B >= 0 && N >= 1 && H >= 1 && H <= 8, ISPK_E_SHAPE, "attn: bad shape B=%d N=%d H=%d (H <= 8)", B, N, H);
+    ISPK_REQUIRE(B <= 65535, ISPK_E_SHAPE, "attn: B=%d exceeds the grid limit 65535", B);
+    ISPK_REQUIRE(ldq >= H * 64 && ldo >= H * 64 && ldkv >= 64, ISPK_E_SHAPE, "attn: leading strides too small");
+    ISPK_REQUIRE(ldq % 8 == 0 && ldkv % 8 == 0 && ldo % 4 == 0, ISPK_E_ALIGN,
+                 "attn: ldq/ldkv must be multiples of 8 and ldo of 4 (bf16)");
+    ISPK_REQUIRE(ispk_aligned(q, 16) && ispk_aligned(k, 16) && ispk_aligned(v, 16) && ispk_aligned(out, 8),
+                 ISPK_E_ALIGN, "attn: q/k/v must be 16-byte and out 8-byte aligned");
+    if (B == 0) return 0;
+    dim3 grid((N + 63) / 64, B), block(2 * H * 64);
+    hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv,
+                       slopes, key_len, out, ldo, N, H);
+    return ispk_launch_status();
 }

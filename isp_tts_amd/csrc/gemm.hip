@@ -53,10 +53,17 @@ __device__ __forceinline__ void epilogue_store(const GemmParams& p, int i, int j
         off = (int64_t)bb * p.bstride + (int64_t)i * p.ldc + (j - bb * p.cpb);
     } else {
         off = (int64_t)i * p.ldc + j;
-        if (p.resid) v += static_cast<const float*>(p.resid)[(int64_t)i * p.ldr + j];
+        if (p.resid) {
+            const int64_t ro = (int64_t)i * p.ldr + j;
+            v += (p.flags & ISPK_EP_RESID_BF16) ? bf16_to_f32(static_cast<const uint16_t*>(p.resid)[ro])
+                                                : static_cast<const float*>(p.resid)[ro];
+        }
     }
     if (p.flags & ISPK_EP_MASK_OUT) v *= mk;
-    static_cast<float*>(p.C)[off] = v;
+    if (p.flags & ISPK_EP_OUT_BF16)
+        static_cast<uint16_t*>(p.C)[off] = f32_to_bf16(v);
+    else
+        static_cast<float*>(p.C)[off] = v;
 }
 
 template <int TM, int TN>
@@ -147,6 +154,114 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 path: v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  Same skeleton; a K step is 64 deep (128-B rows padded to
+// 144 B = 36 dwords, so the ds_read_b128 fragment reads stay conflict-free), a lane's A/B fragment is 8 consecutive k
+// (lane half h owns k = 16*ks + 8h .. +7: the MFMA's natural operand map, guide §3), 16 MFMAs per wave and K step for
+// the 128x128 block.  Epilogue identical (fp32 math), output/residual fp32 or bf16 by flag.
+constexpr int kLdtH = 72;  // padded LDS row length in bf16 elements (64 + 8)
+
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint16_t* As = reinterpret_cast<uint16_t*>(smem_raw);  // [2][BM][kLdtH]
+    uint16_t* Bs = As + 2 * BM * kLdtH;                    // [2][BN][kLdtH]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* W = static_cast<const uint16_t*>(p.W);
+
+    const int r0 = tid >> 3, c8 = (tid & 7) * 8;  // staging: 8 lanes x 16 B cover one 128-B row segment
+    uint4 ra[BM / 32], rb[BN / 32];
+    auto gload = [&](int kt) {
+        const int k = kt * 64 + c8;
+        const bool kin = k < p.K;
+#pragma unroll
+        for (int q = 0; q < BM / 32; ++q) {
+            const int row = m0 + r0 + 32 * q;
+            ra[q] = (kin && row < p.M) ? *reinterpret_cast<const uint4*>(A + (int64_t)row * p.lda + k)
+                                       : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q) {
+            const int row = n0 + r0 + 32 * q;
+            rb[q] = (kin && row < p.N) ? *reinterpret_cast<const uint4*>(W + (int64_t)row * p.ldw + k)
+                                       : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < BM / 32; ++q)
+            *reinterpret_cast<uint4*>(As + ((buf * BM) + r0 + 32 * q) * kLdtH + c8) = ra[q];
+#pragma unroll
+        for (int q = 0; q < BN / 32; ++q)
+            *reinterpret_cast<uint4*>(Bs + ((buf * BN) + r0 + 32 * q) * kLdtH + c8) = rb[q];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const int nk = (p.K + 63) / 64;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const uint16_t* Ab = As + (buf * BM + wm * 32 * TM + l31) * kLdtH + h * 8;
+        const uint16_t* Bb = Bs + (buf * BN + wn * 32 * TN + l31) * kLdtH + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 a[TM], b[TN];
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi) a[mi] = *reinterpret_cast<const bf16x8*>(Ab + mi * 32 * kLdtH + ks * 16);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) b[ni] = *reinterpret_cast<const bf16x8*>(Bb + ni * 32 * kLdtH + ks * 16);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+        if (kt + 1 < nk) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int j = n0 + (wn * TN + ni) * 32 + l31;
+            const int ib = m0 + (wm * TM + mi) * 32 + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epilogue_store(p, ib + (r & 3) + 8 * (r >> 2), j, acc[mi][ni][r]);
+        }
+}
+
+template <int TM, int TN>
+int32_t launch_bf16(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * kLdtH * sizeof(uint16_t);
+    static_assert(lds <= 64 * 1024 || true, "");
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) ISPK_FAIL((int32_t)e, "gemm: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    }
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+    hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN>), grid, dim3(256), lds, s, p);
+    return ispk_launch_status();
+}
+
 template <int TM, int TN>
 int32_t launch_f32(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -211,5 +326,13 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
                                   const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M,
                                   int32_t N, int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride,
                                   ispk_stream_t stream) {
-    ISPK_FAIL(ISPK_E_UNSUPPORTED, "gemm_bf16: not implemented in this build");
+    GemmParams p{A, lda, W, ldw, C, ldc, bias, resid, ldr, mask, M, N, K, flags, cols_per_batch, batch_stride};
+    if (int32_t rc = check_common(p, 2)) return rc;
+    if (M == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (ispk_gemm_f32_tile(M, N, K)) {  // same occupancy rule as the fp32 path
+        case 22: return launch_bf16<2, 2>(p, s);
+        case 12: return launch_bf16<1, 2>(p, s);
+    }
+    return launch_bf16<1, 1>(p, s);
 }

@@ -252,3 +252,68 @@ def test_abi_argument_errors_are_reported():
     assert lib.ispk_mas_f32(None, None, None, None, None, None, 1, 1, 1, 1, 1, None) == -1
     name, cus = runtime.device_info()
     assert "gfx950" in name and cus >= 128
+
+
+# ------------------------------------------------------------------------------------------------ bf16 path
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (32768, 512, 384), (300, 1536, 384), (777, 384, 1536),
+                                   (64, 64, 8), (130, 80, 384)])
+def test_gemm_bf16_shapes(M, N, K):
+    """bf16 operands, fp32 accumulation: compared with a float64 product of the SAME bf16-rounded operands, so the only
+    differences are accumulation order (fp32) and the output rounding (bf16: 2^-9 relative)."""
+    a, w = _bf(synth._normal(f"t/gemm/a{M}x{K}", (M, K))), _bf(synth._normal(f"t/gemm/w{N}x{K}", (N, K), K ** -0.5))
+    ref = a.double() @ w.double().T
+    out32 = runtime.gemm(a.to(DEV), w.to(DEV), out_dtype=torch.float32).cpu()
+    assert (out32.double() - ref).abs().max() < 2e-5
+    out16 = runtime.gemm(a.to(DEV), w.to(DEV)).cpu()
+    assert out16.dtype == torch.bfloat16
+    assert ((out16.double() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-6).all()
+
+
+def test_gemm_bf16_epilogues():
+    B, T, K, N = 3, 210, 384, 384
+    a, w = _bf(synth._normal("t/gemm/ea", (B, T, K))), _bf(synth._normal("t/gemm/ew", (N, K), K ** -0.5))
+    bias, resid = synth._normal("t/gemm/eb", (N,)), synth._normal("t/gemm/er", (B, T, N))
+    mask = torch.arange(T)[None] < torch.tensor([T, 100, 1])[:, None]
+    d = lambda t: t.to(DEV)  # noqa: E731
+    out = runtime.gemm(d(a), d(w), bias=d(bias), flags=runtime.EP_GELU, out_dtype=torch.float32).cpu()
+    assert (out.double() - _gemm_ref(a, w, bias=bias, act="gelu")).abs().max() < 2e-5
+    out = runtime.gemm(d(a), d(w), resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_ACC, out_dtype=torch.float32).cpu()
+    assert (out.double() - _gemm_ref(a, w, resid=resid, mask=mask, mask_acc=True)).abs().max() < 2e-5
+    out = runtime.gemm(d(a), d(w), resid=d(_bf(resid)), mask=d(mask), flags=runtime.EP_MASK_OUT,
+                       out_dtype=torch.float32).cpu()
+    assert (out.double() - _gemm_ref(a, w, resid=_bf(resid), mask=mask, mask_out=True)).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("B,N,H,lens", [(2, 100, 6, [100, 73]), (2, 512, 6, [512, 390]), (3, 37, 4, [37, 1, 20]),
+                                        (2, 64, 6, None), (1, 129, 8, [65])])
+def test_attention_bf16(B, N, H, lens):
+    """bf16 Q/K/V and bf16 P (8 mantissa bits), fp32 statistics: compared with float64 attention on the same
+    bf16-rounded inputs.  Bar: 1.5e-2 absolute on O(1) outputs (P quantisation 2^-9 relative per weight)."""
+    q = _bf(synth._normal(f"t/at/q{N}", (B, N, H * 64)))
+    kv = _bf(synth._normal(f"t/at/kv{N}", (B, N, 128)))
+    slopes = torch.tensor(synth.alibi_default_slopes(H)) * 1.1
+    mask = None if lens is None else torch.arange(N)[None] < torch.tensor(lens)[:, None]
+    bias = slopes.view(H, 1, 1).double() * orc.alibi_int_bias(N, N).double()
+    qd = q.view(B, N, H, 64).transpose(1, 2).double()
+    sc = qd @ kv[..., :64].double().transpose(1, 2)[:, None] / 8.0 + bias[None]
+    if mask is not None:
+        sc = sc.masked_fill(~mask[:, None, None, :], float("-inf"))
+    exact = (sc.softmax(-1) @ kv[..., 64:].double()[:, None]).transpose(1, 2).reshape(B, N, H * 64)
+    key_len = None if lens is None else torch.tensor(lens, device=DEV)
+    out = runtime.alibi_mqa_attention(torch.cat([q, kv], -1).to(DEV), H, slopes.to(DEV), key_len).cpu()
+    assert out.dtype == torch.bfloat16
+    err = (out.double() - exact).abs().max().item()
+    assert err < 1.5e-2, err
+
+
+def test_layernorm_bf16_output_and_cast():
+    x = synth._normal("t/ln/xb", (5, 33, 384), 2.0, 0.5)
+    g, b = synth._normal("t/ln/g", (384,), 0.1, 1.0), synth._normal("t/ln/b", (384,), 0.1)
+    ref = F.layer_norm(x, (384,), g, b, 1e-5).to(torch.bfloat16)
+    out = runtime.layernorm(x.to(DEV), g.to(DEV), b.to(DEV), out_dtype=torch.bfloat16).cpu()
+    assert out.dtype == torch.bfloat16 and (out.float() - ref.float()).abs().max() <= 2 ** -6
+    assert torch.equal(runtime.cast_bf16(x.to(DEV)).cpu(), x.to(torch.bfloat16))

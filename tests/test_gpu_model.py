@@ -145,3 +145,28 @@ def test_full_size_forward_properties(gpu_model):
     out4 = gpu_model(dev["text"][sub], dev["text_len"][sub], dev["mel"][sub], dev["mel_len"][sub], dev["pitch"][sub],
                      dev["energy"][sub], flow_noise=dev["flow_x0"][sub], flow_time=dev["flow_t"][sub])
     assert _maxdiff(out4.mel, out.mel[sub]) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ bf16 throughput path
+BF16_MEL_TOL = 6e-2   # bf16 operands (8 mantissa bits) through 12 layers, fp32 residual stream; stated, not the 1e-4 bar
+
+
+def test_bf16_forward_error_vs_reference(gpu_model):
+    """The bf16 path (BASELINE config 3 dtype) against the fp32 reference golden: reported and bounded, NOT held to 1e-4."""
+    g = golden("forward.npz")
+    inp = _forward_inputs()
+    try:
+        gpu_model.set_compute_dtype(torch.bfloat16)
+        out = gpu_model(**{k: v.to(DEV) for k, v in inp.items()})
+        torch.cuda.synchronize()
+    finally:
+        gpu_model.set_compute_dtype(torch.float32)
+    ref = torch.from_numpy(g["mel"])
+    err = (out.mel.cpu() - ref).abs()
+    rel_rms = (err.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    print(f"bf16 forward: mel L-inf = {err.max().item():.3e}, relative RMS = {rel_rms:.3e}")
+    assert err.max().item() < BF16_MEL_TOL and rel_rms < 1e-2
+    assert np.array_equal(out.adaptor_output.dec_lengths.cpu().numpy(), g["dec_lengths"])
+    # back on the fp32 path the 1e-4 bar holds again (staged weights are rebuilt per dtype)
+    out = gpu_model(**{k: v.to(DEV) for k, v in inp.items()})
+    assert _maxdiff(out.mel, g["mel"]) < MEL_TOL

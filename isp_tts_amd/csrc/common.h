@@ -44,6 +44,19 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU(erf) with the Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7): 1 rcp + 1 exp + 7 FMA instead of libm erff.
+// Used where the result is rounded to bf16 anyway (relative step 2^-9); the fp32 parity path keeps erff.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
+    const float erf_abs = 1.0f - poly * t * e;
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 constexpr int kWave = 64;

@@ -16,6 +16,8 @@
 //
 // Replaces the nn.Linear call sites listed in include/ispk.h (attention.py:105,111,168; feedforward.py:33-36;
 // transformer.py:170; model.py:167-168 of the reference) and fuses the surrounding bias / GELU / residual / mask ops.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -42,7 +44,7 @@ constexpr int kLdt = 36;  // padded LDS row length in dwords (32 + 4)
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int i, int j, float v) {
     if (i >= p.M || j >= p.N) return;
     if (p.bias) v += p.bias[(p.flags & ISPK_EP_BIAS_ROW) ? i : j];
-    if (p.flags & ISPK_EP_GELU) v = gelu_erf(v);
+    if (p.flags & ISPK_EP_GELU) v = (p.flags & ISPK_EP_OUT_BF16) ? gelu_fast(v) : gelu_erf(v);
     if (p.flags & ISPK_EP_SILU) v = silu(v);
     float mk = 1.0f;
     if (p.mask) mk = p.mask[(p.flags & ISPK_EP_MASK_COL) ? j : i] ? 1.0f : 0.0f;
@@ -262,6 +264,283 @@ int32_t launch_bf16(const GemmParams& p, hipStream_t s) {
     return ispk_launch_status();
 }
 
+// Epilogue for the transposed-compute kernels: 4 consecutive output features n..n+3 of activation row m.
+// Same operation order as epilogue_store; bias/residual/output move as 8- or 16-byte vectors.
+__device__ __forceinline__ void epilogue_vec4(const GemmParams& p, int m, int n, float (&v)[4], float mk) {
+    if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+    if (p.flags & ISPK_EP_GELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (p.flags & ISPK_EP_OUT_BF16) ? gelu_fast(v[e]) : gelu_erf(v[e]);
+    }
+    if (p.flags & ISPK_EP_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+    }
+    if (p.flags & ISPK_EP_MASK_ACC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= mk;
+    }
+    if (p.resid) {
+        const int64_t ro = (int64_t)m * p.ldr + n;
+        if (p.flags & ISPK_EP_RESID_BF16) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p.resid) + ro);
+            v[0] += bf16_to_f32((uint16_t)(rr.x & 0xffffu)); v[1] += bf16_to_f32((uint16_t)(rr.x >> 16));
+            v[2] += bf16_to_f32((uint16_t)(rr.y & 0xffffu)); v[3] += bf16_to_f32((uint16_t)(rr.y >> 16));
+        } else {
+            const float4 rr = *reinterpret_cast<const float4*>(static_cast<const float*>(p.resid) + ro);
+            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+        }
+    }
+    if (p.flags & ISPK_EP_MASK_OUT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= mk;
+    }
+    const int64_t co = (int64_t)m * p.ldc + n;
+    if (p.flags & ISPK_EP_OUT_BF16) {
+        uint2 o;
+        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.C) + co) = o;
+    } else {
+        *reinterpret_cast<float4*>(static_cast<float*>(p.C) + co) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 "wide" GEMM for the long reductions (FFN second Linear: K = 1536 -> N = 384; adaptor: K = 1024 -> N = 256).
+// One workgroup = 128 activation rows x ALL N output features, so the big operand (the [rows, K] hidden activations,
+// 100 MB per decoder layer) is read exactly once; 8 waves as 4 (rows) x 2 (feature halves), a wave holds 32 rows x
+// TN 32-wide feature tiles in accumulators (TN = 6 -> 96 registers).  K advances in 64-deep chunks through
+// double-buffered, padded (conflict-free) LDS tiles filled by fully coalesced 128-B row segments; computed transposed
+// (D = W_chunk · Xᵀ) for the vector epilogue.  Per chunk a wave issues 4*TN MFMAs for 4*(TN+1) ds_read_b128.
+template <int TN>
+__global__ __launch_bounds__(512) void gemm_bf16_wide_kernel(GemmParams p) {
+    constexpr int BM = 128, BN = 64 * TN, LD = 72;      // LD: 64 + 8 bf16 per LDS row
+    constexpr int XCH = BM * 8 / 512, WCH = BN * 8 / 512;  // 16-B chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint16_t* Xs = reinterpret_cast<uint16_t*>(smem_raw);  // [2][BM][LD]
+    uint16_t* Ws = Xs + 2 * BM * LD;                       // [2][BN][LD]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* W = static_cast<const uint16_t*>(p.W);
+
+    uint4 rx[XCH], rw[WCH];
+    auto gload = [&](int kt) {
+        const int k = kt * 64;
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 8;
+            const int row = m0 + r;
+            rx[i] = (row < p.M && k + c < p.K) ? *reinterpret_cast<const uint4*>(A + (int64_t)row * p.lda + k + c)
+                                               : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 8;
+            rw[i] = (r < p.N && k + c < p.K) ? *reinterpret_cast<const uint4*>(W + (int64_t)r * p.ldw + k + c)
+                                             : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto swrite = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < XCH; ++i) {
+            const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 8;
+            *reinterpret_cast<uint4*>(Xs + (buf * BM + r) * LD + c) = rx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < WCH; ++i) {
+            const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 8;
+            *reinterpret_cast<uint4*>(Ws + (buf * BN + r) * LD + c) = rw[i];
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nk = (p.K + 63) / 64;
+    gload(0);
+    swrite(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) gload(kt + 1);
+        const uint16_t* xp = Xs + (buf * BM + wm * 32 + l31) * LD + 8 * h;
+        const uint16_t* wp = Ws + (buf * BN + wn * 32 * TN + l31) * LD + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + 16 * ks);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wp + t * 32 * LD + 16 * ks);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t], 0, 0, 0);
+            }
+        }
+        if (kt + 1 < nk) swrite(buf ^ 1);
+        __syncthreads();
+    }
+
+    const int m = m0 + wm * 32 + l31;
+    if (m < p.M) {
+        const float mk = p.mask ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = (wn * TN + t) * 32 + 8 * g + 4 * h;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[t][4 * g + e];
+                epilogue_vec4(p, m, n, v, mk);
+            }
+    }
+}
+
+template <int TN>
+int32_t launch_wide(const GemmParams& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)2 * (128 + 64 * TN) * 72 * sizeof(uint16_t);
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_wide_kernel<TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) ISPK_FAIL((int32_t)e, "gemm: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    hipLaunchKernelGGL((gemm_bf16_wide_kernel<TN>), dim3((p.M + 127) / 128), dim3(512), lds, s, p);
+    return ispk_launch_status();
+}
+
+bool vec_epilogue_ok(const GemmParams& p) {
+    const bool out16 = p.flags & ISPK_EP_OUT_BF16, res16 = p.flags & ISPK_EP_RESID_BF16;
+    return p.N % 4 == 0 && p.cpb <= 0 && !(p.flags & (ISPK_EP_BIAS_ROW | ISPK_EP_MASK_COL)) && p.ldc % 4 == 0 &&
+           ispk_aligned(p.C, out16 ? 8 : 16) && (!p.resid || (p.ldr % 4 == 0 && ispk_aligned(p.resid, res16 ? 8 : 16))) &&
+           (!p.bias || ispk_aligned(p.bias, 16));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 "panel" GEMM for this model's small reduction dims (K = 256 or 384: to_q/to_kv, to_out, FFN1, adaptor stacks).
+// The generic tile loop above is latency-bound here: with K = 384 a 128x128 tile has six dependent
+// load -> barrier -> compute steps and then a scalar epilogue.  This kernel is built around the shape instead:
+//   * a wave owns 32 activation rows and keeps them, for the FULL K, as MFMA operand fragments in registers
+//     (K/16 fragments of 8 bf16: 96 VGPRs at K = 384), loaded by ONE burst of K/16 independent 16-B loads per lane —
+//     the activation matrix is read exactly once from HBM with all of a wave's loads in flight together;
+//   * weights stream through LDS as [64 out-features][K] tiles (50 KB, conflict-free padded rows), the next tile
+//     prefetched into registers while the current one feeds the MFMAs, so a step is 2 x K/16 MFMAs per wave with one
+//     ds_read_b128 per MFMA;
+//   * the tile is computed TRANSPOSED (D = W_tile · Xᵀ): the MFMA C/D fragment then has the activation row on the lane
+//     and 4 consecutive output features in consecutive registers, so bias / residual / output are 8- or 16-byte
+//     vector accesses (4 store instructions per 32x32 tile instead of 16 scalar ones);
+//   * the N range is split over blockIdx.x so that >= 512 workgroups exist (2 per CU).
+template <int KC>  // K = 64 * KC
+__global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, int tiles_per_wg) {
+    constexpr int K = 64 * KC, LDW = K + 8, KS = K / 16, CPR = K / 8;  // CPR: 16-B chunks per weight row
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint16_t* Ws = reinterpret_cast<uint16_t*>(smem_raw);  // [64][LDW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m = blockIdx.y * 128 + wave * 32 + l31;
+    const int mrow = m < p.M ? m : p.M - 1;
+    const int ntiles = (p.N + 63) / 64;
+    const int nt0 = blockIdx.x * tiles_per_wg;
+    const int nt1 = nt0 + tiles_per_wg < ntiles ? nt0 + tiles_per_wg : ntiles;
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* W = static_cast<const uint16_t*>(p.W);
+
+    uint4 wr[2 * KC];
+    auto wload = [&](int nt) {
+#pragma unroll
+        for (int i = 0; i < 2 * KC; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / CPR, c = id - r * CPR;
+            const int n = nt * 64 + r;
+            wr[i] = n < p.N ? *reinterpret_cast<const uint4*>(W + (int64_t)n * p.ldw + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+    auto wstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2 * KC; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / CPR, c = id - r * CPR;
+            *reinterpret_cast<uint4*>(Ws + r * LDW + c * 8) = wr[i];
+        }
+    };
+
+    wload(nt0);
+    bf16x8 xf[KS];
+    {
+        const uint16_t* xp = A + (int64_t)mrow * p.lda + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + 16 * ks);
+    }
+    wstore();
+    __syncthreads();
+
+    const float mk = p.mask ? (p.mask[mrow] ? 1.0f : 0.0f) : 1.0f;
+    for (int nt = nt0; nt < nt1; ++nt) {
+        if (nt + 1 < nt1) wload(nt + 1);
+        f32x16 acc[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+        const uint16_t* wp = Ws + l31 * LDW + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp + 16 * ks);
+            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 32 * LDW + 16 * ks);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[ks], acc[1], 0, 0, 0);
+        }
+        // epilogue: register 4g+e of tile t is output feature n = nt*64 + t*32 + 8g + 4h + e, row m (this lane)
+        if (p.cpb == -7) {  // ablation (experiments only): keep the accumulators live, skip the epilogue
+            if (acc[0][0] + acc[1][5] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
+        } else if (m < p.M) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nt * 64 + t * 32 + 8 * g + 4 * h;
+                    if (n >= p.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[t][4 * g + e];
+                    epilogue_vec4(p, m, n, v, mk);
+                }
+        }
+        __syncthreads();  // every wave has finished reading the current weight tile
+        if (nt + 1 < nt1) wstore();
+        __syncthreads();
+    }
+}
+
+template <int KC>
+int32_t launch_panel(const GemmParams& p, hipStream_t s) {
+    constexpr size_t lds = (size_t)64 * (64 * KC + 8) * sizeof(uint16_t);
+    const int ntiles = (p.N + 63) / 64, mblocks = (p.M + 127) / 128;
+    int nsplit = (512 + mblocks - 1) / mblocks;          // aim for >= 512 workgroups (2 per CU)
+    if (const char* e = getenv("ISPK_PANEL_NSPLIT")) nsplit = atoi(e);  // experiments only
+    nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
+    const int per = (ntiles + nsplit - 1) / nsplit;
+    dim3 grid((ntiles + per - 1) / per, mblocks);
+    hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC>), grid, dim3(256), lds, s, p, per);
+    return ispk_launch_status();
+}
+
+bool panel_ok(const GemmParams& p) {
+    return (p.K == 256 || p.K == 384) && vec_epilogue_ok(p) && getenv("ISPK_NO_PANEL") == nullptr;
+}
+
+bool wide_ok(const GemmParams& p) {
+    return p.K >= 512 && (p.N == 384 || p.N == 256) && p.M >= 128 * 64 && vec_epilogue_ok(p) &&
+           getenv("ISPK_NO_WIDE") == nullptr;
+}
+
 template <int TM, int TN>
 int32_t launch_f32(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -287,7 +566,7 @@ int32_t check_common(const GemmParams& p, int elt) {
     ISPK_REQUIRE(!((p.flags & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT)) && !p.mask), ISPK_E_NULL,
                  "gemm: mask flag set but mask is NULL");
     ISPK_REQUIRE(!(p.cpb > 0 && p.resid), ISPK_E_UNSUPPORTED, "gemm: resid with a batched (transposed) store");
-    ISPK_REQUIRE(p.cpb >= 0 && (p.cpb == 0 || p.N % p.cpb == 0), ISPK_E_SHAPE, "gemm: N %% cols_per_batch != 0");
+    ISPK_REQUIRE(p.cpb >= -7 && (p.cpb <= 0 || p.N % p.cpb == 0), ISPK_E_SHAPE, "gemm: N %% cols_per_batch != 0");
     ISPK_REQUIRE((p.flags & ISPK_EP_GELU) == 0 || (p.flags & ISPK_EP_SILU) == 0, ISPK_E_UNSUPPORTED,
                  "gemm: GELU and SILU together");
     return 0;
@@ -298,6 +577,7 @@ int32_t check_common(const GemmParams& p, int elt) {
 // tile choice: the largest tile that still gives every one of the 256 CUs a workgroup.  Returns TM*10 + TN.
 extern "C" int32_t ispk_gemm_f32_tile(int32_t M, int32_t N, int32_t K) {
     (void)K;
+    if (const char* e = getenv("ISPK_GEMM_TILE")) return atoi(e);  // experiments only (tools/bench_kernels.py)
     const int64_t wg128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
     const int64_t wg64x128 = (int64_t)((M + 63) / 64) * ((N + 127) / 128);
     if (wg128 >= 256) return 22;
@@ -327,9 +607,12 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
                                   int32_t N, int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride,
                                   ispk_stream_t stream) {
     GemmParams p{A, lda, W, ldw, C, ldc, bias, resid, ldr, mask, M, N, K, flags, cols_per_batch, batch_stride};
+    if (getenv("ISPK_PANEL_NOEPI")) p.cpb = -7;  // experiments only
     if (int32_t rc = check_common(p, 2)) return rc;
     if (M == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (panel_ok(p)) return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
+    if (wide_ok(p)) return N == 384 ? launch_wide<6>(p, s) : launch_wide<4>(p, s);
     switch (ispk_gemm_f32_tile(M, N, K)) {  // same occupancy rule as the fp32 path
         case 22: return launch_bf16<2, 2>(p, s);
         case 12: return launch_bf16<1, 2>(p, s);

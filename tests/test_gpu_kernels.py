@@ -260,7 +260,9 @@ def _bf(t):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (32768, 512, 384), (300, 1536, 384), (777, 384, 1536),
-                                   (64, 64, 8), (130, 80, 384)])
+                                   (64, 64, 8), (130, 80, 384),
+                                   (8200, 384, 1536), (8300, 256, 1024),      # "wide" kernel (long K), ragged M
+                                   (6400, 384, 256), (515, 1024, 256)])       # "panel" kernel with K = 256
 def test_gemm_bf16_shapes(M, N, K):
     """bf16 operands, fp32 accumulation: compared with a float64 product of the SAME bf16-rounded operands, so the only
     differences are accumulation order (fp32) and the output rounding (bf16: 2^-9 relative)."""
@@ -273,12 +275,16 @@ def test_gemm_bf16_shapes(M, N, K):
     assert ((out16.double() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-6).all()
 
 
-def test_gemm_bf16_epilogues():
-    B, T, K, N = 3, 210, 384, 384
+@pytest.mark.parametrize("K", [384, 1536])
+def test_gemm_bf16_epilogues(K):
+    B, T, N = 3, 2810, 384      # 8430 rows: K=384 -> panel kernel, K=1536 -> wide kernel
     a, w = _bf(synth._normal("t/gemm/ea", (B, T, K))), _bf(synth._normal("t/gemm/ew", (N, K), K ** -0.5))
     bias, resid = synth._normal("t/gemm/eb", (N,)), synth._normal("t/gemm/er", (B, T, N))
     mask = torch.arange(T)[None] < torch.tensor([T, 100, 1])[:, None]
     d = lambda t: t.to(DEV)  # noqa: E731
+    out = runtime.gemm(d(a), d(w), bias=d(bias), flags=runtime.EP_GELU).cpu()      # bf16 out: fast GELU + rounding
+    ref = _gemm_ref(a, w, bias=bias, act="gelu")
+    assert ((out.double() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-5).all()
     out = runtime.gemm(d(a), d(w), bias=d(bias), flags=runtime.EP_GELU, out_dtype=torch.float32).cpu()
     assert (out.double() - _gemm_ref(a, w, bias=bias, act="gelu")).abs().max() < 2e-5
     out = runtime.gemm(d(a), d(w), resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_ACC, out_dtype=torch.float32).cpu()

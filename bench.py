@@ -35,6 +35,7 @@ from isp_tts_amd import runtime, synth  # noqa: E402
 from isp_tts_amd.acoustic import AcousticModel  # noqa: E402
 from isp_tts_amd.config import AcousticDims  # noqa: E402
 from isp_tts_amd.dist import all_gather_mel  # noqa: E402
+from isp_tts_amd.graph import GraphedForward  # noqa: E402
 
 # gfx950 peaks from /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters", dense, no sparsity)
 PEAK = {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3, "mfma_bf16_TFs": 2500.0}
@@ -51,6 +52,7 @@ def parse():
     ap.add_argument("--mel-len", type=int, default=512)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (no roofline object)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=5)
@@ -142,9 +144,17 @@ def main():
     inp = synth.make_inputs(B, L, M, seed=synth.SEED + rank)           # each rank owns different utterances
     d = {k: v.to(dev) for k, v in inp.items()}
 
+    def eager_step():
+        return model(d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
+                     flow_noise=d["flow_x0"], flow_time=d["flow_t"])
+
+    graphed = None
+    if not args.no_graph:   # the whole forward as one HIP graph: ~300 launches per step would otherwise be host-bound
+        graphed = GraphedForward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
+                                 d["flow_x0"], d["flow_t"])
+
     def step():
-        out = model(d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
-                    flow_noise=d["flow_x0"], flow_time=d["flow_t"])
+        out = graphed.replay() if graphed is not None else eager_step()
         if world > 1:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather)
             all_gather_mel(out.mel, out.adaptor_output.dec_lengths, max_frames=M, max_batch=B)
         return out
@@ -158,8 +168,8 @@ def main():
     for _ in range(args.warmup):
         step()
     prof = None
-    if not args.no_kernel_events and rank == 0:
-        prof = runtime.LaunchProfiler()
+    if not args.no_kernel_events and rank == 0 and graphed is None:
+        prof = runtime.LaunchProfiler()          # eager mode: events around every launch of the timed region
         runtime.set_profiler(prof)
     fence()
     t0 = time.perf_counter()
@@ -169,6 +179,16 @@ def main():
     elapsed = time.perf_counter() - t0
     runtime.set_profiler(None)
     assert torch.isfinite(out.mel).all()
+    prof_steps = args.steps
+    if not args.no_kernel_events and rank == 0 and graphed is not None:
+        # graph replays cannot carry timing events: time the SAME kernels, launched eagerly, right after the timed region
+        prof = runtime.LaunchProfiler()
+        runtime.set_profiler(prof)
+        prof_steps = min(args.steps, 5)
+        for _ in range(prof_steps):
+            eager_step()
+        torch.cuda.synchronize()
+        runtime.set_profiler(None)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -188,11 +208,15 @@ def main():
                                    "random-init weights of the recipe architecture (23.2 M params)",
                        "batch_per_gpu": B, "global_batch": world * B, "text_len": L, "mel_len": M,
                        "parallelism": f"dp{world} (utterances sharded, RCCL all-gather of mel)" if world > 1 else "single GPU",
-                       "device": name, "compute_units": cus},
+                       "device": name, "compute_units": cus,
+                       "launch": "eager" if graphed is None else "HIP graph replay"},
             "model_TFLOPs": round(value * FLOP_PER_FRAME / 1e12, 2),
         }
         if prof is not None:
-            line["roofline"] = roofline(prof.summary(), args.steps, args.dtype)
+            line["roofline"] = roofline(prof.summary(), prof_steps, args.dtype)
+            line["roofline"]["timing"] = ("HIP events around every launch of the timed region" if graphed is None else
+                                          f"HIP events around every launch of {prof_steps} eager passes of the same step "
+                                          "(the timed region replays them as one HIP graph)")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args, sd)
             line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)

@@ -176,9 +176,7 @@ extern "C" int32_t ispk_alibi_mqa_attn_f32(const float* q, int64_t ldq, const fl
     if (B == 0) return 0;
     constexpr size_t lds = (size_t)4 * kTileKeys * kLdk * sizeof(float);  // 69,632 B
     static_assert(lds <= 160 * 1024, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) ISPK_FAIL((int32_t)e, "attn: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    ISPK_RESERVE_LDS(&attn_f32_kernel, lds, "attn");
     dim3 grid((N + 63) / 64, B), block(2 * H * 64);
     hipLaunchKernelGGL(attn_f32_kernel, grid, block, lds, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv,
                        slopes, key_len, out, ldo, N, H);

@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "../../include/ispk.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,6 +25,21 @@ char* ispk_err_buf();
 #define ISPK_REQUIRE(cond, code, ...) \
     do {                              \
         if (!(cond)) ISPK_FAIL(code, __VA_ARGS__); \
+    } while (0)
+
+// Dynamic LDS above 64 KiB needs a one-time per-kernel opt-in.  Done once per call site (an idempotent cache, the only
+// mutable state in the library) so that launch functions stay free of non-stream API calls and can be graph-captured.
+#define ISPK_RESERVE_LDS(kernel, bytes, what)                                                                       \
+    do {                                                                                                            \
+        static std::atomic<size_t> reserved_{0};                                                                    \
+        if ((size_t)(bytes) > 64 * 1024 && reserved_.load(std::memory_order_acquire) < (size_t)(bytes)) {           \
+            hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),                              \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes));          \
+            if (e_ != hipSuccess)                                                                                   \
+                ISPK_FAIL((int32_t)e_, what ": cannot reserve %zu B of LDS: %s", (size_t)(bytes),                   \
+                          hipGetErrorString(e_));                                                                   \
+            reserved_.store((size_t)(bytes), std::memory_order_release);                                            \
+        }                                                                                                           \
     } while (0)
 
 static inline int32_t ispk_launch_status() {

@@ -254,11 +254,7 @@ int32_t launch_bf16(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr size_t lds = (size_t)2 * (BM + BN) * kLdtH * sizeof(uint16_t);
     static_assert(lds <= 64 * 1024 || true, "");
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<TM, TN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) ISPK_FAIL((int32_t)e, "gemm: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-    }
+    ISPK_RESERVE_LDS((&gemm_bf16_kernel<TM, TN>), lds, "gemm");
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
     hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN>), grid, dim3(256), lds, s, p);
     return ispk_launch_status();
@@ -410,9 +406,7 @@ template <int TN>
 int32_t launch_wide(const GemmParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * (128 + 64 * TN) * 72 * sizeof(uint16_t);
     static_assert(lds <= 160 * 1024, "LDS budget");
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_wide_kernel<TN>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) ISPK_FAIL((int32_t)e, "gemm: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
+    ISPK_RESERVE_LDS((&gemm_bf16_wide_kernel<TN>), lds, "gemm");
     hipLaunchKernelGGL((gemm_bf16_wide_kernel<TN>), dim3((p.M + 127) / 128), dim3(512), lds, s, p);
     return ispk_launch_status();
 }
@@ -545,11 +539,7 @@ template <int TM, int TN>
 int32_t launch_f32(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr size_t lds = (size_t)2 * (BM + BN) * kLdt * sizeof(float);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<TM, TN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) ISPK_FAIL((int32_t)e, "gemm: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-    }
+    ISPK_RESERVE_LDS((&gemm_f32_kernel<TM, TN>), lds, "gemm");
     dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
     hipLaunchKernelGGL((gemm_f32_kernel<TM, TN>), grid, dim3(256), lds, s, p);
     return ispk_launch_status();

@@ -187,11 +187,7 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
 template <int NC>
 int32_t launch(const float* logits, const int64_t* text_len, const int64_t* mel_len, int16_t* attn_hard, int64_t* dur,
                int16_t* path, int B, int M_max, int L_max, int64_t sb, int64_t sm, size_t lds, hipStream_t stream) {
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mas_kernel<NC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) ISPK_FAIL((int32_t)e, "mas: cannot reserve %zu B of LDS: %s", lds, hipGetErrorString(e));
-    }
+    ISPK_RESERVE_LDS((&mas_kernel<NC>), lds, "mas");
     hipLaunchKernelGGL(mas_kernel<NC>, dim3(B), dim3(256), lds, stream, logits, text_len, mel_len, attn_hard, dur, path,
                        M_max, L_max, sb, sm);
     return ispk_launch_status();

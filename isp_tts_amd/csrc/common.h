@@ -5,6 +5,7 @@
 #include <stdio.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "../../include/ispk.h"
 
@@ -12,6 +13,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
 typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));  // native vector: HIP's uint4 (a union type) can block SROA
 
 // thread-local last-error text (set by ISPK_FAIL, read through ispk_last_error_string)
 char* ispk_err_buf();
@@ -61,19 +63,65 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) {
 }
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// GELU(erf) with the Abramowitz-Stegun 7.1.26 erf (|error| <= 1.5e-7): 1 rcp + 1 exp + 7 FMA instead of libm erff.
-// Used where the result is rounded to bf16 anyway (relative step 2^-9); the fp32 parity path keeps erff.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// GELU(erf) for outputs that are rounded to bf16 anyway, two elements at a time so the polynomial runs on packed fp32
+// (v_pk_fma_f32 / v_pk_mul_f32).  erf by Abramowitz-Stegun 7.1.28: erf(z) = 1 - (1 + a1 z + .. + a6 z^6)^-16, z >= 0,
+// |error| <= 3e-7; then gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - 0.5 |x| q^-16.
+// 6 FMA + 4 squarings + 1 rcp per element (libm erff: ~40 instructions with branches).  The fp32 parity path keeps erff.
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    f32x2 ax;
+    ax.x = fabsf(x.x);
+    ax.y = fabsf(x.y);
+    const f32x2 z = ax * 0.70710678118654752440f;
+    f32x2 q = z * 0.0000430638f + 0.0002765672f;
+    q = q * z + 0.0001520143f;
+    q = q * z + 0.0092705272f;
+    q = q * z + 0.0422820123f;
+    q = q * z + 0.0705230784f;
+    q = q * z + 1.0f;
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    q = q * q;  // q^16 (overflows to +inf for |x| > ~25: the reciprocal is then exactly 0, as it should be)
+    f32x2 r;
+    r.x = __builtin_amdgcn_rcpf(q.x);
+    r.y = __builtin_amdgcn_rcpf(q.y);
+    f32x2 pos;
+    pos.x = fmaxf(x.x, 0.0f);
+    pos.y = fmaxf(x.y, 0.0f);
+    return pos - (ax * 0.5f) * r;
+}
 __device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float poly = fmaf(1.061405429f, t, -1.453152027f);
-    poly = fmaf(poly, t, 1.421413741f);
-    poly = fmaf(poly, t, -0.284496736f);
-    poly = fmaf(poly, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);
-    const float erf_abs = 1.0f - poly * t * e;
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    f32x2 v;
+    v.x = x;
+    v.y = x;
+    return gelu_fast2(v).x;
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 constexpr int kWave = 64;
+
+// ---- hand-scheduled LDS reads (guide §5.7): hipcc sinks every ds_read next to its consumer and keeps at most two in
+// flight, which makes short MFMA loops LDS-latency-bound.  These reads are opaque to its scheduler; the caller counts
+// them with lds_wait<N>() (LDS operations complete in order, so "at most N outstanding" retires everything older)
+// and fences the consumer with __builtin_amdgcn_sched_barrier(0) after the wait (rule 18).
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_asm(bf16x8& dst, uint32_t lds_byte_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void lds_wait() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}

@@ -268,8 +268,16 @@ __device__ __forceinline__ void epilogue_vec4(const GemmParams& p, int m, int n,
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
     }
     if (p.flags & ISPK_EP_GELU) {
+        if (p.flags & ISPK_EP_OUT_BF16) {
+            f32x2 a, b;
+            a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+            a = gelu_fast2(a);
+            b = gelu_fast2(b);
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (p.flags & ISPK_EP_OUT_BF16) ? gelu_fast(v[e]) : gelu_erf(v[e]);
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
     }
     if (p.flags & ISPK_EP_SILU) {
 #pragma unroll
@@ -303,6 +311,119 @@ __device__ __forceinline__ void epilogue_vec4(const GemmParams& p, int m, int n,
     } else {
         *reinterpret_cast<float4*>(static_cast<float*>(p.C) + co) = make_float4(v[0], v[1], v[2], v[3]);
     }
+}
+
+// ---- row-coalescing epilogue for the transposed-compute kernels.
+// In the MFMA C/D fragment a lane owns ONE activation row and scattered groups of 4 output features, so direct stores
+// write 16-byte pieces of 32 different rows per instruction — the memory system then handles 8 partial writes per 128-B
+// line and the epilogue, not the MFMA loop, bounds the kernel (measured: 0.53 vs 1.0 PFLOP/s incremental).  Here a
+// wave passes its tile through a private 32 x 144-B LDS patch (no barrier: LDS operations of one wave complete in order)
+// and comes out with lane = (row, 16-byte chunk), so the residual is read and the output written as full 128-B rows.
+constexpr int kStageRow = 144;               // bytes per staged row (128 + 16: keeps ds_read_b128 aligned, spreads banks)
+constexpr int kStageBytes = 32 * kStageRow;  // per wave
+
+__device__ __forceinline__ void pre_stage(const GemmParams& p, int n, float (&v)[4], float mk) {
+    if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+    if (p.flags & ISPK_EP_GELU) {
+        if (p.flags & ISPK_EP_OUT_BF16) {
+            f32x2 a, b;
+            a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
+            a = gelu_fast2(a);
+            b = gelu_fast2(b);
+            v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+    }
+    if (p.flags & ISPK_EP_SILU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
+    }
+    if (p.flags & ISPK_EP_MASK_ACC) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= mk;
+    }
+}
+
+// fp32 output: one 32-feature tile (features n0 .. n0+31) of the wave's 32 rows (m0 .. m0+31)
+__device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage, int m0, int n0, const f32x16& acc,
+                                               float mk, int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e];
+        const int n = n0 + 8 * g + 4 * h;
+        pre_stage(p, n < p.N ? n : 0, v, mk);
+        *reinterpret_cast<float4*>(stage + l31 * kStageRow + (8 * g + 4 * h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    const int c = lane & 7, n = n0 + 4 * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3), m = m0 + r;
+        float4 v = *reinterpret_cast<const float4*>(stage + r * kStageRow + c * 16);
+        if (m < p.M && n < p.N) {
+            if (p.resid) {
+                const int64_t ro = (int64_t)m * p.ldr + n;
+                if (p.flags & ISPK_EP_RESID_BF16) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p.resid) + ro);
+                    v.x += bf16_to_f32((uint16_t)(rr.x & 0xffffu)); v.y += bf16_to_f32((uint16_t)(rr.x >> 16));
+                    v.z += bf16_to_f32((uint16_t)(rr.y & 0xffffu)); v.w += bf16_to_f32((uint16_t)(rr.y >> 16));
+                } else {
+                    const float4 rr = *reinterpret_cast<const float4*>(static_cast<const float*>(p.resid) + ro);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+            }
+            if (p.flags & ISPK_EP_MASK_OUT) {
+                const float mo = p.mask[m] ? 1.0f : 0.0f;
+                v.x *= mo; v.y *= mo; v.z *= mo; v.w *= mo;
+            }
+            *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = v;
+        }
+    }
+}
+
+// bf16 output: two adjacent 32-feature tiles (features n0 .. n0+63); no residual on this path
+__device__ __forceinline__ void store_rows_bf16(const GemmParams& p, char* stage, int m0, int n0, const f32x16& acc0,
+                                                const f32x16& acc1, float mk, int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = t ? acc1[4 * g + e] : acc0[4 * g + e];
+            const int n = n0 + t * 32 + 8 * g + 4 * h;
+            pre_stage(p, n < p.N ? n : 0, v, mk);
+            if (p.flags & ISPK_EP_MASK_OUT) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= mk;
+            }
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (t * 32 + 8 * g + 4 * h) * 2) = o;
+        }
+    const int c = lane & 7, n = n0 + 8 * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = 8 * i + (lane >> 3), m = m0 + r;
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
+        if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.C) + (int64_t)m * p.ldc + n) = v;
+    }
+}
+
+// can the row-coalescing epilogue be used?  (else: epilogue_vec4)
+inline bool rows_epilogue_ok(const GemmParams& p) {
+    if (p.flags & ISPK_EP_OUT_BF16)
+        return !p.resid && p.N % 8 == 0 && p.ldc % 8 == 0 && ((uintptr_t)p.C & 15) == 0;
+    return true;  // fp32 out: vec_epilogue_ok() already guarantees 16-byte alignment of C / resid rows
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -386,8 +507,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_wide_kernel(GemmParams p) {
     }
 
     const int m = m0 + wm * 32 + l31;
-    if (m < p.M) {
-        const float mk = p.mask ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+    const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+    if (!(p.flags & ISPK_EP_OUT_BF16)) {
+        // the K loop is over: its LDS tiles are dead, every wave takes a private patch of them for the row transpose
+        char* stage = smem_raw + wave * kStageBytes;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) store_rows_f32(p, stage, m0 + wm * 32, (wn * TN + t) * 32, acc[t], mk, lane);
+    } else if (m < p.M) {
 #pragma unroll
         for (int t = 0; t < TN; ++t)
 #pragma unroll
@@ -433,101 +559,143 @@ bool vec_epilogue_ok(const GemmParams& p) {
 //     vector accesses (4 store instructions per 32x32 tile instead of 16 scalar ones);
 //   * the N range is split over blockIdx.x so that >= 512 workgroups exist (2 per CU).
 template <int KC>  // K = 64 * KC
-__global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, int tiles_per_wg) {
-    constexpr int K = 64 * KC, LDW = K + 8, KS = K / 16, CPR = K / 8;  // CPR: 16-B chunks per weight row
+__global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, int tiles_per_wg, int nsplit, int mblocks) {
+    constexpr int K = 64 * KC, LDW = K + 8, KS = K / 16, CPR = K / 8;  // CPR: 16-B chunks per row
+    constexpr int HCH = 32 * CPR / 256;                                 // chunks per thread per 32-row half tile (= KC)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint16_t* Ws = reinterpret_cast<uint16_t*>(smem_raw);  // [64][LDW]
+    uint16_t* Ws = reinterpret_cast<uint16_t*>(smem_raw);  // [64][LDW]: weight tile as two 32-row halves
+
+    // XCD-aware block mapping: blocks b and b+8 share an XCD (and its L2).  The nsplit blocks that re-read the same 128
+    // activation rows are placed on ONE XCD, back to back, so only the first of them goes to HBM for those rows.
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ns = jj % nsplit, mb = (jj / nsplit) * 8 + xcd;
+    if (mb >= mblocks) return;  // whole workgroup, before any barrier
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int m = blockIdx.y * 128 + wave * 32 + l31;
-    const int mrow = m < p.M ? m : p.M - 1;
+    const int m = mb * 128 + wave * 32 + l31;
     const int ntiles = (p.N + 63) / 64;
-    const int nt0 = blockIdx.x * tiles_per_wg;
+    const int nt0 = ns * tiles_per_wg;
     const int nt1 = nt0 + tiles_per_wg < ntiles ? nt0 + tiles_per_wg : ntiles;
+    if (nt0 >= nt1) return;
     const uint16_t* A = static_cast<const uint16_t*>(p.A);
     const uint16_t* W = static_cast<const uint16_t*>(p.W);
 
-    uint4 wr[2 * KC];
-    auto wload = [&](int nt) {
+    // ---- half-tile (32 weight rows) staging: registers <-> LDS.  Separately named register arrays and statically
+    // indexed, unconditional loads (row index clamped; rows >= N only feed outputs that are never stored): anything
+    // runtime-indexed or predicated here ends up in scratch or behind per-load branches.
+    u32x4 wr0[HCH], wr1[HCH];
+    const int ntc = nt1 - 1;
+    auto wload = [&](u32x4 (&dst)[HCH], int nt, int half) {
+        nt = nt < ntc ? nt : ntc;
 #pragma unroll
-        for (int i = 0; i < 2 * KC; ++i) {
+        for (int i = 0; i < HCH; ++i) {
             const int id = tid + 256 * i;
             const int r = id / CPR, c = id - r * CPR;
-            const int n = nt * 64 + r;
-            wr[i] = n < p.N ? *reinterpret_cast<const uint4*>(W + (int64_t)n * p.ldw + c * 8) : make_uint4(0u, 0u, 0u, 0u);
+            int n = nt * 64 + half * 32 + r;
+            n = n < p.N ? n : p.N - 1;
+            dst[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * p.ldw + c * 8);
         }
     };
-    auto wstore = [&]() {
+    auto wstore = [&](const u32x4 (&src)[HCH], int half) {
 #pragma unroll
-        for (int i = 0; i < 2 * KC; ++i) {
+        for (int i = 0; i < HCH; ++i) {
             const int id = tid + 256 * i;
             const int r = id / CPR, c = id - r * CPR;
-            *reinterpret_cast<uint4*>(Ws + r * LDW + c * 8) = wr[i];
+            *reinterpret_cast<u32x4*>(Ws + (half * 32 + r) * LDW + c * 8) = src[i];
         }
     };
 
-    wload(nt0);
+    // ---- prologue: ONE burst of K/16 independent 16-B loads per lane puts the wave's 32 activation rows, for the whole
+    // K, straight into MFMA B-operand fragments (lane = row, half h = k offset 8h).  Four consecutive k-steps share a
+    // 128-B line and are issued back to back, so the line is fetched once.  (Staging the panel through LDS instead
+    // was tried: the conditional per-wave fragment reads made hipcc spill the staging registers to scratch.)
     bf16x8 xf[KS];
     {
+        const int mrow = m < p.M ? m : p.M - 1;
         const uint16_t* xp = A + (int64_t)mrow * p.lda + 8 * h;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + 16 * ks);
     }
-    wstore();
+    wload(wr0, nt0, 0);
+    wload(wr1, nt0, 1);
+    wstore(wr0, 0);
+    wstore(wr1, 1);
+    wload(wr0, nt0 + 1, 0);
+    wload(wr1, nt0 + 1, 1);
     __syncthreads();
 
-    const float mk = p.mask ? (p.mask[mrow] ? 1.0f : 0.0f) : 1.0f;
+    const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+    const uint32_t wbase = lds_addr(Ws + l31 * LDW + 8 * h);
+    char* stage = smem_raw + (size_t)64 * LDW * sizeof(uint16_t) + wave * kStageBytes;  // wave-private epilogue patch
+    const int mw0 = mb * 128 + wave * 32;
     for (int nt = nt0; nt < nt1; ++nt) {
-        if (nt + 1 < nt1) wload(nt + 1);
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
-        const uint16_t* wp = Ws + l31 * LDW + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 w0 = *reinterpret_cast<const bf16x8*>(wp + 16 * ks);
-            const bf16x8 w1 = *reinterpret_cast<const bf16x8*>(wp + 32 * LDW + 16 * ks);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[ks], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[ks], acc[1], 0, 0, 0);
+        // The 2*KS weight-fragment reads of a tile form ONE stream through a D-deep register ring: the read for step
+        // s+D is issued right after step s's MFMA, so D ds_read_b128 stay in flight (left to itself hipcc keeps two and
+        // every MFMA waits on LDS latency; it also dissolves a ring written in plain C++, hence the opaque asm reads
+        // with hand-counted waits).  Half 0 (steps < KS) is refilled with tile nt+1 after barrier 1 while half 1
+        // computes, and vice versa; half 1's reads may be issued before barrier 1 (that half is stable by then).
+        constexpr int D = 3, NS = 2 * KS;
+        bf16x8 wq[D];
+        static_for<0, D>([&](auto ic) {
+            constexpr int st = decltype(ic)::value;
+            lds_read_b128_asm<((st / KS) * 32 * LDW + 16 * (st % KS)) * 2>(wq[st], wbase);
+        });
+        static_for<0, NS>([&](auto ic) {
+            constexpr int st = decltype(ic)::value;
+            if constexpr (st == KS) {
+                __syncthreads();  // barrier 1: every wave is done with half 0
+                if (nt + 1 < nt1) {
+                    wstore(wr0, 0);
+                    wload(wr0, nt + 2, 0);
+                }
+            }
+            constexpr int younger = (NS - 1 - st) < (D - 1) ? (NS - 1 - st) : (D - 1);
+            lds_wait<younger>();
+            __builtin_amdgcn_sched_barrier(0);
+            acc[st / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[st % D], xf[st % KS], acc[st / KS], 0, 0, 0);
+            if constexpr (st + D < NS) {
+                constexpr int nx = st + D;
+                lds_read_b128_asm<((nx / KS) * 32 * LDW + 16 * (nx % KS)) * 2>(wq[st % D], wbase);
+            }
+        });
+        __syncthreads();  // barrier 2: every wave is done with half 1
+        if (nt + 1 < nt1) {
+            wstore(wr1, 1);
+            wload(wr1, nt + 2, 1);
         }
-        // epilogue: register 4g+e of tile t is output feature n = nt*64 + t*32 + 8g + 4h + e, row m (this lane)
+        // epilogue: register 4g+e of tile half t is output feature n = nt*64 + t*32 + 8g + 4h + e, row m (this lane)
         if (p.cpb == -7) {  // ablation (experiments only): keep the accumulators live, skip the epilogue
             if (acc[0][0] + acc[1][5] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
-        } else if (m < p.M) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = nt * 64 + t * 32 + 8 * g + 4 * h;
-                    if (n >= p.N) continue;
-                    float v[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[t][4 * g + e];
-                    epilogue_vec4(p, m, n, v, mk);
-                }
+        } else if (p.flags & ISPK_EP_OUT_BF16) {
+            store_rows_bf16(p, stage, mw0, nt * 64, acc[0], acc[1], mk, lane);
+        } else {
+            store_rows_f32(p, stage, mw0, nt * 64, acc[0], mk, lane);
+            store_rows_f32(p, stage, mw0, nt * 64 + 32, acc[1], mk, lane);
         }
-        __syncthreads();  // every wave has finished reading the current weight tile
-        if (nt + 1 < nt1) wstore();
-        __syncthreads();
     }
 }
 
 template <int KC>
 int32_t launch_panel(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)64 * (64 * KC + 8) * sizeof(uint16_t);
+    constexpr size_t lds = (size_t)64 * (64 * KC + 8) * sizeof(uint16_t) + 4 * kStageBytes;
     const int ntiles = (p.N + 63) / 64, mblocks = (p.M + 127) / 128;
     int nsplit = (512 + mblocks - 1) / mblocks;          // aim for >= 512 workgroups (2 per CU)
     if (const char* e = getenv("ISPK_PANEL_NSPLIT")) nsplit = atoi(e);  // experiments only
     nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
     const int per = (ntiles + nsplit - 1) / nsplit;
-    dim3 grid((ntiles + per - 1) / per, mblocks);
-    hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC>), grid, dim3(256), lds, s, p, per);
+    nsplit = (ntiles + per - 1) / per;
+    const int mb8 = (mblocks + 7) / 8 * 8;
+    ISPK_RESERVE_LDS((&gemm_bf16_panel_kernel<KC>), lds, "gemm");
+    hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC>), dim3(mb8 * nsplit), dim3(256), lds, s, p, per, nsplit, mblocks);
     return ispk_launch_status();
 }
 
 bool panel_ok(const GemmParams& p) {
-    return (p.K == 256 || p.K == 384) && vec_epilogue_ok(p) && getenv("ISPK_NO_PANEL") == nullptr;
+    return (p.K == 256 || p.K == 384) && vec_epilogue_ok(p) && rows_epilogue_ok(p) && getenv("ISPK_NO_PANEL") == nullptr;
 }
 
 bool wide_ok(const GemmParams& p) {

@@ -14,16 +14,21 @@ R = int(sys.argv[sys.argv.index("--rows") + 1]) if "--rows" in sys.argv else 327
 dev = "cuda"
 
 
-def time_it(fn, rounds=20):
+def time_it(fn, rounds=7, inner=20):
+    """Median over rounds of (time of `inner` back-to-back launches) / inner: excludes the ~15 us idle-launch +
+    event floor that a single timed launch carries."""
     for _ in range(3):
         fn()
     torch.cuda.synchronize()
     ts = []
     for _ in range(rounds):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record()
+        e0.record()
+        for _ in range(inner):
+            fn()
+        e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.append(e0.elapsed_time(e1) * 1e3 / inner)
     ts.sort()
     return ts[len(ts) // 2], ts[0]
 

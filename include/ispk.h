@@ -89,7 +89,8 @@ int32_t ispk_layernorm_f32_bf16(const float* x, int64_t ldx, const float* gamma,
  *          (to_mel: A = weight [80][384], "W" = activations [B*M][384], cpb = M, ldc = M, batch_stride = 80*M
  *           -> mel[B][80][M] written with consecutive lanes along the mel-frame axis)
  *
- * Requirements: K % 8 == 0; lda, ldw % 4 == 0 (fp32) / % 8 (bf16); A, W 16-byte aligned.
+ * Requirements: K % 8 == 0; lda, ldw % 4 == 0 (fp32) / % 8 (bf16); A, W 16-byte aligned.  lda may be SMALLER than K:
+ * rows then overlap in memory (the sliding-window view that turns a padded channel-last Conv1d into a GEMM, see below).
  * _f32      : fp32 in, v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate), fp32 out.
  * _bf16     : bf16 in, v_mfma_f32_32x32x16_bf16 (fp32 accumulate), epilogue in fp32; C/resid dtype per flags.
  */
@@ -140,6 +141,43 @@ int32_t ispk_alibi_mqa_attn_f32(const float* q, int64_t ldq, const float* k, con
 int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v, int64_t ldkv,
                                  const float* slopes, const int64_t* key_len, uint16_t* out, int64_t ldo, int32_t B,
                                  int32_t N, int32_t H, ispk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Aligner front-end (the ConvAttention that produces the MAS input), fp32, channel-last padded layout.
+ * Replaces: models/acoustic/modules/alignment.py:69-83 (ConvBlock1D), :159-208 (ConvAttention.forward), :18-37
+ * (batch_diagonal_prior) and modules/normalization.py:160-208 (_masked_norm "instance").
+ *
+ * Layout: activations are [B][T+4][C] — channel-last, two zero rows before and after every utterance.  A Conv1d with
+ * kernel 5 / padding 2 over such a buffer is ONE ispk_gemm_f32 call over overlapping rows (lda = C, K = 5*C,
+ * M = B*(T+4) - 4, weight [O][5*C] = conv.weight.permute(0,2,1)); output row b*(T+4)+t is frame t.
+ *
+ * ispk_pad_rows_f32        out[b][t+2][c] = t < len[b] ? x[b*sb + t*st + c*sc] : 0, pad rows zero
+ *                          (x*mask of alignment.py:75 plus the layout change; strides in elements, so a channel-first
+ *                           mel [B][C][T] is read with st = 1, sc = T).
+ * ispk_masked_instnorm_f32 y: conv output [B][T+4][C] (row t = frame t); per (b, c) mean / biased variance over frames
+ *                          t < len[b]; out[b][t+2][c] = t < len[b] ? (y - mean)/sqrt(var + eps)*weight[c] + bias[c] : 0,
+ *                          pad rows zero — i.e. the norm, the affine AND the next block's `x * input_mask`.
+ * ispk_aligner_scores_f32  q_enc [B][..][128] (frame rows at q_stride_b per utterance), k_enc likewise (text rows):
+ *                          S = q·k / sqrt(128) clamped to fp32 max; attn_logits = log_softmax(S over all L columns)
+ *                          + log(prior + 1e-6) with the diagonal prior evaluated analytically (gamma 0.1, rows normalised
+ *                          with +1e-5, entries < 1e-4 zeroed, zero outside the lengths); attn_soft = softmax over the
+ *                          keys < text_len of attn_logits, zero for keys >= text_len and frames >= mel_len.
+ *                          Both outputs [B][M][L] fp32 contiguous.  L <= 320, attention_dim 128.
+ * ispk_soft_average_f32    TemporalAverager soft branch for pitch and energy plus log1p(duration)
+ *                          (models/acoustic/modules/temporal_adaptor.py:257-269, :446-449):
+ *                          feats[b][l] = { log1p(dur[b][l]), mask*sum_m pitch[b][m] A[b][m][l] / (sum_m A + 1e-5), same for
+ *                          energy }, feats [B][L][3].
+ */
+int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_c, const int64_t* len,
+                          float* out, int32_t B, int32_t T, int32_t C, ispk_stream_t stream);
+int32_t ispk_masked_instnorm_f32(const float* y, const float* weight, const float* bias, const int64_t* len, float* out,
+                                 int32_t B, int32_t T, int32_t C, float eps, ispk_stream_t stream);
+int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_b, const float* k_enc, int64_t k_stride_b,
+                                const int64_t* text_len, const int64_t* mel_len, float* attn_logits, float* attn_soft,
+                                int32_t B, int32_t M, int32_t L, int32_t D, ispk_stream_t stream);
+int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const float* energy, const int64_t* duration,
+                              const int64_t* text_len, float* feats, int32_t B, int32_t M, int32_t L,
+                              ispk_stream_t stream);
 
 /* fp32 -> bf16 conversion (round-to-nearest-even) of a [rows][cols] matrix; used to stage weights/activations. */
 int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int32_t rows, int32_t cols,

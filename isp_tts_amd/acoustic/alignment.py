@@ -1,8 +1,10 @@
 """Aligner: ConvAttention front-end + MAS (tts/models/acoustic/modules/alignment.py of the reference).
 
-Scope: the MAS binarisation is the hand-written kernel (`ispk_mas_f32`); the convolutional front-end that
-PRODUCES the MAS input (conv k5 + GELU + masked instance norm, QKᵀ, log-softmax + diagonal prior) is row f1 "next" and
-runs here as stock PyTorch-ROCm ops with the reference's exact order of operations (Appendix A items 8-9).
+Both halves run on hand-written kernels: the MAS binarisation (`ispk_mas_f32`) and the convolutional
+front-end that PRODUCES the MAS input (csrc/aligner.hip): padded channel-last activations so that every
+Conv1d is one MFMA GEMM over overlapping rows, a fused masked instance norm, and one fused kernel for
+QKᵀ + log-softmax + analytic diagonal prior + masked softmax, with the reference's exact order of operations
+(Appendix A items 8-9).  The nn.Module layout below only exists to keep the reference's parameter names.
 """
 from __future__ import annotations
 
@@ -14,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch import Tensor
 
+from .. import runtime
 from ..modules.aligner import mas_device
 from ..modules.constructor import Constructor
 from ..utils import get_mask_from_lengths, max_dtype_value, min_dtype_value
@@ -97,28 +100,38 @@ class ConvAttention(nn.Module, Constructor):
             ConvBlock1D(mel_dim * 2, mel_dim, query_kernel_size[1], activation, normalization, bias=False),
             ConvBlock1D(mel_dim, attention_dim, 1, "linear", None, bias=False)])
         self.attention_prior = attention_prior
+        self._cache: dict = {}
+
+    def _staged(self):
+        """Conv weights as GEMM weights [O][k*C] (tap-major, matching the padded channel-last window)."""
+        ps = [c.conv.weight for c in list(self.key_proj) + list(self.query_proj)]
+        key = tuple((p.data_ptr(), p._version, p.device) for p in ps)
+        if self._cache.get("key") != key:
+            w2d = [p.detach().permute(0, 2, 1).reshape(p.shape[0], -1).contiguous() for p in ps]
+            self._cache = {"key": key, "k": w2d[:2], "q": w2d[2:]}
+        return self._cache["k"], self._cache["q"]
 
     def forward(self, queries: Tensor, keys: Tensor, query_len: Tensor, key_len: Tensor):
-        """alignment.py:159-208.  queries [B, mel_dim, M], keys [B, text_dim, L] -> (attn_soft, attn_logits) [B,M,L]."""
+        """alignment.py:159-208.  queries (mel) [B, mel_dim, M] channel-first as the collator gives it; keys (encoder
+        output) [B, text_dim, L] — a transposed view of the encoder's [B, L, text_dim] is read in place.
+        -> (attn_soft, attn_logits), both [B, M, L] fp32.  11 launches: 2 pads, 5 conv GEMMs (GELU fused), 3 masked
+        instance norms, 1 fused scores kernel."""
+        if not self.attention_prior:
+            raise NotImplementedError("the aligner is built with its diagonal prior (recipes: attention_prior default)")
+        wk, wq = self._staged()
         max_q, max_k = queries.shape[2], keys.shape[2]
-        key_mask = get_mask_from_lengths(key_len, max_k).unsqueeze(1)
-        query_mask = get_mask_from_lengths(query_len, max_q).unsqueeze(1)
-        mask = query_mask.transpose(1, 2) & key_mask
-        k = keys
-        for conv in self.key_proj:
-            k = conv(k, key_mask, key_mask)
-        q = queries
-        for conv in self.query_proj:
-            q = conv(q, query_mask, query_mask)
-        attn = torch.matmul(q.transpose(1, 2), k) * self.scale
-        attn = torch.clamp(attn, max=max_dtype_value(attn))
-        if self.attention_prior:
-            prior = batch_diagonal_prior(key_len, query_len, max_text=max_k, max_mel=max_q)
-            attn = F.log_softmax(attn, dim=2, dtype=torch.float32) + torch.log(prior + 1e-6)
-        attn_logits = attn.clone()
-        attn = attn.masked_fill(~mask[:, :1], min_dtype_value(attn))
-        attn = F.softmax(attn, dim=2, dtype=torch.float32) * mask
-        return attn, attn_logits
+        gelu = runtime.EP_GELU
+        k = runtime.pad_rows(keys.float(), key_len, channel_first=True)
+        k = runtime.conv5_padded(k, wk[0], gelu)
+        k = runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len)
+        k = runtime.conv5_padded(k, wk[1])
+        q = runtime.pad_rows(queries.float(), query_len, channel_first=True)
+        q = runtime.conv5_padded(q, wq[0], gelu)
+        q = runtime.masked_instnorm(q, self.query_proj[0].norm.weight, self.query_proj[0].norm.bias, query_len)
+        q = runtime.conv5_padded(q, wq[1], gelu)
+        q = runtime.masked_instnorm(q, self.query_proj[1].norm.weight, self.query_proj[1].norm.bias, query_len)
+        q = runtime.conv5_padded(q, wq[2])
+        return runtime.aligner_scores(q, k, key_len, query_len, max_q, max_k)
 
 
 class AlignerOutput(NamedTuple):

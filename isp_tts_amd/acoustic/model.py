@@ -64,7 +64,13 @@ class AcousticModel(nn.Module, Constructor):
         return self
 
     def _to_mel(self, dec_out: Tensor, dec_mask: Optional[Tensor]) -> Tensor:
-        return runtime.to_mel(dec_out, self.to_mel.weight, self.to_mel.bias, dec_mask)
+        w = self.to_mel.weight
+        if dec_out.dtype == torch.bfloat16:
+            key = (w.data_ptr(), w._version, w.device)
+            if self._cache.get("key") != key:
+                self._cache = {"key": key, "w16": w.detach().to(torch.bfloat16).contiguous()}
+            w = self._cache["w16"]
+        return runtime.to_mel(dec_out, w, self.to_mel.bias, dec_mask)
 
     @torch.no_grad()
     def forward(self, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Optional[Tensor] = None,
@@ -80,10 +86,11 @@ class AcousticModel(nn.Module, Constructor):
         adaptor_output = self.temporal_adaptor(
             enc_out=enc_out, enc_mask=enc_mask, max_dec_len=mel.size(2),
             duration_target=aligner_output.attn_hard_duration, alignment=aligner_output.attn_soft,
-            pitch_target_dense=pitch, energy_target_dense=energy, noise=flow_noise, time_steps=flow_time)
+            pitch_target_dense=pitch, energy_target_dense=energy, noise=flow_noise, time_steps=flow_time,
+            enc_len=text_len)
         dec_len = adaptor_output.dec_lengths
         dec_mask = get_mask_from_lengths(dec_len, adaptor_output.enc_out.shape[1])
-        dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, key_len=dec_len).out
+        dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, key_len=dec_len, out_dtype=self.compute_dtype).out
         mel_out = self._to_mel(dec_out, dec_mask)
         return AcousticModelOutput(mel=mel_out, adaptor_output=adaptor_output, aligner_output=aligner_output)
 
@@ -115,7 +122,7 @@ class AcousticModel(nn.Module, Constructor):
         dec_mask = None
         if batch_infer:
             dec_mask = get_mask_from_lengths(adaptor_output.dec_lengths, adaptor_output.enc_out.shape[1])
-        dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask).out
+        dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, out_dtype=self.compute_dtype).out
         return self._to_mel(dec_out, dec_mask), adaptor_output
 
     def prepare_inputs(self, inputs: dict) -> dict:

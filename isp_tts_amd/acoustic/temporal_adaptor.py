@@ -189,14 +189,16 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
     def forward(self, enc_out: Tensor, enc_mask: Tensor, max_dec_len: int, duration_target: Optional[Tensor] = None,
                 alignment: Optional[Tensor] = None, pitch_target_dense: Optional[Tensor] = None,
                 energy_target_dense: Optional[Tensor] = None, *, noise: Optional[Tensor] = None,
-                time_steps: Optional[Tensor] = None) -> TemporalAdaptorOutput:
-        """temporal_adaptor.py:238-312 (teacher-forced: the decoder input uses the TARGET pitch/energy, :284,:292)."""
+                time_steps: Optional[Tensor] = None, enc_len: Optional[Tensor] = None) -> TemporalAdaptorOutput:
+        """temporal_adaptor.py:238-312 (teacher-forced: the decoder input uses the TARGET pitch/energy, :284,:292).
+        The three flow targets (log1p duration, soft-averaged pitch and energy, :257-269) come from ONE kernel."""
         assert alignment is not None and duration_target is not None
         assert pitch_target_dense is not None and energy_target_dense is not None
         m3 = enc_mask[..., None]
-        pitch_target = self._process_target(pitch_target_dense, duration_target, alignment, m3)
-        energy_target = self._process_target(energy_target_dense, duration_target, alignment, m3)
-        targets = torch.cat([torch.log1p(duration_target)[..., None], pitch_target, energy_target], dim=-1)
+        if enc_len is None:
+            enc_len = enc_mask.sum(dim=1)
+        targets = runtime.soft_average(alignment, pitch_target_dense, energy_target_dense, duration_target, enc_len)
+        pitch_target, energy_target = targets[..., 1:2], targets[..., 2:3]
         pred, losses = self.predictor(enc_out, targets, m3, noise=noise, time_steps=time_steps)
         log_duration_pred = pred[..., 0]
         duration_pred = torch.clamp(torch.exp(log_duration_pred) - 1, min=0)

@@ -1,0 +1,354 @@
+// Aligner front-end (the ConvAttention that produces the MAS input) for gfx950, fp32.
+//
+// Reference: /root/reference/tts/models/acoustic/modules/alignment.py:69-83 (ConvBlock1D: x*mask -> Conv1d -> GELU ->
+// masked instance norm), :159-208 (ConvAttention.forward), :18-37 (batch_diagonal_prior), and
+// modules/normalization.py:160-208 (_masked_norm, "instance").  The reference runs ~100 small PyTorch kernels here
+// (masks, convs through a channel-first layout, a 16-op instance norm three times, matmul, clamp, prior, log-softmax,
+// clone, masked-fill, softmax, mask).  Here:
+//   * activations are channel-LAST and padded in time, [B][T+4][C] with two zero rows on each side of every utterance.
+//     A Conv1d with kernel 5 / padding 2 is then ONE GEMM over OVERLAPPING rows: output row r is the dot of the weight
+//     [O][5*C] with the 5*C contiguous floats starting at padded row r (leading stride C < K).  No im2col buffer exists;
+//     the GEMM is the same MFMA kernel as every other Linear (ispk_gemm_f32, GELU in its epilogue);
+//   * `ispk_pad_rows_f32` builds the first padded buffer (mask applied, optional channel-first -> channel-last transpose);
+//   * `ispk_masked_instnorm_f32` does statistics over the valid frames, normalises, applies the affine, re-applies the
+//     mask for the next convolution and writes straight into the next padded buffer;
+//   * `ispk_aligner_scores_f32` fuses Q·Kᵀ/sqrt(d), the clamp, log-softmax over ALL key columns (padded ones included,
+//     alignment.py:196), the analytic diagonal prior (never materialised), `attn_logits`, the key-masked softmax and the
+//     final mask into one pass, computing Sᵀ = K·Qᵀ on the fp32 MFMA so a lane owns one mel row and the row reductions
+//     are in-register.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ pad + mask (+T)
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ x, int64_t sb, int64_t st, int64_t sc,
+                                                       const int64_t* __restrict__ len, float* __restrict__ out, int T,
+                                                       int C, int64_t total) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t row = idx / C;
+    const int tp = (int)(row % (T + 4)), b = (int)(row / (T + 4));
+    const int t = tp - 2;
+    float v = 0.f;
+    if (t >= 0 && t < T && t < (int)len[b]) v = x[b * sb + t * st + c * sc];
+    out[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ masked instance norm
+// grid (ceil(C/64), B), 256 threads = 4 time lanes x 64 channels.  y: [B][T+4][C] rows starting at its padded row 0
+// (conv output row r = b*(T+4) + t); out: next padded buffer, row t+2.
+__global__ __launch_bounds__(256) void masked_instnorm_kernel(const float* __restrict__ y, const float* __restrict__ w,
+                                                              const float* __restrict__ bias,
+                                                              const int64_t* __restrict__ len, float* __restrict__ out,
+                                                              int T, int C, float eps) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), tl = threadIdx.x >> 6;
+    const bool cok = c < C;
+    int n = (int)len[b];
+    n = n < 1 ? 1 : (n > T ? T : n);
+    const float* yb = y + (int64_t)b * (T + 4) * C;
+    float* ob = out + (int64_t)b * (T + 4) * C;
+    float s = 0.f;
+    if (cok)
+        for (int t = tl; t < n; t += 4) s += yb[(int64_t)t * C + c];
+    red[tl][threadIdx.x & 63] = s;
+    __syncthreads();
+    const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
+                        red[3][threadIdx.x & 63]) / (float)n;
+    __syncthreads();
+    float ss = 0.f;
+    if (cok)
+        for (int t = tl; t < n; t += 4) {
+            const float d = yb[(int64_t)t * C + c] - mean;
+            ss += d * d;
+        }
+    red[tl][threadIdx.x & 63] = ss;
+    __syncthreads();
+    const float var = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
+                       red[3][threadIdx.x & 63]) / (float)n;
+    if (!cok) return;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float g = w[c], be = bias[c];
+    for (int tp = tl; tp < T + 4; tp += 4) {
+        const int t = tp - 2;
+        float v = 0.f;
+        if (t >= 0 && t < n) v = (yb[(int64_t)t * C + c] - mean) * rstd * g + be;
+        ob[(int64_t)tp * C + c] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ scores + softmaxes
+constexpr int kAD = 128;        // attention_dim of the aligner
+// Key tile in LDS: [keys][128] fp32, UNPADDED (320 keys x 512 B = exactly the 160 KiB of a CU) with the 16-byte chunk
+// index XOR-ed with the key row (chunk' = chunk ^ (row & 31)), so the 16 lanes of a ds_read_b128 group, which read the
+// same chunk of 16 different rows, land on 16 different 4-bank slots.
+__device__ __forceinline__ int ks_off(int row, int chunk) { return row * kAD + ((chunk ^ (row & 31)) << 2); }
+
+// grid (ceil(M/128), B), 256 threads: wave w owns mel rows blockIdx.x*128 + w*32 .. +31.
+// NB = ceil(L_max / 32) 32-key blocks held in registers (NB <= 10: L_max <= 320).
+template <int NB>
+__global__ __launch_bounds__(256) void aligner_scores_kernel(const float* __restrict__ qe, int64_t q_stride_b,
+                                                             const float* __restrict__ ke, int64_t k_stride_b,
+                                                             const int64_t* __restrict__ text_len,
+                                                             const int64_t* __restrict__ mel_len,
+                                                             float* __restrict__ logits, float* __restrict__ soft,
+                                                             int M, int L, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Ks = reinterpret_cast<float*>(smem_raw);                        // [NB*32][128], swizzled (ks_off)
+    char* stage = smem_raw + (threadIdx.x >> 6) * (32 * 144);  // per-wave transpose patch: aliases Ks once S is done
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int m0 = blockIdx.x * 128 + wave * 32;
+    int tl = (int)text_len[b], ml = (int)mel_len[b];
+    tl = tl < 1 ? 1 : (tl > L ? L : tl);
+    ml = ml < 1 ? 1 : (ml > M ? M : ml);
+    const float ninf = -__builtin_huge_valf();
+
+    // stage the encoded keys of this utterance (rows >= L zero-filled)
+    const float* kb = ke + (int64_t)b * k_stride_b;
+    for (int idx = tid; idx < NB * 32 * (kAD / 4); idx += 256) {
+        const int row = idx / (kAD / 4), c4 = (idx - row * (kAD / 4)) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < L) v = *reinterpret_cast<const float4*>(kb + (int64_t)row * kAD + c4);
+        *reinterpret_cast<float4*>(Ks + ks_off(row, c4 >> 2)) = v;
+    }
+    // this lane's mel row as the MFMA B operand: half h owns dims 64h .. 64h+63
+    const int m = m0 + l31;
+    const int mrow = m < M ? m : M - 1;
+    f32x4 qf[16];
+    {
+        const float* qp = qe + (int64_t)b * q_stride_b + (int64_t)mrow * kAD + h * 64;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) qf[c] = *reinterpret_cast<const f32x4*>(qp + c * 4);
+    }
+    __syncthreads();
+
+    // S^T[key][mel]: register r of block kb_ is key 32*kb_ + (r&3) + 8(r>>2) + 4h
+    f32x16 s[NB];
+#pragma unroll
+    for (int kb_ = 0; kb_ < NB; ++kb_) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[kb_][r] = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + ks_off(kb_ * 32 + l31, h * 16 + c));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[kb_] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[kb_], 0, 0, 0);
+        }
+    }
+
+    __syncthreads();  // every wave has its scores in registers: the key tile is dead, its space becomes the patches
+
+    // ---- log_softmax over ALL L key columns of scale*S (clamped to the fp32 max like the reference, alignment.py:192)
+    float rmax = ninf;
+#pragma unroll
+    for (int kb_ = 0; kb_ < NB; ++kb_)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = fminf(s[kb_][r] * scale, 3.4028234663852886e+38f);
+            v = key < L ? v : ninf;
+            s[kb_][r] = v;
+            rmax = fmaxf(rmax, v);
+        }
+    rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
+    float rsum = 0.f, psum = 0.f;
+    const float mq = (float)m / (float)ml;
+#pragma unroll
+    for (int kb_ = 0; kb_ < NB; ++kb_)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            rsum += expf(s[kb_][r] - rmax);  // exp(-inf) = 0 for key >= L
+            // un-normalised diagonal prior (alignment.py:22-32): exp(-(t/T - m/M)^2 / (2 * 0.1^2)), 0 outside the lengths
+            if (key < tl && m < ml) {
+                const float g = (float)key / (float)tl - mq;
+                psum += expf(-(g * g) / (2.0f * 0.1f * 0.1f));
+            }
+        }
+    rsum += __shfl_xor(rsum, 32, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    const float lse = rmax + logf(rsum);
+    const float pinv = 1.0f / (psum + 1e-5f);
+
+    // ---- logits = log_softmax + log(prior + 1e-6); soft = mask * softmax(logits with masked keys)
+    float smax = ninf;
+#pragma unroll
+    for (int kb_ = 0; kb_ < NB; ++kb_)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float pr = 0.f;
+            if (key < tl && m < ml) {
+                const float g = (float)key / (float)tl - mq;
+                pr = expf(-(g * g) / (2.0f * 0.1f * 0.1f)) * pinv;
+                pr = pr < 1e-4f ? 0.f : pr;
+            }
+            const float lg = (s[kb_][r] - lse) + logf(pr + 1e-6f);
+            s[kb_][r] = lg;  // keys >= L: -inf (never stored)
+            if (key < tl) smax = fmaxf(smax, lg);
+        }
+    smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
+    float esum = 0.f;
+#pragma unroll
+    for (int kb_ = 0; kb_ < NB; ++kb_)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (key < tl) esum += expf(s[kb_][r] - smax);
+        }
+    esum += __shfl_xor(esum, 32, 64);
+    const float einv = (m < ml) ? 1.0f / esum : 0.f;
+
+    // ---- transpose each 32-key block through the wave's LDS patch and write 128-B row segments of both outputs
+    float* lb = logits + (int64_t)b * M * L;
+    float* sbp = soft + (int64_t)b * M * L;
+    const int c = lane & 7;
+    const bool vec = (L % 4) == 0;
+#pragma unroll
+    for (int kb_ = 0; kb_ < NB; ++kb_) {
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 v;
+                float* pv = &v.x;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = kb_ * 32 + 8 * g + 4 * h + e;
+                    const float lg = s[kb_][4 * g + e];
+                    pv[e] = pass == 0 ? lg : (key < tl ? expf(lg - smax) * einv : 0.f);
+                }
+                *reinterpret_cast<float4*>(stage + l31 * 144 + (8 * g + 4 * h) * 4) = v;
+            }
+            float* dst = pass == 0 ? lb : sbp;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + (lane >> 3), mm = m0 + r, key = kb_ * 32 + 4 * c;
+                const float4 v = *reinterpret_cast<const float4*>(stage + r * 144 + c * 16);
+                if (mm < M && key < L) {
+                    float* o = dst + (int64_t)mm * L + key;
+                    if (vec) {
+                        *reinterpret_cast<float4*>(o) = v;
+                    } else {
+                        const float* pv = &v.x;
+                        for (int e = 0; e < 4 && key + e < L; ++e) o[e] = pv[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ soft averages
+// TemporalAverager, soft branch (temporal_adaptor.py:446-449), for pitch and energy at once, plus log1p(duration):
+// feats[b][l][0] = log1p(dur[b][l]); feats[b][l][1+f] = mask * sum_m x_f[b][m] A[b][m][l] / (sum_m A[b][m][l] + 1e-5)
+// grid (ceil(L/64), B), 256 threads = 4 frame lanes x 64 text columns.
+__global__ __launch_bounds__(256) void soft_average_kernel(const float* __restrict__ attn, const float* __restrict__ pitch,
+                                                           const float* __restrict__ energy,
+                                                           const int64_t* __restrict__ dur,
+                                                           const int64_t* __restrict__ text_len, float* __restrict__ feats,
+                                                           int M, int L) {
+    __shared__ float red[3][4][64];
+    const int b = blockIdx.y, l = blockIdx.x * 64 + (threadIdx.x & 63), ml = threadIdx.x >> 6;
+    const bool ok = l < L;
+    const float* ab = attn + (int64_t)b * M * L;
+    float sa = 0.f, sp = 0.f, se = 0.f;
+    if (ok)
+        for (int mm = ml; mm < M; mm += 4) {
+            const float a = ab[(int64_t)mm * L + l];
+            sa += a;
+            sp = fmaf(pitch[(int64_t)b * M + mm], a, sp);
+            se = fmaf(energy[(int64_t)b * M + mm], a, se);
+        }
+    red[0][ml][threadIdx.x & 63] = sa;
+    red[1][ml][threadIdx.x & 63] = sp;
+    red[2][ml][threadIdx.x & 63] = se;
+    __syncthreads();
+    if (ml == 0 && ok) {
+        const int j = threadIdx.x & 63;
+        const float a = red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j];
+        const float pp = red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j];
+        const float ee = red[2][0][j] + red[2][1][j] + red[2][2][j] + red[2][3][j];
+        const float mk = l < (int)text_len[b] ? 1.0f : 0.0f;
+        float* f = feats + ((int64_t)b * L + l) * 3;
+        f[0] = log1pf((float)dur[(int64_t)b * L + l]);
+        f[1] = pp / (a + 1e-5f) * mk;
+        f[2] = ee / (a + 1e-5f) * mk;
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_c,
+                                     const int64_t* len, float* out, int32_t B, int32_t T, int32_t C,
+                                     ispk_stream_t stream) {
+    ISPK_REQUIRE(x && len && out, ISPK_E_NULL, "pad_rows: null pointer");
+    ISPK_REQUIRE(B >= 0 && T >= 1 && C >= 1, ISPK_E_SHAPE, "pad_rows: bad shape B=%d T=%d C=%d", B, T, C);
+    if (B == 0) return 0;
+    const int64_t total = (int64_t)B * (T + 4) * C;
+    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, stride_b, stride_t, stride_c, len, out, T, C, total);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_masked_instnorm_f32(const float* y, const float* weight, const float* bias, const int64_t* len,
+                                            float* out, int32_t B, int32_t T, int32_t C, float eps,
+                                            ispk_stream_t stream) {
+    ISPK_REQUIRE(y && weight && bias && len && out, ISPK_E_NULL, "masked_instnorm: null pointer");
+    ISPK_REQUIRE(B >= 0 && T >= 1 && C >= 1, ISPK_E_SHAPE, "masked_instnorm: bad shape B=%d T=%d C=%d", B, T, C);
+    ISPK_REQUIRE(B <= 65535, ISPK_E_SHAPE, "masked_instnorm: B=%d exceeds the grid limit", B);
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(masked_instnorm_kernel, dim3((C + 63) / 64, B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), y, weight, bias, len, out, T, C, eps);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_b, const float* k_enc,
+                                           int64_t k_stride_b, const int64_t* text_len, const int64_t* mel_len,
+                                           float* attn_logits, float* attn_soft, int32_t B, int32_t M, int32_t L,
+                                           int32_t D, ispk_stream_t stream) {
+    ISPK_REQUIRE(q_enc && k_enc && text_len && mel_len && attn_logits && attn_soft, ISPK_E_NULL,
+                 "aligner_scores: null pointer");
+    ISPK_REQUIRE(D == kAD, ISPK_E_UNSUPPORTED, "aligner_scores: attention_dim %d (built for 128)", D);
+    ISPK_REQUIRE(B >= 0 && M >= 1 && L >= 1 && L <= 320, ISPK_E_SHAPE, "aligner_scores: bad shape B=%d M=%d L=%d (L <= 320)",
+                 B, M, L);
+    ISPK_REQUIRE(B <= 65535, ISPK_E_SHAPE, "aligner_scores: B=%d exceeds the grid limit", B);
+    ISPK_REQUIRE(ispk_aligned(q_enc, 16) && ispk_aligned(k_enc, 16) && ispk_aligned(attn_logits, 16) &&
+                     ispk_aligned(attn_soft, 16) && q_stride_b % 4 == 0 && k_stride_b % 4 == 0,
+                 ISPK_E_ALIGN, "aligner_scores: 16-byte alignment required");
+    if (B == 0) return 0;
+    const int nb = (L + 31) / 32;
+    size_t lds = (size_t)nb * 32 * kAD * 4;
+    if (lds < 4 * 32 * 144) lds = 4 * 32 * 144;
+    const float scale = 1.0f / sqrtf((float)D);
+    dim3 grid((M + 127) / 128, B), block(256);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#define ISPK_AL_CASE(NB)                                                                                              \
+    case NB:                                                                                                          \
+        ISPK_RESERVE_LDS((&aligner_scores_kernel<NB>), lds, "aligner_scores");                                        \
+        hipLaunchKernelGGL((aligner_scores_kernel<NB>), grid, block, lds, s, q_enc, q_stride_b, k_enc, k_stride_b,     \
+                           text_len, mel_len, attn_logits, attn_soft, M, L, scale);                                   \
+        break;
+    switch (nb) {
+        ISPK_AL_CASE(1) ISPK_AL_CASE(2) ISPK_AL_CASE(3) ISPK_AL_CASE(4) ISPK_AL_CASE(5) ISPK_AL_CASE(6) ISPK_AL_CASE(7)
+        ISPK_AL_CASE(8) ISPK_AL_CASE(9) ISPK_AL_CASE(10)
+        default: ISPK_FAIL(ISPK_E_SHAPE, "aligner_scores: unsupported L=%d", L);
+    }
+#undef ISPK_AL_CASE
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const float* energy,
+                                         const int64_t* duration, const int64_t* text_len, float* feats, int32_t B,
+                                         int32_t M, int32_t L, ispk_stream_t stream) {
+    ISPK_REQUIRE(attn_soft && pitch && energy && duration && text_len && feats, ISPK_E_NULL, "soft_average: null pointer");
+    ISPK_REQUIRE(B >= 0 && M >= 1 && L >= 1 && B <= 65535, ISPK_E_SHAPE, "soft_average: bad shape B=%d M=%d L=%d", B, M, L);
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(soft_average_kernel, dim3((L + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       attn_soft, pitch, energy, duration, text_len, feats, M, L);
+    return ispk_launch_status();
+}

@@ -699,7 +699,7 @@ bool panel_ok(const GemmParams& p) {
 }
 
 bool wide_ok(const GemmParams& p) {
-    return p.K >= 512 && (p.N == 384 || p.N == 256) && p.M >= 128 * 64 && vec_epilogue_ok(p) &&
+    return p.K >= 512 && (p.N == 384 || p.N == 256) && p.M >= 128 * 16 && vec_epilogue_ok(p) &&
            getenv("ISPK_NO_WIDE") == nullptr;
 }
 
@@ -718,8 +718,8 @@ int32_t check_common(const GemmParams& p, int elt) {
     ISPK_REQUIRE(p.M >= 0 && p.N >= 1 && p.K >= 1, ISPK_E_SHAPE, "gemm: bad shape M=%d N=%d K=%d", p.M, p.N, p.K);
     const int vec = 16 / elt;
     ISPK_REQUIRE(p.K % 8 == 0, ISPK_E_SHAPE, "gemm: K=%d must be a multiple of 8", p.K);
-    ISPK_REQUIRE(p.lda % vec == 0 && p.ldw % vec == 0 && p.lda >= p.K && p.ldw >= p.K, ISPK_E_ALIGN,
-                 "gemm: lda=%lld / ldw=%lld must be >= K and multiples of %d", (long long)p.lda, (long long)p.ldw, vec);
+    ISPK_REQUIRE(p.lda % vec == 0 && p.ldw % vec == 0 && p.lda >= 1 && p.ldw >= p.K, ISPK_E_ALIGN,
+                 "gemm: lda=%lld / ldw=%lld must be multiples of %d (ldw >= K)", (long long)p.lda, (long long)p.ldw, vec);
     ISPK_REQUIRE(ispk_aligned(p.A, 16) && ispk_aligned(p.W, 16), ISPK_E_ALIGN, "gemm: A/W must be 16-byte aligned");
     ISPK_REQUIRE(!((p.flags & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT)) && !p.mask), ISPK_E_NULL,
                  "gemm: mask flag set but mask is NULL");

@@ -125,9 +125,11 @@ class Transformer(nn.Module, Constructor):
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 adaptive_condition: Optional[Tensor] = None, return_intermediates: bool = False, *,
-                key_len: Optional[Tensor] = None, projected: Optional[Tensor] = None):
+                key_len: Optional[Tensor] = None, projected: Optional[Tensor] = None,
+                out_dtype: torch.dtype = torch.float32):
         """`projected` lets a caller that already holds project_emb(x) (e.g. the Euler loop, which re-projects only the
-        3 flow channels per step) skip the projection."""
+        3 flow channels per step) skip the projection.  `out_dtype=torch.bfloat16` makes the final LayerNorm emit bf16
+        for a bf16 consumer (the decoder's to_mel GEMM on the bf16 path)."""
         if projected is not None:
             out = projected
         elif isinstance(self.project_emb, nn.Identity):
@@ -143,5 +145,6 @@ class Transformer(nn.Module, Constructor):
             out = res.out
             if return_intermediates:
                 intermediates.append(res.intermediates)
-        out = runtime.layernorm(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps)
+        out = runtime.layernorm(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps,
+                                out_dtype=out_dtype)
         return TransformerOutput(out=out, intermediates=intermediates)

@@ -36,6 +36,10 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_cast_f32_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
+    "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
+    "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    "ispk_soft_average_f32": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
 }
 
 _lib = None
@@ -305,6 +309,78 @@ def alibi_mqa_attention(qkv: Tensor, heads: int, slopes: Tensor, key_len: Option
     assert W == heads * 64 + 128 and qkv.is_contiguous()
     return alibi_mqa_attention_raw(qkv, W, qkv[..., heads * 64:], qkv[..., heads * 64 + 64:], W, slopes, key_len, B, N,
                                    heads)
+
+
+# ------------------------------------------------------------------------------------------------- aligner front-end
+def pad_rows(x: Tensor, lengths: Tensor, channel_first: bool = False) -> Tensor:
+    """ispk_pad_rows_f32: [B,T,C] (or [B,C,T] with channel_first) -> masked, zero-padded channel-last [B,T+4,C]."""
+    _dev(x, lengths)
+    assert x.dtype == torch.float32 and x.ndim == 3
+    if channel_first:
+        B, C, T = x.shape
+        sb, sc, st = x.stride()
+    else:
+        B, T, C = x.shape
+        sb, st, sc = x.stride()
+    lengths = lengths.to(torch.int64).contiguous()
+    out = torch.empty((B, T + 4, C), dtype=torch.float32, device=x.device)
+    _launch("pad_rows_kernel", 0.0, 8.0 * B * T * C, lib().ispk_pad_rows_f32, x.data_ptr(), sb, st, sc,
+            lengths.data_ptr(), out.data_ptr(), B, T, C, _stream())
+    return out
+
+
+def conv5_padded(xpad: Tensor, w2d: Tensor, flags: int = 0) -> Tensor:
+    """Conv1d(kernel k, padding (k-1)/2, no bias) over a padded channel-last buffer as ONE GEMM over overlapping rows.
+    xpad [B, T+4, C]; w2d [O, k*C] (= conv.weight.permute(0,2,1).reshape(O, k*C)), k = 5 or 1.  Returns [B, T+4, O] whose
+    row t (not t+2) of every utterance is frame t; the last 4 rows per utterance are scratch."""
+    _dev(xpad, w2d)
+    B, TP, C = xpad.shape
+    O, K = w2d.shape
+    taps = K // C
+    assert taps * C == K and taps in (1, 5) and xpad.is_contiguous() and w2d.is_contiguous()
+    out = torch.empty((B, TP, O), dtype=torch.float32, device=xpad.device)
+    a_ptr = xpad.data_ptr() + (0 if taps == 5 else 2 * C * 4)       # k=1: frame t sits at padded row t+2
+    M = B * TP - 4
+    _launch(_gemm_label(False, M, O, K), 2.0 * M * O * K, 4.0 * (M * C + O * K + M * O), lib().ispk_gemm_f32, a_ptr, C,
+            w2d.data_ptr(), K, out.data_ptr(), O, None, None, 0, None, M, O, K, flags, 0, 0, _stream())
+    return out
+
+
+def masked_instnorm(y: Tensor, weight: Tensor, bias: Tensor, lengths: Tensor, eps: float = 1e-5) -> Tensor:
+    """ispk_masked_instnorm_f32: conv output [B,T+4,C] (row t = frame t) -> normalised, masked, re-padded [B,T+4,C]."""
+    _dev(y, weight, bias, lengths)
+    B, TP, C = y.shape
+    out = torch.empty_like(y)
+    lengths = lengths.to(torch.int64).contiguous()
+    _launch("masked_instnorm_kernel", 0.0, 16.0 * B * TP * C, lib().ispk_masked_instnorm_f32, y.data_ptr(),
+            weight.data_ptr(), bias.data_ptr(), lengths.data_ptr(), out.data_ptr(), B, TP - 4, C, eps, _stream())
+    return out
+
+
+def aligner_scores(q_enc: Tensor, k_enc: Tensor, text_len: Tensor, mel_len: Tensor, M: int, L: int):
+    """ispk_aligner_scores_f32: q_enc [B, M+4, 128], k_enc [B, L+4, 128] (row t = frame/token t) ->
+    (attn_soft, attn_logits), both [B, M, L]."""
+    _dev(q_enc, k_enc, text_len, mel_len)
+    B, D = q_enc.shape[0], q_enc.shape[2]
+    logits = torch.empty((B, M, L), dtype=torch.float32, device=q_enc.device)
+    soft = torch.empty((B, M, L), dtype=torch.float32, device=q_enc.device)
+    text_len = text_len.to(torch.int64).contiguous()
+    mel_len = mel_len.to(torch.int64).contiguous()
+    _launch("aligner_scores_kernel", 2.0 * B * M * L * D, 4.0 * B * (M * D + L * D + 2 * M * L),
+            lib().ispk_aligner_scores_f32, q_enc.data_ptr(), q_enc.stride(0), k_enc.data_ptr(), k_enc.stride(0),
+            text_len.data_ptr(), mel_len.data_ptr(), logits.data_ptr(), soft.data_ptr(), B, M, L, D, _stream())
+    return soft, logits
+
+
+def soft_average(attn_soft: Tensor, pitch: Tensor, energy: Tensor, duration: Tensor, text_len: Tensor) -> Tensor:
+    """ispk_soft_average_f32 -> feats [B, L, 3] = (log1p(duration), pitch target, energy target)."""
+    _dev(attn_soft, pitch, energy, duration, text_len)
+    B, M, L = attn_soft.shape
+    feats = torch.empty((B, L, 3), dtype=torch.float32, device=attn_soft.device)
+    _launch("soft_average_kernel", 0.0, 4.0 * B * M * L, lib().ispk_soft_average_f32, attn_soft.contiguous().data_ptr(),
+            pitch.contiguous().data_ptr(), energy.contiguous().data_ptr(), duration.to(torch.int64).contiguous().data_ptr(),
+            text_len.to(torch.int64).contiguous().data_ptr(), feats.data_ptr(), B, M, L, _stream())
+    return feats
 
 
 def cast_bf16(x: Tensor) -> Tensor:

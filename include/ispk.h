@@ -151,6 +151,8 @@ int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t*
  * kernel 5 / padding 2 over such a buffer is ONE ispk_gemm_f32 call over overlapping rows (lda = C, K = 5*C,
  * M = B*(T+4) - 4, weight [O][5*C] = conv.weight.permute(0,2,1)); output row b*(T+4)+t is frame t.
  *
+ * Both kernels read fp32 and write fp32, or bf16 when out_bf16 != 0 (the bf16 throughput path then runs the conv GEMMs
+ * on ispk_gemm_bf16 with fp32 outputs, so statistics and scores stay fp32).
  * ispk_pad_rows_f32        out[b][t+2][c] = t < len[b] ? x[b*sb + t*st + c*sc] : 0, pad rows zero
  *                          (x*mask of alignment.py:75 plus the layout change; strides in elements, so a channel-first
  *                           mel [B][C][T] is read with st = 1, sc = T).
@@ -169,9 +171,9 @@ int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t*
  *                          energy }, feats [B][L][3].
  */
 int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_c, const int64_t* len,
-                          float* out, int32_t B, int32_t T, int32_t C, ispk_stream_t stream);
-int32_t ispk_masked_instnorm_f32(const float* y, const float* weight, const float* bias, const int64_t* len, float* out,
-                                 int32_t B, int32_t T, int32_t C, float eps, ispk_stream_t stream);
+                          void* out, int32_t out_bf16, int32_t B, int32_t T, int32_t C, ispk_stream_t stream);
+int32_t ispk_masked_instnorm_f32(const float* y, const float* weight, const float* bias, const int64_t* len, void* out,
+                                 int32_t out_bf16, int32_t B, int32_t T, int32_t C, float eps, ispk_stream_t stream);
 int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_b, const float* k_enc, int64_t k_stride_b,
                                 const int64_t* text_len, const int64_t* mel_len, float* attn_logits, float* attn_soft,
                                 int32_t B, int32_t M, int32_t L, int32_t D, ispk_stream_t stream);

@@ -100,14 +100,15 @@ class ConvAttention(nn.Module, Constructor):
             ConvBlock1D(mel_dim * 2, mel_dim, query_kernel_size[1], activation, normalization, bias=False),
             ConvBlock1D(mel_dim, attention_dim, 1, "linear", None, bias=False)])
         self.attention_prior = attention_prior
+        self.compute_dtype = torch.float32
         self._cache: dict = {}
 
     def _staged(self):
         """Conv weights as GEMM weights [O][k*C] (tap-major, matching the padded channel-last window)."""
         ps = [c.conv.weight for c in list(self.key_proj) + list(self.query_proj)]
-        key = tuple((p.data_ptr(), p._version, p.device) for p in ps)
+        key = (self.compute_dtype,) + tuple((p.data_ptr(), p._version, p.device) for p in ps)
         if self._cache.get("key") != key:
-            w2d = [p.detach().permute(0, 2, 1).reshape(p.shape[0], -1).contiguous() for p in ps]
+            w2d = [p.detach().permute(0, 2, 1).reshape(p.shape[0], -1).to(self.compute_dtype).contiguous() for p in ps]
             self._cache = {"key": key, "k": w2d[:2], "q": w2d[2:]}
         return self._cache["k"], self._cache["q"]
 
@@ -120,16 +121,18 @@ class ConvAttention(nn.Module, Constructor):
             raise NotImplementedError("the aligner is built with its diagonal prior (recipes: attention_prior default)")
         wk, wq = self._staged()
         max_q, max_k = queries.shape[2], keys.shape[2]
-        gelu = runtime.EP_GELU
-        k = runtime.pad_rows(keys.float(), key_len, channel_first=True)
+        gelu, dt = runtime.EP_GELU, self.compute_dtype   # bf16 path: bf16 conv operands, fp32 conv outputs / statistics
+        k = runtime.pad_rows(keys.float(), key_len, channel_first=True, out_dtype=dt)
         k = runtime.conv5_padded(k, wk[0], gelu)
-        k = runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len)
+        k = runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len, out_dtype=dt)
         k = runtime.conv5_padded(k, wk[1])
-        q = runtime.pad_rows(queries.float(), query_len, channel_first=True)
+        q = runtime.pad_rows(queries.float(), query_len, channel_first=True, out_dtype=dt)
         q = runtime.conv5_padded(q, wq[0], gelu)
-        q = runtime.masked_instnorm(q, self.query_proj[0].norm.weight, self.query_proj[0].norm.bias, query_len)
+        q = runtime.masked_instnorm(q, self.query_proj[0].norm.weight, self.query_proj[0].norm.bias, query_len,
+                                    out_dtype=dt)
         q = runtime.conv5_padded(q, wq[1], gelu)
-        q = runtime.masked_instnorm(q, self.query_proj[1].norm.weight, self.query_proj[1].norm.bias, query_len)
+        q = runtime.masked_instnorm(q, self.query_proj[1].norm.weight, self.query_proj[1].norm.bias, query_len,
+                                    out_dtype=dt)
         q = runtime.conv5_padded(q, wq[2])
         return runtime.aligner_scores(q, k, key_len, query_len, max_q, max_k)
 

@@ -60,6 +60,7 @@ class AcousticModel(nn.Module, Constructor):
         self.decoder.set_compute_dtype(dtype)
         self.temporal_adaptor.predictor.transformer.set_compute_dtype(dtype)
         self.temporal_adaptor.embedding.transformer.set_compute_dtype(dtype)
+        self.aligner.attention.compute_dtype = dtype
         self.compute_dtype = dtype
         return self
 

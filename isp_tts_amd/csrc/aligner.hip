@@ -21,8 +21,13 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------------ pad + mask (+T)
+template <typename T_> __device__ __forceinline__ void put(T_* p, float v);
+template <> __device__ __forceinline__ void put<float>(float* p, float v) { *p = v; }
+template <> __device__ __forceinline__ void put<uint16_t>(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+
+template <typename OutT>
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ x, int64_t sb, int64_t st, int64_t sc,
-                                                       const int64_t* __restrict__ len, float* __restrict__ out, int T,
+                                                       const int64_t* __restrict__ len, OutT* __restrict__ out, int T,
                                                        int C, int64_t total) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -32,49 +37,57 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
     const int t = tp - 2;
     float v = 0.f;
     if (t >= 0 && t < T && t < (int)len[b]) v = x[b * sb + t * st + c * sc];
-    out[idx] = v;
+    put<OutT>(out + idx, v);
 }
 
 // ------------------------------------------------------------------------------------------------ masked instance norm
-// grid (ceil(C/64), B), 256 threads = 4 time lanes x 64 channels.  y: [B][T+4][C] rows starting at its padded row 0
-// (conv output row r = b*(T+4) + t); out: next padded buffer, row t+2.
-__global__ __launch_bounds__(256) void masked_instnorm_kernel(const float* __restrict__ y, const float* __restrict__ w,
-                                                              const float* __restrict__ bias,
-                                                              const int64_t* __restrict__ len, float* __restrict__ out,
-                                                              int T, int C, float eps) {
-    __shared__ float red[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), tl = threadIdx.x >> 6;
+// grid (ceil(C/64), B), 1024 threads = 16 time lanes x 64 channels (256-B coalesced rows).  y: [B][T+4][C] conv output
+// (row r = b*(T+4) + t is frame t); out: next padded buffer, frame t at row t+2.  Two passes like the reference
+// (mean, then centred variance), a third to write.
+constexpr int kTL = 16;
+template <typename OutT>
+__global__ __launch_bounds__(1024) void masked_instnorm_kernel(const float* __restrict__ y, const float* __restrict__ w,
+                                                               const float* __restrict__ bias,
+                                                               const int64_t* __restrict__ len, OutT* __restrict__ out,
+                                                               int T, int C, float eps) {
+    __shared__ float red[kTL][64];
+    const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
+    const int b = blockIdx.y, c = blockIdx.x * 64 + cl;
     const bool cok = c < C;
     int n = (int)len[b];
     n = n < 1 ? 1 : (n > T ? T : n);
     const float* yb = y + (int64_t)b * (T + 4) * C;
-    float* ob = out + (int64_t)b * (T + 4) * C;
+    OutT* ob = out + (int64_t)b * (T + 4) * C;
+    auto total = [&]() {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < kTL; ++i) v += red[i][cl];
+        return v;
+    };
     float s = 0.f;
     if (cok)
-        for (int t = tl; t < n; t += 4) s += yb[(int64_t)t * C + c];
-    red[tl][threadIdx.x & 63] = s;
+        for (int t = tl; t < n; t += kTL) s += yb[(int64_t)t * C + c];
+    red[tl][cl] = s;
     __syncthreads();
-    const float mean = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
-                        red[3][threadIdx.x & 63]) / (float)n;
+    const float mean = total() / (float)n;
     __syncthreads();
     float ss = 0.f;
     if (cok)
-        for (int t = tl; t < n; t += 4) {
+        for (int t = tl; t < n; t += kTL) {
             const float d = yb[(int64_t)t * C + c] - mean;
             ss += d * d;
         }
-    red[tl][threadIdx.x & 63] = ss;
+    red[tl][cl] = ss;
     __syncthreads();
-    const float var = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] +
-                       red[3][threadIdx.x & 63]) / (float)n;
+    const float var = total() / (float)n;
     if (!cok) return;
     const float rstd = 1.0f / sqrtf(var + eps);
     const float g = w[c], be = bias[c];
-    for (int tp = tl; tp < T + 4; tp += 4) {
+    for (int tp = tl; tp < T + 4; tp += kTL) {
         const int t = tp - 2;
         float v = 0.f;
         if (t >= 0 && t < n) v = (yb[(int64_t)t * C + c] - mean) * rstd * g + be;
-        ob[(int64_t)tp * C + c] = v;
+        put<OutT>(ob + (int64_t)tp * C + c, v);
     }
 }
 
@@ -284,26 +297,38 @@ __global__ __launch_bounds__(256) void soft_average_kernel(const float* __restri
 }  // namespace
 
 extern "C" int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_c,
-                                     const int64_t* len, float* out, int32_t B, int32_t T, int32_t C,
+                                     const int64_t* len, void* out, int32_t out_bf16, int32_t B, int32_t T, int32_t C,
                                      ispk_stream_t stream) {
     ISPK_REQUIRE(x && len && out, ISPK_E_NULL, "pad_rows: null pointer");
     ISPK_REQUIRE(B >= 0 && T >= 1 && C >= 1, ISPK_E_SHAPE, "pad_rows: bad shape B=%d T=%d C=%d", B, T, C);
     if (B == 0) return 0;
     const int64_t total = (int64_t)B * (T + 4) * C;
-    hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), x, stride_b, stride_t, stride_c, len, out, T, C, total);
+    dim3 grid((unsigned)((total + 255) / 256));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (out_bf16)
+        hipLaunchKernelGGL(pad_rows_kernel<uint16_t>, grid, dim3(256), 0, s, x, stride_b, stride_t, stride_c, len,
+                           static_cast<uint16_t*>(out), T, C, total);
+    else
+        hipLaunchKernelGGL(pad_rows_kernel<float>, grid, dim3(256), 0, s, x, stride_b, stride_t, stride_c, len,
+                           static_cast<float*>(out), T, C, total);
     return ispk_launch_status();
 }
 
 extern "C" int32_t ispk_masked_instnorm_f32(const float* y, const float* weight, const float* bias, const int64_t* len,
-                                            float* out, int32_t B, int32_t T, int32_t C, float eps,
+                                            void* out, int32_t out_bf16, int32_t B, int32_t T, int32_t C, float eps,
                                             ispk_stream_t stream) {
     ISPK_REQUIRE(y && weight && bias && len && out, ISPK_E_NULL, "masked_instnorm: null pointer");
     ISPK_REQUIRE(B >= 0 && T >= 1 && C >= 1, ISPK_E_SHAPE, "masked_instnorm: bad shape B=%d T=%d C=%d", B, T, C);
     ISPK_REQUIRE(B <= 65535, ISPK_E_SHAPE, "masked_instnorm: B=%d exceeds the grid limit", B);
     if (B == 0) return 0;
-    hipLaunchKernelGGL(masked_instnorm_kernel, dim3((C + 63) / 64, B), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), y, weight, bias, len, out, T, C, eps);
+    dim3 grid((C + 63) / 64, B);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (out_bf16)
+        hipLaunchKernelGGL(masked_instnorm_kernel<uint16_t>, grid, dim3(1024), 0, s, y, weight, bias, len,
+                           static_cast<uint16_t*>(out), T, C, eps);
+    else
+        hipLaunchKernelGGL(masked_instnorm_kernel<float>, grid, dim3(1024), 0, s, y, weight, bias, len,
+                           static_cast<float*>(out), T, C, eps);
     return ispk_launch_status();
 }
 

@@ -36,8 +36,8 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_cast_f32_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
-    "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _P],
-    "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _F32, _P],
+    "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P],
+    "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F32, _P],
     "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_soft_average_f32": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
 }
@@ -312,7 +312,7 @@ def alibi_mqa_attention(qkv: Tensor, heads: int, slopes: Tensor, key_len: Option
 
 
 # ------------------------------------------------------------------------------------------------- aligner front-end
-def pad_rows(x: Tensor, lengths: Tensor, channel_first: bool = False) -> Tensor:
+def pad_rows(x: Tensor, lengths: Tensor, channel_first: bool = False, out_dtype: torch.dtype = torch.float32) -> Tensor:
     """ispk_pad_rows_f32: [B,T,C] (or [B,C,T] with channel_first) -> masked, zero-padded channel-last [B,T+4,C]."""
     _dev(x, lengths)
     assert x.dtype == torch.float32 and x.ndim == 3
@@ -323,9 +323,9 @@ def pad_rows(x: Tensor, lengths: Tensor, channel_first: bool = False) -> Tensor:
         B, T, C = x.shape
         sb, st, sc = x.stride()
     lengths = lengths.to(torch.int64).contiguous()
-    out = torch.empty((B, T + 4, C), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, T + 4, C), dtype=out_dtype, device=x.device)
     _launch("pad_rows_kernel", 0.0, 8.0 * B * T * C, lib().ispk_pad_rows_f32, x.data_ptr(), sb, st, sc,
-            lengths.data_ptr(), out.data_ptr(), B, T, C, _stream())
+            lengths.data_ptr(), out.data_ptr(), int(out_dtype == torch.bfloat16), B, T, C, _stream())
     return out
 
 
@@ -338,22 +338,27 @@ def conv5_padded(xpad: Tensor, w2d: Tensor, flags: int = 0) -> Tensor:
     O, K = w2d.shape
     taps = K // C
     assert taps * C == K and taps in (1, 5) and xpad.is_contiguous() and w2d.is_contiguous()
-    out = torch.empty((B, TP, O), dtype=torch.float32, device=xpad.device)
-    a_ptr = xpad.data_ptr() + (0 if taps == 5 else 2 * C * 4)       # k=1: frame t sits at padded row t+2
+    assert xpad.dtype == w2d.dtype
+    bf16 = xpad.dtype == torch.bfloat16
+    out = torch.empty((B, TP, O), dtype=torch.float32, device=xpad.device)      # fp32 out on both paths
+    a_ptr = xpad.data_ptr() + (0 if taps == 5 else 2 * C * xpad.element_size())  # k=1: frame t sits at padded row t+2
     M = B * TP - 4
-    _launch(_gemm_label(False, M, O, K), 2.0 * M * O * K, 4.0 * (M * C + O * K + M * O), lib().ispk_gemm_f32, a_ptr, C,
-            w2d.data_ptr(), K, out.data_ptr(), O, None, None, 0, None, M, O, K, flags, 0, 0, _stream())
+    fn = lib().ispk_gemm_bf16 if bf16 else lib().ispk_gemm_f32
+    _launch(_gemm_label(bf16, M, O, K), 2.0 * M * O * K, float(xpad.element_size()) * (M * C + O * K) + 4.0 * M * O, fn,
+            a_ptr, C, w2d.data_ptr(), K, out.data_ptr(), O, None, None, 0, None, M, O, K, flags, 0, 0, _stream())
     return out
 
 
-def masked_instnorm(y: Tensor, weight: Tensor, bias: Tensor, lengths: Tensor, eps: float = 1e-5) -> Tensor:
+def masked_instnorm(y: Tensor, weight: Tensor, bias: Tensor, lengths: Tensor, eps: float = 1e-5,
+                    out_dtype: torch.dtype = torch.float32) -> Tensor:
     """ispk_masked_instnorm_f32: conv output [B,T+4,C] (row t = frame t) -> normalised, masked, re-padded [B,T+4,C]."""
     _dev(y, weight, bias, lengths)
     B, TP, C = y.shape
-    out = torch.empty_like(y)
+    out = torch.empty(y.shape, dtype=out_dtype, device=y.device)
     lengths = lengths.to(torch.int64).contiguous()
     _launch("masked_instnorm_kernel", 0.0, 16.0 * B * TP * C, lib().ispk_masked_instnorm_f32, y.data_ptr(),
-            weight.data_ptr(), bias.data_ptr(), lengths.data_ptr(), out.data_ptr(), B, TP - 4, C, eps, _stream())
+            weight.data_ptr(), bias.data_ptr(), lengths.data_ptr(), out.data_ptr(), int(out_dtype == torch.bfloat16), B,
+            TP - 4, C, eps, _stream())
     return out
 
 

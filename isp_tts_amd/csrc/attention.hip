@@ -282,23 +282,32 @@ __global__ __launch_bounds__(1024) void attn_bf16_kernel(const uint16_t* __restr
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
             }
+            // log2-domain score: s*log2(e)/8 - slope*log2(e)*|key - query|.  The distance is fp32 from the start
+            // (d0 + compile-time register offset), so an element costs one add and one FMA with an |.| source modifier;
+            // the key-length mask is applied only in the one block that straddles key_len (wave-uniform test).
+            const float d0 = (float)(key0 + 4 * h - qi);
             float smax = ninf;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int dist = key > qi ? key - qi : qi - key;
-                float val = fmaf(s[r], scale2, -slope2 * (float)dist);
-                val = key < klen ? val : ninf;
-                s[r] = val;
-                smax = fmaxf(smax, val);
+                const float dist = fabsf(d0 + (float)((r & 3) + 8 * (r >> 2)));
+                s[r] = fmaf(s[r], scale2, -slope2 * dist);
             }
+            if (key0 + 32 > klen) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    s[r] = key < klen ? s[r] : ninf;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) smax = fmaxf(smax, s[r]);
             smax = xhalf_max(smax);
             const float m_new = fmaxf(m_run, smax);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // bare v_exp_f32; exp2(-inf) = 0 on first block
             float psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pexp = exp2f(s[r] - m_new);
+                const float pexp = __builtin_amdgcn_exp2f(s[r] - m_new);
                 s[r] = pexp;
                 psum += pexp;
             }

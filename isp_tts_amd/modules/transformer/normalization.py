@@ -41,7 +41,13 @@ class AdaptiveLayerNorm(nn.Module):
             nn.init.zeros_(self.bias.bias)
 
     def forward(self, x: Tensor, condition: Optional[Tensor] = None, row_mask: Optional[Tensor] = None,
-                out_dtype: torch.dtype = torch.float32) -> Tensor:
+                out_dtype: torch.dtype = torch.float32, scale_shift: Optional[tuple] = None) -> Tensor:
+        """`scale_shift` = (scale [Bc,D], shift [Bc,D]) already projected from the condition (the Transformer projects
+        the condition for ALL of its adaptive norms in one launch)."""
+        if scale_shift is not None:
+            rows_per_batch = x.numel() // (x.shape[0] * x.shape[-1])
+            return runtime.layernorm(x, None, None, scale_shift[0], scale_shift[1], rows_per_batch, row_mask, self.eps,
+                                     out_dtype)
         if condition is None:  # reference: weight 1, bias 0 -> plain non-affine LN
             return runtime.layernorm(x, None, None, row_mask=row_mask, eps=self.eps, out_dtype=out_dtype)
         cond = condition.reshape(-1, condition.shape[-1]).float().contiguous()

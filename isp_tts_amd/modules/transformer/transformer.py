@@ -64,8 +64,9 @@ class TransformerLayer(nn.Module, Constructor):
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 adaptive_condition: Optional[Tensor] = None, cache: Optional[TransformerLayerIntermediates] = None,
-                shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None):
-        assert not self.adaptive_norm or adaptive_condition is not None, \
+                shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None,
+                ada: Optional[tuple] = None):
+        assert not self.adaptive_norm or adaptive_condition is not None or ada is not None, \
             "`adaptive_condition` should be provided for AdaptiveLayerNorm"
         if cache is not None:
             raise NotImplementedError("KV caches are not on the acoustic-model forward path")
@@ -73,10 +74,12 @@ class TransformerLayer(nn.Module, Constructor):
         cdt = self.attention.compute_dtype
         if mask is not None and key_len is None:
             key_len = mask.sum(dim=1)
-        h = self.attention_norm(x, adaptive_condition, out_dtype=cdt)
+        kw1 = {"scale_shift": ada[0]} if ada is not None else {}
+        kw2 = {"scale_shift": ada[1]} if ada is not None else {}
+        h = self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
         x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
                                            attention_mask=attention_mask, key_len=key_len, residual=x)
-        h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt)
+        h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt, **kw2)
         y = self.feed_forward(h2, residual=x1, mask=mask)
         return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                       shared_intermediates=shared)
@@ -114,6 +117,25 @@ class Transformer(nn.Module, Constructor):
         self.pos_emb = None
         self.project_emb = nn.Linear(emb_dim, dim) if emb_dim != dim else nn.Identity()  # transformer.py:170
         self.norm = nn.LayerNorm(dim)                                                      # transformer.py:172
+        self._ada_cache: dict = {}
+
+    def _ada_all(self, condition: Tensor):
+        """Projects the condition for every AdaptiveLayerNorm of the stack in ONE launch (2 norms x 2 Linears per layer
+        would otherwise be 4*depth tiny launches): concatenated [4*depth*dim, cond] weight, sliced per norm."""
+        norms = [n for layer in self.layers for n in (layer.attention_norm, layer.feed_forward_norm)]
+        ps = [p for n in norms for p in (n.weight.weight, n.weight.bias, n.bias.weight, n.bias.bias)]
+        key = tuple((p.data_ptr(), p._version, p.device) for p in ps)
+        if self._ada_cache.get("key") != key:
+            with torch.no_grad():
+                w = torch.cat([torch.cat([n.weight.weight, n.bias.weight]) for n in norms]).contiguous()
+                b = torch.cat([torch.cat([n.weight.bias, n.bias.bias]) for n in norms]).contiguous()
+            self._ada_cache = {"key": key, "w": w, "b": b}
+        cond = condition.reshape(-1, condition.shape[-1]).float().contiguous()
+        proj = runtime.linear_small(cond, self._ada_cache["w"], self._ada_cache["b"])       # [Bc, 2*len(norms)*dim]
+        d = self.dim
+        parts = [(proj[:, (2 * i) * d:(2 * i + 1) * d], proj[:, (2 * i + 1) * d:(2 * i + 2) * d])
+                 for i in range(len(norms))]
+        return [(parts[2 * li], parts[2 * li + 1]) for li in range(len(self.layers))]
 
     def set_compute_dtype(self, dtype: torch.dtype):
         assert dtype in (torch.float32, torch.bfloat16)
@@ -139,9 +161,10 @@ class Transformer(nn.Module, Constructor):
         if mask is not None and key_len is None:
             key_len = mask.sum(dim=1)
         intermediates = []
-        for layer in self.layers:
+        ada = self._ada_all(adaptive_condition) if (self.adaptive_norm and adaptive_condition is not None) else None
+        for li, layer in enumerate(self.layers):
             res = layer(out, mask=mask, context=context, context_mask=context_mask, attention_mask=attention_mask,
-                        adaptive_condition=adaptive_condition, key_len=key_len)
+                        adaptive_condition=adaptive_condition, key_len=key_len, ada=None if ada is None else ada[li])
             out = res.out
             if return_intermediates:
                 intermediates.append(res.intermediates)

@@ -174,10 +174,15 @@ def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ada_sc
     rows, D = x2.shape
     y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
     ada_stride = 0
-    if ada_scale is not None:
-        ada_scale = ada_scale.reshape(-1, D).contiguous()
-        ada_shift = ada_shift.reshape(-1, D).contiguous() if ada_shift is not None else None
-        ada_stride = D if ada_scale.shape[0] > 1 else 0
+    if ada_scale is not None:   # [Bc, D] rows, possibly column slices of one wide projection (row stride kept, no copy)
+        ada_scale = ada_scale.reshape(-1, D) if ada_scale.ndim != 2 else ada_scale
+        if ada_scale.stride(1) != 1:
+            ada_scale = ada_scale.contiguous()
+        if ada_shift is not None:
+            ada_shift = ada_shift.reshape(-1, D) if ada_shift.ndim != 2 else ada_shift
+            if ada_shift.stride(1) != 1 or ada_shift.stride(0) != ada_scale.stride(0):
+                ada_scale, ada_shift = ada_scale.contiguous(), ada_shift.contiguous()
+        ada_stride = ada_scale.stride(0) if ada_scale.shape[0] > 1 else 0
     if row_mask is not None:
         row_mask = row_mask.reshape(-1).contiguous()
         assert row_mask.dtype == torch.bool and row_mask.numel() == rows

@@ -433,10 +433,10 @@ inline bool rows_epilogue_ok(const GemmParams& p) {
 // TN 32-wide feature tiles in accumulators (TN = 6 -> 96 registers).  K advances in 64-deep chunks through
 // double-buffered, padded (conflict-free) LDS tiles filled by fully coalesced 128-B row segments; computed transposed
 // (D = W_chunk · Xᵀ) for the vector epilogue.  Per chunk a wave issues 4*TN MFMAs for 4*(TN+1) ds_read_b128.
-template <int TN>
-__global__ __launch_bounds__(512) void gemm_bf16_wide_kernel(GemmParams p) {
-    constexpr int BM = 128, BN = 64 * TN, LD = 72;      // LD: 64 + 8 bf16 per LDS row
-    constexpr int XCH = BM * 8 / 512, WCH = BN * 8 / 512;  // 16-B chunks per thread per stage
+template <int TN, int WM>  // WM row-waves (32 rows each) x 2 feature-waves (TN 32-wide tiles each)
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) {
+    constexpr int BM = 32 * WM, BN = 64 * TN, LD = 72, NT = WM * 128;  // LD: 64 + 8 bf16 per LDS row
+    constexpr int XCH = (BM * 8 + NT - 1) / NT, WCH = (BN * 8 + NT - 1) / NT;  // 16-B chunks per thread per stage
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint16_t* Xs = reinterpret_cast<uint16_t*>(smem_raw);  // [2][BM][LD]
     uint16_t* Ws = Xs + 2 * BM * LD;                       // [2][BN][LD]
@@ -445,36 +445,38 @@ __global__ __launch_bounds__(512) void gemm_bf16_wide_kernel(GemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM;
+    const int nb0 = blockIdx.y * BN;  // feature offset of this workgroup (grid.y > 1 only for small M)
     const uint16_t* A = static_cast<const uint16_t*>(p.A);
     const uint16_t* W = static_cast<const uint16_t*>(p.W);
 
-    uint4 rx[XCH], rw[WCH];
+    u32x4 rx[XCH], rw[WCH];
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
     auto gload = [&](int kt) {
         const int k = kt * 64;
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 8;
+            const int id = tid + NT * i, r = id >> 3, c = (id & 7) * 8;
             const int row = m0 + r;
-            rx[i] = (row < p.M && k + c < p.K) ? *reinterpret_cast<const uint4*>(A + (int64_t)row * p.lda + k + c)
-                                               : make_uint4(0u, 0u, 0u, 0u);
+            rx[i] = (id < BM * 8 && row < p.M && k + c < p.K)
+                        ? *reinterpret_cast<const u32x4*>(A + (int64_t)row * p.lda + k + c) : zero4;
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
-            const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 8;
-            rw[i] = (r < p.N && k + c < p.K) ? *reinterpret_cast<const uint4*>(W + (int64_t)r * p.ldw + k + c)
-                                             : make_uint4(0u, 0u, 0u, 0u);
+            const int id = tid + NT * i, r = id >> 3, c = (id & 7) * 8;
+            rw[i] = (id < BN * 8 && nb0 + r < p.N && k + c < p.K)
+                        ? *reinterpret_cast<const u32x4*>(W + (int64_t)(nb0 + r) * p.ldw + k + c) : zero4;
         }
     };
     auto swrite = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < XCH; ++i) {
-            const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 8;
-            *reinterpret_cast<uint4*>(Xs + (buf * BM + r) * LD + c) = rx[i];
+            const int id = tid + NT * i, r = id >> 3, c = (id & 7) * 8;
+            if (id < BM * 8) *reinterpret_cast<u32x4*>(Xs + (buf * BM + r) * LD + c) = rx[i];
         }
 #pragma unroll
         for (int i = 0; i < WCH; ++i) {
-            const int id = tid + 512 * i, r = id >> 3, c = (id & 7) * 8;
-            *reinterpret_cast<uint4*>(Ws + (buf * BN + r) * LD + c) = rw[i];
+            const int id = tid + NT * i, r = id >> 3, c = (id & 7) * 8;
+            if (id < BN * 8) *reinterpret_cast<u32x4*>(Ws + (buf * BN + r) * LD + c) = rw[i];
         }
     };
 
@@ -512,13 +514,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_wide_kernel(GemmParams p) {
         // the K loop is over: its LDS tiles are dead, every wave takes a private patch of them for the row transpose
         char* stage = smem_raw + wave * kStageBytes;
 #pragma unroll
-        for (int t = 0; t < TN; ++t) store_rows_f32(p, stage, m0 + wm * 32, (wn * TN + t) * 32, acc[t], mk, lane);
+        for (int t = 0; t < TN; ++t)
+            store_rows_f32(p, stage, m0 + wm * 32, nb0 + (wn * TN + t) * 32, acc[t], mk, lane);
     } else if (m < p.M) {
 #pragma unroll
         for (int t = 0; t < TN; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = (wn * TN + t) * 32 + 8 * g + 4 * h;
+                const int n = nb0 + (wn * TN + t) * 32 + 8 * g + 4 * h;
                 if (n >= p.N) continue;
                 float v[4];
 #pragma unroll
@@ -528,12 +531,15 @@ __global__ __launch_bounds__(512) void gemm_bf16_wide_kernel(GemmParams p) {
     }
 }
 
-template <int TN>
+template <int TN, int WM>
 int32_t launch_wide(const GemmParams& p, hipStream_t s) {
-    constexpr size_t lds = (size_t)2 * (128 + 64 * TN) * 72 * sizeof(uint16_t);
+    constexpr int BM = 32 * WM, BN = 64 * TN;
+    constexpr size_t lds_tiles = (size_t)2 * (BM + BN) * 72 * sizeof(uint16_t);
+    constexpr size_t lds = lds_tiles > (size_t)WM * 2 * kStageBytes ? lds_tiles : (size_t)WM * 2 * kStageBytes;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    ISPK_RESERVE_LDS((&gemm_bf16_wide_kernel<TN>), lds, "gemm");
-    hipLaunchKernelGGL((gemm_bf16_wide_kernel<TN>), dim3((p.M + 127) / 128), dim3(512), lds, s, p);
+    ISPK_RESERVE_LDS((&gemm_bf16_wide_kernel<TN, WM>), lds, "gemm");
+    hipLaunchKernelGGL((gemm_bf16_wide_kernel<TN, WM>), dim3((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), dim3(WM * 128), lds,
+                       s, p);
     return ispk_launch_status();
 }
 
@@ -770,7 +776,12 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
     if (M == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (panel_ok(p)) return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
-    if (wide_ok(p)) return N == 384 ? launch_wide<6>(p, s) : launch_wide<4>(p, s);
+    if (wide_ok(p)) {
+        // all N features per workgroup when there are enough rows to fill the chip with 128-row blocks; for the short
+        // sequences (encoder: 6,400 rows) 64-row blocks x half the features so that >= 200 workgroups exist
+        if (M >= 128 * 160) return N == 384 ? launch_wide<6, 4>(p, s) : launch_wide<4, 4>(p, s);
+        return N == 384 ? launch_wide<3, 2>(p, s) : launch_wide<2, 2>(p, s);
+    }
     switch (ispk_gemm_f32_tile(M, N, K)) {  // same occupancy rule as the fp32 path
         case 22: return launch_bf16<2, 2>(p, s);
         case 12: return launch_bf16<1, 2>(p, s);

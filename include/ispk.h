@@ -109,6 +109,9 @@ int32_t ispk_gemm_f32_tile(int32_t M, int32_t N, int32_t K);
 int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, const float* bias,
                       const float* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N, int32_t K,
                       uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);
+/* Kernel instance dispatched by this thread's last ispk_gemm_bf16 call (profiler labels): 1000+KC panel<KC>,
+ * 2000+10*TN+WM wide<TN,WM>, 3000+10*TM+TN generic<TM,TN>. */
+int32_t ispk_gemm_bf16_last_variant(void);
 int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
                        const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N,
                        int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);

@@ -31,6 +31,7 @@ SIGNATURES = {
     "ispk_layernorm_f32_bf16": [_P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _F32, _P],
     "ispk_gemm_f32_tile": [_I32, _I32, _I32],
     "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
+    "ispk_gemm_bf16_last_variant": [],
     "ispk_gemm_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -105,6 +106,10 @@ def _launch(label: str, flops: float, nbytes: float, fn, *args) -> None:
     rc = fn(*args)
     e1.record()
     _check(rc, label)
+    if label == "gemm_bf16_kernel":   # resolve to the instance the library actually dispatched
+        v = lib().ispk_gemm_bf16_last_variant()
+        label = {1: f"gemm_bf16_panel_kernel<{v % 1000}>", 2: f"gemm_bf16_wide_kernel<{(v % 1000) // 10},{v % 10}>",
+                 3: f"gemm_bf16_kernel<{(v % 1000) // 10},{v % 10}>"}.get(v // 1000, label)
     _profiler.records.append((label, flops, nbytes, e0, e1))
 
 

@@ -116,6 +116,18 @@ int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_
                        const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N,
                        int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);
 
+/* Linear + the NEXT LayerNorm in one kernel (bf16 operands):  C = epilogue(A·Wᵀ) exactly as ispk_gemm_bf16 with an fp32
+ * row-major C, and additionally  ln_out[i][:] = [mask[i]] * ( (C[i][:] - mean_i) / sqrt(var_i + ln_eps) * ln_gamma + ln_beta ).
+ * Replaces, on the bf16 path, the LayerNorm that the reference applies to this Linear's output before the next Linear:
+ * transformer.py:91-102 (to_out + residual -> feed_forward_norm -> * mask), :105-110 + :79 of the next layer (second FFN
+ * Linear + residual + mask -> next attention_norm) and :205-206 (final norm * mask).  N must be 256 or 384 (a workgroup
+ * holds whole rows); statistics are two-pass fp32 over the fp32 result.  ln_flags: 1 = multiply ln_out rows by `mask`,
+ * 2 = ln_out is bf16 (else fp32).  ln_ld: leading stride of ln_out. */
+int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc,
+                          const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N,
+                          int32_t K, uint32_t flags, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out,
+                          int64_t ln_ld, uint32_t ln_flags, ispk_stream_t stream);
+
 /* Small / odd-shaped Linear (any K, N): one thread per output, fp32 FMA chain in k order.
  * Replaces the tiny nn.Linear sites: embeddings.py:149-153 (time MLP 65->32->32), normalization.py:43-51 (AdaLN
  * condition projections 32->D), temporal_adaptor.py:43,98 (linear_layer D->3), transformer.py:170 with

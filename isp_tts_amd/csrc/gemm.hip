@@ -37,6 +37,13 @@ struct GemmParams {
     uint32_t flags;
     int cpb;
     int64_t bstride;
+    // fused LayerNorm of the OUTPUT rows (wide bf16 kernel only, ispk_gemm_bf16_ln)
+    const float* ln_gamma = nullptr;
+    const float* ln_beta = nullptr;
+    void* ln_out = nullptr;
+    int64_t ln_ld = 0;
+    float ln_eps = 1e-5f;
+    uint32_t ln_flags = 0;
 };
 
 constexpr int kLdt = 36;  // padded LDS row length in dwords (32 + 4)
@@ -341,7 +348,7 @@ __device__ __forceinline__ void pre_stage(const GemmParams& p, int n, float (&v)
 
 // fp32 output: one 32-feature tile (features n0 .. n0+31) of the wave's 32 rows (m0 .. m0+31)
 __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage, int m0, int n0, const f32x16& acc,
-                                               float mk, int lane) {
+                                               float mk, int lane, float4* keep = nullptr) {
     const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -375,6 +382,7 @@ __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage,
             }
             *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = v;
         }
+        if (keep) keep[i] = v;  // final values in row layout: rows 8i + (lane>>3), features n0 + 4(lane&7) .. +3
     }
 }
 
@@ -423,7 +431,7 @@ inline bool rows_epilogue_ok(const GemmParams& p) {
 // TN 32-wide feature tiles in accumulators (TN = 6 -> 96 registers).  K advances in 64-deep chunks through
 // double-buffered, padded (conflict-free) LDS tiles filled by fully coalesced 128-B row segments; computed transposed
 // (D = W_chunk · Xᵀ) for the vector epilogue.  Per chunk a wave issues 4*TN MFMAs for 4*(TN+1) ds_read_b128.
-template <int TN, int WM>  // WM row-waves (32 rows each) x 2 feature-waves (TN 32-wide tiles each)
+template <int TN, int WM, bool LN = false>  // WM row-waves (32 rows each) x 2 feature-waves (TN 32-wide tiles each)
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) {
     constexpr int BM = 32 * WM, BN = 64 * TN, LD = 72, NT = WM * 128;  // LD: 64 + 8 bf16 per LDS row
     constexpr int XCH = (BM * 8 + NT - 1) / NT, WCH = (BN * 8 + NT - 1) / NT;  // 16-B chunks per thread per stage
@@ -500,7 +508,81 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) 
 
     const int m = m0 + wm * 32 + l31;
     const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
-    if (!(p.flags & ISPK_EP_OUT_BF16)) {
+    if constexpr (LN) {
+        // ---- fused LayerNorm of the finished rows (this workgroup holds ALL N features of its rows: BN == N).
+        // Writes C = the GEMM result (fp32 residual stream) AND ln_out = LN(C) * [mask], so the consumer GEMM needs no
+        // separate normalisation pass (normalization.py:20-27 + transformer.py:101-102 / :205-206 of the reference).
+        // Two-pass statistics in fp32 from registers; a row is spread over 8 lanes x TN tiles x 2 waves.
+        char* stage = smem_raw + wave * kStageBytes;
+        float* red = reinterpret_cast<float*>(smem_raw + WM * 2 * kStageBytes);  // [2 passes][WM][2 waves][32 rows]
+        float4 yv[TN][4];
+        float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+            store_rows_f32(p, stage, m0 + wm * 32, (wn * TN + t) * 32, acc[t], mk, lane, yv[t]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[i] += (yv[t][i].x + yv[t][i].y) + (yv[t][i].z + yv[t][i].w);
+        }
+        auto row_total = [&](float (&v)[4], int pass) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] += __shfl_xor(v[i], 1, 64);
+                v[i] += __shfl_xor(v[i], 2, 64);
+                v[i] += __shfl_xor(v[i], 4, 64);
+                if ((lane & 7) == 0) red[((pass * WM + wm) * 2 + wn) * 32 + 8 * i + (lane >> 3)] = v[i];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + (lane >> 3);
+                v[i] = red[((pass * WM + wm) * 2 + 0) * 32 + r] + red[((pass * WM + wm) * 2 + 1) * 32 + r];
+            }
+        };
+        row_total(rs, 0);
+        float mean[4], qs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mean[i] = rs[i] * (1.0f / (float)BN);
+            qs[i] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = yv[t][i].x - mean[i], b = yv[t][i].y - mean[i], c = yv[t][i].z - mean[i],
+                            d = yv[t][i].w - mean[i];
+                qs[i] += (a * a + b * b) + (c * c + d * d);
+            }
+        row_total(qs, 1);
+        const int c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mr = m0 + wm * 32 + 8 * i + (lane >> 3);
+            if (mr >= p.M) continue;
+            const float rstd = 1.0f / sqrtf(qs[i] * (1.0f / (float)BN) + p.ln_eps);
+            const float mo = ((p.ln_flags & 1u) && p.mask) ? (p.mask[mr] ? 1.0f : 0.0f) : 1.0f;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) {
+                const int n = (wn * TN + t) * 32 + c4;
+                const float4 g = *reinterpret_cast<const float4*>(p.ln_gamma + n);
+                const float4 be = *reinterpret_cast<const float4*>(p.ln_beta + n);
+                float4 o;
+                o.x = ((yv[t][i].x - mean[i]) * rstd * g.x + be.x) * mo;
+                o.y = ((yv[t][i].y - mean[i]) * rstd * g.y + be.y) * mo;
+                o.z = ((yv[t][i].z - mean[i]) * rstd * g.z + be.z) * mo;
+                o.w = ((yv[t][i].w - mean[i]) * rstd * g.w + be.w) * mo;
+                const int64_t off = (int64_t)mr * p.ln_ld + n;
+                if (p.ln_flags & 2u) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(o.z) | ((uint32_t)f32_to_bf16(o.w) << 16);
+                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.ln_out) + off) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(static_cast<float*>(p.ln_out) + off) = o;
+                }
+            }
+        }
+    } else if (!(p.flags & ISPK_EP_OUT_BF16)) {
         // the K loop is over: its LDS tiles are dead, every wave takes a private patch of them for the row transpose
         char* stage = smem_raw + wave * kStageBytes;
 #pragma unroll
@@ -521,15 +603,16 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) 
     }
 }
 
-template <int TN, int WM>
+template <int TN, int WM, bool LN = false>
 int32_t launch_wide(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 64 * TN;
     constexpr size_t lds_tiles = (size_t)2 * (BM + BN) * 72 * sizeof(uint16_t);
-    constexpr size_t lds = lds_tiles > (size_t)WM * 2 * kStageBytes ? lds_tiles : (size_t)WM * 2 * kStageBytes;
+    constexpr size_t lds_epi = (size_t)WM * 2 * kStageBytes + (LN ? (size_t)2 * WM * 2 * 32 * sizeof(float) : 0);
+    constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    ISPK_RESERVE_LDS((&gemm_bf16_wide_kernel<TN, WM>), lds, "gemm");
-    hipLaunchKernelGGL((gemm_bf16_wide_kernel<TN, WM>), dim3((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), dim3(WM * 128), lds,
-                       s, p);
+    ISPK_RESERVE_LDS((&gemm_bf16_wide_kernel<TN, WM, LN>), lds, "gemm");
+    hipLaunchKernelGGL((gemm_bf16_wide_kernel<TN, WM, LN>), dim3((p.M + BM - 1) / BM, (p.N + BN - 1) / BN),
+                       dim3(WM * 128), lds, s, p);
     return ispk_launch_status();
 }
 
@@ -695,7 +778,8 @@ bool panel_ok(const GemmParams& p) {
 }
 
 bool wide_ok(const GemmParams& p) {
-    return p.K >= 512 && (p.N == 384 || p.N == 256 || p.N % 192 == 0) && p.M >= 128 * 16 && vec_epilogue_ok(p) &&
+    return (p.K >= 512 || getenv("ISPK_FORCE_WIDE")) && (p.N == 384 || p.N == 256 || p.N % 192 == 0) && p.M >= 128 * 16 &&
+           vec_epilogue_ok(p) &&
            !(p.flags & ISPK_EP_OUT_BF16) && getenv("ISPK_NO_WIDE") == nullptr;
 }
 
@@ -771,7 +855,7 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
     if (int32_t rc = check_common(p, 2)) return rc;
     if (M == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (panel_ok(p)) {
+    if (panel_ok(p) && !(getenv("ISPK_FORCE_WIDE") && (N == 384 || N == 256) && !(flags & ISPK_EP_OUT_BF16))) {
         g_last_bf16_variant = 1000 + K / 64;
         return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
     }
@@ -792,4 +876,24 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
         case 12: return launch_bf16<1, 2>(p, s);
     }
     return launch_bf16<1, 1>(p, s);
+}
+
+extern "C" int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc,
+                                     const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M,
+                                     int32_t N, int32_t K, uint32_t flags, const float* ln_gamma, const float* ln_beta,
+                                     float ln_eps, void* ln_out, int64_t ln_ld, uint32_t ln_flags, ispk_stream_t stream) {
+    GemmParams p{A, lda, W, ldw, C, ldc, bias, resid, ldr, mask, M, N, K, flags, 0, 0};
+    if (int32_t rc = check_common(p, 2)) return rc;
+    ISPK_REQUIRE(ln_gamma && ln_beta && ln_out, ISPK_E_NULL, "gemm_ln: null LayerNorm argument");
+    ISPK_REQUIRE(N == 384 || N == 256, ISPK_E_UNSUPPORTED, "gemm_ln: N=%d (a workgroup must hold whole rows: 256 or 384)", N);
+    ISPK_REQUIRE(!(flags & (ISPK_EP_OUT_BF16 | ISPK_EP_BIAS_ROW | ISPK_EP_MASK_COL)) && vec_epilogue_ok(p), ISPK_E_UNSUPPORTED,
+                 "gemm_ln: needs an fp32 row-major output with 16-byte aligned rows");
+    ISPK_REQUIRE(ln_ld % 4 == 0 && ispk_aligned(ln_out, (ln_flags & 2u) ? 8 : 16) && ispk_aligned(ln_gamma, 16) &&
+                     ispk_aligned(ln_beta, 16), ISPK_E_ALIGN, "gemm_ln: LayerNorm buffers must be 16-byte aligned");
+    ISPK_REQUIRE(!((ln_flags & 1u) && !mask), ISPK_E_NULL, "gemm_ln: ln mask flag set but mask is NULL");
+    if (M == 0) return 0;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_out = ln_out; p.ln_ld = ln_ld; p.ln_eps = ln_eps; p.ln_flags = ln_flags;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (M >= 128 * 160) return N == 384 ? launch_wide<6, 4, true>(p, s) : launch_wide<4, 4, true>(p, s);
+    return N == 384 ? launch_wide<6, 2, true>(p, s) : launch_wide<4, 2, true>(p, s);
 }

@@ -85,6 +85,33 @@ class TransformerLayer(nn.Module, Constructor):
                                       shared_intermediates=shared)
 
 
+    def forward_fused(self, x: Tensor, h: Tensor, mask: Optional[Tensor], key_len: Optional[Tensor], next_norm: tuple):
+        """bf16 path with LayerNorms fused into the producing GEMMs (5 launches per layer instead of 7):
+            qkv = h · [Wq;Wkv]ᵀ ; o = attention(qkv)
+            x1, h2 = gemm_ln(o · Woᵀ : x + mask*(.),  LN = feed_forward_norm, * mask)       transformer.py:91-102
+            f = gelu(h2 · W1ᵀ)
+            y, hn = gemm_ln(f · W2ᵀ : mask*(x1 + .),  LN = next_norm)                        :105-110, next :79 / :205
+        `h` = attention_norm(x) in bf16 (from the previous layer's epilogue); `next_norm` = (weight, bias, apply_mask,
+        dtype) of the norm that consumes this layer's output.  Returns (y, hn, AttentionIntermediates)."""
+        att, ff = self.attention, self.feed_forward
+        wqkv, wo, slopes = att._staged(torch.bfloat16)
+        w1, w2 = ff._staged(torch.bfloat16)
+        b, n, _ = x.shape
+        qkv = runtime.gemm(h, wqkv)
+        o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
+        x1, h2 = runtime.gemm_ln(o, wo, self.feed_forward_norm.weight, self.feed_forward_norm.bias, resid=x, mask=mask,
+                                 flags=runtime.EP_MASK_ACC if mask is not None else 0, ln_mask=True,
+                                 ln_eps=self.feed_forward_norm.eps)
+        f = runtime.gemm(h2, w1, bias=ff.net[0].bias, flags=ff.act_flag)
+        nw, nb, nmask, ndtype = next_norm
+        y, hn = runtime.gemm_ln(f, w2, nw, nb, resid=x1, mask=mask, bias=ff.net[3].bias,
+                                flags=runtime.EP_MASK_OUT if mask is not None else 0, ln_mask=nmask, ln_dtype=ndtype)
+        hq = att.heads * 64
+        inter = AttentionIntermediates(queries=qkv[..., :hq].view(b, n, att.heads, 64).transpose(1, 2),
+                                       keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])
+        return y, hn, inter
+
+
 class TransformerOutput(NamedTuple):
     out: Tensor
     intermediates: Optional[list] = None
@@ -137,6 +164,20 @@ class Transformer(nn.Module, Constructor):
                  for i in range(len(norms))]
         return [(parts[2 * li], parts[2 * li + 1]) for li in range(len(self.layers))]
 
+    # Fusing each LayerNorm into the epilogue of the GEMM that produces its input (ispk_gemm_bf16_ln) is implemented and
+    # parity-tested but OFF by default: measured on MI355X at the benchmark shape it is 3 % SLOWER (4.27 vs 4.15 ms/step).
+    # The wide kernel runs one round of 256 workgroups that all reach their epilogue together, so the extra HBM phase
+    # (residual in, fp32 + bf16 rows out) overlaps with no MFMA work, and its 64-row variant under-fills the chip on the
+    # 6,400-row encoder.  Kept for the next round (needs an epilogue that overlaps with the following tile's K loop).
+    fuse_layernorm = False
+
+    def _fusable(self, context, context_mask, attention_mask) -> bool:
+        att = self.layers[0].attention
+        return (self.fuse_layernorm and att.compute_dtype == torch.bfloat16 and not self.adaptive_norm and context is None
+                and context_mask is None and attention_mask is None and self.dim in (256, 384)
+                and all(not (l.training and (l.attention.attend.dropout > 0 or l.feed_forward.dropout_p > 0))
+                        for l in self.layers) and self.norm.eps == 1e-5)
+
     def set_compute_dtype(self, dtype: torch.dtype):
         assert dtype in (torch.float32, torch.bfloat16)
         for layer in self.layers:
@@ -161,6 +202,21 @@ class Transformer(nn.Module, Constructor):
         if mask is not None and key_len is None:
             key_len = mask.sum(dim=1)
         intermediates = []
+        if self._fusable(context, context_mask, attention_mask):
+            # bf16 path: every LayerNorm except the first rides in the epilogue of the GEMM that produces its input
+            out = out.float().contiguous()
+            h = runtime.layernorm(out, self.layers[0].attention_norm.weight, self.layers[0].attention_norm.bias,
+                                  eps=self.layers[0].attention_norm.eps, out_dtype=torch.bfloat16)
+            for li, layer in enumerate(self.layers):
+                if li + 1 < len(self.layers):
+                    nn_ = self.layers[li + 1].attention_norm
+                    nxt = (nn_.weight, nn_.bias, False, torch.bfloat16)
+                else:
+                    nxt = (self.norm.weight, self.norm.bias, mask is not None, out_dtype)
+                out, h, inter = layer.forward_fused(out, h, mask, key_len, nxt)
+                if return_intermediates:
+                    intermediates.append(TransformerLayerIntermediates(attention=inter))
+            return TransformerOutput(out=h, intermediates=intermediates)
         ada = self._ada_all(adaptive_condition) if (self.adaptive_norm and adaptive_condition is not None) else None
         for li, layer in enumerate(self.layers):
             res = layer(out, mask=mask, context=context, context_mask=context_mask, attention_mask=attention_mask,

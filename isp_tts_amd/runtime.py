@@ -33,6 +33,8 @@ SIGNATURES = {
     "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_gemm_bf16_last_variant": [],
     "ispk_gemm_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
+    "ispk_gemm_bf16_ln": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64, _U32,
+                          _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -234,6 +236,32 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Optional[Te
             w.data_ptr(), w.stride(0), c2.data_ptr(), c2.stride(0), _ptr(bias), _ptr(r2),
             r2.stride(0) if r2 is not None else 0, _ptr(mask), M, N, K, flags, 0, 0, _stream())
     return out
+
+
+def gemm_ln(a: Tensor, w: Tensor, ln_weight: Tensor, ln_bias: Tensor, resid: Optional[Tensor] = None,
+            mask: Optional[Tensor] = None, flags: int = 0, bias: Optional[Tensor] = None, ln_mask: bool = False,
+            ln_dtype: torch.dtype = torch.bfloat16, ln_eps: float = 1e-5):
+    """ispk_gemm_bf16_ln: (C fp32 [..., N], LN(C) [..., N] in ln_dtype) from bf16 a[..., K] @ w[N, K]^T."""
+    _dev(a, w, ln_weight, ln_bias, resid, mask, bias)
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    a2 = _rows2d(a)
+    M, K = a2.shape
+    N = w.shape[0]
+    out = torch.empty((*a.shape[:-1], N), dtype=torch.float32, device=a.device)
+    ln_out = torch.empty((*a.shape[:-1], N), dtype=ln_dtype, device=a.device)
+    r2 = _rows2d(resid) if resid is not None else None
+    if r2 is not None and r2.dtype == torch.bfloat16:
+        flags |= EP_RESID_BF16
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+    lnf = (1 if (ln_mask and mask is not None) else 0) | (2 if ln_dtype == torch.bfloat16 else 0)
+    nb = a2.numel() * 2 + w.numel() * 2 + out.numel() * 4 + ln_out.numel() * ln_out.element_size() + \
+        (r2.numel() * r2.element_size() if r2 is not None else 0)
+    _launch(f"gemm_bf16_wide_kernel<{N // 64},{4 if M >= 20480 else 2},ln>", 2.0 * M * N * K, float(nb),
+            lib().ispk_gemm_bf16_ln, a2.data_ptr(), a2.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), N, _ptr(bias),
+            _ptr(r2), r2.stride(0) if r2 is not None else 0, _ptr(mask), M, N, K, flags, ln_weight.data_ptr(),
+            ln_bias.data_ptr(), ln_eps, ln_out.data_ptr(), N, lnf, _stream())
+    return out, ln_out
 
 
 def _gemm_label(bf16: bool, M: int, N: int, K: int) -> str:

@@ -358,3 +358,37 @@ def test_soft_average_targets():
                       orc.soft_average(energy[:, None], attn).transpose(1, 2) * mask], dim=-1)
     got = runtime.soft_average(attn.to(DEV), pitch.to(DEV), energy.to(DEV), dur.to(DEV), tl.to(DEV)).cpu()
     assert (got - want).abs().max() < 2e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(21000, 384, 1536), (6400, 384, 384), (2100, 256, 1024)])
+def test_gemm_bf16_with_fused_layernorm(M, N, K):
+    """ispk_gemm_bf16_ln: C = mask*(resid + A·Wᵀ) in fp32 and LN(C)*mask in bf16 from one kernel."""
+    a, w = _bf(synth._normal(f"t/gln/a{M}", (M, K))), _bf(synth._normal(f"t/gln/w{N}x{K}", (N, K), K ** -0.5))
+    resid = synth._normal("t/gln/r", (M, N))
+    g, b = synth._normal("t/gln/g", (N,), 0.1, 1.0), synth._normal("t/gln/b", (N,), 0.1)
+    mask = torch.arange(M) % 7 != 3
+    d = lambda t: t.to(DEV)  # noqa: E731
+    out, ln = runtime.gemm_ln(d(a), d(w), d(g), d(b), resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT, ln_mask=True)
+    ref = _gemm_ref(a, w, resid=resid, mask=mask, mask_out=True)
+    assert (out.cpu().double() - ref).abs().max() < 3e-5
+    ln_ref = F.layer_norm(ref, (N,), g.double(), b.double(), 1e-5) * mask[:, None]
+    assert ln.dtype == torch.bfloat16
+    assert ((ln.cpu().double() - ln_ref).abs() <= ln_ref.abs() * 2 ** -8 + 2e-5).all()
+    out32, ln32 = runtime.gemm_ln(d(a), d(w), d(g), d(b), resid=d(resid), ln_dtype=torch.float32)
+    ref2 = _gemm_ref(a, w, resid=resid)
+    assert (ln32.cpu().double() - F.layer_norm(ref2, (N,), g.double(), b.double(), 1e-5)).abs().max() < 3e-5
+
+
+def test_transformer_with_fused_layernorm_matches_unfused(gpu_model):
+    x = synth._normal("t/fln/x", (3, 100, 384)).to(DEV)
+    mask = (torch.arange(100)[None] < torch.tensor([100, 61, 9])[:, None]).to(DEV)
+    enc = gpu_model.encoder
+    try:
+        enc.set_compute_dtype(torch.bfloat16)
+        base = enc(x, mask=mask).out
+        enc.fuse_layernorm = True
+        fused = enc(x, mask=mask).out
+    finally:
+        enc.fuse_layernorm = False
+        enc.set_compute_dtype(torch.float32)
+    assert (fused - base).abs().max() < 3e-2 and (fused - base).pow(2).mean().sqrt() < 4e-3

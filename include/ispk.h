@@ -128,6 +128,17 @@ int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int
                           int32_t K, uint32_t flags, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out,
                           int64_t ln_ld, uint32_t ln_flags, ispk_stream_t stream);
 
+/* The whole feed-forward block in one kernel (bf16 operands, fp32 accumulation):
+ *   out[i][:] = [mask[i]] * ( resid[i][:] + gelu_erf( x[i][:]·W1ᵀ + bias1 )·W2ᵀ + bias2 )
+ * Replaces: feedforward.py:33-40 (Linear -> GELU -> Linear; W1 [inner][dim], W2 [dim][inner] as nn.Linear stores them)
+ * with the residual add and row mask of transformer.py:105-110.  The [rows][inner] hidden activations never reach HBM.
+ * x bf16 [rows][dim]; resid / out fp32 [rows][dim]; dim 256 or 384; inner % 32 == 0; flags: ISPK_EP_MASK_OUT (mask after
+ * the residual add) or ISPK_EP_MASK_ACC (before). */
+int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
+                      const uint16_t* W2, int64_t ldw2, const float* bias2, const float* resid, int64_t ldr,
+                      const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
+                      ispk_stream_t stream);
+
 /* Small / odd-shaped Linear (any K, N): one thread per output, fp32 FMA chain in k order.
  * Replaces the tiny nn.Linear sites: embeddings.py:149-153 (time MLP 65->32->32), normalization.py:43-51 (AdaLN
  * condition projections 32->D), temporal_adaptor.py:43,98 (linear_layer D->3), transformer.py:170 with

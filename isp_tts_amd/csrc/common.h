@@ -110,6 +110,18 @@ template <int OFF>
 __device__ __forceinline__ void lds_read_b128_asm(bf16x8& dst, uint32_t lds_byte_addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF) : "memory");
 }
+// two 8-byte reads (byte offsets 8*O0 and 8*O1 from the address) into one 128-bit fragment
+template <int O0, int O1>
+__device__ __forceinline__ void lds_read2_b64_asm(bf16x8& dst, uint32_t lds_byte_addr) {
+    asm volatile("ds_read2_b64 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(lds_byte_addr), "n"(O0), "n"(O1) : "memory");
+}
+// same read with the destination in the ACCUMULATOR half of the unified register file ("=a"): for kernels whose arch
+// VGPRs are full, where hipcc otherwise loads to a VGPR and copies to an AGPR (4 v_accvgpr_write + hazard nops) before
+// every MFMA.  MFMA A/B operands may be AGPRs on gfx950.
+template <int OFF>
+__device__ __forceinline__ void lds_read_b128_asm_acc(bf16x8& dst, uint32_t lds_byte_addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(dst) : "v"(lds_byte_addr), "n"(OFF) : "memory");
+}
 template <int N>
 __device__ __forceinline__ void lds_wait() {
     asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");

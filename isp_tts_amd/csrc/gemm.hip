@@ -878,6 +878,209 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
     return launch_bf16<1, 1>(p, s);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fused feed-forward block (bf16):  out = mask * ( resid + gelu(x · W1ᵀ + b1) · W2ᵀ + b2 )     feedforward.py:33-40 plus
+// the residual add and row mask of transformer.py:105-110 — ONE kernel, the [rows, inner] hidden activations never
+// leave the CU (unfused they cost 2 x rows x inner x 2 B of HBM traffic: 200 MB per decoder layer at the benchmark shape,
+// more than everything else the layer moves).
+//
+// A workgroup owns 128 rows (4 waves x 32 rows, one wave per SIMD with the whole 512-register file):
+//   xf   : the wave's 32 input rows x D as MFMA fragments, loaded once                            (D/16 x 4 VGPRs)
+//   acc2 : the wave's 32 rows x D outputs, transposed (feature on the row axis, row on the lane)   (D/32 x 16 regs)
+// and walks the inner dimension in chunks of 32 hidden units.  Per chunk:
+//   1. acc1 = W1[chunk] · xfᵀ          (D/16 MFMAs; W1 chunk [32][D] streamed through LDS)
+//   2. GELU on the 16 accumulator registers, packed pairwise to bf16 — which IS the B operand of the next product
+//      (register 8s+j of lane half h = hidden 16s + 8(j>>2) + 4h + (j&3): accumulator-as-operand, guide §3)
+//   3. acc2[nt] += W2[nt-th 32 features][chunk] · Pᵀ   (D/32 x 2 MFMAs; W2 chunk [D][32] in LDS, its 32 hidden columns
+//      stored permuted into that same order so that each fragment is ONE conflict-free ds_read_b128)
+// Weight chunks are double-buffered in LDS and prefetched one chunk ahead through registers; one barrier per chunk.
+// Epilogue: the row-coalescing transpose (store_rows_f32) with residual and mask.
+template <int KC, bool B1>  // D = 64 * KC; B1: first Linear has a bias (recipes: no)
+__global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const uint16_t* __restrict__ W2, int64_t ldw2,
+                                                          const float* __restrict__ bias1, int F) {
+    constexpr int D = 64 * KC, KS = D / 16, NT = D / 32, HC = 32;
+    constexpr int LD1 = D + 8, LD2 = HC + 8;         // padded LDS rows (bf16 elements)
+    constexpr int C1 = HC * (D / 8) / 256;            // 16-B chunks per thread: W1 chunk (32 rows x D/8)
+    constexpr int C2 = D * (HC / 8) / 256;            //                          W2 chunk (D rows x 4)
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    uint16_t* W1s = reinterpret_cast<uint16_t*>(smem_raw);   // [2][HC][LD1]
+    uint16_t* W2s = W1s + 2 * HC * LD1;                      // [2][D][LD2]
+    char* stage = smem_raw + (size_t)(2 * HC * LD1 + 2 * D * LD2) * 2 + (threadIdx.x >> 6) * kStageBytes;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int mw0 = blockIdx.x * 128 + wave * 32;
+    const int m = mw0 + l31;
+    const uint16_t* X = static_cast<const uint16_t*>(p.A);
+    const uint16_t* W1 = static_cast<const uint16_t*>(p.W);
+    const int nchunks = F / HC;
+
+    // per-thread element offsets of its staging pieces inside chunk 0 (32-bit, computed once); a chunk then only adds a
+    // wave-uniform step, so the loads are "uniform base + 32-bit lane offset" with no 64-bit arithmetic in the loop
+    u32x4 r1[C1], r2[C2];
+    int o1[C1], o2[C2];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        const int id = tid + 256 * i, r = id / (D / 8), cc = id - r * (D / 8);
+        o1[i] = r * (int)p.ldw + cc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < C2; ++i) {
+        const int id = tid + 256 * i, n = id >> 2, cc = id & 3;
+        o2[i] = n * (int)ldw2 + cc * 8;
+    }
+    const int step1 = HC * (int)p.ldw;
+    auto load_chunk = [&](int c) {
+        c = c < nchunks ? c : nchunks - 1;
+        const uint16_t* b1 = W1 + (int64_t)c * step1;
+        const uint16_t* b2 = W2 + c * HC;
+#pragma unroll
+        for (int i = 0; i < C1; ++i) r1[i] = *reinterpret_cast<const u32x4*>(b1 + o1[i]);
+#pragma unroll
+        for (int i = 0; i < C2; ++i) r2[i] = *reinterpret_cast<const u32x4*>(b2 + o2[i]);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < C1; ++i) {
+            const int id = tid + 256 * i, r = id / (D / 8), cc = id - r * (D / 8);
+            *reinterpret_cast<u32x4*>(W1s + (buf * HC + r) * LD1 + cc * 8) = r1[i];
+        }
+        // W2 chunk rows are stored PERMUTED in the hidden order of the accumulator fragment (LDS position 16s + 8h + j
+        // holds hidden 16s + 8(j>>2) + 4h + (j&3)), so a lane's k-step fragment is one aligned 16-byte run: the global
+        // 16-byte piece cc (hidden 8cc .. 8cc+7; s = cc>>1, a = cc&1) lands as two 8-byte halves at 16s + 4a (h = 0)
+        // and 16s + 8 + 4a (h = 1).
+#pragma unroll
+        for (int i = 0; i < C2; ++i) {
+            const int id = tid + 256 * i, n = id >> 2, cc = id & 3;
+            uint16_t* row = W2s + (buf * D + n) * LD2 + 16 * (cc >> 1) + 4 * (cc & 1);
+            uint2 lo, hi;
+            lo.x = r2[i][0]; lo.y = r2[i][1]; hi.x = r2[i][2]; hi.y = r2[i][3];
+            *reinterpret_cast<uint2*>(row) = lo;
+            *reinterpret_cast<uint2*>(row + 8) = hi;
+        }
+    };
+
+    load_chunk(0);
+    bf16x8 xf[KS];
+    {
+        const int mrow = m < p.M ? m : p.M - 1;
+        const uint16_t* xp = X + (int64_t)mrow * p.lda + 8 * h;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + 16 * ks);
+    }
+    store_chunk(0);
+    load_chunk(1);
+    f32x16 acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
+    __syncthreads();
+
+    // One wave per SIMD: nothing hides an LDS round trip, so the KS + 2*NT operand reads of a chunk run as ONE stream
+    // through an RD-deep register ring of opaque asm reads with hand-counted waits (see gemm_bf16_panel_kernel); the
+    // W2 reads are issued while the GELU of the chunk is still running.
+    constexpr int RD = 8, NS = KS + 2 * NT;
+    const uint32_t w1base = lds_addr(W1s + l31 * LD1 + 8 * h);
+    const uint32_t w2base = lds_addr(W2s + l31 * LD2 + 8 * h);
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        const uint32_t a1 = w1base + buf * (HC * LD1 * 2);
+        const uint32_t a2 = w2base + buf * (D * LD2 * 2);
+        bf16x8 q[RD];
+        auto issue = [&](auto ic) {
+            constexpr int st = decltype(ic)::value;
+            if constexpr (st < KS) {
+                lds_read_b128_asm_acc<st * 32>(q[st % RD], a1);
+            } else {
+                constexpr int nt = (st - KS) / 2, s2 = (st - KS) % 2;
+                lds_read_b128_asm_acc<(nt * 32 * LD2 + 16 * s2) * 2>(q[st % RD], a2);
+            }
+        };
+        static_for<0, RD>(issue);
+        f32x16 acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+        union { uint32_t u[4]; bf16x8 f; } pf[2];
+        static_for<0, NS>([&](auto ic) {
+            constexpr int st = decltype(ic)::value;
+            if constexpr (st == KS) {
+                // bias, GELU, pack: accumulator registers 8s .. 8s+7 become the B fragment of k-step s
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f32x2 v;
+                        v.x = acc1[8 * s + 2 * e];
+                        v.y = acc1[8 * s + 2 * e + 1];
+                        if constexpr (B1) {
+                            const int hid = c * HC + ((2 * e) & 3) + 8 * ((8 * s + 2 * e) >> 2) + 4 * h;
+                            v.x += bias1[hid];
+                            v.y += bias1[hid + 1];
+                        }
+                        v = gelu_fast2(v);
+                        pf[s].u[e] = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+                    }
+            }
+            constexpr int younger = (NS - 1 - st) < (RD - 1) ? (NS - 1 - st) : (RD - 1);
+            lds_wait<younger>();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (st < KS) {
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[st % RD], xf[st], acc1, 0, 0, 0);
+            } else {
+                constexpr int nt = (st - KS) / 2, s2 = (st - KS) % 2;
+                acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[st % RD], pf[s2].f, acc2[nt], 0, 0, 0);
+            }
+            if constexpr (st + RD < NS) issue(std::integral_constant<int, st + RD>{});
+        });
+        // ---- stage chunk c+1 (already in registers) into the other buffer, fetch chunk c+2
+        if (c + 1 < nchunks) {
+            store_chunk(buf ^ 1);
+            load_chunk(c + 2);
+        }
+        __syncthreads();
+    }
+
+    const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) store_rows_f32(p, stage, mw0, nt * 32, acc2[nt], mk, lane);
+}
+
+extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
+                                 const uint16_t* W2, int64_t ldw2, const float* bias2, const float* resid, int64_t ldr,
+                                 const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F,
+                                 uint32_t flags, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && W1 && W2 && out, ISPK_E_NULL, "ffn: null pointer");
+    ISPK_REQUIRE(D == 384 || D == 256, ISPK_E_UNSUPPORTED, "ffn: dim %d (built for 256 / 384)", D);
+    ISPK_REQUIRE(rows >= 0 && F >= 64 && F % 32 == 0, ISPK_E_SHAPE, "ffn: bad shape rows=%d inner=%d", rows, F);
+    ISPK_REQUIRE((flags & ~(ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) == 0, ISPK_E_UNSUPPORTED, "ffn: unsupported flags");
+    ISPK_REQUIRE(!((flags & (ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) && !mask), ISPK_E_NULL, "ffn: mask flag without mask");
+    ISPK_REQUIRE(ldx % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0 && ldo % 4 == 0 && (!resid || ldr % 4 == 0) && ldx >= D &&
+                     ldw1 >= D && ldw2 >= F && ldo >= D,
+                 ISPK_E_ALIGN, "ffn: leading strides must be multiples of 8 (bf16) / 4 (fp32)");
+    ISPK_REQUIRE(ispk_aligned(x, 16) && ispk_aligned(W1, 16) && ispk_aligned(W2, 16) && ispk_aligned(out, 16) &&
+                     (!resid || ispk_aligned(resid, 16)) && (!bias2 || ispk_aligned(bias2, 16)),
+                 ISPK_E_ALIGN, "ffn: pointers must be 16-byte aligned");
+    if (rows == 0) return 0;
+    GemmParams p{x, ldx, W1, ldw1, out, ldo, bias2, resid, ldr, mask, rows, D, D, flags & ~ISPK_EP_GELU, 0, 0};
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((rows + 127) / 128);
+    ISPK_REQUIRE((int64_t)F * ldw1 < (1ll << 30) && (int64_t)D * ldw2 < (1ll << 30), ISPK_E_SHAPE, "ffn: weights too large");
+#define ISPK_FFN_LAUNCH(KC_, B1_)                                                                         \
+    do {                                                                                                  \
+        constexpr size_t lds = (size_t)(2 * 32 * (64 * KC_ + 8) + 2 * 64 * KC_ * 40) * 2 + 4 * kStageBytes; \
+        ISPK_RESERVE_LDS((&ffn_bf16_kernel<KC_, B1_>), lds, "ffn");                                       \
+        hipLaunchKernelGGL((ffn_bf16_kernel<KC_, B1_>), grid, dim3(256), lds, s, p, W2, ldw2, bias1, F);   \
+    } while (0)
+    if (D == 384) {
+        if (bias1) ISPK_FFN_LAUNCH(6, true); else ISPK_FFN_LAUNCH(6, false);
+    } else {
+        if (bias1) ISPK_FFN_LAUNCH(4, true); else ISPK_FFN_LAUNCH(4, false);
+    }
+#undef ISPK_FFN_LAUNCH
+    return ispk_launch_status();
+}
+
 extern "C" int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc,
                                      const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M,
                                      int32_t N, int32_t K, uint32_t flags, const float* ln_gamma, const float* ln_beta,

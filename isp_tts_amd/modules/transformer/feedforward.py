@@ -42,6 +42,9 @@ class FeedForward(nn.Module, Constructor):
                                  nn.Dropout(dropout) if dropout > 0. else nn.Identity(),
                                  nn.Linear(inner_dim, dim, bias=bias))
         self.compute_dtype = torch.float32
+        # the fused kernel gives a workgroup 128 rows: below ~256 workgroups it under-fills the chip and the two-GEMM
+        # path (which splits the feature axis as well) is faster
+        self.fused_min_rows = 128 * 128
         self._cache: dict = {}
 
     def _staged(self, dtype: torch.dtype):
@@ -59,6 +62,12 @@ class FeedForward(nn.Module, Constructor):
         w1, w2 = self._staged(dt)
         if x.dtype != dt:
             x = runtime.cast_bf16(x) if dt == torch.bfloat16 else x.float()
+        rows = x.numel() // x.shape[-1]
+        if (dt == torch.bfloat16 and self.act_flag == runtime.EP_GELU and x.shape[-1] in (256, 384)
+                and rows >= self.fused_min_rows):
+            # one kernel for Linear -> GELU -> Linear (+ residual, mask): the hidden activations never reach HBM
+            return runtime.ffn_fused(x, w1, w2, resid=residual, mask=mask, bias1=self.net[0].bias, bias2=self.net[3].bias,
+                                     flags=runtime.EP_MASK_OUT if mask is not None else 0)
         hidden = runtime.gemm(x, w1, bias=self.net[0].bias, flags=self.act_flag)
         flags = runtime.EP_MASK_OUT if mask is not None else 0
         return runtime.gemm(hidden, w2, bias=self.net[3].bias, resid=residual, mask=mask, flags=flags,

@@ -392,3 +392,24 @@ def test_transformer_with_fused_layernorm_matches_unfused(gpu_model):
         enc.fuse_layernorm = False
         enc.set_compute_dtype(torch.float32)
     assert (fused - base).abs().max() < 3e-2 and (fused - base).pow(2).mean().sqrt() < 4e-3
+
+
+@pytest.mark.parametrize("R,D,Fi", [(777, 384, 1536), (16500, 384, 1536), (300, 256, 1024)])
+def test_fused_ffn_bf16(R, D, Fi):
+    """ispk_ffn_bf16 vs float64 FFN on the same bf16-rounded operands, with the hidden rounded to bf16 as the kernel
+    does (it feeds the second MFMA product as bf16)."""
+    x = _bf(synth._normal(f"t/ffn/x{R}", (R, D)))
+    w1, w2 = _bf(synth._normal(f"t/ffn/w1{D}", (Fi, D), D ** -0.5)), _bf(synth._normal(f"t/ffn/w2{D}", (D, Fi), Fi ** -0.5))
+    resid = synth._normal("t/ffn/r", (R, D))
+    mask = torch.arange(R) % 5 != 2
+    hid = F.gelu(x.double() @ w1.double().T).to(torch.bfloat16).double()
+    ref = (resid.double() + hid @ w2.double().T) * mask[:, None]
+    d = lambda t: t.to(DEV)  # noqa: E731
+    out = runtime.ffn_fused(d(x), d(w1), d(w2), resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT).cpu()
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-2, err          # bf16 rounding of the hidden: a 1-ulp flip of a hidden of size ~3 moves an output by ~1e-3
+    assert (out.double() - ref).pow(2).mean().sqrt() < 1e-3
+    b1, b2 = synth._normal("t/ffn/b1", (Fi,), 0.1), synth._normal("t/ffn/b2", (D,), 0.1)
+    out = runtime.ffn_fused(d(x), d(w1), d(w2), bias1=d(b1), bias2=d(b2)).cpu()
+    ref = F.gelu(x.double() @ w1.double().T + b1.double()).to(torch.bfloat16).double() @ w2.double().T + b2.double()
+    assert (out.double() - ref).pow(2).mean().sqrt() < 1e-3 and (out.double() - ref).abs().max() < 2e-2

@@ -170,3 +170,60 @@ def test_bf16_forward_error_vs_reference(gpu_model):
     # back on the fp32 path the 1e-4 bar holds again (staged weights are rebuilt per dtype)
     out = gpu_model(**{k: v.to(DEV) for k, v in inp.items()})
     assert _maxdiff(out.mel, g["mel"]) < MEL_TOL
+
+
+def test_bf16_fused_ffn_matches_two_gemm_path_at_full_size(gpu_model):
+    """Decoder stack at the benchmark shape (B=64 x 512 frames -> 32,768 rows, where FeedForward takes the fused
+    ispk_ffn_bf16 kernel) against the same stack forced onto the two-GEMM path."""
+    x = synth._normal("t/ffnfull/x", (64, 512, 384)).to(DEV)
+    lens = torch.full((64,), 512, device=DEV)
+    lens[1::3] = 300
+    mask = torch.arange(512, device=DEV)[None] < lens[:, None]
+    dec = gpu_model.decoder
+    try:
+        dec.set_compute_dtype(torch.bfloat16)
+        fused = dec(x, mask=mask, key_len=lens).out
+        for layer in dec.layers:
+            layer.feed_forward.fused_min_rows = 1 << 30
+        plain = dec(x, mask=mask, key_len=lens).out
+    finally:
+        for layer in dec.layers:
+            layer.feed_forward.fused_min_rows = 128 * 128
+        dec.set_compute_dtype(torch.float32)
+    assert (fused - plain).abs().max() < 4e-2 and (fused - plain).pow(2).mean().sqrt() < 3e-3
+    assert (fused * ~mask[..., None]).abs().max() == 0
+
+
+def test_config2_encoder_decoder_scope_fp32(gpu_model, state_dict):
+    """BASELINE config 2 scope (TextEncoder + MelDecoder + to_mel on given activations, fp32) against the oracle."""
+    tok = synth._normal("t/c2/tok", (4, 100, 384))
+    dec_in = synth._normal("t/c2/dec", (4, 512, 384))
+    tl, ml = torch.tensor([100, 80, 100, 33]), torch.tensor([512, 512, 301, 77])
+    em = torch.arange(100)[None] < tl[:, None]
+    dm = torch.arange(512)[None] < ml[:, None]
+    enc_ref, mel_ref = orc.encoder_decoder(state_dict, tok, em, dec_in, dm)
+    enc = gpu_model.encoder(tok.to(DEV), mask=em.to(DEV)).out
+    dec = gpu_model.decoder(dec_in.to(DEV), mask=dm.to(DEV)).out
+    mel = gpu_model._to_mel(dec, dm.to(DEV))
+    assert _maxdiff(enc, enc_ref) < OP_TOL and _maxdiff(mel, mel_ref) < MEL_TOL
+
+
+def test_rccl_all_gather_of_mel_single_rank():
+    """The one collective of the path through RCCL itself (backend "nccl" on ROCm), world_size 1 on this one-GPU box;
+    the world_size-2 logic is covered on CPU over gloo (tests/test_host_logic.py)."""
+    import os
+    import torch.distributed as dist
+    from isp_tts_amd import dist as idist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 1000))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        mel = synth._normal("t/rccl/mel", (5, 80, 64)).to(DEV)
+        lens = torch.tensor([64, 10, 33, 64, 1], device=DEV)
+        g, l = idist.all_gather_mel(mel, lens)
+        assert g.shape == (1, 5, 80, 64) and torch.equal(g[0], mel) and torch.equal(l[0], lens)
+        g2, l2 = idist.all_gather_mel(mel, lens, max_frames=64, max_batch=5)
+        assert torch.equal(g2[0], mel)
+        full, dec = idist.unshard(g, l, [[3, 0, 4, 1, 2]])
+        assert torch.equal(full[3], mel[0]) and int(dec[2]) == 1
+    finally:
+        dist.destroy_process_group()

@@ -60,3 +60,7 @@ print(f"dtype={dt} rows={R}")
 for name, fn, flops, nbytes in cases:
     med, mn = time_it(fn)
     print(f"{name:34s} median {med:8.1f} us  min {mn:8.1f} us  {flops / med / 1e6:8.1f} TFLOP/s  {nbytes / med / 1e3:8.1f} GB/s")
+if dt == torch.bfloat16:
+    med, mn = time_it(lambda: runtime.ffn_fused(x384, w["f1"], w["f2"], resid=resid, mask=mask, flags=runtime.EP_MASK_OUT))
+    fl = 4 * R * 384 * 1536
+    print(f"{'fused ffn [R,384]->1536->384+res':34s} median {med:8.1f} us  min {mn:8.1f} us  {fl / med / 1e6:8.1f} TFLOP/s")

@@ -163,10 +163,14 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # ISPK_BENCH_FORCE_DIST=1: take the distributed path (RCCL init, all-gather, barriers) even with one rank — lets the
+    # multi-GPU code be rehearsed on a one-GPU box
+    use_dist = world > 1 or os.environ.get("ISPK_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
 
     sd = synth.make_state_dict()
     model = AcousticModel.init(AcousticDims().model_config()).eval()
@@ -189,13 +193,13 @@ def main():
 
     def step():
         out = graphed.replay() if graphed is not None else eager_step()
-        if world > 1:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather)
+        if use_dist:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather)
             all_gather_mel(out.mel, out.adaptor_output.dec_lengths, max_frames=M, max_batch=B)
         return out
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -223,7 +227,7 @@ def main():
             eager_step()
         torch.cuda.synchronize()
         runtime.set_profiler(None)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -270,7 +274,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args, sd)
             line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -28,7 +28,8 @@ constexpr int kTileKeys = 64;
 __device__ __forceinline__ float xhalf_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float xhalf_sum(float v) { return v + __shfl_xor(v, 32, 64); }
 
-__global__ __launch_bounds__(1024) void attn_f32_kernel(const float* __restrict__ q, int64_t ldq,
+template <int MAXT>  // 768 (H <= 6: 3 waves per SIMD, 168 VGPRs) or 1024 (H = 7, 8)
+__global__ __launch_bounds__(MAXT) void attn_f32_kernel(const float* __restrict__ q, int64_t ldq,
                                                         const float* __restrict__ k, const float* __restrict__ v,
                                                         int64_t ldkv, const float* __restrict__ slopes,
                                                         const int64_t* __restrict__ key_len, float* __restrict__ out,
@@ -70,24 +71,41 @@ __global__ __launch_bounds__(1024) void attn_f32_kernel(const float* __restrict_
     const float* vb = v + (int64_t)b * N * ldkv;
     const int ntiles = (klen + kTileKeys - 1) / kTileKeys;
 
-    auto stage = [&](int t, int buf) {
-        // 64 keys x 16 float4 for K and the same for V
-        for (int idx = tid; idx < kTileKeys * 32; idx += nthreads) {
-            const int isv = idx >> 10;  // 0: K, 1: V
-            const int rem = idx & 1023;
+    // K/V tile staging is split (guide T14): the global loads of tile t+1 are ISSUED before tile t is computed and their
+    // LDS writes happen after it, so a tile's HBM/L2 latency hides under the previous tile's MFMAs instead of stalling
+    // every wave at the top of each tile.  2048 float4 per tile over <= 1024 threads: 3 (at 768 threads) per thread.
+    constexpr int kStageMax = 4;  // ceil(2048 / 512): enough down to 8 waves (H = 4)
+    f32x4 sreg[kStageMax];
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < kStageMax; ++i) {
+            const int idx = tid + i * nthreads;
+            const int isv = idx >> 10, rem = idx & 1023;
             const int row = rem >> 4, c4 = (rem & 15) * 4;
             const int key = t * kTileKeys + row;
-            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (key < N) val = *reinterpret_cast<const float4*>((isv ? vb : kb) + (int64_t)key * ldkv + c4);
-            *reinterpret_cast<float4*>((isv ? Vs : Ks) + (buf * kTileKeys + row) * kLdk + c4) = val;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (idx < kTileKeys * 32 && key < N)
+                val = *reinterpret_cast<const f32x4*>((isv ? vb : kb) + (int64_t)key * ldkv + c4);
+            sreg[i] = val;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < kStageMax; ++i) {
+            const int idx = tid + i * nthreads;
+            const int isv = idx >> 10, rem = idx & 1023;
+            const int row = rem >> 4, c4 = (rem & 15) * 4;
+            if (idx < kTileKeys * 32)
+                *reinterpret_cast<f32x4*>((isv ? Vs : Ks) + (buf * kTileKeys + row) * kLdk + c4) = sreg[i];
         }
     };
 
-    stage(0, 0);
+    stage_load(0);
+    stage_store(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
-        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        if (t + 1 < ntiles) stage_load(t + 1);
 #pragma unroll 1
         for (int kblk = 0; kblk < 2; ++kblk) {
             const int key0 = t * kTileKeys + kblk * 32;
@@ -140,6 +158,7 @@ __global__ __launch_bounds__(1024) void attn_f32_kernel(const float* __restrict_
                 o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vr[32], s[r], o1, 0, 0, 0);
             }
         }
+        if (t + 1 < ntiles) stage_store(buf ^ 1);
         __syncthreads();
     }
 
@@ -176,10 +195,16 @@ extern "C" int32_t ispk_alibi_mqa_attn_f32(const float* q, int64_t ldq, const fl
     if (B == 0) return 0;
     constexpr size_t lds = (size_t)4 * kTileKeys * kLdk * sizeof(float);  // 69,632 B
     static_assert(lds <= 160 * 1024, "LDS budget");
-    ISPK_RESERVE_LDS(&attn_f32_kernel, lds, "attn");
     dim3 grid((N + 63) / 64, B), block(2 * H * 64);
-    hipLaunchKernelGGL(attn_f32_kernel, grid, block, lds, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv,
-                       slopes, key_len, out, ldo, N, H);
+    if (H <= 6) {
+        ISPK_RESERVE_LDS(&attn_f32_kernel<768>, lds, "attn");
+        hipLaunchKernelGGL(attn_f32_kernel<768>, grid, block, lds, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
+                           ldkv, slopes, key_len, out, ldo, N, H);
+    } else {
+        ISPK_RESERVE_LDS(&attn_f32_kernel<1024>, lds, "attn");
+        hipLaunchKernelGGL(attn_f32_kernel<1024>, grid, block, lds, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
+                           ldkv, slopes, key_len, out, ldo, N, H);
+    }
     return ispk_launch_status();
 }
 
@@ -202,7 +227,8 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 }
 
-__global__ __launch_bounds__(1024) void attn_bf16_kernel(const uint16_t* __restrict__ q, int64_t ldq,
+template <int MAXT>
+__global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restrict__ q, int64_t ldq,
                                                          const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                                                          int64_t ldkv, const float* __restrict__ slopes,
                                                          const int64_t* __restrict__ key_len,
@@ -241,34 +267,49 @@ __global__ __launch_bounds__(1024) void attn_bf16_kernel(const uint16_t* __restr
     const uint16_t* vb = v + (int64_t)b * N * ldkv;
     const int ntiles = (klen + kTileKeys - 1) / kTileKeys;
 
-    auto stage = [&](int t, int buf) {
-        // K: 64 keys x 8 chunks of 8 bf16, row-major.  V: the same chunks, scattered transposed into Vt[d][key].
-        for (int idx = tid; idx < kTileKeys * 16; idx += nthreads) {
-            const int isv = idx >> 9;
-            const int rem = idx & 511;
+    // split staging (see attn_f32_kernel): 1024 16-byte pieces per tile (K row-major; V scattered transposed into
+    // Vt[d][key]), loads issued before the current tile's compute, LDS writes after it.
+    constexpr int kStageMax = 2;  // ceil(1024 / 512)
+    u32x4 sreg[kStageMax];
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < kStageMax; ++i) {
+            const int idx = tid + i * nthreads;
+            const int isv = idx >> 9, rem = idx & 511;
             const int row = rem >> 3, c8 = (rem & 7) * 8;
             const int key = t * kTileKeys + row;
-            uint4 val = make_uint4(0u, 0u, 0u, 0u);
-            if (key < N) val = *reinterpret_cast<const uint4*>((isv ? vb : kb) + (int64_t)key * ldkv + c8);
+            u32x4 val = {0u, 0u, 0u, 0u};
+            if (idx < kTileKeys * 16 && key < N)
+                val = *reinterpret_cast<const u32x4*>((isv ? vb : kb) + (int64_t)key * ldkv + c8);
+            sreg[i] = val;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < kStageMax; ++i) {
+            const int idx = tid + i * nthreads;
+            if (idx >= kTileKeys * 16) continue;
+            const int isv = idx >> 9, rem = idx & 511;
+            const int row = rem >> 3, c8 = (rem & 7) * 8;
             if (!isv) {
-                *reinterpret_cast<uint4*>(Ks + (buf * kTileKeys + row) * kLdh + c8) = val;
+                *reinterpret_cast<u32x4*>(Ks + (buf * kTileKeys + row) * kLdh + c8) = sreg[i];
             } else {
                 uint16_t* dst = Vt + (buf * 64 + c8) * kLdh + row;
-                const uint32_t w[4] = {val.x, val.y, val.z, val.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    dst[(2 * e) * kLdh] = (uint16_t)(w[e] & 0xffffu);
-                    dst[(2 * e + 1) * kLdh] = (uint16_t)(w[e] >> 16);
+                    dst[(2 * e) * kLdh] = (uint16_t)(sreg[i][e] & 0xffffu);
+                    dst[(2 * e + 1) * kLdh] = (uint16_t)(sreg[i][e] >> 16);
                 }
             }
         }
     };
 
-    stage(0, 0);
+    stage_load(0);
+    stage_store(0);
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
-        if (t + 1 < ntiles) stage(t + 1, buf ^ 1);
+        if (t + 1 < ntiles) stage_load(t + 1);
 #pragma unroll 1
         for (int kblk = 0; kblk < 2; ++kblk) {
             const int key0 = t * kTileKeys + kblk * 32;
@@ -336,6 +377,7 @@ __global__ __launch_bounds__(1024) void attn_bf16_kernel(const uint16_t* __restr
                 o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc.f, pf.f, o1, 0, 0, 0);
             }
         }
+        if (t + 1 < ntiles) stage_store(buf ^ 1);
         __syncthreads();
     }
 
@@ -370,7 +412,11 @@ extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, cons
                  ISPK_E_ALIGN, "attn: q/k/v must be 16-byte and out 8-byte aligned");
     if (B == 0) return 0;
     dim3 grid((N + 63) / 64, B), block(2 * H * 64);
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, block, 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v, ldkv,
-                       slopes, key_len, out, ldo, N, H);
+    if (H <= 6)
+        hipLaunchKernelGGL(attn_bf16_kernel<768>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
+                           ldkv, slopes, key_len, out, ldo, N, H);
+    else
+        hipLaunchKernelGGL(attn_bf16_kernel<1024>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
+                           ldkv, slopes, key_len, out, ldo, N, H);
     return ispk_launch_status();
 }

@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
     // One wave per SIMD: nothing hides an LDS round trip, so the KS + 2*NT operand reads of a chunk run as ONE stream
     // through an RD-deep register ring of opaque asm reads with hand-counted waits (see gemm_bf16_panel_kernel); the
     // W2 reads are issued while the GELU of the chunk is still running.
-    constexpr int RD = 8, NS = KS + 2 * NT;
+    constexpr int RD = 4, NS = KS + 2 * NT;
     const uint32_t w1base = lds_addr(W1s + l31 * LD1 + 8 * h);
     const uint32_t w2base = lds_addr(W2s + l31 * LD2 + 8 * h);
     for (int c = 0; c < nchunks; ++c) {

@@ -16,11 +16,16 @@
 //   * backtrack: 64 rows at a time, lane r holds the ballot words of row (top - r); the serial walk reads them with
 //     v_readlane (SGPR chain), no LDS round trip per row.
 //   * the 4 waves of the block then write the one-hot int16 rows (16-B stores), the path and the durations.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int kRowsAhead = 8;
+// logits rows prefetched ahead of the DP, per chunk count (register budget: kRowsAhead * NC * 2 VGPRs).  One wave has
+// only these loads in flight, so the depth sets the memory-level parallelism: with 8 rows the DP ran at 146 ns/row
+// (latency-bound); with 32 it is bound by the dependent VALU chain instead.
+template <int NC> constexpr int rows_ahead() { return NC <= 2 ? 32 : (NC <= 4 ? 16 : 8); }
 
 __device__ __forceinline__ float dpp_shr1(float src, float lane0_value) {
     // lane l <- lane l-1 ; lane 0 keeps `lane0_value` (bound_ctrl off: invalid source lanes keep `old`)
@@ -61,6 +66,8 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
     const float ninf = -__builtin_huge_valf();
 
     for (int j = tid; j < L_max; j += 256) cnt[j] = 0;
+    const int abl = (int)(stride_m >> 40);   // experiments only: phase ablation code smuggled in the high stride bits
+    stride_m &= ((int64_t)1 << 40) - 1;
 
     if (wave == 0) {
         // ---------------------------------------------------------------- forward DP
@@ -68,6 +75,7 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
 #pragma unroll
         for (int c = 0; c < NC; ++c) q[c] = (lane + 64 * c == 0) ? lp[0] : ninf;
 
+        constexpr int kRowsAhead = rows_ahead<NC>();
         float cur[kRowsAhead][NC], nxt[kRowsAhead][NC];
         auto load_rows = [&](float (&dst)[kRowsAhead][NC], int base) {
 #pragma unroll
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
     }
     __syncthreads();
 
-    if (wave == 0) {
+    if (wave == 0 && abl != 1) {
         // ---------------------------------------------------------------- backtrack, 64 rows per pass
         int j = m - 1;
         for (int top = n - 1; top >= 0; top -= 64) {
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
     }
     __syncthreads();
 
+    if (abl == 1 || abl == 2) return;
     // -------------------------------------------------------------------- outputs (all 4 waves)
     for (int i = tid; i < n; i += 256) atomicAdd(&cnt[path[i]], 1);
     if (path_out) {
@@ -188,6 +197,7 @@ template <int NC>
 int32_t launch(const float* logits, const int64_t* text_len, const int64_t* mel_len, int16_t* attn_hard, int64_t* dur,
                int16_t* path, int B, int M_max, int L_max, int64_t sb, int64_t sm, size_t lds, hipStream_t stream) {
     ISPK_RESERVE_LDS((&mas_kernel<NC>), lds, "mas");
+    if (const char* e = getenv("ISPK_MAS_ABLATE")) sm |= (int64_t)atoi(e) << 40;  // experiments only
     hipLaunchKernelGGL(mas_kernel<NC>, dim3(B), dim3(256), lds, stream, logits, text_len, mel_len, attn_hard, dur, path,
                        M_max, L_max, sb, sm);
     return ispk_launch_status();

@@ -356,7 +356,7 @@ def alibi_mqa_attention_raw(q: Tensor, ldq: int, k: Tensor, v: Tensor, ldkv: int
     slopes = slopes.to(torch.float32).contiguous()
     fn = lib().ispk_alibi_mqa_attn_f32 if q.dtype == torch.float32 else lib().ispk_alibi_mqa_attn_bf16
     es = q.element_size()
-    _launch("attn_f32_kernel" if es == 4 else "attn_bf16_kernel", 256.0 * B * N * N * heads,
+    _launch(("attn_f32_kernel" if es == 4 else "attn_bf16_kernel") + ("<768>" if heads <= 6 else "<1024>"), 256.0 * B * N * N * heads,
             float(B) * N * (2 * heads * 64 + 128) * es, fn, q.data_ptr(), ldq, k.data_ptr(), v.data_ptr(), ldkv,
             slopes.data_ptr(), _ptr(key_len), out.data_ptr(), heads * 64, B, N, heads, _stream())
     return out

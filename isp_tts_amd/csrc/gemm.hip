@@ -324,29 +324,57 @@ __device__ __forceinline__ void epilogue_vec4(const GemmParams& p, int m, int n,
 constexpr int kStageRow = 144;               // bytes per staged row (128 + 16: keeps ds_read_b128 aligned, spreads banks)
 constexpr int kStageBytes = 32 * kStageRow;  // per wave
 
+// Compile-time epilogue description.  EP < 0 (kEpDyn): every flag / optional pointer is tested at run time (generic);
+// EP >= 0: the ISPK_EP_* flag word plus kEpBias / kEpResid, promised by the launcher to equal the run-time values — the
+// flag tests then fold away and a hot instance carries no branches, no dead GELU/SiLU code and no bias round trip.
+constexpr int kEpDyn = -1;
+constexpr int kEpBias = 1 << 16, kEpResid = 1 << 17;
+template <int EP> __device__ __forceinline__ bool ep_flag(const GemmParams& p, uint32_t f) {
+    if constexpr (EP < 0) return (p.flags & f) != 0; else return ((uint32_t)EP & f) != 0;
+}
+template <int EP> __device__ __forceinline__ bool ep_bias(const GemmParams& p) {
+    if constexpr (EP < 0) return p.bias != nullptr; else return (EP & kEpBias) != 0;
+}
+template <int EP> __device__ __forceinline__ bool ep_resid(const GemmParams& p) {
+    if constexpr (EP < 0) return p.resid != nullptr; else return (EP & kEpResid) != 0;
+}
+inline int ep_key(const GemmParams& p) {
+    return (int)(p.flags & 0xffffu) | (p.bias ? kEpBias : 0) | (p.resid ? kEpResid : 0);
+}
+
+// two fp32 -> packed bf16x2 in ONE v_cvt_pk_bf16_f32 (round to nearest even)
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    f32x2 v;
+    v.x = lo; v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+
+template <int EP = kEpDyn>
 __device__ __forceinline__ void pre_stage(const GemmParams& p, int n, float (&v)[4], float mk) {
-    if (p.bias) {
+    if (ep_bias<EP>(p)) {
         const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
     }
-    if (p.flags & ISPK_EP_GELU) {  // bf16-operand kernels only: the packed A&S erf (|err| <= 3e-7) is far below their noise
+    if (ep_flag<EP>(p, ISPK_EP_GELU)) {  // bf16-operand kernels only: the packed A&S erf (|err| <= 3e-7) is far below their noise
         f32x2 a, b;
         a.x = v[0]; a.y = v[1]; b.x = v[2]; b.y = v[3];
         a = gelu_fast2(a);
         b = gelu_fast2(b);
         v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
     }
-    if (p.flags & ISPK_EP_SILU) {
+    if (ep_flag<EP>(p, ISPK_EP_SILU)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = silu(v[e]);
     }
-    if (p.flags & ISPK_EP_MASK_ACC) {
+    if (ep_flag<EP>(p, ISPK_EP_MASK_ACC)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] *= mk;
     }
 }
 
 // fp32 output: one 32-feature tile (features n0 .. n0+31) of the wave's 32 rows (m0 .. m0+31)
+template <int EP = kEpDyn>
 __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage, int m0, int n0, const f32x16& acc,
                                                float mk, int lane, float4* keep = nullptr) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -356,7 +384,7 @@ __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage,
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[4 * g + e];
         const int n = n0 + 8 * g + 4 * h;
-        pre_stage(p, n < p.N ? n : 0, v, mk);
+        pre_stage<EP>(p, n < p.N ? n : 0, v, mk);
         *reinterpret_cast<float4*>(stage + l31 * kStageRow + (8 * g + 4 * h) * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
     const int c = lane & 7, n = n0 + 4 * c;
@@ -365,9 +393,9 @@ __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage,
         const int r = 8 * i + (lane >> 3), m = m0 + r;
         float4 v = *reinterpret_cast<const float4*>(stage + r * kStageRow + c * 16);
         if (m < p.M && n < p.N) {
-            if (p.resid) {
+            if (ep_resid<EP>(p)) {
                 const int64_t ro = (int64_t)m * p.ldr + n;
-                if (p.flags & ISPK_EP_RESID_BF16) {
+                if (ep_flag<EP>(p, ISPK_EP_RESID_BF16)) {
                     const uint2 rr = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p.resid) + ro);
                     v.x += bf16_to_f32((uint16_t)(rr.x & 0xffffu)); v.y += bf16_to_f32((uint16_t)(rr.x >> 16));
                     v.z += bf16_to_f32((uint16_t)(rr.y & 0xffffu)); v.w += bf16_to_f32((uint16_t)(rr.y >> 16));
@@ -376,7 +404,7 @@ __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage,
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
             }
-            if (p.flags & ISPK_EP_MASK_OUT) {
+            if (ep_flag<EP>(p, ISPK_EP_MASK_OUT)) {
                 const float mo = p.mask[m] ? 1.0f : 0.0f;
                 v.x *= mo; v.y *= mo; v.z *= mo; v.w *= mo;
             }
@@ -387,6 +415,7 @@ __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage,
 }
 
 // bf16 output: two adjacent 32-feature tiles (features n0 .. n0+63); no residual on this path
+template <int EP = kEpDyn>
 __device__ __forceinline__ void store_rows_bf16(const GemmParams& p, char* stage, int m0, int n0, const f32x16& acc0,
                                                 const f32x16& acc1, float mk, int lane) {
     const int l31 = lane & 31, h = lane >> 5;
@@ -398,14 +427,14 @@ __device__ __forceinline__ void store_rows_bf16(const GemmParams& p, char* stage
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = t ? acc1[4 * g + e] : acc0[4 * g + e];
             const int n = n0 + t * 32 + 8 * g + 4 * h;
-            pre_stage(p, n < p.N ? n : 0, v, mk);
-            if (p.flags & ISPK_EP_MASK_OUT) {
+            pre_stage<EP>(p, n < p.N ? n : 0, v, mk);
+            if (ep_flag<EP>(p, ISPK_EP_MASK_OUT)) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] *= mk;
             }
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
             *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (t * 32 + 8 * g + 4 * h) * 2) = o;
         }
     const int c = lane & 7, n = n0 + 8 * c;
@@ -637,8 +666,10 @@ bool vec_epilogue_ok(const GemmParams& p) {
 //     and 4 consecutive output features in consecutive registers, so bias / residual / output are 8- or 16-byte
 //     vector accesses (4 store instructions per 32x32 tile instead of 16 scalar ones);
 //   * the N range is split over blockIdx.x so that >= 512 workgroups exist (2 per CU).
-template <int KC>  // K = 64 * KC
+template <int KC, int EP = kEpDyn, bool ST = false>  // K = 64 * KC; EP: compile-time epilogue; ST: phase stamps (experiments)
 __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, int tiles_per_wg, int nsplit, int mblocks) {
+    [[maybe_unused]] uint64_t tsum[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, tA = 0, tB = 0, tC = 0, tD = 0;
+    if constexpr (ST) t0 = __builtin_readcyclecounter();
     constexpr int K = 64 * KC, LDW = K + 8, KS = K / 16, CPR = K / 8;  // CPR: 16-B chunks per row
     constexpr int HCH = 32 * CPR / 256;                                 // chunks per thread per 32-row half tile (= KC)
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -665,16 +696,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
     // runtime-indexed or predicated here ends up in scratch or behind per-load branches.
     u32x4 wr0[HCH], wr1[HCH];
     const int ntc = nt1 - 1;
-    auto wload = [&](u32x4 (&dst)[HCH], int nt, int half) {
+    // piece i of a half tile: weight row 32*half + (tid + 256 i) / CPR, 16-byte column chunk (tid + 256 i) % CPR
+    auto wload1 = [&](u32x4& dst, int i, int nt, int half) {
         nt = nt < ntc ? nt : ntc;
+        const int id = tid + 256 * i;
+        const int r = id / CPR, c = id - r * CPR;
+        int n = nt * 64 + half * 32 + r;
+        n = n < p.N ? n : p.N - 1;
+        dst = *reinterpret_cast<const u32x4*>(W + (int64_t)n * p.ldw + c * 8);
+    };
+    auto wload = [&](u32x4 (&dst)[HCH], int nt, int half) {
 #pragma unroll
-        for (int i = 0; i < HCH; ++i) {
-            const int id = tid + 256 * i;
-            const int r = id / CPR, c = id - r * CPR;
-            int n = nt * 64 + half * 32 + r;
-            n = n < p.N ? n : p.N - 1;
-            dst[i] = *reinterpret_cast<const u32x4*>(W + (int64_t)n * p.ldw + c * 8);
-        }
+        for (int i = 0; i < HCH; ++i) wload1(dst[i], i, nt, half);
     };
     auto wstore = [&](const u32x4 (&src)[HCH], int half) {
 #pragma unroll
@@ -685,75 +718,125 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
         }
     };
 
-    // ---- prologue: ONE burst of K/16 independent 16-B loads per lane puts the wave's 32 activation rows, for the whole
-    // K, straight into MFMA B-operand fragments (lane = row, half h = k offset 8h).  Four consecutive k-steps share a
-    // 128-B line and are issued back to back, so the line is fetched once.  (Staging the panel through LDS instead
-    // was tried: the conditional per-wave fragment reads made hipcc spill the staging registers to scratch.)
-    bf16x8 xf[KS];
-    {
-        const int mrow = m < p.M ? m : p.M - 1;
-        const uint16_t* xp = A + (int64_t)mrow * p.lda + 8 * h;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + 16 * ks);
-    }
+    // ---- prologue.  The first weight tile's loads go out first (they are needed first and fly during the rest).  Then
+    // the wave's 32 activation rows x K - one contiguous 32*K*2-byte block when lda == K - are fetched with fully
+    // coalesced 16-byte loads (64 lanes = 1 KB = 8 whole lines per instruction) and turned into MFMA B-operand
+    // fragments (lane = row, half h = k offset 8h) through a wave-private LDS patch, one K-half at a time: patch rows
+    // are padded by 16 bytes so that both the row-major writes and the ds_read_b128 fragment reads are conflict-free.
+    // (Fragment-shaped global loads - 16 bytes from each of 32 rows per instruction - cost 4x the tag lookups and
+    // made this prologue as long as four weight tiles.)  The patches alias the weight-tile area, hence the barrier.
+    constexpr int KH = K / 2, CPH = KH / 8, XCH = 32 * CPH / 64, XLD = KH * 2 + 16;   // per K-half; XLD in bytes
+    static_assert(4 * 32 * XLD <= 64 * LDW * 2 + 4 * kStageBytes, "x staging patches must fit the workgroup's LDS");
     wload(wr0, nt0, 0);
     wload(wr1, nt0, 1);
+    bf16x8 xf[KS];
+    {
+        char* xs = smem_raw + wave * (32 * XLD);
+        const int mwave = mb * 128 + wave * 32;
+        u32x4 t[2][XCH];   // both K-halves in flight at once: one memory round trip for the whole panel
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int id = lane + 64 * j, r = id / CPH, c = id - r * CPH;
+                const int row = mwave + r < p.M ? mwave + r : p.M - 1;
+                t[half][j] = *reinterpret_cast<const u32x4*>(A + (int64_t)row * p.lda + half * KH + c * 8);
+            }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int id = lane + 64 * j, r = id / CPH, c = id - r * CPH;
+                *reinterpret_cast<u32x4*>(xs + r * XLD + c * 16) = t[half][j];
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS / 2; ++ks)
+                xf[half * (KS / 2) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLD + ks * 32 + h * 16);
+        }
+    }
+    __syncthreads();   // every wave has its fragments: the patches may be overwritten by the weight tile
     wstore(wr0, 0);
     wstore(wr1, 1);
     wload(wr0, nt0 + 1, 0);
-    wload(wr1, nt0 + 1, 1);
     __syncthreads();
 
-    const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+    float mk = 1.0f;
+    if (EP < 0 || ((uint32_t)EP & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT))) mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
     const uint32_t wbase = lds_addr(Ws + l31 * LDW + 8 * h);
     char* stage = smem_raw + (size_t)64 * LDW * sizeof(uint16_t) + wave * kStageBytes;  // wave-private epilogue patch
     const int mw0 = mb * 128 + wave * 32;
+    if constexpr (ST) { tA = __builtin_readcyclecounter(); tsum[0] = tA - t0; }
     for (int nt = nt0; nt < nt1; ++nt) {
+        if constexpr (ST) { t0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
         f32x16 acc[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
         // The 2*KS weight-fragment reads of a tile form ONE stream through a D-deep register ring: the read for step
         // s+D is issued right after step s's MFMA, so D ds_read_b128 stay in flight (left to itself hipcc keeps two and
         // every MFMA waits on LDS latency; it also dissolves a ring written in plain C++, hence the opaque asm reads
-        // with hand-counted waits).  Half 0 (steps < KS) is refilled with tile nt+1 after barrier 1 while half 1
-        // computes, and vice versa; half 1's reads may be issued before barrier 1 (that half is stable by then).
+        // with hand-counted waits).
+        // Weight prefetch: a burst of HCH global loads per wave blocks instruction issue for ~16 cycles x HCH x 4 waves
+        // (the CU's one texture-address path), so the loads are spread ONE per second MFMA gap instead:
+        //   half-0 steps: wr1 <- tile nt+1, half 1   (stored after barrier 2, >= 24 MFMAs later)
+        //   half-1 steps: wr0 <- tile nt+2, half 0   (stored after barrier 1 of the next tile)
+        // Barrier 1 (every wave is done with half 0) is followed by the first D reads of half 1 - which must not be issued
+        // earlier: the other waves' stores of that half (after barrier 2 of the previous tile) are only ordered by this
+        // barrier - and then by the HCH LDS stores of wr0.  LDS operations retire in order, so the waits of those D
+        // steps count the stores as younger operations instead of draining them, and the stores' issue time covers
+        // most of the reads' latency.
         constexpr int D = 3, NS = 2 * KS;
+        static_assert(2 * HCH <= KS && D - 1 + HCH <= 15, "prefetch slots / lgkmcnt range");
         bf16x8 wq[D];
-        static_for<0, D>([&](auto ic) {
+        auto rd = [&](auto ic) {
             constexpr int st = decltype(ic)::value;
-            lds_read_b128_asm<((st / KS) * 32 * LDW + 16 * (st % KS)) * 2>(wq[st], wbase);
-        });
+            lds_read_b128_asm<((st / KS) * 32 * LDW + 16 * (st % KS)) * 2>(wq[st % D], wbase);
+        };
+        static_for<0, D>(rd);
         static_for<0, NS>([&](auto ic) {
             constexpr int st = decltype(ic)::value;
             if constexpr (st == KS) {
-                __syncthreads();  // barrier 1: every wave is done with half 0
-                if (nt + 1 < nt1) {
-                    wstore(wr0, 0);
-                    wload(wr0, nt + 2, 0);
-                }
+                if constexpr (ST) { __builtin_amdgcn_sched_barrier(0); tA = __builtin_readcyclecounter(); }
+                __syncthreads();  // barrier 1
+                static_for<KS, KS + D>(rd);
+                wstore(wr0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ST) { tB = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
             }
-            constexpr int younger = (NS - 1 - st) < (D - 1) ? (NS - 1 - st) : (D - 1);
+            constexpr int hend = st < KS ? KS : NS;
+            constexpr int reads_after = (hend - 1 - st) < (D - 1) ? (hend - 1 - st) : (D - 1);
+            constexpr int younger = (st >= KS && st < KS + D) ? D - 1 + HCH : reads_after;
             lds_wait<younger>();
             __builtin_amdgcn_sched_barrier(0);
             acc[st / KS] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wq[st % D], xf[st % KS], acc[st / KS], 0, 0, 0);
-            if constexpr (st + D < NS) {
-                constexpr int nx = st + D;
-                lds_read_b128_asm<((nx / KS) * 32 * LDW + 16 * (nx % KS)) * 2>(wq[st % D], wbase);
+            if constexpr (st + D < hend) rd(std::integral_constant<int, st + D>{});
+            if constexpr (st % 2 == 0 && (st % KS) / 2 < HCH) {
+                constexpr int i = (st % KS) / 2;
+                if constexpr (st < KS) wload1(wr1[i], i, nt + 1, 1); else wload1(wr0[i], i, nt + 2, 0);
             }
         });
+        if constexpr (ST) { __builtin_amdgcn_sched_barrier(0); tC = __builtin_readcyclecounter(); }
         __syncthreads();  // barrier 2: every wave is done with half 1
-        if (nt + 1 < nt1) {
-            wstore(wr1, 1);
-            wload(wr1, nt + 2, 1);
-        }
+        wstore(wr1, 1);
+        if constexpr (ST) { __builtin_amdgcn_sched_barrier(0); tD = __builtin_readcyclecounter(); }
         // epilogue: register 4g+e of tile half t is output feature n = nt*64 + t*32 + 8g + 4h + e, row m (this lane)
         if (p.cpb == -7) {  // ablation (experiments only): keep the accumulators live, skip the epilogue
             if (acc[0][0] + acc[1][5] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
-        } else if (p.flags & ISPK_EP_OUT_BF16) {
-            store_rows_bf16(p, stage, mw0, nt * 64, acc[0], acc[1], mk, lane);
+        } else if (ep_flag<EP>(p, ISPK_EP_OUT_BF16)) {
+            store_rows_bf16<EP>(p, stage, mw0, nt * 64, acc[0], acc[1], mk, lane);
         } else {
-            store_rows_f32(p, stage, mw0, nt * 64, acc[0], mk, lane);
-            store_rows_f32(p, stage, mw0, nt * 64 + 32, acc[1], mk, lane);
+            store_rows_f32<EP>(p, stage, mw0, nt * 64, acc[0], mk, lane);
+            store_rows_f32<EP>(p, stage, mw0, nt * 64 + 32, acc[1], mk, lane);
+        }
+        if constexpr (ST) {
+            __builtin_amdgcn_sched_barrier(0);
+            const uint64_t tE = __builtin_readcyclecounter();
+            tsum[1] += tA - t0; tsum[2] += tB - tA; tsum[3] += tC - tB; tsum[4] += tD - tC; tsum[5] += tE - tD;
+        }
+    }
+    if constexpr (ST) {
+        if (lane == 0) {
+            uint64_t* dbg = static_cast<uint64_t*>(p.ln_out) + ((int64_t)blockIdx.x * 4 + wave) * 6;
+            for (int i = 0; i < 6; ++i) dbg[i] = tsum[i];
         }
     }
 }
@@ -768,9 +851,30 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
     const int per = (ntiles + nsplit - 1) / nsplit;
     nsplit = (ntiles + per - 1) / per;
     const int mb8 = (mblocks + 7) / 8 * 8;
-    ISPK_RESERVE_LDS((&gemm_bf16_panel_kernel<KC>), lds, "gemm");
-    hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC>), dim3(mb8 * nsplit), dim3(256), lds, s, p, per, nsplit, mblocks);
-    return ispk_launch_status();
+#define ISPK_PANEL_GO(EP_, ST_, P_)                                                                                   \
+    do {                                                                                                               \
+        ISPK_RESERVE_LDS((&gemm_bf16_panel_kernel<KC, EP_, ST_>), lds, "gemm");                                      \
+        hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC, EP_, ST_>), dim3(mb8 * nsplit), dim3(256), lds, s, P_, per, nsplit, \
+                           mblocks);                                                                                   \
+        return ispk_launch_status();                                                                                   \
+    } while (0)
+    // the model's hot epilogues get branch-free instances (tools/trace_gemms.py lists what a forward launches)
+    constexpr int kQkv = ISPK_EP_OUT_BF16, kFfn1 = ISPK_EP_OUT_BF16 | ISPK_EP_GELU, kProj = ISPK_EP_MASK_ACC | kEpResid;
+    const int key = p.cpb == -7 ? -2 : ep_key(p);
+    if (const char* e = getenv("ISPK_PANEL_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][6]
+        GemmParams q = p;
+        q.ln_out = reinterpret_cast<void*>(strtoull(e, nullptr, 16));
+        if (key == kQkv) ISPK_PANEL_GO(kQkv, true, q);
+        if (key == kFfn1) ISPK_PANEL_GO(kFfn1, true, q);
+        ISPK_PANEL_GO(kEpDyn, true, q);
+    }
+    if (getenv("ISPK_EP_DYN") == nullptr) {   // (set: experiments, forces the generic epilogue)
+        if (key == kQkv) ISPK_PANEL_GO(kQkv, false, p);
+        if (key == kFfn1) ISPK_PANEL_GO(kFfn1, false, p);
+        if (key == kProj) ISPK_PANEL_GO(kProj, false, p);
+    }
+    ISPK_PANEL_GO(kEpDyn, false, p);
+#undef ISPK_PANEL_GO
 }
 
 bool panel_ok(const GemmParams& p) {
@@ -887,21 +991,31 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
 // A workgroup owns 128 rows (4 waves x 32 rows, one wave per SIMD with the whole 512-register file):
 //   xf   : the wave's 32 input rows x D as MFMA fragments, loaded once                            (D/16 x 4 VGPRs)
 //   acc2 : the wave's 32 rows x D outputs, transposed (feature on the row axis, row on the lane)   (D/32 x 16 regs)
-// and walks the inner dimension in chunks of 32 hidden units.  Per chunk:
-//   1. acc1 = W1[chunk] · xfᵀ          (D/16 MFMAs; W1 chunk [32][D] streamed through LDS)
-//   2. GELU on the 16 accumulator registers, packed pairwise to bf16 — which IS the B operand of the next product
-//      (register 8s+j of lane half h = hidden 16s + 8(j>>2) + 4h + (j&3): accumulator-as-operand, guide §3)
-//   3. acc2[nt] += W2[nt-th 32 features][chunk] · Pᵀ   (D/32 x 2 MFMAs; W2 chunk [D][32] in LDS, its 32 hidden columns
-//      stored permuted into that same order so that each fragment is ONE conflict-free ds_read_b128)
-// Weight chunks are double-buffered in LDS and prefetched one chunk ahead through registers; one barrier per chunk.
+// and walks the inner dimension in chunks of 32 hidden units, software-pipelined by one chunk.  Iteration c:
+//   phase A  acc1' = W1[chunk c+1] · xfᵀ   (D/16 MFMAs; W1 chunk [32][D] streamed through LDS)  - and, in the gaps
+//            between those MFMAs, the GELU of chunk c's accumulators, packed pairwise to bf16: which IS the B operand
+//            of phase B (register 8s+j of lane half h = hidden 16s + 8(j>>2) + 4h + (j&3): accumulator-as-operand)
+//   phase B  acc2[nt] += W2[nt-th 32 features][chunk c] · Pᵀ   (D/32 x 2 MFMAs; W2 chunk [D][32] in LDS, its 32 hidden
+//            columns in that same permuted order so that each fragment is ONE conflict-free ds_read_b128)
+// With one wave per SIMD nothing else hides anything, so every non-MFMA instruction is placed by hand in an MFMA gap
+// (measured with in-kernel stamps, tools/stamp_ffn.py: unscheduled, GELU and the weight staging bursts each took as
+// long as a 24-MFMA phase):
+//   * GELU: 8 register pairs x 3 stages of ~7 packed-fp32 instructions, one stage per phase-A gap;
+//   * LDS stores of the prefetched W1 chunk c+2 / W2 chunk c+1 (already in registers): one per gap at the start of
+//     phase A; they retire in order with the operand reads, so the hand-counted lgkmcnt waits count them as younger
+//     operations instead of draining them;
+//   * the global loads of W1 chunk c+3 / W2 chunk c+2 into those registers: one per gap at the start of phase B (a
+//     burst of 12 loads blocks the wave's issue for 12 x 16 cycles x 4 waves on the CU's one address path).
+// The operand reads of both phases run as ONE stream through an RD-deep ring of opaque asm reads.  One barrier per chunk.
 // Epilogue: the row-coalescing transpose (store_rows_f32) with residual and mask.
-template <int KC, bool B1>  // D = 64 * KC; B1: first Linear has a bias (recipes: no)
+template <int KC, bool B1, bool PK, int EP = kEpDyn, bool ST = false>  // D = 64 KC; B1: Linear 1 has a bias; PK: packed W2
 __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const uint16_t* __restrict__ W2, int64_t ldw2,
                                                           const float* __restrict__ bias1, int F) {
     constexpr int D = 64 * KC, KS = D / 16, NT = D / 32, HC = 32;
     constexpr int LD1 = D + 8, LD2 = HC + 8;         // padded LDS rows (bf16 elements)
-    constexpr int C1 = HC * (D / 8) / 256;            // 16-B chunks per thread: W1 chunk (32 rows x D/8)
+    constexpr int C1 = HC * (D / 8) / 256;            // 16-B pieces per thread: W1 chunk (32 rows x D/8)
     constexpr int C2 = D * (HC / 8) / 256;            //                          W2 chunk (D rows x 4)
+    constexpr int W2OPS = PK ? 1 : 2;                 // LDS stores per W2 piece
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     uint16_t* W1s = reinterpret_cast<uint16_t*>(smem_raw);   // [2][HC][LD1]
     uint16_t* W2s = W1s + 2 * HC * LD1;                      // [2][D][LD2]
@@ -915,61 +1029,99 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
     const uint16_t* W1 = static_cast<const uint16_t*>(p.W);
     const int nchunks = F / HC;
 
-    // per-thread element offsets of its staging pieces inside chunk 0 (32-bit, computed once); a chunk then only adds a
-    // wave-uniform step, so the loads are "uniform base + 32-bit lane offset" with no 64-bit arithmetic in the loop
-    u32x4 r1[C1], r2[C2];
-    int o1[C1], o2[C2];
-#pragma unroll
-    for (int i = 0; i < C1; ++i) {
-        const int id = tid + 256 * i, r = id / (D / 8), cc = id - r * (D / 8);
-        o1[i] = r * (int)p.ldw + cc * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < C2; ++i) {
-        const int id = tid + 256 * i, n = id >> 2, cc = id & 3;
-        o2[i] = n * (int)ldw2 + cc * 8;
-    }
-    const int step1 = HC * (int)p.ldw;
-    auto load_chunk = [&](int c) {
+    // Weight staging: ONE set of C = D/64 16-byte registers per thread alternates between the two operands - in phase A
+    // gap i it holds W2 piece i of chunk c+1 (stored to LDS there, then reloaded with W1 piece i of chunk c+2), in phase
+    // B gap i that W1 piece (stored, then reloaded with W2 piece i of chunk c+2): each load has one 24-MFMA phase to
+    // land (the weights are L2-resident), and only C x 4 registers are tied up instead of 2C x 4 - this kernel sits at
+    // the edge of the 256 + 256 register file.  Addresses are "uniform base + one lane offset" (W1 rows are contiguous,
+    // ldw1 == D, checked by the launcher): piece i of a chunk is 16-byte unit tid + 256 i.
+    constexpr int C = C1;
+    static_assert(C1 == C2, "D/64 pieces of either operand per thread");
+    u32x4 R[C];
+    const uint32_t lane_off1 = tid * 8;                                                    // elements
+    const uint32_t lane_off2 = PK ? tid * 8 : (tid >> 2) * (uint32_t)ldw2 + (tid & 3) * 8;
+    const int step1 = HC * D;
+    const int step2 = PK ? D * HC : HC;              // packed: chunk c is one contiguous [D][32] block
+    const int pstep2 = PK ? 2048 : 64 * (int)ldw2;   // piece i -> i + 1 (uniform)
+    auto load1 = [&](int i, int c) {      // chunk indices past the end re-read the last chunk (never consumed)
         c = c < nchunks ? c : nchunks - 1;
-        const uint16_t* b1 = W1 + (int64_t)c * step1;
-        const uint16_t* b2 = W2 + c * HC;
-#pragma unroll
-        for (int i = 0; i < C1; ++i) r1[i] = *reinterpret_cast<const u32x4*>(b1 + o1[i]);
-#pragma unroll
-        for (int i = 0; i < C2; ++i) r2[i] = *reinterpret_cast<const u32x4*>(b2 + o2[i]);
+        R[i] = *reinterpret_cast<const u32x4*>(W1 + ((int64_t)c * step1 + i * 2048) + lane_off1);
     };
-    auto store_chunk = [&](int buf) {
+    auto load2 = [&](int i, int c) {
+        c = c < nchunks ? c : nchunks - 1;
+        R[i] = *reinterpret_cast<const u32x4*>(W2 + ((int64_t)c * step2 + (int64_t)i * pstep2) + lane_off2);
+    };
+    uint32_t s1off[C];   // LDS byte offset of W1 piece i inside a buffer: row (tid + 256 i) / (D/8), 16-byte column
 #pragma unroll
-        for (int i = 0; i < C1; ++i) {
-            const int id = tid + 256 * i, r = id / (D / 8), cc = id - r * (D / 8);
-            *reinterpret_cast<u32x4*>(W1s + (buf * HC + r) * LD1 + cc * 8) = r1[i];
-        }
-        // W2 chunk rows are stored PERMUTED in the hidden order of the accumulator fragment (LDS position 16s + 8h + j
-        // holds hidden 16s + 8(j>>2) + 4h + (j&3)), so a lane's k-step fragment is one aligned 16-byte run: the global
-        // 16-byte piece cc (hidden 8cc .. 8cc+7; s = cc>>1, a = cc&1) lands as two 8-byte halves at 16s + 4a (h = 0)
-        // and 16s + 8 + 4a (h = 1).
-#pragma unroll
-        for (int i = 0; i < C2; ++i) {
-            const int id = tid + 256 * i, n = id >> 2, cc = id & 3;
-            uint16_t* row = W2s + (buf * D + n) * LD2 + 16 * (cc >> 1) + 4 * (cc & 1);
+    for (int i = 0; i < C; ++i) {
+        const int id = tid + 256 * i, r = id / (D / 8), cc = id - r * (D / 8);
+        s1off[i] = (r * LD1 + cc * 8) * 2;
+    }
+    auto store1 = [&](int i, int buf) {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(W1s) + buf * (HC * LD1 * 2) + s1off[i]) = R[i];
+    };
+    // Row-major W2: chunk rows are stored PERMUTED into the hidden order of the accumulator fragment (LDS position
+    // 16s + 8h + j holds hidden 16s + 8(j>>2) + 4h + (j&3)), so a lane's k-step fragment is one aligned 16-byte run: the
+    // global 16-byte piece cc (hidden 8cc .. 8cc+7; s = cc>>1, a = cc&1) lands as two 8-byte halves at 16s + 4a (h = 0)
+    // and 16s + 8 + 4a (h = 1).  The packed image is already in that order.
+    const int s2cc = tid & 3;
+    uint16_t* const s2row = W2s + (tid >> 2) * LD2 + (PK ? s2cc * 8 : 16 * (s2cc >> 1) + 4 * (s2cc & 1));
+    auto store2 = [&](int i, int buf) {
+        uint16_t* row = s2row + (buf * D + 64 * i) * LD2;
+        if constexpr (PK) {
+            *reinterpret_cast<u32x4*>(row) = R[i];
+        } else {
             uint2 lo, hi;
-            lo.x = r2[i][0]; lo.y = r2[i][1]; hi.x = r2[i][2]; hi.y = r2[i][3];
+            lo.x = R[i][0]; lo.y = R[i][1]; hi.x = R[i][2]; hi.y = R[i][3];
             *reinterpret_cast<uint2*>(row) = lo;
             *reinterpret_cast<uint2*>(row + 8) = hi;
         }
     };
 
-    load_chunk(0);
+    // ---- prologue: W1 chunk 0 on its way, then the wave's 32 rows x D as MFMA fragments through a wave-private LDS
+    // patch (coalesced 16-byte loads; see gemm_bf16_panel_kernel), one D-half at a time
+#pragma unroll
+    for (int i = 0; i < C; ++i) load1(i, 0);
     bf16x8 xf[KS];
     {
-        const int mrow = m < p.M ? m : p.M - 1;
-        const uint16_t* xp = X + (int64_t)mrow * p.lda + 8 * h;
+        constexpr int KH = D / 2, CPH = KH / 8, XCH = 32 * CPH / 64, XLD = KH * 2 + 16;
+        static_assert(4 * 32 * XLD <= (2 * HC * LD1 + 2 * D * LD2) * 2, "x staging patches alias the weight buffers");
+        char* xs = smem_raw + wave * (32 * XLD);
+        u32x4 t[2][XCH];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xp + 16 * ks);
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int id = lane + 64 * j, r = id / CPH, c = id - r * CPH;
+                const int row = mw0 + r < p.M ? mw0 + r : p.M - 1;
+                t[half][j] = *reinterpret_cast<const u32x4*>(X + (int64_t)row * p.lda + half * KH + c * 8);
+            }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int j = 0; j < XCH; ++j) {
+                const int id = lane + 64 * j, r = id / CPH, c = id - r * CPH;
+                *reinterpret_cast<u32x4*>(xs + r * XLD + c * 16) = t[half][j];
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS / 2; ++ks)
+                xf[half * (KS / 2) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLD + ks * 32 + h * 16);
+        }
     }
-    store_chunk(0);
-    load_chunk(1);
+    __syncthreads();   // the patches alias the weight buffers
+    // LDS <- W1 chunks 0 and 1, W2 chunk 0; R <- W2 chunk 1 (stored in phase A of iteration 0)
+#pragma unroll
+    for (int i = 0; i < C; ++i) store1(i, 0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) load2(i, 0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) store2(i, 0);
+#pragma unroll
+    for (int i = 0; i < C; ++i) load1(i, 1);
+#pragma unroll
+    for (int i = 0; i < C; ++i) store1(i, 1);
+#pragma unroll
+    for (int i = 0; i < C; ++i) load2(i, 1);
     f32x16 acc2[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -977,16 +1129,76 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
         for (int r = 0; r < 16; ++r) acc2[t][r] = 0.f;
     __syncthreads();
 
-    // One wave per SIMD: nothing hides an LDS round trip, so the KS + 2*NT operand reads of a chunk run as ONE stream
-    // through an RD-deep register ring of opaque asm reads with hand-counted waits (see gemm_bf16_panel_kernel); the
-    // W2 reads are issued while the GELU of the chunk is still running.
-    constexpr int RD = 4, NS = KS + 2 * NT;
     const uint32_t w1base = lds_addr(W1s + l31 * LD1 + 8 * h);
     const uint32_t w2base = lds_addr(W2s + l31 * LD2 + 8 * h);
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        const uint32_t a1 = w1base + buf * (HC * LD1 * 2);
-        const uint32_t a2 = w2base + buf * (D * LD2 * 2);
+
+    // GELU of one accumulator register pair in three stages of ~7 packed-fp32 instructions (= gelu_fast2, same operation
+    // order): stage 0 reads the accumulators, stage 2 writes the packed bf16 pair into the next phase's B operand.
+    union Frag { uint32_t u[4]; bf16x8 f; };
+    f32x16 acc1;
+    Frag pfC[2], pfN[2];                  // B operand of the running phase B / being produced for the next one
+    f32x2 gx[8], gax[8], gz[8], gq[8];   // per-pair state between stages (one or two pairs live at a time)
+    auto gelu_stage = [&](auto gc, int c) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value, pr = g / 3, sg = g % 3;   // register pair, stage
+        constexpr int r0 = 8 * (pr >> 2) + 2 * (pr & 3);                  // accumulator registers r0, r0 + 1
+        if constexpr (sg == 0) {
+            f32x2 v;
+            v.x = acc1[r0]; v.y = acc1[r0 + 1];
+            if constexpr (B1) {
+                const int hid = c * HC + (r0 & 3) + 8 * (r0 >> 2) + 4 * h;
+                v.x += bias1[hid]; v.y += bias1[hid + 1];
+            }
+            gx[pr] = v;
+            f32x2 ax;
+            ax.x = fabsf(v.x); ax.y = fabsf(v.y);
+            gax[pr] = ax;
+            const f32x2 z = ax * 0.70710678118654752440f;
+            gz[pr] = z;
+            f32x2 qq = z * 0.0000430638f + 0.0002765672f;
+            qq = qq * z + 0.0001520143f;
+            qq = qq * z + 0.0092705272f;
+            gq[pr] = qq * z + 0.0422820123f;
+        } else if constexpr (sg == 1) {
+            const f32x2 z = gz[pr];
+            f32x2 qq = gq[pr] * z + 0.0705230784f;
+            qq = qq * z + 1.0f;
+            qq = qq * qq; qq = qq * qq; qq = qq * qq; qq = qq * qq;
+            f32x2 r;
+            r.x = __builtin_amdgcn_rcpf(qq.x); r.y = __builtin_amdgcn_rcpf(qq.y);
+            gq[pr] = r;
+        } else {
+            f32x2 pos;
+            pos.x = fmaxf(gx[pr].x, 0.0f); pos.y = fmaxf(gx[pr].y, 0.0f);
+            const f32x2 o = pos - (gax[pr] * 0.5f) * gq[pr];
+            pfN[pr >> 2].u[pr & 3] = pack_bf16x2(o.x, o.y);
+        }
+    };
+
+    {   // pipeline fill: acc1 = W1[chunk 0] · xfᵀ and its GELU (plain reads, no overlap)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(W1s + l31 * LD1 + 8 * h + 16 * ks);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[ks], acc1, 0, 0, 0);
+        }
+        static_for<0, 24>([&](auto gc) { gelu_stage(gc, 0); });
+        pfC[0].f = pfN[0].f;
+        pfC[1].f = pfN[1].f;
+    }
+    __syncthreads();   // iteration 1 overwrites W1s[0]
+
+    // Iteration c = 1 .. nchunks:  phase A  acc1 = W1[chunk c] · xfᵀ            (reads W1s[c & 1]; chunk nchunks: a re-run
+    //                                                                           of the last chunk, never consumed)
+    //                              phase B  acc2 += W2[chunk c-1] · pfCᵀ        (reads W2s[(c-1) & 1]) + GELU(chunk c) -> pfN
+    constexpr int RD = 4, NB = 2 * NT, NS = KS + NB;
+    static_assert(C <= KS && C <= NB && RD - 1 + RD * W2OPS <= 15, "staging slots / lgkmcnt range");
+    [[maybe_unused]] uint64_t tsum[3] = {0, 0, 0}, t0 = 0, tA = 0, tB = 0;
+    for (int c = 1; c <= nchunks; ++c) {
+        if constexpr (ST) t0 = __builtin_readcyclecounter();
+        const int pc = c & 1;
+        const uint32_t a1 = w1base + pc * (HC * LD1 * 2);
+        const uint32_t a2 = w2base + (pc ^ 1) * (D * LD2 * 2);
         bf16x8 q[RD];
         auto issue = [&](auto ic) {
             constexpr int st = decltype(ic)::value;
@@ -998,52 +1210,88 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
             }
         };
         static_for<0, RD>(issue);
-        f32x16 acc1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc1[r] = 0.f;
-        union { uint32_t u[4]; bf16x8 f; } pf[2];
         static_for<0, NS>([&](auto ic) {
             constexpr int st = decltype(ic)::value;
-            if constexpr (st == KS) {
-                // bias, GELU, pack: accumulator registers 8s .. 8s+7 become the B fragment of k-step s
-#pragma unroll
-                for (int s = 0; s < 2; ++s)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        f32x2 v;
-                        v.x = acc1[8 * s + 2 * e];
-                        v.y = acc1[8 * s + 2 * e + 1];
-                        if constexpr (B1) {
-                            const int hid = c * HC + ((2 * e) & 3) + 8 * ((8 * s + 2 * e) >> 2) + 4 * h;
-                            v.x += bias1[hid];
-                            v.y += bias1[hid + 1];
-                        }
-                        v = gelu_fast2(v);
-                        pf[s].u[e] = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-                    }
-            }
-            constexpr int younger = (NS - 1 - st) < (RD - 1) ? (NS - 1 - st) : (RD - 1);
-            lds_wait<younger>();
+            if constexpr (ST && st == KS) { __builtin_amdgcn_sched_barrier(0); tA = __builtin_readcyclecounter(); }
+            // LDS operations younger than read(st): the later reads of the ring plus the stores of gaps st-RD .. st-1
+            // (W2 pieces in phase-A gaps 0 .. C-1, W1 pieces in phase-B gaps KS .. KS+C-1)
+            constexpr int reads_after = (NS - 1 - st) < (RD - 1) ? (NS - 1 - st) : (RD - 1);
+            constexpr int g0 = st - RD < 0 ? 0 : st - RD;
+            constexpr int n2 = (st < C ? st : C) - (g0 < C ? g0 : C);
+            constexpr int hi1 = st < KS ? KS : (st < KS + C ? st : KS + C), lo1 = g0 < KS ? KS : (g0 < KS + C ? g0 : KS + C);
+            lds_wait<reads_after + n2 * W2OPS + (hi1 - lo1)>();
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (st < KS) {
+            if constexpr (st == 0) {
+                f32x16 z;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) z[r] = 0.f;
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[st % RD], xf[st], z, 0, 0, 0);
+            } else if constexpr (st < KS) {
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[st % RD], xf[st], acc1, 0, 0, 0);
             } else {
                 constexpr int nt = (st - KS) / 2, s2 = (st - KS) % 2;
-                acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[st % RD], pf[s2].f, acc2[nt], 0, 0, 0);
+                acc2[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q[st % RD], pfC[s2].f, acc2[nt], 0, 0, 0);
             }
             if constexpr (st + RD < NS) issue(std::integral_constant<int, st + RD>{});
+            // ---- gap work
+            if constexpr (st < C) {                        // phase A: W2 chunk c -> LDS, W1 chunk c+1 -> register
+                store2(st, pc);
+                load1(st, c + 1);
+            }
+            if constexpr (st >= KS && st - KS < C) {        // phase B: W1 chunk c+1 -> LDS, W2 chunk c+1 -> register
+                store1(st - KS, pc ^ 1);
+                load2(st - KS, c + 1);
+            }
+            if constexpr (st >= KS) {                      // phase B: the GELU stages that fall into this gap (the first
+                static_for<0, 24>([&](auto gc) {           // gap is left to the last phase-A MFMA's latency)
+                    constexpr int g = decltype(gc)::value;
+                    constexpr int gap = (g * NB / 24 + 1) < NB ? (g * NB / 24 + 1) : NB - 1;
+                    if constexpr (gap == st - KS) gelu_stage(gc, c);
+                });
+            }
         });
-        // ---- stage chunk c+1 (already in registers) into the other buffer, fetch chunk c+2
-        if (c + 1 < nchunks) {
-            store_chunk(buf ^ 1);
-            load_chunk(c + 2);
-        }
+        pfC[0].f = pfN[0].f;
+        pfC[1].f = pfN[1].f;
+        if constexpr (ST) { __builtin_amdgcn_sched_barrier(0); tB = __builtin_readcyclecounter(); }
         __syncthreads();
+        if constexpr (ST) {
+            const uint64_t tE = __builtin_readcyclecounter();
+            tsum[0] += tA - t0; tsum[1] += tB - tA; tsum[2] += tE - tB;
+        }
+    }
+    if constexpr (ST) {
+        if (lane == 0) {
+            uint64_t* dbg = static_cast<uint64_t*>(p.ln_out) + (blockIdx.x * 4 + wave) * 3;
+            for (int i = 0; i < 3; ++i) dbg[i] = tsum[i];
+        }
     }
 
-    const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+    float mk = 1.0f;
+    if (EP < 0 || ((uint32_t)EP & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT))) mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) store_rows_f32(p, stage, mw0, nt * 32, acc2[nt], mk, lane);
+    for (int nt = 0; nt < NT; ++nt) store_rows_f32<EP>(p, stage, mw0, nt * 32, acc2[nt], mk, lane);
+}
+
+// W2 [D][F] (nn.Linear layout) -> [F/32][D][32] with each chunk's 32 hidden units in accumulator-fragment order
+// (position 16s + 8h + 4a + b holds hidden 16s + 8a + 4h + b): a chunk becomes ONE contiguous 64*D-byte block, so the
+// fused kernel streams it with full-line loads spread over every L2 channel (the [D][F] layout reads 64 bytes from each
+// of D rows 2*F bytes apart) and stages it with straight 16-byte LDS stores.
+__global__ void ffn_pack_w2_kernel(const uint16_t* __restrict__ W2, int64_t ldw2, uint16_t* __restrict__ out, int D, int F) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one output element
+    if (idx >= (int64_t)D * F) return;
+    const int pos = idx & 31, n = (idx >> 5) % D, c = (idx >> 5) / D;
+    const int hid = (pos & 16) | ((pos & 4) << 1) | ((pos & 8) >> 1) | (pos & 3);
+    out[idx] = W2[(int64_t)n * ldw2 + c * 32 + hid];
+}
+
+extern "C" int32_t ispk_ffn_pack_w2_bf16(const uint16_t* W2, int64_t ldw2, int32_t D, int32_t F, uint16_t* packed,
+                                         ispk_stream_t stream) {
+    ISPK_REQUIRE(W2 && packed, ISPK_E_NULL, "ffn_pack_w2: null pointer");
+    ISPK_REQUIRE(D >= 1 && F >= 32 && F % 32 == 0 && ldw2 >= F, ISPK_E_SHAPE, "ffn_pack_w2: bad shape D=%d inner=%d", D, F);
+    const int64_t n = (int64_t)D * F;
+    hipLaunchKernelGGL(ffn_pack_w2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), W2, ldw2, packed, D, F);
+    return ispk_launch_status();
 }
 
 extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
@@ -1056,7 +1304,7 @@ extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t*
     ISPK_REQUIRE((flags & ~(ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) == 0, ISPK_E_UNSUPPORTED, "ffn: unsupported flags");
     ISPK_REQUIRE(!((flags & (ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) && !mask), ISPK_E_NULL, "ffn: mask flag without mask");
     ISPK_REQUIRE(ldx % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0 && ldo % 4 == 0 && (!resid || ldr % 4 == 0) && ldx >= D &&
-                     ldw1 >= D && ldw2 >= F && ldo >= D,
+                     ldw1 >= D && (ldw2 >= F || ldw2 == 0) && ldo >= D,
                  ISPK_E_ALIGN, "ffn: leading strides must be multiples of 8 (bf16) / 4 (fp32)");
     ISPK_REQUIRE(ispk_aligned(x, 16) && ispk_aligned(W1, 16) && ispk_aligned(W2, 16) && ispk_aligned(out, 16) &&
                      (!resid || ispk_aligned(resid, 16)) && (!bias2 || ispk_aligned(bias2, 16)),
@@ -1066,18 +1314,35 @@ extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t*
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((rows + 127) / 128);
     ISPK_REQUIRE((int64_t)F * ldw1 < (1ll << 30) && (int64_t)D * ldw2 < (1ll << 30), ISPK_E_SHAPE, "ffn: weights too large");
-#define ISPK_FFN_LAUNCH(KC_, B1_)                                                                         \
-    do {                                                                                                  \
-        constexpr size_t lds = (size_t)(2 * 32 * (64 * KC_ + 8) + 2 * 64 * KC_ * 40) * 2 + 4 * kStageBytes; \
-        ISPK_RESERVE_LDS((&ffn_bf16_kernel<KC_, B1_>), lds, "ffn");                                       \
-        hipLaunchKernelGGL((ffn_bf16_kernel<KC_, B1_>), grid, dim3(256), lds, s, p, W2, ldw2, bias1, F);   \
-    } while (0)
-    if (D == 384) {
-        if (bias1) ISPK_FFN_LAUNCH(6, true); else ISPK_FFN_LAUNCH(6, false);
-    } else {
-        if (bias1) ISPK_FFN_LAUNCH(4, true); else ISPK_FFN_LAUNCH(4, false);
+    ISPK_REQUIRE(ldw1 == D, ISPK_E_UNSUPPORTED, "ffn: W1 rows must be contiguous (ldw1 == dim)");
+    constexpr int kHot = ISPK_EP_MASK_OUT | kEpResid;   // the transformer layer's call (transformer.py:105-110), no bias2
+    const bool hot = ep_key(p) == kHot && getenv("ISPK_EP_DYN") == nullptr;
+    const bool packed = ldw2 == 0;   // W2 laid out by ispk_ffn_pack_w2_bf16
+    void* stamp = nullptr;
+    if (const char* e = getenv("ISPK_FFN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][3]
+        stamp = reinterpret_cast<void*>(strtoull(e, nullptr, 16));
+        ISPK_REQUIRE(D == 384 && packed && !bias1 && hot, ISPK_E_UNSUPPORTED, "ffn stamps: the hot instance only");
+        p.ln_out = stamp;
     }
-#undef ISPK_FFN_LAUNCH
+#define ISPK_FFN_GO(KC_, B1_, PK_, EP_, ST_)                                                                          \
+    do {                                                                                                              \
+        constexpr size_t lds = (size_t)(2 * 32 * (64 * KC_ + 8) + 2 * 64 * KC_ * 40) * 2 + 4 * kStageBytes;             \
+        ISPK_RESERVE_LDS((&ffn_bf16_kernel<KC_, B1_, PK_, EP_, ST_>), lds, "ffn");                                    \
+        hipLaunchKernelGGL((ffn_bf16_kernel<KC_, B1_, PK_, EP_, ST_>), grid, dim3(256), lds, s, p, W2, ldw2, bias1, F); \
+        return ispk_launch_status();                                                                                  \
+    } while (0)
+#define ISPK_FFN_KC(KC_)                                                   \
+    do {                                                                   \
+        if (stamp) ISPK_FFN_GO(6, false, true, kHot, true);                \
+        if (!bias1 && packed && hot) ISPK_FFN_GO(KC_, false, true, kHot, false);  \
+        if (!bias1 && packed) ISPK_FFN_GO(KC_, false, true, kEpDyn, false);  \
+        if (!bias1) ISPK_FFN_GO(KC_, false, false, kEpDyn, false);          \
+        if (packed) ISPK_FFN_GO(KC_, true, true, kEpDyn, false);            \
+        ISPK_FFN_GO(KC_, true, false, kEpDyn, false);                       \
+    } while (0)
+    if (D == 384) ISPK_FFN_KC(6); else ISPK_FFN_KC(4);
+#undef ISPK_FFN_KC
+#undef ISPK_FFN_GO
     return ispk_launch_status();
 }
 

@@ -55,6 +55,12 @@ class FeedForward(nn.Module, Constructor):
                            "w2": ps[1].detach().to(dtype).contiguous()}
         return self._cache["w1"], self._cache["w2"]
 
+    def _packed_w2(self) -> Tensor:
+        """W2 in the fused kernel's chunk-contiguous layout, staged once per weight version."""
+        if "w2p" not in self._cache:
+            self._cache["w2p"] = runtime.ffn_pack_w2(self._cache["w2"])
+        return self._cache["w2p"]
+
     def forward(self, x: Tensor, *, residual: Optional[Tensor] = None, mask: Optional[Tensor] = None) -> Tensor:
         if self.training and self.dropout_p > 0:
             raise NotImplementedError("feed-forward dropout (training) is outside the forward-path scope")
@@ -66,7 +72,7 @@ class FeedForward(nn.Module, Constructor):
         if (dt == torch.bfloat16 and self.act_flag == runtime.EP_GELU and x.shape[-1] in (256, 384)
                 and rows >= self.fused_min_rows):
             # one kernel for Linear -> GELU -> Linear (+ residual, mask): the hidden activations never reach HBM
-            return runtime.ffn_fused(x, w1, w2, resid=residual, mask=mask, bias1=self.net[0].bias, bias2=self.net[3].bias,
+            return runtime.ffn_fused(x, w1, self._packed_w2(), resid=residual, mask=mask, bias1=self.net[0].bias, bias2=self.net[3].bias,
                                      flags=runtime.EP_MASK_OUT if mask is not None else 0)
         hidden = runtime.gemm(x, w1, bias=self.net[0].bias, flags=self.act_flag)
         flags = runtime.EP_MASK_OUT if mask is not None else 0

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ispk_gemm_bf16_ln": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64, _U32,
                           _P],
     "ispk_ffn_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P],
+    "ispk_ffn_pack_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -265,22 +266,39 @@ def gemm_ln(a: Tensor, w: Tensor, ln_weight: Tensor, ln_bias: Tensor, resid: Opt
     return out, ln_out
 
 
+def ffn_pack_w2(w2: Tensor) -> Tensor:
+    """ispk_ffn_pack_w2_bf16: W2 bf16 [D, inner] -> packed [inner/32, D, 32] (one-time weight staging for ffn_fused)."""
+    _dev(w2)
+    assert w2.dtype == torch.bfloat16 and w2.dim() == 2 and w2.stride(1) == 1
+    D, Fi = w2.shape
+    out = torch.empty((Fi // 32, D, 32), dtype=torch.bfloat16, device=w2.device)
+    _launch("ffn_pack_w2_kernel", 0.0, 4.0 * D * Fi, lib().ispk_ffn_pack_w2_bf16, w2.data_ptr(), w2.stride(0), D, Fi,
+            out.data_ptr(), _stream())
+    return out
+
+
 def ffn_fused(x: Tensor, w1: Tensor, w2: Tensor, resid: Optional[Tensor] = None, mask: Optional[Tensor] = None,
               bias1: Optional[Tensor] = None, bias2: Optional[Tensor] = None, flags: int = 0) -> Tensor:
-    """ispk_ffn_bf16: out fp32 [..., D] = [mask] * (resid + gelu(x @ w1^T + bias1) @ w2^T + bias2), x / w1 / w2 bf16."""
+    """ispk_ffn_bf16: out fp32 [..., D] = [mask] * (resid + gelu(x @ w1^T + bias1) @ w2^T + bias2), x / w1 / w2 bf16.
+    w2 is either [D, inner] (nn.Linear layout) or the 3-D packed image from `ffn_pack_w2` (faster)."""
     _dev(x, w1, w2, resid, mask, bias1, bias2)
     assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2.dtype == torch.bfloat16
     x2 = _rows2d(x)
     R, D = x2.shape
     Fi = w1.shape[0]
-    assert w1.shape == (Fi, D) and w2.shape == (D, Fi) and w1.stride(1) == 1 and w2.stride(1) == 1
+    assert w1.shape == (Fi, D) and w1.stride(1) == 1
+    packed = w2.dim() == 3
+    if packed:
+        assert w2.shape == (Fi // 32, D, 32) and w2.is_contiguous()
+    else:
+        assert w2.shape == (D, Fi) and w2.stride(1) == 1
     out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
     r2 = _rows2d(resid) if resid is not None else None
     if mask is not None:
         mask = mask.reshape(-1).contiguous()
     nb = x2.numel() * 2 + (w1.numel() + w2.numel()) * 2 + out.numel() * 4 + (r2.numel() * 4 if r2 is not None else 0)
     _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16, x2.data_ptr(), x2.stride(0),
-            w1.data_ptr(), w1.stride(0), _ptr(bias1), w2.data_ptr(), w2.stride(0), _ptr(bias2), _ptr(r2),
+            w1.data_ptr(), w1.stride(0), _ptr(bias1), w2.data_ptr(), 0 if packed else w2.stride(0), _ptr(bias2), _ptr(r2),
             r2.stride(0) if r2 is not None else 0, _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, _stream())
     return out
 

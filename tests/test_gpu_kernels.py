@@ -413,3 +413,11 @@ def test_fused_ffn_bf16(R, D, Fi):
     out = runtime.ffn_fused(d(x), d(w1), d(w2), bias1=d(b1), bias2=d(b2)).cpu()
     ref = F.gelu(x.double() @ w1.double().T + b1.double()).to(torch.bfloat16).double() @ w2.double().T + b2.double()
     assert (out.double() - ref).pow(2).mean().sqrt() < 1e-3 and (out.double() - ref).abs().max() < 2e-2
+    # the packed-W2 image computes the same products in the same order: bit-identical to the row-major path
+    w2p = runtime.ffn_pack_w2(d(w2))
+    pos = torch.arange(32)
+    hid_of_pos = (pos & 16) | ((pos & 4) << 1) | ((pos & 8) >> 1) | (pos & 3)
+    expect = w2.view(D, Fi // 32, 32)[:, :, hid_of_pos].permute(1, 0, 2).contiguous()
+    assert torch.equal(w2p.cpu().view(torch.int16), expect.view(torch.int16))
+    out_p = runtime.ffn_fused(d(x), d(w1), w2p, bias1=d(b1), bias2=d(b2)).cpu()
+    assert torch.equal(out_p, out)

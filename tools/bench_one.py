@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Graph-replay timing of single kernels at the benchmark shapes (20 launches per replay, 7 rounds, min / median)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from isp_tts_amd import runtime, synth
+R, dev, dt = 32768, "cuda", torch.bfloat16
+x = synth._normal("b/x", (R, 384)).to(dev).to(dt)
+x1536 = synth._normal("b/x2", (R, 1536)).to(dev).to(dt)
+resid = synth._normal("b/r", (R, 384)).to(dev)
+mask = torch.ones(R, dtype=torch.bool, device=dev)
+w1 = synth._normal("b/wf1", (1536, 384), 384 ** -0.5).to(dev).to(dt)
+w2 = synth._normal("b/wf2", (384, 1536), 1536 ** -0.5).to(dev).to(dt)
+wqkv = synth._normal("b/wqkv", (512, 384), 384 ** -0.5).to(dev).to(dt)
+wo = synth._normal("b/wo", (384, 384), 384 ** -0.5).to(dev).to(dt)
+w2p = runtime.ffn_pack_w2(w2)
+cases = {
+    "ffn_fused": (lambda: runtime.ffn_fused(x, w1, w2p, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),
+    "panel 384->1536 gelu bf16": (lambda: runtime.gemm(x, w1, flags=runtime.EP_GELU), 2.0 * R * 384 * 1536),
+    "panel 384->512 bf16": (lambda: runtime.gemm(x, wqkv), 2.0 * R * 384 * 512),
+    "panel 384->384 f32+resid": (lambda: runtime.gemm(x, wo, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT, out_dtype=torch.float32), 2.0 * R * 384 * 384),
+    "wide 1536->384 f32+resid": (lambda: runtime.gemm(x1536, w2, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT, out_dtype=torch.float32), 2.0 * R * 384 * 1536),
+}
+only = sys.argv[1:]
+graphs = {}
+for name, (fn, _) in cases.items():
+    if only and not any(o in name for o in only):
+        continue
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(20):
+            fn()
+    graphs[name] = g
+res = {k: [] for k in graphs}
+for _ in range(7):
+    for name, g in graphs.items():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        res[name].append(e0.elapsed_time(e1) / 20 * 1e3)
+for k, v in res.items():
+    v.sort()
+    print(f"{k:28s} min {v[0]:7.1f} us  median {v[len(v)//2]:7.1f} us   {cases[k][1]/v[0]*1e-6:6.0f} TF/s")

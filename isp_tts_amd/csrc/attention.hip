@@ -217,171 +217,295 @@ namespace {
 //   * the Pᵀ accumulator (fp32, register r = key (r&3) + 8(r>>2) + 4h) is packed pairwise to bf16 and used directly as
 //     the B operand of Oᵀ += Vᵀ·Pᵀ: registers 8s..8s+7 form k-step s, whose element j is key 16s + 8(j>>2) + 4h + (j&3)
 //     (guide §3 "An accumulator tile as the next MFMA's operand").  The A operand must present V in that same key order,
-//     so the V tile is staged TRANSPOSED in LDS (Vt[d][key]): a lane reads two 8-byte runs of 4 consecutive keys;
+//     V stays ROW-major in LDS ([key][d], staged with plain 16-byte stores like K) and is read with the transposing
+//     ds_read_b64_tr_b16 (guide T10): per 16-lane group a 4-key x 16-dim block comes back with one dim per lane and
+//     its 4 consecutive keys packed in 8 bytes - two such reads are one A fragment.  Rows are padded to 192 bytes:
+//     the 32 lanes of a half then touch every one of the 64 banks exactly once;
 //   * exp() runs as v_exp_f32 on log2-domain scores: s*log2(e)/8 - slope*log2(e)*|i-j| in one FMA.
 // Per 32x32 (key x query) block a wave issues 8 MFMAs (256 cycles) but ~16 exp + ~130 VALU ops, so this kernel is
 // VALU-bound, not MFMA-bound; 3 waves per SIMD overlap one wave's softmax with another's MFMAs.
-constexpr int kLdh = 72;  // padded row of the bf16 K / Vt tiles (64 + 8 elements = 144 B)
-
-__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+constexpr int kLdh = 72;  // padded row of the bf16 K tile (64 + 8 elements = 144 B)
+constexpr int kLdv = 96;  // padded row of the bf16 V tile (192 B, see above)
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ void lds_read_tr16_b64(u32x2& dst, uint32_t lds_byte_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF) : "memory");
 }
 
-template <int MAXT>
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {   // ONE v_cvt_pk_bf16_f32
+    f32x2 v;
+    v.x = lo; v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
+// max over the two 32-lane halves without the LDS round trip of a bpermute: v_permlane32_swap exchanges the upper half
+// of one register with the lower half of another (gfx950).  (Inline asm: the builtin's second result was miscompiled.)
+// v_max3_f32 without the canonicalising v_max x, x that fmaxf() puts in front of every operand (scores are never sNaN)
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float xhalf_max_swap(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
+// K/V staging.  The loop was latency-bound with register-staged 64-key tiles one tile ahead (a tile's 2,000 cycles of
+// work cannot cover a 4,000-cycle miss; deeper register prefetch does not fit 168 VGPRs).  Now K and V stream into a
+// 4-slot LDS ring of 128-key chunks by LDS-DMA (global_load_lds_dwordx4: no registers, no LDS store instructions), up
+// to three chunks (96 KB) in flight; for N <= 512 the whole sequence is requested before the first score.  A DMA
+// instruction writes 64 lanes x 16 B = 8 rows linearly, so rows are unpadded 128 B and bank conflicts are avoided by an
+// XOR swizzle applied on the SOURCE side: LDS position (row r, 16-byte slot pc) holds logical chunk pc ^ sw(r),
+//     K: sw = (r >> 1) & 7          -> the 16 rows of a ds_read_b128 lane group land on 16 distinct (parity, slot) pairs
+//     V: sw = ((r >> 1) & 1) << 2   -> the 4-key x 16-dim blocks of a half's ds_read_b64_tr_b16 cover all 64 banks once
+// The first 8 waves are the loaders (IPL DMA instructions per chunk each: K and V rows 16w .. 16w+15); every wave
+// waits for its own DMAs with a counted vmcnt and one raw s_barrier per chunk publishes the chunk (and retires the
+// slot the next DMA overwrites).  No other vector-memory instruction is issued inside the loop, so vmcnt counts DMAs.
+constexpr int kChunkKeys = 128, kSlots = 4;
+constexpr int kSlotBytes = kChunkKeys * 128;            // one operand of one slot
+constexpr size_t kAttnLds = (size_t)2 * kSlots * kSlotBytes;   // 128 KB
+
+template <int MAXT, int IPL, bool ST = false>   // IPL: DMA instructions per loader wave per chunk = 32 / (loader waves)
 __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restrict__ q, int64_t ldq,
                                                          const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
                                                          int64_t ldkv, const float* __restrict__ slopes,
                                                          const int64_t* __restrict__ key_len,
-                                                         uint16_t* __restrict__ out, int64_t ldo, int N, int H) {
-    __shared__ __attribute__((aligned(16))) uint16_t Ks[2 * kTileKeys * kLdh];  // [2][key][d]
-    __shared__ __attribute__((aligned(16))) uint16_t Vt[2 * 64 * kLdh];         // [2][d][key]
+                                                         uint16_t* __restrict__ out, int64_t ldo, int N, int H, int qpw,
+                                                         uint64_t* __restrict__ stamps = nullptr) {
+    [[maybe_unused]] uint64_t ts[6] = {0, 0, 0, 0, 0, 0}, tk0 = 0, ta = 0, tb = 0, tc = 0, td = 0;
+    if constexpr (ST) tk0 = __builtin_readcyclecounter();
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    char* const Kl = smem_raw;                          // [kSlots][128 rows][128 B]
+    char* const Vl = smem_raw + kSlots * kSlotBytes;
 
-    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int head = wave % H, qhalf = wave / H;
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + qhalf * 32;
     int klen = key_len ? (int)key_len[b] : N;
     klen = klen < 1 ? 1 : (klen > N ? N : klen);
     constexpr float kLog2e = 1.4426950408889634f;
-    const float slope2 = slopes[head] * kLog2e;
     const float scale2 = 0.125f * kLog2e;
     const float ninf = -__builtin_huge_valf();
+    const int nchunks = (klen + kChunkKeys - 1) / kChunkKeys;
 
-    const int qi = q0 + l31;
-    const int qrow = qi < N ? qi : N - 1;
-    bf16x8 qf[4];
-    {
+    // ---- loaders: DMA instruction i of a chunk (i < IPL) moves 8 rows of K (i even) or V (i odd)
+    constexpr int NL = 32 / IPL;                        // loader waves
+    const bool loader = wave < NL;
+    const uint16_t* kb = k + (int64_t)b * N * ldkv;
+    const uint16_t* vb = v + (int64_t)b * N * ldkv;
+    const int lrow = lane >> 3, lpc = lane & 7;         // this lane's row within the 8-row group and its LDS slot
+    auto issue_chunk = [&](int c) {
+        const int slot = c & (kSlots - 1);
+#pragma unroll
+        for (int i = 0; i < IPL; ++i) {
+            const int isv = i & 1, grp = wave * (IPL / 2) + (i >> 1);      // 8-row group 0..15 of the chunk
+            const int r = grp * 8 + lrow;                                  // row within the chunk
+            const int sw = isv ? ((r >> 1) & 1) << 2 : (r >> 1) & 7;
+            int key = c * kChunkKeys + r;
+            key = key < N ? key : N - 1;                                   // rows past the end: a valid row, masked later
+            const uint16_t* src = (isv ? vb : kb) + (int64_t)key * ldkv + ((lpc ^ sw) * 8);
+            char* dst = (isv ? Vl : Kl) + slot * kSlotBytes + grp * 1024;  // wave-uniform; lane L lands at + 16 L
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    // A workgroup serves qpw consecutive 64-query tiles of its batch element.  When the whole key range fits the ring
+    // (resident: nchunks <= kSlots) K/V are fetched ONCE, all chunks requested up front, and every tile after the first
+    // runs without a single wait or barrier; the launcher picks qpw > 1 only then.
+    const bool resident = nchunks <= kSlots;
+    const int ahead = resident ? kSlots : kSlots - 1;      // chunks in flight
+    // Q fragments are loaded by opaque asm (hipcc would drain every DMA with vmcnt(0) at their first use): they are
+    // issued BEFORE the DMAs of the first tile, so the counted vmcnt that admits chunk 0 has retired them too.
+    auto load_q = [&](bf16x8 (&qf)[4], int q0) {
+        const int qi = q0 + l31;
+        const int qrow = qi < N ? qi : N - 1;
         const uint16_t* qp = q + ((int64_t)b * N + qrow) * ldq + head * 64 + h * 8;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + ks * 16);
+        for (int ks = 0; ks < 4; ++ks)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[ks]) : "v"(qp + ks * 16) : "memory");
+    };
+    bf16x8 qf[4];
+    load_q(qf, (blockIdx.x * qpw) * 64 + qhalf * 32);
+    if (loader) {
+#pragma unroll 1
+        for (int c = 0; c < nchunks && c < ahead; ++c) issue_chunk(c);
     }
 
+    // Softmax bookkeeping, built to keep the per-block VALU work small:
+    //   * the ALiBi bias and the running reference maximum enter the score MFMA as its accumulator INIT,
+    //         acc = q·k + init,   init = (-slope2*|key - query| - m_ref) / scale2 = nsl*|key - query| + mref_s,
+    //     so p = exp2(acc * scale2) needs one packed multiply and one v_exp_f32 per score;
+    //   * away from the diagonal block the distance has a fixed sign and init is "wave base -/+ a per-register
+    //     constant" (8 packed adds); only the key0 == q0 block pays for the |.|;
+    //   * m_ref is a LAZY reference: it is raised (and O, l rescaled) only when a block's scores exceed it by more than
+    //     2^kLazy, so most blocks skip the 32-register rescale of O; exp2 arguments stay <= kLazy and the row's true
+    //     maximum contributes p >= 1, so nothing overflows or underflows (m_ref starts as block 0's exact maximum);
+    //   * the row sum accumulates as packed pairs.
+    constexpr float kLazy = 16.0f;
+    const float nsl = -8.0f * slopes[head];              // = -slope2 / scale2, exact
+    f32x2 cn[8];                                          // nsl * (key offset of accumulator registers 2j, 2j+1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        cn[j].x = nsl * (float)(((2 * j) & 3) + 8 * ((2 * j) >> 2));
+        cn[j].y = nsl * (float)(((2 * j + 1) & 3) + 8 * ((2 * j + 1) >> 2));
+    }
+
+    // per-lane LDS byte offsets inside a slot.  K fragment of k-step ks: row l31 (+ 32 per block), logical chunk 2ks + h.
+    const uint32_t kl_base = lds_addr(Kl), vl_base = lds_addr(Vl);
+    uint32_t koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = kl_base + l31 * 128 + (((2 * ks + h) ^ ((l31 >> 1) & 7)) << 4);
+    // V transposing read: 16-lane group = (h, dim half dh); lane 4qq + p of the group points at key row 4h + qq, dims
+    // 4p .. 4p+3 of the group's 16-dim block, i.e. logical chunk 4dt + 2dh + (p >> 1), byte 8 (p & 1) inside it.
+    const int qq = (lane & 15) >> 2, pp = lane & 3, dh = (lane >> 4) & 1;
+    uint32_t voff[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+        voff[dt] = vl_base + (4 * h + qq) * 128 + (((4 * dt + 2 * dh + (pp >> 1)) ^ ((qq >> 1) << 2)) << 4) + 8 * (pp & 1);
+
+    if constexpr (ST) { ta = __builtin_readcyclecounter(); ts[0] = ta - tk0; }
+    const int nqt = (N + 63) / 64;
+#pragma unroll 1
+    for (int it = 0; it < qpw; ++it) {
+    const int qt = blockIdx.x * qpw + it;
+    if (qt >= nqt) break;                                  // workgroup-uniform
+    const int q0 = qt * 64 + qhalf * 32, qi = q0 + l31;
+    const int q0w = q0;                                    // the wave's first query: the diagonal block has key0 == q0w
+    if (it > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's Q fragments (no DMA is outstanding)
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m_run = ninf, l_run = 0.f;
-
-    const uint16_t* kb = k + (int64_t)b * N * ldkv;
-    const uint16_t* vb = v + (int64_t)b * N * ldkv;
-    const int ntiles = (klen + kTileKeys - 1) / kTileKeys;
-
-    // split staging (see attn_f32_kernel): 1024 16-byte pieces per tile (K row-major; V scattered transposed into
-    // Vt[d][key]), loads issued before the current tile's compute, LDS writes after it.
-    constexpr int kStageMax = 2;  // ceil(1024 / 512)
-    u32x4 sreg[kStageMax];
-    auto stage_load = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < kStageMax; ++i) {
-            const int idx = tid + i * nthreads;
-            const int isv = idx >> 9, rem = idx & 511;
-            const int row = rem >> 3, c8 = (rem & 7) * 8;
-            const int key = t * kTileKeys + row;
-            u32x4 val = {0u, 0u, 0u, 0u};
-            if (idx < kTileKeys * 16 && key < N)
-                val = *reinterpret_cast<const u32x4*>((isv ? vb : kb) + (int64_t)key * ldkv + c8);
-            sreg[i] = val;
+    float mref_s = 0.f;                                    // = -m_ref / scale2
+    f32x2 l2 = {0.f, 0.f};
+    for (int c = 0; c < nchunks; ++c) {
+        if constexpr (ST) ta = __builtin_readcyclecounter();
+        if (it == 0) {
+            // chunk c has landed once only this wave's younger DMAs (chunks c+1 .. c+ahead-1) are outstanding; the Q
+            // loads are older than every DMA.  Waves that load nothing wait for their Q fragments once.
+            if (loader) {
+                const int after = (nchunks - 1 - c) < (ahead - 1) ? (nchunks - 1 - c) : (ahead - 1);
+                if (after >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * IPL) : "memory");
+                else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * IPL) : "memory");
+                else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPL) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            } else if (c == 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();             // publishes chunk c; every wave is done with chunk c-1
+            asm volatile("" ::: "memory");
+            if (loader && !resident && c + ahead < nchunks) issue_chunk(c + ahead);   // into the slot chunk c-1 just left
         }
-    };
-    auto stage_store = [&](int buf) {
+        const int slot = c & (kSlots - 1);
+        if constexpr (ST) { tb = __builtin_readcyclecounter(); ts[1] += tb - ta; }
+#pragma unroll 1
+        for (int kblk = 0; kblk < kChunkKeys / 32; ++kblk) {
+            const int key0 = c * kChunkKeys + kblk * 32;
+            if (key0 >= klen) break;  // wave-uniform
+            if constexpr (ST) { ta = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
+            // the 4 K fragments are requested together (opaque asm reads: hipcc would sink each next to its MFMA and wait
+            // for it there); the 8 transposed V reads follow the score MFMAs and land during the softmax
+            const uint32_t blk = (uint32_t)(slot * kSlotBytes + kblk * 32 * 128);
+            bf16x8 kf[4];
 #pragma unroll
-        for (int i = 0; i < kStageMax; ++i) {
-            const int idx = tid + i * nthreads;
-            if (idx >= kTileKeys * 16) continue;
-            const int isv = idx >> 9, rem = idx & 511;
-            const int row = rem >> 3, c8 = (rem & 7) * 8;
-            if (!isv) {
-                *reinterpret_cast<u32x4*>(Ks + (buf * kTileKeys + row) * kLdh + c8) = sreg[i];
+            for (int ks = 0; ks < 4; ++ks) lds_read_b128_asm<0>(kf[ks], koff[ks] + blk);
+            f32x16 s;
+            const float d0 = (float)(key0 + 4 * h - qi);   // key - query of accumulator register 0
+            if (key0 == q0w) {                              // wave-uniform: the one block that straddles the diagonal
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = fmaf(fabsf(d0 + (float)((r & 3) + 8 * (r >> 2))), nsl, mref_s);
+            } else if (key0 < q0w) {                        // keys before the queries: |d| = -(d0 + c_r)
+                const float base = mref_s - nsl * d0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const f32x2 t = base - cn[j];
+                    s[2 * j] = t.x; s[2 * j + 1] = t.y;
+                }
             } else {
-                uint16_t* dst = Vt + (buf * 64 + c8) * kLdh + row;
+                const float base = mref_s + nsl * d0;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dst[(2 * e) * kLdh] = (uint16_t)(sreg[i][e] & 0xffffu);
-                    dst[(2 * e + 1) * kLdh] = (uint16_t)(sreg[i][e] >> 16);
+                for (int j = 0; j < 8; ++j) {
+                    const f32x2 t = base + cn[j];
+                    s[2 * j] = t.x; s[2 * j + 1] = t.y;
                 }
             }
-        }
-    };
-
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < ntiles) stage_load(t + 1);
-#pragma unroll 1
-        for (int kblk = 0; kblk < 2; ++kblk) {
-            const int key0 = t * kTileKeys + kblk * 32;
-            if (key0 >= klen) break;  // wave-uniform
-            f32x16 s;
+            lds_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
-            const uint16_t* kp = Ks + (buf * kTileKeys + kblk * 32 + l31) * kLdh + h * 8;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            u32x2 vr[2][2][2];   // [st][dim tile][run]: keys key0 + 16st + 4h + 0..3 (run 0) and + 8 (run 1) of this lane's dim
+            static_for<0, 8>([&](auto ic) {
+                constexpr int i8 = decltype(ic)::value, st = i8 >> 2, dt = (i8 >> 1) & 1, run = i8 & 1;
+                lds_read_tr16_b64<(16 * st + 8 * run) * 128>(vr[st][dt][run], voff[dt] + blk);
+            });
+            if (key0 + 32 >= klen && it + 1 < qpw && qt + 1 < nqt) {
+                // the tile's last score product: Q is dead, fetch the next tile's fragments behind the softmax / PV / store
+                __builtin_amdgcn_sched_barrier(0);
+                load_q(qf, (qt + 1) * 64 + qhalf * 32);
             }
-            // log2-domain score: s*log2(e)/8 - slope*log2(e)*|key - query|.  The distance is fp32 from the start
-            // (d0 + compile-time register offset), so an element costs one add and one FMA with an |.| source modifier;
-            // the key-length mask is applied only in the one block that straddles key_len (wave-uniform test).
-            const float d0 = (float)(key0 + 4 * h - qi);
-            float smax = ninf;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float dist = fabsf(d0 + (float)((r & 3) + 8 * (r >> 2)));
-                s[r] = fmaf(s[r], scale2, -slope2 * dist);
-            }
-            if (key0 + 32 > klen) {
+            if constexpr (ST) { __builtin_amdgcn_sched_barrier(0); tb = __builtin_readcyclecounter(); ts[2] += tb - ta; }
+            if (key0 + 32 > klen) {   // the one block that straddles key_len (wave-uniform test)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     s[r] = key < klen ? s[r] : ninf;
                 }
             }
+            float bmax = max3_raw(s[0], s[1], s[2]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) smax = fmaxf(smax, s[r]);
-            smax = xhalf_max(smax);
-            const float m_new = fmaxf(m_run, smax);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // bare v_exp_f32; exp2(-inf) = 0 on first block
-            float psum = 0.f;
+            for (int r = 3; r < 15; r += 2) bmax = max3_raw(bmax, s[r], s[r + 1]);
+            bmax = xhalf_max_swap(fmaxf(bmax, s[15]));
+            const bool first = key0 == 0;
+            if (first || __builtin_amdgcn_ballot_w64(bmax * scale2 > kLazy) != 0) {   // wave-uniform
+                // raise the reference to this block's row maximum (block 0: set it), rescale what was accumulated
+                const float delta = first ? bmax : fmaxf(bmax, 0.f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta * scale2);
+                mref_s -= delta;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pexp = __builtin_amdgcn_exp2f(s[r] - m_new);
-                s[r] = pexp;
-                psum += pexp;
+                for (int r = 0; r < 16; ++r) {
+                    s[r] -= delta;
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+                l2 *= alpha;
             }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
+            for (int j = 0; j < 8; ++j) {
+                f32x2 z;
+                z.x = s[2 * j]; z.y = s[2 * j + 1];
+                z = z * scale2;
+                f32x2 pe;
+                pe.x = __builtin_amdgcn_exp2f(z.x);
+                pe.y = __builtin_amdgcn_exp2f(z.y);
+                s[2 * j] = pe.x; s[2 * j + 1] = pe.y;
+                l2 += pe;
             }
             // P -> bf16 B-operand fragments (k-step st = registers 8st .. 8st+7)
-            const uint16_t* vp = Vt + (buf * 64 + l31) * kLdh + kblk * 32 + 4 * h;
+            union { uint32_t u[4]; bf16x8 f; } pf[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pf[st].u[e] = pack_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
+            if constexpr (ST) { __builtin_amdgcn_sched_barrier(0); tc = __builtin_readcyclecounter(); ts[3] += tc - tb; }
+            lds_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                union { uint32_t u[4]; bf16x8 f; } pf, va, vc;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) pf.u[e] = pack_bf16(s[8 * st + 2 * e], s[8 * st + 2 * e + 1]);
-                // A operand: Vt[d][key0 + 16st + 4h + 0..3] and [.. + 8 + 0..3]
-                const uint2 a_lo = *reinterpret_cast<const uint2*>(vp + 16 * st);
-                const uint2 a_hi = *reinterpret_cast<const uint2*>(vp + 16 * st + 8);
-                va.u[0] = a_lo.x; va.u[1] = a_lo.y; va.u[2] = a_hi.x; va.u[3] = a_hi.y;
-                const uint2 c_lo = *reinterpret_cast<const uint2*>(vp + 32 * kLdh + 16 * st);
-                const uint2 c_hi = *reinterpret_cast<const uint2*>(vp + 32 * kLdh + 16 * st + 8);
-                vc.u[0] = c_lo.x; vc.u[1] = c_lo.y; vc.u[2] = c_hi.x; vc.u[3] = c_hi.y;
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va.f, pf.f, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vc.f, pf.f, o1, 0, 0, 0);
+                union { uint32_t u[4]; bf16x8 f; } a0, a1;
+                a0.u[0] = vr[st][0][0][0]; a0.u[1] = vr[st][0][0][1]; a0.u[2] = vr[st][0][1][0]; a0.u[3] = vr[st][0][1][1];
+                a1.u[0] = vr[st][1][0][0]; a1.u[1] = vr[st][1][0][1]; a1.u[2] = vr[st][1][1][0]; a1.u[3] = vr[st][1][1][1];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0.f, pf[st].f, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1.f, pf[st].f, o1, 0, 0, 0);
             }
+            if constexpr (ST) { __builtin_amdgcn_sched_barrier(0); td = __builtin_readcyclecounter(); ts[4] += td - tc; }
         }
-        if (t + 1 < ntiles) stage_store(buf ^ 1);
-        __syncthreads();
     }
-
-    const float inv = 1.0f / xhalf_sum(l_run);
+    const float inv = 1.0f / xhalf_sum(l2.x + l2.y);
     if (qi < N) {
         uint16_t* op = out + ((int64_t)b * N + qi) * ldo + head * 64 + 4 * h;
 #pragma unroll
@@ -395,6 +519,15 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
             *reinterpret_cast<uint2*>(op + 32 + 8 * g) = c;
         }
     }
+    }   // query tiles
+    if constexpr (ST) {
+        ts[5] = __builtin_readcyclecounter() - tk0;
+        if (lane == 0) {
+            uint64_t* o = stamps + (((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + wave) * 6;
+            for (int i = 0; i < 6; ++i) o[i] = ts[i];
+        }
+    }
+
 }
 
 }  // namespace
@@ -411,12 +544,33 @@ extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, cons
     ISPK_REQUIRE(ispk_aligned(q, 16) && ispk_aligned(k, 16) && ispk_aligned(v, 16) && ispk_aligned(out, 8),
                  ISPK_E_ALIGN, "attn: q/k/v must be 16-byte and out 8-byte aligned");
     if (B == 0) return 0;
-    dim3 grid((N + 63) / 64, B), block(2 * H * 64);
-    if (H <= 6)
-        hipLaunchKernelGGL(attn_bf16_kernel<768>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
-                           ldkv, slopes, key_len, out, ldo, N, H);
-    else
-        hipLaunchKernelGGL(attn_bf16_kernel<1024>, grid, block, 0, reinterpret_cast<hipStream_t>(stream), q, ldq, k, v,
-                           ldkv, slopes, key_len, out, ldo, N, H);
+    // query tiles per workgroup: with the whole key range resident in the ring, one workgroup serves several tiles of its
+    // batch element off a single K/V fetch - as many as still leave >= 256 workgroups (one per CU)
+    const int nqt = (N + 63) / 64;
+    int qpw = 1;
+    if (N <= kChunkKeys * kSlots)
+        while (qpw < 4 && (int64_t)B * ((nqt + 2 * qpw - 1) / (2 * qpw)) >= 256) qpw *= 2;
+    if (const char* e = getenv("ISPK_ATTN_QPW")) qpw = atoi(e) > 0 && N <= kChunkKeys * kSlots ? atoi(e) : 1;   // experiments
+    dim3 grid((nqt + qpw - 1) / qpw, B), block(2 * H * 64);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+#define ISPK_ATTN_GO(MAXT_, IPL_)                                                                                  \
+    do {                                                                                                           \
+        ISPK_RESERVE_LDS((&attn_bf16_kernel<MAXT_, IPL_>), kAttnLds, "attn");                                      \
+        hipLaunchKernelGGL((attn_bf16_kernel<MAXT_, IPL_>), grid, block, kAttnLds, st, q, ldq, k, v, ldkv, slopes,  \
+                           key_len, out, ldo, N, H, qpw, nullptr);                                                 \
+    } while (0)
+    if (const char* e = getenv("ISPK_ATTN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[waves][6]
+        ISPK_REQUIRE(H >= 4 && H <= 6, ISPK_E_UNSUPPORTED, "attn stamps: H = 4..6 only");
+        uint64_t* stamps = reinterpret_cast<uint64_t*>(strtoull(e, nullptr, 16));
+        ISPK_RESERVE_LDS((&attn_bf16_kernel<768, 4, true>), kAttnLds, "attn");
+        hipLaunchKernelGGL((attn_bf16_kernel<768, 4, true>), grid, block, kAttnLds, st, q, ldq, k, v, ldkv, slopes, key_len,
+                           out, ldo, N, H, qpw, stamps);
+        return ispk_launch_status();
+    }
+    if (H >= 7) ISPK_ATTN_GO(1024, 4);       // 14 / 16 waves, 8 loaders
+    else if (H >= 4) ISPK_ATTN_GO(768, 4);   // 8 .. 12 waves, 8 loaders
+    else if (H >= 2) ISPK_ATTN_GO(768, 8);   // 4 / 6 waves, 4 loaders
+    else ISPK_ATTN_GO(768, 16);              // 2 waves, both load
+#undef ISPK_ATTN_GO
     return ispk_launch_status();
 }

@@ -881,10 +881,14 @@ bool panel_ok(const GemmParams& p) {
     return (p.K == 256 || p.K == 384) && vec_epilogue_ok(p) && rows_epilogue_ok(p) && getenv("ISPK_NO_PANEL") == nullptr;
 }
 
+// The row-block kernel fits (a) the long reductions and (b) skinny outputs (N <= 192: the aligner's convolutions over
+// 33,000 mel frames with 80-160 output channels), where one 64-row workgroup covers every output feature and the
+// activations stream through exactly once; the generic 128x128 tiling wastes half its columns there.
 bool wide_ok(const GemmParams& p) {
-    return (p.K >= 512 || getenv("ISPK_FORCE_WIDE")) && (p.N == 384 || p.N == 256 || p.N % 192 == 0) && p.M >= 128 * 16 &&
-           vec_epilogue_ok(p) &&
-           !(p.flags & ISPK_EP_OUT_BF16) && getenv("ISPK_NO_WIDE") == nullptr;
+    const bool long_k = (p.K >= 512 || getenv("ISPK_FORCE_WIDE")) && (p.N == 384 || p.N == 256 || p.N % 192 == 0);
+    const bool skinny = p.N <= 192 && getenv("ISPK_NO_SKINNY") == nullptr;
+    return (long_k || skinny) && p.M >= 128 * 16 && vec_epilogue_ok(p) && !(p.flags & ISPK_EP_OUT_BF16) &&
+           getenv("ISPK_NO_WIDE") == nullptr;
 }
 
 template <int TM, int TN>
@@ -970,8 +974,9 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
             g_last_bf16_variant = 2000 + (N == 384 ? 64 : 44);
             return N == 384 ? launch_wide<6, 4>(p, s) : launch_wide<4, 4>(p, s);
         }
-        g_last_bf16_variant = 2000 + (N % 192 == 0 ? 32 : 22);   // 192- or 128-feature column blocks over grid.y
-        return N % 192 == 0 ? launch_wide<3, 2>(p, s) : launch_wide<2, 2>(p, s);
+        const bool w192 = N <= 192 ? N > 128 : N % 192 == 0;
+        g_last_bf16_variant = 2000 + (w192 ? 32 : 22);   // 192- or 128-feature column blocks over grid.y
+        return w192 ? launch_wide<3, 2>(p, s) : launch_wide<2, 2>(p, s);
     }
     const int tile = ispk_gemm_f32_tile(M, N, K);  // same occupancy rule as the fp32 path
     g_last_bf16_variant = 3000 + tile;

@@ -295,7 +295,8 @@ def test_gemm_bf16_epilogues(K):
 
 
 @pytest.mark.parametrize("B,N,H,lens", [(2, 100, 6, [100, 73]), (2, 512, 6, [512, 390]), (3, 37, 4, [37, 1, 20]),
-                                        (2, 64, 6, None), (1, 129, 8, [65])])
+                                        (2, 64, 6, None), (1, 129, 8, [65]), (2, 700, 6, [700, 531]), (1, 1100, 4, None),
+                                        (2, 300, 2, [300, 129]), (1, 200, 1, None)])
 def test_attention_bf16(B, N, H, lens):
     """bf16 Q/K/V and bf16 P (8 mantissa bits), fp32 statistics: compared with float64 attention on the same
     bf16-rounded inputs.  Bar: 1.5e-2 absolute on O(1) outputs (P quantisation 2^-9 relative per weight)."""
@@ -314,6 +315,20 @@ def test_attention_bf16(B, N, H, lens):
     assert out.dtype == torch.bfloat16
     err = (out.double() - exact).abs().max().item()
     assert err < 1.5e-2, err
+
+
+def test_attention_bf16_several_query_tiles_per_workgroup(monkeypatch):
+    """With the whole key range resident in LDS a workgroup serves several 64-query tiles off one K/V fetch (the launcher
+    does this by itself only for large batches; forced here).  Same values as one tile per workgroup, bit for bit."""
+    B, N, H = 3, 450, 6
+    qkv = _bf(synth._normal("t/at/qpw", (B, N, H * 64 + 128))).to(DEV)
+    slopes = torch.tensor(synth.alibi_default_slopes(H), device=DEV)
+    key_len = torch.tensor([450, 123, 300], device=DEV)
+    monkeypatch.setenv("ISPK_ATTN_QPW", "1")
+    one = runtime.alibi_mqa_attention(qkv, H, slopes, key_len).cpu()
+    for qpw in ("2", "4"):
+        monkeypatch.setenv("ISPK_ATTN_QPW", qpw)
+        assert torch.equal(runtime.alibi_mqa_attention(qkv, H, slopes, key_len).cpu().view(torch.int16), one.view(torch.int16))
 
 
 def test_layernorm_bf16_output_and_cast():

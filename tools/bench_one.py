@@ -13,7 +13,13 @@ w2 = synth._normal("b/wf2", (384, 1536), 1536 ** -0.5).to(dev).to(dt)
 wqkv = synth._normal("b/wqkv", (512, 384), 384 ** -0.5).to(dev).to(dt)
 wo = synth._normal("b/wo", (384, 384), 384 ** -0.5).to(dev).to(dt)
 w2p = runtime.ffn_pack_w2(w2)
+qkv = (synth._normal("b/qkv", (64, 512, 512)) * 2.0).to(dev).to(dt)
+qkv100 = (synth._normal("b/qkv100", (64, 100, 512)) * 2.0).to(dev).to(dt)
+slopes = torch.tensor(synth.alibi_default_slopes(6), device=dev)
+klen = torch.full((64,), 512, dtype=torch.int64, device=dev)
 cases = {
+    "attn B64 T512 H6": (lambda: runtime.alibi_mqa_attention(qkv, 6, slopes, klen), 256.0 * 64 * 512 * 512 * 6),
+    "attn B64 T100 H6": (lambda: runtime.alibi_mqa_attention(qkv100, 6, slopes, None), 256.0 * 64 * 100 * 100 * 6),
     "ffn_fused": (lambda: runtime.ffn_fused(x, w1, w2p, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),
     "panel 384->1536 gelu bf16": (lambda: runtime.gemm(x, w1, flags=runtime.EP_GELU), 2.0 * R * 384 * 1536),
     "panel 384->512 bf16": (lambda: runtime.gemm(x, wqkv), 2.0 * R * 384 * 512),

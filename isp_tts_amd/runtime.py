@@ -196,7 +196,8 @@ def layernorm(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ada_sc
         row_mask = row_mask.reshape(-1).contiguous()
         assert row_mask.dtype == torch.bool and row_mask.numel() == rows
     fn = lib().ispk_layernorm_f32 if out_dtype == torch.float32 else lib().ispk_layernorm_f32_bf16
-    _launch(f"layernorm_kernel<{D // 64}>", 0.0, float(rows) * D * (4 + y.element_size()), fn, x2.data_ptr(),
+    label = f"layernorm_vec_kernel<{D // 128}>" if D % 128 == 0 and D <= 512 else f"layernorm_kernel<{D // 64}>"
+    _launch(label, 0.0, float(rows) * D * (4 + y.element_size()), fn, x2.data_ptr(),
             x2.stride(0), _ptr(gamma), _ptr(beta), _ptr(ada_scale), _ptr(ada_shift), ada_stride, rows_per_batch,
             _ptr(row_mask), y.data_ptr(), D, rows, D, eps, _stream())
     return y

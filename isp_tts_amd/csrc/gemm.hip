@@ -460,13 +460,30 @@ inline bool rows_epilogue_ok(const GemmParams& p) {
 // TN 32-wide feature tiles in accumulators (TN = 6 -> 96 registers).  K advances in 64-deep chunks through
 // double-buffered, padded (conflict-free) LDS tiles filled by fully coalesced 128-B row segments; computed transposed
 // (D = W_chunk · Xᵀ) for the vector epilogue.  Per chunk a wave issues 4*TN MFMAs for 4*(TN+1) ds_read_b128.
+// 16 zero bytes: the source of LDS-DMA lanes whose k index lies beyond K (a DMA cannot zero-fill)
+__device__ __attribute__((aligned(16))) const uint16_t g_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+template <int N>
+__device__ __forceinline__ void vm_wait() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// Operand staging: the K loop of this kernel is a chain of short steps (4*TN MFMAs per wave), and with register staging
+// one step ahead every step waited out a global-load round trip (the encoder's 6,400-row FFN2 ran at 1.7 us per
+// 64-deep chunk).  Both operand tiles now stream by LDS-DMA (global_load_lds_dwordx4) into a ring of S slots with up to
+// S-1 chunks in flight and no staging registers.  A DMA instruction writes 8 rows x 128 B linearly, so rows are
+// unpadded and the bank spread comes from an XOR swizzle applied to the SOURCE address: LDS (row r, 16-byte slot pc)
+// holds logical chunk pc ^ ((r >> 1) & 7), which makes the 16 rows of a ds_read_b128 lane group hit 16 distinct
+// (bank half, slot) pairs.  Each wave issues IPL = (BM + BN) / 8 / waves DMAs per chunk and waits for its own with a
+// counted vmcnt; one raw s_barrier per chunk publishes the chunk and retires the slot the next DMA overwrites.
 template <int TN, int WM, bool LN = false>  // WM row-waves (32 rows each) x 2 feature-waves (TN 32-wide tiles each)
 __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) {
-    constexpr int BM = 32 * WM, BN = 64 * TN, LD = 72, NT = WM * 128;  // LD: 64 + 8 bf16 per LDS row
-    constexpr int XCH = (BM * 8 + NT - 1) / NT, WCH = (BN * 8 + NT - 1) / NT;  // 16-B chunks per thread per stage
+    constexpr int BM = 32 * WM, BN = 64 * TN, NT = WM * 128, NWV = NT / 64;
+    constexpr int kSlot = (BM + BN) * 128;                       // bytes per ring slot: X tile then W tile, 128-B rows
+    constexpr int S = 4 * kSlot <= 128 * 1024 ? 4 : (3 * kSlot <= 144 * 1024 ? 3 : 2);
+    constexpr int IPL = (BM + BN) / 8 / NWV;
+    static_assert((BM + BN) / 8 % NWV == 0 && (S - 1) * IPL <= 63, "DMA split / vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    uint16_t* Xs = reinterpret_cast<uint16_t*>(smem_raw);  // [2][BM][LD]
-    uint16_t* Ws = Xs + 2 * BM * LD;                       // [2][BN][LD]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -476,34 +493,30 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) 
     const uint16_t* A = static_cast<const uint16_t*>(p.A);
     const uint16_t* W = static_cast<const uint16_t*>(p.W);
 
-    u32x4 rx[XCH], rw[WCH];
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    auto gload = [&](int kt) {
-        const int k = kt * 64;
+    // this lane's part of DMA instruction j: row (8-row group wave*IPL + j, row lane>>3), LDS slot lane&7
+    const uint16_t* src_row[IPL];
+    int src_chunk[IPL];
 #pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int id = tid + NT * i, r = id >> 3, c = (id & 7) * 8;
-            const int row = m0 + r;
-            rx[i] = (id < BM * 8 && row < p.M && k + c < p.K)
-                        ? *reinterpret_cast<const u32x4*>(A + (int64_t)row * p.lda + k + c) : zero4;
+    for (int j = 0; j < IPL; ++j) {
+        const int r = (wave * IPL + j) * 8 + (lane >> 3);       // row of the concatenated [X; W] tile
+        const int rr = r < BM ? r : r - BM;
+        src_chunk[j] = ((lane & 7) ^ ((rr >> 1) & 7)) * 8;      // logical k offset (elements) inside the chunk
+        if (r < BM) {
+            const int row = m0 + r < p.M ? m0 + r : p.M - 1;     // rows past the end: a valid row, never stored
+            src_row[j] = A + (int64_t)row * p.lda;
+        } else {
+            const int n = nb0 + rr < p.N ? nb0 + rr : p.N - 1;
+            src_row[j] = W + (int64_t)n * p.ldw;
         }
+    }
+    auto issue = [&](int kt) {
+        char* slot = smem_raw + (kt % S) * kSlot + wave * (IPL * 1024);
 #pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int id = tid + NT * i, r = id >> 3, c = (id & 7) * 8;
-            rw[i] = (id < BN * 8 && nb0 + r < p.N && k + c < p.K)
-                        ? *reinterpret_cast<const u32x4*>(W + (int64_t)(nb0 + r) * p.ldw + k + c) : zero4;
-        }
-    };
-    auto swrite = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < XCH; ++i) {
-            const int id = tid + NT * i, r = id >> 3, c = (id & 7) * 8;
-            if (id < BM * 8) *reinterpret_cast<u32x4*>(Xs + (buf * BM + r) * LD + c) = rx[i];
-        }
-#pragma unroll
-        for (int i = 0; i < WCH; ++i) {
-            const int id = tid + NT * i, r = id >> 3, c = (id & 7) * 8;
-            if (id < BN * 8) *reinterpret_cast<u32x4*>(Ws + (buf * BN + r) * LD + c) = rw[i];
+        for (int j = 0; j < IPL; ++j) {
+            const int k = kt * 64 + src_chunk[j];
+            const uint16_t* src = k < p.K ? src_row[j] + k : g_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(slot + j * 1024), 16, 0, 0);
         }
     };
 
@@ -514,26 +527,53 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) 
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     const int nk = (p.K + 63) / 64;
-    gload(0);
-    swrite(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) gload(kt + 1);
-        const uint16_t* xp = Xs + (buf * BM + wm * 32 + l31) * LD + 8 * h;
-        const uint16_t* wp = Ws + (buf * BN + wn * 32 * TN + l31) * LD + 8 * h;
+#pragma unroll 1
+    for (int kt = 0; kt < nk && kt < S - 1; ++kt) issue(kt);
+
+    // fragment byte offsets inside a slot: k-step ks, logical chunk 2ks + h of row l31 (tile bases are multiples of 16 rows)
+    uint32_t xoff[4], woff[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const bf16x8 xf = *reinterpret_cast<const bf16x8*>(xp + 16 * ks);
-#pragma unroll
-            for (int t = 0; t < TN; ++t) {
-                const bf16x8 wf = *reinterpret_cast<const bf16x8*>(wp + t * 32 * LD + 16 * ks);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, xf, acc[t], 0, 0, 0);
-            }
-        }
-        if (kt + 1 < nk) swrite(buf ^ 1);
-        __syncthreads();
+    for (int ks = 0; ks < 4; ++ks) {
+        const uint32_t sw = (uint32_t)(((2 * ks + h) ^ ((l31 >> 1) & 7)) << 4);
+        xoff[ks] = (wm * 32 + l31) * 128 + sw;
+        woff[ks] = (BM + wn * 32 * TN + l31) * 128 + sw;
     }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int after = (nk - 1 - kt) < (S - 2) ? (nk - 1 - kt) : (S - 2);   // younger chunks this wave has in flight
+        if (S >= 4 && after >= 2) vm_wait<2 * IPL>();
+        else if (S >= 3 && after == 1) vm_wait<IPL>();
+        else vm_wait<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // publishes chunk kt; every wave is done with chunk kt-1
+        asm volatile("" ::: "memory");
+        // Operand fragments of k-step ks: 1 + TN ds_read_b128, requested two k-steps ahead through a double register
+        // set of opaque asm reads with counted waits (hipcc sinks every plain read next to its MFMA and waits there;
+        // with one or two waves per SIMD nothing else hides that round trip - 16 of them made up most of a chunk).
+        const uint32_t sl = lds_addr(smem_raw) + (uint32_t)((kt % S) * kSlot);
+        bf16x8 fr[2][TN + 1];
+        auto rd = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            lds_read_b128_asm<0>(fr[g & 1][0], sl + xoff[g]);
+            static_for<0, TN>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                lds_read_b128_asm<t * 32 * 128>(fr[g & 1][1 + t], sl + woff[g]);
+            });
+        };
+        rd(std::integral_constant<int, 0>{});
+        rd(std::integral_constant<int, 1>{});
+        if (kt + S - 1 < nk) issue(kt + S - 1);  // into the slot chunk kt-1 just left
+        static_for<0, 4>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            if constexpr (ks < 3) lds_wait<TN + 1>(); else lds_wait<0>();   // group ks is in; group ks+1 may be in flight
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ks & 1][1 + t], fr[ks & 1][0], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ks + 2 < 4) rd(std::integral_constant<int, ks + 2>{});
+        });
+    }
+    __syncthreads();   // the epilogue's transposition patches alias the ring
 
     const int m = m0 + wm * 32 + l31;
     const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
@@ -635,7 +675,8 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) 
 template <int TN, int WM, bool LN = false>
 int32_t launch_wide(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 32 * WM, BN = 64 * TN;
-    constexpr size_t lds_tiles = (size_t)2 * (BM + BN) * 72 * sizeof(uint16_t);
+    constexpr size_t slot = (size_t)(BM + BN) * 128;
+    constexpr size_t lds_tiles = (4 * slot <= 128 * 1024 ? 4 : (3 * slot <= 144 * 1024 ? 3 : 2)) * slot;
     constexpr size_t lds_epi = (size_t)WM * 2 * kStageBytes + (LN ? (size_t)2 * WM * 2 * 32 * sizeof(float) : 0);
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");

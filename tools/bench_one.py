@@ -17,7 +17,11 @@ qkv = (synth._normal("b/qkv", (64, 512, 512)) * 2.0).to(dev).to(dt)
 qkv100 = (synth._normal("b/qkv100", (64, 100, 512)) * 2.0).to(dev).to(dt)
 slopes = torch.tensor(synth.alibi_default_slopes(6), device=dev)
 klen = torch.full((64,), 512, dtype=torch.int64, device=dev)
+x6k = synth._normal("b/x6k", (6400, 1536)).to(dev).to(dt)
+r6k = synth._normal("b/r6k", (6400, 384)).to(dev)
+m6k = torch.ones(6400, dtype=torch.bool, device=dev)
 cases = {
+    "wide 6400x1536->384 f32+resid": (lambda: runtime.gemm(x6k, w2, resid=r6k, mask=m6k, flags=runtime.EP_MASK_OUT, out_dtype=torch.float32), 2.0 * 6400 * 384 * 1536),
     "attn B64 T512 H6": (lambda: runtime.alibi_mqa_attention(qkv, 6, slopes, klen), 256.0 * 64 * 512 * 512 * 6),
     "attn B64 T100 H6": (lambda: runtime.alibi_mqa_attention(qkv100, 6, slopes, None), 256.0 * 64 * 100 * 100 * 6),
     "ffn_fused": (lambda: runtime.ffn_fused(x, w1, w2p, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),

@@ -112,20 +112,11 @@ class ConvAttention(nn.Module, Constructor):
             self._cache = {"key": key, "k": w2d[:2], "q": w2d[2:]}
         return self._cache["k"], self._cache["q"]
 
-    def forward(self, queries: Tensor, keys: Tensor, query_len: Tensor, key_len: Tensor):
-        """alignment.py:159-208.  queries (mel) [B, mel_dim, M] channel-first as the collator gives it; keys (encoder
-        output) [B, text_dim, L] — a transposed view of the encoder's [B, L, text_dim] is read in place.
-        -> (attn_soft, attn_logits), both [B, M, L] fp32.  11 launches: 2 pads, 5 conv GEMMs (GELU fused), 3 masked
-        instance norms, 1 fused scores kernel."""
-        if not self.attention_prior:
-            raise NotImplementedError("the aligner is built with its diagonal prior (recipes: attention_prior default)")
-        wk, wq = self._staged()
-        max_q, max_k = queries.shape[2], keys.shape[2]
-        gelu, dt = runtime.EP_GELU, self.compute_dtype   # bf16 path: bf16 conv operands, fp32 conv outputs / statistics
-        k = runtime.pad_rows(keys.float(), key_len, channel_first=True, out_dtype=dt)
-        k = runtime.conv5_padded(k, wk[0], gelu)
-        k = runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len, out_dtype=dt)
-        k = runtime.conv5_padded(k, wk[1])
+    def project_queries(self, queries: Tensor, query_len: Tensor) -> Tensor:
+        """The mel-side half of alignment.py:159-208 (query_proj: conv-GELU-norm, conv-GELU-norm, 1x1 conv).  It needs
+        nothing from the text encoder, so the model runs it on a second stream beside the encoder stack."""
+        _, wq = self._staged()
+        gelu, dt = runtime.EP_GELU, self.compute_dtype
         q = runtime.pad_rows(queries.float(), query_len, channel_first=True, out_dtype=dt)
         q = runtime.conv5_padded(q, wq[0], gelu)
         q = runtime.masked_instnorm(q, self.query_proj[0].norm.weight, self.query_proj[0].norm.bias, query_len,
@@ -133,7 +124,23 @@ class ConvAttention(nn.Module, Constructor):
         q = runtime.conv5_padded(q, wq[1], gelu)
         q = runtime.masked_instnorm(q, self.query_proj[1].norm.weight, self.query_proj[1].norm.bias, query_len,
                                     out_dtype=dt)
-        q = runtime.conv5_padded(q, wq[2])
+        return runtime.conv5_padded(q, wq[2])
+
+    def forward(self, queries: Tensor, keys: Tensor, query_len: Tensor, key_len: Tensor, q_proj: Optional[Tensor] = None):
+        """alignment.py:159-208.  queries (mel) [B, mel_dim, M] channel-first as the collator gives it; keys (encoder
+        output) [B, text_dim, L] — a transposed view of the encoder's [B, L, text_dim] is read in place.
+        -> (attn_soft, attn_logits), both [B, M, L] fp32.  11 launches: 2 pads, 5 conv GEMMs (GELU fused), 3 masked
+        instance norms, 1 fused scores kernel.  q_proj: `project_queries(queries, query_len)` when already computed."""
+        if not self.attention_prior:
+            raise NotImplementedError("the aligner is built with its diagonal prior (recipes: attention_prior default)")
+        wk, _ = self._staged()
+        max_q, max_k = queries.shape[2], keys.shape[2]
+        gelu, dt = runtime.EP_GELU, self.compute_dtype   # bf16 path: bf16 conv operands, fp32 conv outputs / statistics
+        k = runtime.pad_rows(keys.float(), key_len, channel_first=True, out_dtype=dt)
+        k = runtime.conv5_padded(k, wk[0], gelu)
+        k = runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len, out_dtype=dt)
+        k = runtime.conv5_padded(k, wk[1])
+        q = q_proj if q_proj is not None else self.project_queries(queries, query_len)
         return runtime.aligner_scores(q, k, key_len, query_len, max_q, max_k)
 
 
@@ -154,11 +161,12 @@ class Aligner(nn.Module, Constructor):
                                        dropout=dropout, normalization=normalization, activation=activation,
                                        attention_prior=attention_prior)
 
-    def forward(self, mel: Tensor, enc_text: Tensor, mel_len: Tensor, text_len: Tensor) -> AlignerOutput:
+    def forward(self, mel: Tensor, enc_text: Tensor, mel_len: Tensor, text_len: Tensor,
+                q_proj: Optional[Tensor] = None) -> AlignerOutput:
         """alignment.py:259-289.  The duration fix-up of :278-282 (sum of durations != mel_len, possible only when
         text_len > mel_len) is applied unconditionally on the device: adding `mel_len - sum` (zero otherwise) to column
         0 gives the same result without the host round-trip of the reference's `torch.all(...)` check."""
-        attn_soft, attn_logits = self.attention(mel, enc_text, mel_len, text_len)
+        attn_soft, attn_logits = self.attention(mel, enc_text, mel_len, text_len, q_proj=q_proj)
         attn_hard, dur = self.binarize_attention_parallel(attn_logits, text_len, mel_len, return_duration=True)
         dur[:, 0] += mel_len - dur.sum(dim=1)
         return AlignerOutput(attn_soft=attn_soft, attn_logits=attn_logits, attn_hard=attn_hard, attn_hard_duration=dur)

@@ -48,6 +48,8 @@ class AcousticModel(nn.Module, Constructor):
         self.temporal_adaptor = FlowTemporalAdaptor.init(temporal_adaptor, encoder_dim=enc_dim)
         self.decoder = Transformer.init(decoder, emb_dim=enc_dim)
         self.to_mel = nn.Linear(self.decoder.dim, mel_dim)
+        self.overlap_streams = True          # run the aligner's mel-side branch beside the text encoder (forward())
+        self._side_streams: dict = {}
         self.register_buffer("pitch_mean", torch.tensor(float(pitch_mean or 0.)))
         self.register_buffer("pitch_std", torch.tensor(float(pitch_std or 1.)))
         self.compute_dtype = torch.float32
@@ -79,11 +81,24 @@ class AcousticModel(nn.Module, Constructor):
                 flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None) -> AcousticModelOutput:
         """model.py:116-174.  text int64 [B,L], mel fp32 [B,80,M], pitch/energy fp32 [B,M], lengths int64 [B]
         (collator.py:36-55).  Padded shapes define the masks' widths (max length = L / M, as collated batches have)."""
+        # The aligner's mel-side projections (33,000 frames: large, HBM-bound launches) do not depend on the text encoder
+        # (6,400 tokens: small, latency-bound launches), so they run beside it on a second stream; under HIP-graph
+        # capture the fork / join become graph edges.
+        q_proj = None
+        if mel.is_cuda and self.overlap_streams:
+            main = torch.cuda.current_stream()
+            side = self._side_streams.setdefault(mel.device, torch.cuda.Stream(device=mel.device))
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                q_proj = self.aligner.attention.project_queries(mel, mel_len)
         token_emb = self.text_embedding(text)
         enc_mask = get_mask_from_lengths(text_len, text.shape[1])
         enc_out = self.encoder(token_emb, mask=enc_mask, key_len=text_len).out
+        if q_proj is not None:
+            main.wait_stream(side)
+            q_proj.record_stream(main)
         aligner_output = self.aligner(mel=mel, enc_text=enc_out.transpose(1, 2).detach(), mel_len=mel_len,
-                                      text_len=text_len)
+                                      text_len=text_len, q_proj=q_proj)
         adaptor_output = self.temporal_adaptor(
             enc_out=enc_out, enc_mask=enc_mask, max_dec_len=mel.size(2),
             duration_target=aligner_output.attn_hard_duration, alignment=aligner_output.attn_soft,

@@ -14,19 +14,28 @@ import re
 import sys
 
 
+def label_of(kernel_name: str):
+    """rocprofv3 kernel name -> the label bench.py / runtime.py use: the kernel's name plus its leading template arguments
+    (two for the tile / row-block GEMMs, one for the rest)."""
+    m = re.search(r"(\w+_kernel)(?:<([^>]*)>)?", kernel_name)
+    if not m:
+        return None
+    name, targs = m.group(1), [a.strip() for a in (m.group(2) or "").split(",") if a.strip()]
+    if not targs:
+        return name
+    n = 2 if name in ("gemm_bf16_wide_kernel", "gemm_bf16_kernel", "gemm_f32_kernel") else 1
+    return f"{name}<{','.join(targs[:n])}>"
+
+
 def per_kernel(d, counter):
     f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"(gemm_\w+<[^>]*>|attn_\w+_kernel|layernorm_kernel<\d+|mas_kernel<\d>|aligner_scores_kernel"
-                      r"|masked_instnorm_kernel|soft_average_kernel|pad_rows_kernel|linear_small_kernel)", r["Kernel_Name"])
-        if not m:
+        key = label_of(r["Kernel_Name"])
+        if key is None:
             continue
-        key = m.group(1).replace(" ", "")
-        if key.startswith("layernorm_kernel<"):
-            key += ">"
         agg[key][0] += 1
         agg[key][1] += float(r["Counter_Value"])
     return {k: (n, v / n) for k, (n, v) in agg.items()}

@@ -67,7 +67,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // GELU(erf) for outputs that are rounded to bf16 anyway, two elements at a time so the polynomial runs on packed fp32
 // (v_pk_fma_f32 / v_pk_mul_f32).  erf by Abramowitz-Stegun 7.1.28: erf(z) = 1 - (1 + a1 z + .. + a6 z^6)^-16, z >= 0,
-// |error| <= 3e-7; then gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) = max(x, 0) - 0.5 |x| q^-16.
+// |error| <= 3e-7; then gelu(x) = 0.5 x (1 + erf(x / sqrt 2)) = 0.5 x + 0.5 |x| (1 - q^-16).
 // 6 FMA + 4 squarings + 1 rcp per element (libm erff: ~40 instructions with branches).  The fp32 parity path keeps erff.
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     f32x2 ax;
@@ -87,10 +87,8 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     f32x2 r;
     r.x = __builtin_amdgcn_rcpf(q.x);
     r.y = __builtin_amdgcn_rcpf(q.y);
-    f32x2 pos;
-    pos.x = fmaxf(x.x, 0.0f);
-    pos.y = fmaxf(x.y, 0.0f);
-    return pos - (ax * 0.5f) * r;
+    const f32x2 hx = ax * 0.5f;   // max(x, 0) = 0.5 x + 0.5 |x|: three packed operations, no v_max pair with its canonicalising copies
+    return x * 0.5f + (hx - hx * r);
 }
 __device__ __forceinline__ float gelu_fast(float x) {
     f32x2 v;

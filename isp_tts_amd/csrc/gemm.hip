@@ -373,10 +373,47 @@ __device__ __forceinline__ void pre_stage(const GemmParams& p, int n, float (&v)
     }
 }
 
-// fp32 output: one 32-feature tile (features n0 .. n0+31) of the wave's 32 rows (m0 .. m0+31)
+// The residual values one store_rows_f32 call adds, in its store layout (lane -> rows 8i + (lane>>3), features
+// n0 + 4(lane&7) .. +3).  Loaded by the caller ahead of time: inside store_rows_f32 each load would be followed at once
+// by its use, one exposed memory round trip per 32-feature tile (12 of them made up a sixth of the fused FFN's time).
+template <int EP = kEpDyn>
+__device__ __forceinline__ void resid_prefetch(const GemmParams& p, int m0, int n0, int lane, float4 (&r4)[4]) {
+    if (!ep_resid<EP>(p)) return;
+    const int n = n0 + 4 * (lane & 7);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 8 * i + (lane >> 3);
+        r4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < p.M && n < p.N) {
+            const int64_t ro = (int64_t)m * p.ldr + n;
+            if (ep_flag<EP>(p, ISPK_EP_RESID_BF16)) {
+                const uint2 rr = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p.resid) + ro);
+                r4[i].x = bf16_to_f32((uint16_t)(rr.x & 0xffffu)); r4[i].y = bf16_to_f32((uint16_t)(rr.x >> 16));
+                r4[i].z = bf16_to_f32((uint16_t)(rr.y & 0xffffu)); r4[i].w = bf16_to_f32((uint16_t)(rr.y >> 16));
+            } else {
+                r4[i] = *reinterpret_cast<const float4*>(static_cast<const float*>(p.resid) + ro);
+            }
+        }
+    }
+}
+
+// The ISPK_EP_MASK_OUT multipliers of the 4 rows a lane stores (rows m0 + 8i + (lane>>3)): the same for every feature tile
+// of a wave's 32 rows, so they are read once (read inside store_rows_f32 they are one more dependent load per tile).
+template <int EP = kEpDyn>
+__device__ __forceinline__ void mask_rows(const GemmParams& p, int m0, int lane, float (&mo4)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + 8 * i + (lane >> 3);
+        mo4[i] = (ep_flag<EP>(p, ISPK_EP_MASK_OUT) && p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+    }
+}
+
+// fp32 output: one 32-feature tile (features n0 .. n0+31) of the wave's 32 rows (m0 .. m0+31).  pre: the tile's residual
+// values from resid_prefetch (nullptr: loaded here); mo4: mask_rows() of these rows (nullptr: read here).
 template <int EP = kEpDyn>
 __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage, int m0, int n0, const f32x16& acc,
-                                               float mk, int lane, float4* keep = nullptr) {
+                                               float mk, int lane, float4* keep = nullptr, const float4* pre = nullptr,
+                                               const float* mo4 = nullptr) {
     const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -394,18 +431,22 @@ __device__ __forceinline__ void store_rows_f32(const GemmParams& p, char* stage,
         float4 v = *reinterpret_cast<const float4*>(stage + r * kStageRow + c * 16);
         if (m < p.M && n < p.N) {
             if (ep_resid<EP>(p)) {
-                const int64_t ro = (int64_t)m * p.ldr + n;
-                if (ep_flag<EP>(p, ISPK_EP_RESID_BF16)) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p.resid) + ro);
-                    v.x += bf16_to_f32((uint16_t)(rr.x & 0xffffu)); v.y += bf16_to_f32((uint16_t)(rr.x >> 16));
-                    v.z += bf16_to_f32((uint16_t)(rr.y & 0xffffu)); v.w += bf16_to_f32((uint16_t)(rr.y >> 16));
+                if (pre) {
+                    v.x += pre[i].x; v.y += pre[i].y; v.z += pre[i].z; v.w += pre[i].w;
                 } else {
-                    const float4 rr = *reinterpret_cast<const float4*>(static_cast<const float*>(p.resid) + ro);
-                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    const int64_t ro = (int64_t)m * p.ldr + n;
+                    if (ep_flag<EP>(p, ISPK_EP_RESID_BF16)) {
+                        const uint2 rr = *reinterpret_cast<const uint2*>(static_cast<const uint16_t*>(p.resid) + ro);
+                        v.x += bf16_to_f32((uint16_t)(rr.x & 0xffffu)); v.y += bf16_to_f32((uint16_t)(rr.x >> 16));
+                        v.z += bf16_to_f32((uint16_t)(rr.y & 0xffffu)); v.w += bf16_to_f32((uint16_t)(rr.y >> 16));
+                    } else {
+                        const float4 rr = *reinterpret_cast<const float4*>(static_cast<const float*>(p.resid) + ro);
+                        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                    }
                 }
             }
             if (ep_flag<EP>(p, ISPK_EP_MASK_OUT)) {
-                const float mo = p.mask[m] ? 1.0f : 0.0f;
+                const float mo = mo4 ? mo4[i] : (p.mask[m] ? 1.0f : 0.0f);
                 v.x *= mo; v.y *= mo; v.z *= mo; v.w *= mo;
             }
             *reinterpret_cast<float4*>(static_cast<float*>(p.C) + (int64_t)m * p.ldc + n) = v;
@@ -654,9 +695,14 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) 
     } else if (!(p.flags & ISPK_EP_OUT_BF16)) {
         // the K loop is over: its LDS tiles are dead, every wave takes a private patch of them for the row transpose
         char* stage = smem_raw + wave * kStageBytes;
+        float mo4[4];
+        mask_rows(p, m0 + wm * 32, lane, mo4);
+        float4 rres[TN][4];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) resid_prefetch(p, m0 + wm * 32, nb0 + (wn * TN + t) * 32, lane, rres[t]);
 #pragma unroll
         for (int t = 0; t < TN; ++t)
-            store_rows_f32(p, stage, m0 + wm * 32, nb0 + (wn * TN + t) * 32, acc[t], mk, lane);
+            store_rows_f32(p, stage, m0 + wm * 32, nb0 + (wn * TN + t) * 32, acc[t], mk, lane, nullptr, rres[t], mo4);
     } else if (m < p.M) {
 #pragma unroll
         for (int t = 0; t < TN; ++t)
@@ -806,6 +852,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
     const uint32_t wbase = lds_addr(Ws + l31 * LDW + 8 * h);
     char* stage = smem_raw + (size_t)64 * LDW * sizeof(uint16_t) + wave * kStageBytes;  // wave-private epilogue patch
     const int mw0 = mb * 128 + wave * 32;
+    float mo4[4];
+    mask_rows<EP>(p, mw0, lane, mo4);
     if constexpr (ST) { tA = __builtin_readcyclecounter(); tsum[0] = tA - t0; }
     for (int nt = nt0; nt < nt1; ++nt) {
         if constexpr (ST) { t0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
@@ -864,9 +912,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
             if (acc[0][0] + acc[1][5] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
         } else if (ep_flag<EP>(p, ISPK_EP_OUT_BF16)) {
             store_rows_bf16<EP>(p, stage, mw0, nt * 64, acc[0], acc[1], mk, lane);
+        } else if constexpr (EP >= 0) {   // (the generic instance is out of registers: it loads the residual in place)
+            float4 r0[4], r1[4];
+            resid_prefetch<EP>(p, mw0, nt * 64, lane, r0);
+            resid_prefetch<EP>(p, mw0, nt * 64 + 32, lane, r1);
+            store_rows_f32<EP>(p, stage, mw0, nt * 64, acc[0], mk, lane, nullptr, r0, mo4);
+            store_rows_f32<EP>(p, stage, mw0, nt * 64 + 32, acc[1], mk, lane, nullptr, r1, mo4);
         } else {
-            store_rows_f32<EP>(p, stage, mw0, nt * 64, acc[0], mk, lane);
-            store_rows_f32<EP>(p, stage, mw0, nt * 64 + 32, acc[1], mk, lane);
+            store_rows_f32<EP>(p, stage, mw0, nt * 64, acc[0], mk, lane, nullptr, nullptr, mo4);
+            store_rows_f32<EP>(p, stage, mw0, nt * 64 + 32, acc[1], mk, lane, nullptr, nullptr, mo4);
         }
         if constexpr (ST) {
             __builtin_amdgcn_sched_barrier(0);
@@ -1057,6 +1111,8 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
 template <int KC, bool B1, bool PK, int EP = kEpDyn, bool ST = false>  // D = 64 KC; B1: Linear 1 has a bias; PK: packed W2
 __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const uint16_t* __restrict__ W2, int64_t ldw2,
                                                           const float* __restrict__ bias1, int F) {
+    [[maybe_unused]] uint64_t tk0 = 0;
+    if constexpr (ST) tk0 = __builtin_readcyclecounter();
     constexpr int D = 64 * KC, KS = D / 16, NT = D / 32, HC = 32;
     constexpr int LD1 = D + 8, LD2 = HC + 8;         // padded LDS rows (bf16 elements)
     constexpr int C1 = HC * (D / 8) / 256;            // 16-B pieces per thread: W1 chunk (32 rows x D/8)
@@ -1213,9 +1269,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
             r.x = __builtin_amdgcn_rcpf(qq.x); r.y = __builtin_amdgcn_rcpf(qq.y);
             gq[pr] = r;
         } else {
-            f32x2 pos;
-            pos.x = fmaxf(gx[pr].x, 0.0f); pos.y = fmaxf(gx[pr].y, 0.0f);
-            const f32x2 o = pos - (gax[pr] * 0.5f) * gq[pr];
+            const f32x2 hx = gax[pr] * 0.5f;                  // max(x, 0) = 0.5 x + 0.5 |x|
+            const f32x2 o = gx[pr] * 0.5f + (hx - hx * gq[pr]);
             pfN[pr >> 2].u[pr & 3] = pack_bf16x2(o.x, o.y);
         }
     };
@@ -1239,7 +1294,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
     //                              phase B  acc2 += W2[chunk c-1] · pfCᵀ        (reads W2s[(c-1) & 1]) + GELU(chunk c) -> pfN
     constexpr int RD = 4, NB = 2 * NT, NS = KS + NB;
     static_assert(C <= KS && C <= NB && RD - 1 + RD * W2OPS <= 15, "staging slots / lgkmcnt range");
-    [[maybe_unused]] uint64_t tsum[3] = {0, 0, 0}, t0 = 0, tA = 0, tB = 0;
+    [[maybe_unused]] uint64_t tsum[5] = {0, 0, 0, 0, 0}, t0 = 0, tA = 0, tB = 0;
+    if constexpr (ST) tsum[3] = __builtin_readcyclecounter() - tk0;
     for (int c = 1; c <= nchunks; ++c) {
         if constexpr (ST) t0 = __builtin_readcyclecounter();
         const int pc = c & 1;
@@ -1305,17 +1361,32 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
             tsum[0] += tA - t0; tsum[1] += tB - tA; tsum[2] += tE - tB;
         }
     }
-    if constexpr (ST) {
-        if (lane == 0) {
-            uint64_t* dbg = static_cast<uint64_t*>(p.ln_out) + (blockIdx.x * 4 + wave) * 3;
-            for (int i = 0; i < 3; ++i) dbg[i] = tsum[i];
-        }
-    }
+    if constexpr (ST) tk0 = __builtin_readcyclecounter();
 
     float mk = 1.0f;
     if (EP < 0 || ((uint32_t)EP & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT))) mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) store_rows_f32<EP>(p, stage, mw0, nt * 32, acc2[nt], mk, lane);
+    // epilogue: the residual rows of tile nt+3 are requested while tile nt is transposed and stored
+    constexpr int PF = 3;
+    float mo4[4];
+    mask_rows<EP>(p, mw0, lane, mo4);
+    float4 rres[PF + 1][4];
+    static_for<0, PF>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (t < NT) resid_prefetch<EP>(p, mw0, t * 32, lane, rres[t]);
+    });
+    static_for<0, NT>([&](auto tc) {
+        constexpr int nt = decltype(tc)::value;
+        if constexpr (nt + PF < NT) resid_prefetch<EP>(p, mw0, (nt + PF) * 32, lane, rres[(nt + PF) % (PF + 1)]);
+        store_rows_f32<EP>(p, stage, mw0, nt * 32, acc2[nt], mk, lane, nullptr, rres[nt % (PF + 1)], mo4);
+    });
+    if constexpr (ST) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        tsum[4] = __builtin_readcyclecounter() - tk0;
+        if (lane == 0) {
+            uint64_t* dbg = static_cast<uint64_t*>(p.ln_out) + (blockIdx.x * 4 + wave) * 5;
+            for (int i = 0; i < 5; ++i) dbg[i] = tsum[i];
+        }
+    }
 }
 
 // W2 [D][F] (nn.Linear layout) -> [F/32][D][32] with each chunk's 32 hidden units in accumulator-fragment order

@@ -199,8 +199,28 @@ __global__ __launch_bounds__(256) void linear_small_kernel(const float* __restri
     const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
     const float* ar = a + (int64_t)i * lda;
     const float* wr = w + (int64_t)j * ldw;
+    // one FMA chain in k order (the summation order of the CPU oracle); the loads of 8 steps are issued together - with a
+    // plain loop every step waited for its own two loads, which made these tiny launches 20-50 us long
     float acc = 0.f;
-    for (int k = 0; k < K; ++k) acc = fmaf(ar[k], wr[k], acc);
+    int k = 0;
+    for (; k + 8 <= K; k += 8) {
+        float av[8], wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = ar[k + u]; wv[u] = wr[k + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(av[u], wv[u], acc);
+    }
+    if (k < K) {   // tail of up to 7 steps, loads again issued together (clamped index, zero weight past the end:
+        float av[8], wv[8];   // fma(a, +0, acc) leaves acc unchanged for finite a)
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int kk = k + u < K ? k + u : K - 1;
+            av[u] = ar[kk];
+            wv[u] = k + u < K ? wr[kk] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) acc = fmaf(av[u], wv[u], acc);
+    }
     if (bias) acc += bias[j];
     if (act & ISPK_EP_GELU) acc = gelu_erf(acc);
     if (act & ISPK_EP_SILU) acc = silu(acc);

@@ -8,7 +8,8 @@
 //   * lane l of wave 0 owns text columns l, l+64, ... (NC = ceil(L/64) registers), so a logits row is read with one
 //     coalesced 256-B load per 64 columns and never re-read: 4 B/cell in, and nothing but the result goes back out.
 //   * Q[i-1][j-1] comes from the neighbouring lane through a DPP wave shift (v_mov_b32_dpp wave_shr:1); the carry
-//     between 64-column chunks is one v_readlane.  No LDS or barrier inside the row loop.
+//     between 64-column chunks is a second DPP (wave_ror:1 of the previous chunk supplies lane 0's value).  No LDS
+//     or barrier inside the row loop.
 //   * the back-pointer of a cell is ONE bit: per row and chunk the wave's ballot (64 bits) is stored in LDS
 //     (M*NC*8 bytes: 8 KB at M=512, L=100; 69 KB at M=1723, L=300).
 //   * logits rows are prefetched R rows ahead into registers, so the dependent chain per row is
@@ -32,6 +33,22 @@ __device__ __forceinline__ float dpp_shr1(float src, float lane0_value) {
     return __builtin_bit_cast(
         float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, lane0_value), __builtin_bit_cast(int, src), 0x138,
                                            0xf, 0xf, false));
+}
+
+// lane `lane` of dst <- the wave-uniform value src (v_writelane_b32; this clang has no builtin for it)
+// lane LANE of (lo, hi) <- the wave-uniform 64-bit value (src_lo, src_hi).  v_writelane_b32 has no builtin in this
+// clang; inside inline asm the compiler's hazard recogniser does not see it, and a v_writelane issued right behind the
+// v_cmp that produced its SGPR operand reads the STALE register (observed: every row stored the previous row's word) -
+// hence the 4 wait states in front.
+template <int LANE>
+__device__ __forceinline__ void writelane64(uint32_t& lo, uint32_t& hi, uint32_t src_lo, uint32_t src_hi) {
+    asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi) : "s"(src_lo), "s"(src_hi), "n"(LANE));
+}
+
+__device__ __forceinline__ float dpp_ror1(float src) {
+    // lane l <- lane l-1, lane 0 <- lane 63 (wave_ror:1): carries a chunk's last column to the next chunk's lane 0
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x13C, 0xf, 0xf, false));
 }
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
@@ -85,34 +102,40 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
                 const float* row = lp + (int64_t)i * stride_m;
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    int col = lane + 64 * c;
-                    dst[r][c] = col < m ? row[col] : 0.0f;
+                    const int col = lane + 64 * c;           // (columns >= m never influence columns < m; any finite
+                    dst[r][c] = row[col < m ? col : m - 1];  //  value will do, and a clamped load needs no exec branch)
                 }
             }
         };
         load_rows(cur, 1);
+        // Row step, per 64-column chunk: DPP shift, compare, select, add - and nothing else on the dependent chain:
+        //   * the compare's lane mask IS the row's back-pointer word; it is parked in lane r of two VGPRs with
+        //     v_writelane and the wave stores a whole block of kRowsAhead rows to LDS at once (a per-row `if (lane == 0)`
+        //     LDS store costs an exec save / restore and an LDS instruction on every row);
+        //   * column 0 needs no `j > 0` test: its "left neighbour" is NaN, and NaN >= x is false;
+        //   * no per-row `i < n` branch: rows past the end recompute the last row (clamped loads) and are not stored.
+        const float qnan = __builtin_nanf("");
         for (int base = 1; base < n; base += kRowsAhead) {
             load_rows(nxt, base + kRowsAhead);
+            uint32_t wlo[NC], whi[NC];
 #pragma unroll
-            for (int r = 0; r < kRowsAhead; ++r) {
-                const int i = base + r;
-                if (i < n) {  // wave-uniform
-                    float left[NC];
+            for (int c = 0; c < NC; ++c) wlo[c] = whi[c] = 0u;
+            static_for<0, kRowsAhead>([&](auto rc) {
+                constexpr int r = decltype(rc)::value;
+                float left[NC];
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        float carry = c > 0 ? readlane_f(q[c - 1], 63) : 0.0f;
-                        left[c] = dpp_shr1(q[c], carry);
-                    }
+                for (int c = 0; c < NC; ++c) left[c] = dpp_shr1(q[c], c > 0 ? dpp_ror1(q[c - 1]) : qnan);
 #pragma unroll
-                    for (int c = 0; c < NC; ++c) {
-                        const int col = lane + 64 * c;
-                        const bool diag = (col > 0) && (left[c] >= q[c]);
-                        const float best = diag ? left[c] : q[c];
-                        q[c] = cur[r][c] + best;
-                        const uint64_t word = __ballot(diag);
-                        if (lane == 0) bp[(size_t)i * NC + c] = word;
-                    }
+                for (int c = 0; c < NC; ++c) {
+                    const bool diag = left[c] >= q[c];
+                    const uint64_t word = __ballot(diag);
+                    q[c] = cur[r][c] + (diag ? left[c] : q[c]);
+                    writelane64<r>(wlo[c], whi[c], (uint32_t)word, (uint32_t)(word >> 32));
                 }
+            });
+            if (lane < kRowsAhead && base + lane < n) {
+#pragma unroll
+                for (int c = 0; c < NC; ++c) bp[(size_t)(base + lane) * NC + c] = ((uint64_t)whi[c] << 32) | wlo[c];
             }
 #pragma unroll
             for (int r = 0; r < kRowsAhead; ++r)
@@ -133,15 +156,24 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
                 w_hi = bp[(size_t)myrow * NC + c_hi];
                 if (c_hi > 0) w_lo = bp[(size_t)myrow * NC + c_hi - 1];
             }
+            // 16 rows at a time: their ballot words go to SGPRs first (32 independent v_readlane pairs), so the serial
+            // walk itself is scalar arithmetic only - with a readlane inside every step each row waited for a
+            // VALU -> SGPR round trip.  Rows above the top of the utterance hold zero words and leave j unchanged.
             int myj = -1;
-            const int steps = top + 1 < 64 ? top + 1 : 64;
-            for (int r = 0; r < steps; ++r) {
-                if (lane == r) myj = j;
-                const uint64_t hi = readlane_u64(w_hi, r);
-                const uint64_t lo = readlane_u64(w_lo, r);
-                const uint64_t w = (j >> 6) == c_hi ? hi : lo;
-                j -= (int)((w >> (j & 63)) & 1);
-                j = __builtin_amdgcn_readfirstlane(j);
+#pragma unroll 1
+            for (int r0 = 0; r0 < 64; r0 += 16) {
+                uint64_t hi[16], lo[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    hi[u] = readlane_u64(w_hi, r0 + u);
+                    lo[u] = readlane_u64(w_lo, r0 + u);
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    if (lane == r0 + u) myj = j;
+                    const uint64_t w = (j >> 6) == c_hi ? hi[u] : lo[u];
+                    j -= (int)((w >> (j & 63)) & 1);
+                }
             }
             if (myrow >= 0) path[myrow] = (int16_t)myj;
         }

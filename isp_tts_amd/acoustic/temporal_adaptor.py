@@ -30,12 +30,22 @@ class TransformerTemporalModule(nn.Module, Constructor):
         self.transformer = Transformer.init(transformer, emb_dim=input_dim)
         self.linear_layer = nn.Linear(self.transformer.dim, output_dim, bias=True)
         self.detach_inputs = detach_inputs
+        self._cache: dict = {}
+
+    def _weight(self, dtype: torch.dtype) -> Tensor:
+        w = self.linear_layer.weight
+        key = (w.data_ptr(), w._version, w.device, dtype)
+        if self._cache.get("key") != key:
+            self._cache = {"key": key, "w": w.detach().to(dtype).contiguous()}
+        return self._cache["w"]
 
     def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
         m2 = mask[..., 0] if mask is not None else None
-        out = self.transformer(x, mask=m2).out
+        cdt = self.transformer.layers[0].attention.compute_dtype   # bf16 path: the output Linear is an MFMA GEMM too
+        out = self.transformer(x, mask=m2, out_dtype=cdt).out
         flags = runtime.EP_MASK_OUT if m2 is not None else 0
-        return runtime.gemm(out, self.linear_layer.weight, bias=self.linear_layer.bias, mask=m2, flags=flags)
+        return runtime.gemm(out, self._weight(cdt), bias=self.linear_layer.bias, mask=m2, flags=flags,
+                            out_dtype=torch.float32)
 
     def infer(self, x: Tensor, mask: Optional[Tensor] = None, steps: int = 4) -> Tensor:
         return self.forward(x, mask)
@@ -57,11 +67,11 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         self.output_dim, self.sigma, self.detach_inputs = output_dim, sigma, detach_inputs
         self._cache: dict = {}
 
-    def _cond_weight(self) -> Tensor:
+    def _cond_weight(self, dtype: torch.dtype) -> Tensor:
         w = self.transformer.project_emb.weight
-        key = (w.data_ptr(), w._version, w.device)
+        key = (w.data_ptr(), w._version, w.device, dtype)
         if self._cache.get("key") != key:
-            self._cache = {"key": key, "wc": w.detach()[:, self.output_dim:].contiguous()}
+            self._cache = {"key": key, "wc": w.detach()[:, self.output_dim:].to(dtype).contiguous()}
         return self._cache["wc"]
 
     def _project(self, x_t: Tensor, cond_proj: Tensor) -> Tensor:
@@ -69,7 +79,11 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         return runtime.linear_small(x_t.contiguous(), w[:, :self.output_dim], None, resid=cond_proj)
 
     def _cond_projection(self, cond: Tensor) -> Tensor:
-        return runtime.gemm(cond.float().contiguous(), self._cond_weight(), bias=self.transformer.project_emb.bias)
+        cdt = self.transformer.layers[0].attention.compute_dtype   # bf16 path: bf16 operands, fp32 result (residual stream)
+        c = cond.float().contiguous()
+        if cdt == torch.bfloat16:
+            c = runtime.cast_bf16(c)
+        return runtime.gemm(c, self._cond_weight(cdt), bias=self.transformer.project_emb.bias, out_dtype=torch.float32)
 
     def forward(self, x: Tensor, targets: Tensor, mask: Optional[Tensor] = None, *, noise: Optional[Tensor] = None,
                 time_steps: Optional[Tensor] = None):

@@ -17,11 +17,22 @@ def max_dtype_value(tensor: Tensor) -> float:
     return 65504.0 if tensor.dtype == torch.float16 else 3.4028234663852886e+38
 
 
+_ARANGE: dict = {}
+
+
+def _arange(n: int, device) -> Tensor:
+    """0 .. n-1 on `device`, built once (a constant; one launch less per mask on the hot path)."""
+    key = (n, str(device))
+    if key not in _ARANGE:
+        _ARANGE[key] = torch.arange(n, device=device)
+    return _ARANGE[key]
+
+
 def get_mask_from_lengths(lengths: Tensor, max_len: Optional[int] = None) -> Tensor:
     """functions.py:61-65.  `max_len=None` reads `lengths.max()` back to the host exactly like the reference;
     pass `max_len` on the hot path to stay asynchronous."""
     max_len = int(lengths.max().item()) if max_len is None else max_len
-    return torch.arange(max_len, device=lengths.device)[None, :] < lengths[:, None]
+    return _arange(max_len, lengths.device)[None, :] < lengths[:, None]
 
 
 def get_float_mask_from_lengths(lengths: Tensor, max_len: Optional[int] = None) -> Tensor:

@@ -102,6 +102,10 @@ int32_t ispk_layernorm_f32_bf16(const float* x, int64_t ldx, const float* gamma,
 #define ISPK_EP_MASK_COL 32u
 #define ISPK_EP_OUT_BF16 64u   /* _bf16 entry only: C is bf16 (default fp32) */
 #define ISPK_EP_RESID_BF16 128u /* _bf16 entry only: resid is bf16 (default fp32) */
+#define ISPK_EP_ROWS_T 256u     /* _bf16 entry, K = 256 / 384, fp32 C, no resid: the M rows are [batch][T] frames with
+                                   T = cols_per_batch and C is stored transposed per batch,
+                                   C[(i / T) * batch_stride + j * ldc + (i % T)]  (bias by column j, mask by row i): the
+                                   Linear + transpose(1, 2) of model.py:167-168 with frame-contiguous 128-B stores */
 
 /* Which block tile ispk_gemm_f32 will use for (M, N, K): TM*10 + TN, block = 64*TM x 64*TN (22 -> 128x128).  Lets a
  * profiler label a launch with the kernel instance rocprof will report. */

@@ -487,6 +487,26 @@ __device__ __forceinline__ void store_rows_bf16(const GemmParams& p, char* stage
     }
 }
 
+// ISPK_EP_ROWS_T: the wave's 32 rows are frames t of batch item b = m / T; output feature n goes to C[b][n][t].  In the
+// transposed-compute accumulator the frame sits on the lane, so each register is already a frame-contiguous 128-byte
+// segment (x 2 halves) of one output channel: no LDS pass.  cb = &C[b][0][t] of this lane's row (nullptr: row >= M).
+template <int EP = kEpDyn>
+__device__ __forceinline__ void store_rows_t(const GemmParams& p, float* cb, int n0, const f32x16& acc, float mo, int h) {
+    if (cb == nullptr) return;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int n = n0 + 8 * g + 4 * h;
+        if (n >= p.N) continue;   // N % 4 == 0 (checked by the launcher)
+        float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ep_bias<EP>(p)) bb = *reinterpret_cast<const float4*>(p.bias + n);
+        float* c = cb + (int64_t)n * p.ldc;
+        c[0] = (acc[4 * g] + bb.x) * mo;
+        c[p.ldc] = (acc[4 * g + 1] + bb.y) * mo;
+        c[2 * p.ldc] = (acc[4 * g + 2] + bb.z) * mo;
+        c[3 * p.ldc] = (acc[4 * g + 3] + bb.w) * mo;
+    }
+}
+
 // can the row-coalescing epilogue be used?  (else: epilogue_vec4)
 inline bool rows_epilogue_ok(const GemmParams& p) {
     if (p.flags & ISPK_EP_OUT_BF16)
@@ -854,6 +874,11 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
     const int mw0 = mb * 128 + wave * 32;
     float mo4[4];
     mask_rows<EP>(p, mw0, lane, mo4);
+    float* ct = nullptr;   // ISPK_EP_ROWS_T: &C[batch of this lane's row][0][frame]
+    if (ep_flag<EP>(p, ISPK_EP_ROWS_T) && m < p.M) {
+        const int bi = m / p.cpb;
+        ct = static_cast<float*>(p.C) + (int64_t)bi * p.bstride + (m - bi * p.cpb);
+    }
     if constexpr (ST) { tA = __builtin_readcyclecounter(); tsum[0] = tA - t0; }
     for (int nt = nt0; nt < nt1; ++nt) {
         if constexpr (ST) { t0 = __builtin_readcyclecounter(); __builtin_amdgcn_sched_barrier(0); }
@@ -910,6 +935,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
         // epilogue: register 4g+e of tile half t is output feature n = nt*64 + t*32 + 8g + 4h + e, row m (this lane)
         if (p.cpb == -7) {  // ablation (experiments only): keep the accumulators live, skip the epilogue
             if (acc[0][0] + acc[1][5] == 123.456f) static_cast<float*>(p.C)[0] = 1.f;
+        } else if (ep_flag<EP>(p, ISPK_EP_ROWS_T)) {
+            store_rows_t<EP>(p, ct, nt * 64, acc[0], ep_flag<EP>(p, ISPK_EP_MASK_OUT) ? mk : 1.0f, h);
+            store_rows_t<EP>(p, ct, nt * 64 + 32, acc[1], ep_flag<EP>(p, ISPK_EP_MASK_OUT) ? mk : 1.0f, h);
         } else if (ep_flag<EP>(p, ISPK_EP_OUT_BF16)) {
             store_rows_bf16<EP>(p, stage, mw0, nt * 64, acc[0], acc[1], mk, lane);
         } else if constexpr (EP >= 0) {   // (the generic instance is out of registers: it loads the residual in place)
@@ -955,6 +983,7 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
     } while (0)
     // the model's hot epilogues get branch-free instances (tools/trace_gemms.py lists what a forward launches)
     constexpr int kQkv = ISPK_EP_OUT_BF16, kFfn1 = ISPK_EP_OUT_BF16 | ISPK_EP_GELU, kProj = ISPK_EP_MASK_ACC | kEpResid;
+    constexpr int kMelT = ISPK_EP_ROWS_T | ISPK_EP_MASK_OUT | kEpBias;   // to_mel (model.py:167-168)
     const int key = p.cpb == -7 ? -2 : ep_key(p);
     if (const char* e = getenv("ISPK_PANEL_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][6]
         GemmParams q = p;
@@ -967,6 +996,7 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
         if (key == kQkv) ISPK_PANEL_GO(kQkv, false, p);
         if (key == kFfn1) ISPK_PANEL_GO(kFfn1, false, p);
         if (key == kProj) ISPK_PANEL_GO(kProj, false, p);
+        if (key == kMelT) ISPK_PANEL_GO(kMelT, false, p);
     }
     ISPK_PANEL_GO(kEpDyn, false, p);
 #undef ISPK_PANEL_GO
@@ -1007,7 +1037,11 @@ int32_t check_common(const GemmParams& p, int elt) {
     ISPK_REQUIRE(!((p.flags & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT)) && !p.mask), ISPK_E_NULL,
                  "gemm: mask flag set but mask is NULL");
     ISPK_REQUIRE(!(p.cpb > 0 && p.resid), ISPK_E_UNSUPPORTED, "gemm: resid with a batched (transposed) store");
-    ISPK_REQUIRE(p.cpb >= -7 && (p.cpb <= 0 || p.N % p.cpb == 0), ISPK_E_SHAPE, "gemm: N %% cols_per_batch != 0");
+    if (p.flags & ISPK_EP_ROWS_T) {
+        ISPK_REQUIRE(p.cpb > 0 && p.M % p.cpb == 0, ISPK_E_SHAPE, "gemm: ROWS_T needs M %% cols_per_batch == 0");
+    } else {
+        ISPK_REQUIRE(p.cpb >= -7 && (p.cpb <= 0 || p.N % p.cpb == 0), ISPK_E_SHAPE, "gemm: N %% cols_per_batch != 0");
+    }
     ISPK_REQUIRE((p.flags & ISPK_EP_GELU) == 0 || (p.flags & ISPK_EP_SILU) == 0, ISPK_E_UNSUPPORTED,
                  "gemm: GELU and SILU together");
     return 0;
@@ -1032,8 +1066,8 @@ extern "C" int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, in
                                  ispk_stream_t stream) {
     GemmParams p{A, lda, W, ldw, C, ldc, bias, resid, ldr, mask, M, N, K, flags, cols_per_batch, batch_stride};
     if (int32_t rc = check_common(p, 4)) return rc;
-    ISPK_REQUIRE((flags & (ISPK_EP_OUT_BF16 | ISPK_EP_RESID_BF16)) == 0, ISPK_E_UNSUPPORTED,
-                 "gemm_f32: bf16 output/residual flags belong to ispk_gemm_bf16");
+    ISPK_REQUIRE((flags & (ISPK_EP_OUT_BF16 | ISPK_EP_RESID_BF16 | ISPK_EP_ROWS_T)) == 0, ISPK_E_UNSUPPORTED,
+                 "gemm_f32: bf16 output/residual and ROWS_T flags belong to ispk_gemm_bf16");
     if (M == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     switch (ispk_gemm_f32_tile(M, N, K)) {
@@ -1058,6 +1092,14 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
     if (int32_t rc = check_common(p, 2)) return rc;
     if (M == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (flags & ISPK_EP_ROWS_T) {
+        ISPK_REQUIRE((K == 256 || K == 384) && !resid && N % 4 == 0 && ldc >= cols_per_batch &&
+                         !(flags & (ISPK_EP_OUT_BF16 | ISPK_EP_BIAS_ROW | ISPK_EP_MASK_COL | ISPK_EP_GELU | ISPK_EP_SILU |
+                                    ISPK_EP_MASK_ACC)) && (!bias || ispk_aligned(bias, 16)) && ispk_aligned(C, 4),
+                     ISPK_E_UNSUPPORTED, "gemm_bf16: ROWS_T is built for K = 256 / 384, fp32 C, bias + MASK_OUT only");
+        g_last_bf16_variant = 1000 + K / 64;
+        return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
+    }
     if (panel_ok(p) && !(getenv("ISPK_FORCE_WIDE") && (N == 384 || N == 256) && !(flags & ISPK_EP_OUT_BF16))) {
         g_last_bf16_variant = 1000 + K / 64;
         return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);

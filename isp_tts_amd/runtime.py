@@ -16,8 +16,8 @@ from torch import Tensor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libispk.so")
 
-EP_GELU, EP_SILU, EP_MASK_ACC, EP_MASK_OUT, EP_BIAS_ROW, EP_MASK_COL, EP_OUT_BF16, EP_RESID_BF16 = (
-    1, 2, 4, 8, 16, 32, 64, 128)
+EP_GELU, EP_SILU, EP_MASK_ACC, EP_MASK_OUT, EP_BIAS_ROW, EP_MASK_COL, EP_OUT_BF16, EP_RESID_BF16, EP_ROWS_T = (
+    1, 2, 4, 8, 16, 32, 64, 128, 256)
 
 _P, _I32, _I64, _U32, _F32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
 
@@ -325,6 +325,16 @@ def to_mel(dec: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor]) ->
     C = weight.shape[0]
     x2 = _rows2d(dec)
     out = torch.empty((B, C, T), dtype=torch.float32, device=dec.device)
+    if dec.dtype == torch.bfloat16 and D in (256, 384) and C % 4 == 0 and bias is not None:
+        # bf16, K = 256 / 384: the panel GEMM with frames as rows and the transposed per-batch store (ISPK_EP_ROWS_T)
+        flags = EP_ROWS_T
+        if mask is not None:
+            mask = mask.reshape(-1).contiguous()
+            flags |= EP_MASK_OUT
+        _launch("gemm_bf16_kernel", 2.0 * C * B * T * D, _gemm_bytes(x2, weight, out, None), lib().ispk_gemm_bf16,
+                x2.data_ptr(), x2.stride(0), weight.data_ptr(), weight.stride(0), out.data_ptr(), T, _ptr(bias), None, 0,
+                _ptr(mask), B * T, C, D, flags, T, C * T, _stream())
+        return out
     flags = EP_BIAS_ROW | EP_MASK_COL
     if mask is not None:
         mask = mask.reshape(-1).contiguous()

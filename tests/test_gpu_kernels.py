@@ -184,6 +184,23 @@ def test_to_mel_transposed_masked_store():
     assert (out.double() - (x.double() @ w.double().T + b.double()).transpose(1, 2)).abs().max() < 2e-5
 
 
+@pytest.mark.parametrize("B,T,D", [(3, 203, 384), (2, 512, 384), (5, 64, 256)])
+def test_to_mel_bf16_rows_t(B, T, D):
+    """bf16 to_mel = panel GEMM with frames as rows + ISPK_EP_ROWS_T store: float64 reference on the bf16-rounded operands
+    (products of bf16 values are exact in fp32; only the summation order differs)."""
+    C = 80
+    x = _bf(synth._normal(f"t/melb/x{T}", (B, T, D)))
+    w, b = _bf(synth._normal(f"t/melb/w{D}", (C, D), D ** -0.5)), synth._normal("t/melb/b", (C,))
+    lens = torch.tensor([T, max(1, T // 3), 5, T - 1, 1][:B])
+    mask = torch.arange(T)[None] < lens[:, None]
+    ref = (x.double() @ w.double().T + b.double()).transpose(1, 2) * mask[:, None]
+    out = runtime.to_mel(x.to(DEV), w.to(DEV), b.to(DEV), mask.to(DEV)).cpu()
+    assert out.shape == (B, C, T) and out.dtype == torch.float32
+    assert (out.double() - ref).abs().max() < 2e-5
+    out = runtime.to_mel(x.to(DEV), w.to(DEV), b.to(DEV), None).cpu()
+    assert (out.double() - (x.double() @ w.double().T + b.double()).transpose(1, 2)).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize("M,N,K", [(7, 32, 65), (200, 256, 3), (200, 3, 256), (1, 256, 32), (200, 256, 2)])
 def test_linear_small(M, N, K):
     a, w = synth._normal("t/ls/a", (M, K)), synth._normal("t/ls/w", (N, K), K ** -0.5)

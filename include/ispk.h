@@ -145,6 +145,18 @@ int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_
                       const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
                       ispk_stream_t stream);
 
+/* ispk_ffn_bf16 that ALSO emits the LayerNorm of its result for the next Linear:
+ *   ln_out[i][:] = [mask[i]] * ( (out[i][:] - mean_i) * rstd_i * ln_gamma + ln_beta )       two-pass fp32 statistics
+ * Replaces: the block above plus normalization.py:20-27 as applied by the NEXT layer (transformer.py:79) or by the
+ * stack's final norm (:205-206): the separate LayerNorm launch and its re-read of the residual stream disappear.
+ * W2 must be the packed image (ispk_ffn_pack_w2_bf16); no first-Linear bias.  ln_flags: bit 0 = multiply ln_out by the
+ * row mask, bit 1 = ln_out is bf16 (else fp32); ln_ld: leading stride of ln_out. */
+int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed,
+                         const float* bias2, const float* resid, int64_t ldr, const uint8_t* mask, float* out, int64_t ldo,
+                         int32_t rows, int32_t dim, int32_t inner, uint32_t flags, const float* ln_gamma,
+                         const float* ln_beta, float ln_eps, void* ln_out, int64_t ln_ld, uint32_t ln_flags,
+                         ispk_stream_t stream);
+
 /* One-time weight staging for ispk_ffn_bf16: W2 [dim][inner] (nn.Linear layout, feedforward.py:27) ->
  * packed [inner/32][dim][32], each chunk's 32 hidden units in MFMA accumulator-fragment order.  packed holds
  * dim*inner bf16 elements; inner % 32 == 0. */

@@ -1150,7 +1150,7 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
 //     burst of 12 loads blocks the wave's issue for 12 x 16 cycles x 4 waves on the CU's one address path).
 // The operand reads of both phases run as ONE stream through an RD-deep ring of opaque asm reads.  One barrier per chunk.
 // Epilogue: the row-coalescing transpose (store_rows_f32) with residual and mask.
-template <int KC, bool B1, bool PK, int EP = kEpDyn, bool ST = false>  // D = 64 KC; B1: Linear 1 has a bias; PK: packed W2
+template <int KC, bool B1, bool PK, int EP = kEpDyn, bool ST = false, bool LN = false>  // D = 64 KC; B1: Linear 1 bias; PK: packed W2; LN: + LayerNorm of the result
 __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const uint16_t* __restrict__ W2, int64_t ldw2,
                                                           const float* __restrict__ bias1, int F) {
     [[maybe_unused]] uint64_t tk0 = 0;
@@ -1407,8 +1407,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
 
     float mk = 1.0f;
     if (EP < 0 || ((uint32_t)EP & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT))) mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
-    // epilogue: the residual rows of tile nt+3 are requested while tile nt is transposed and stored
-    constexpr int PF = 3;
+    // epilogue: the residual rows of tile nt+PF are requested while tile nt is transposed and stored
+    constexpr int PF = LN ? 1 : 3;   // (the LayerNorm variant keeps all final values in registers)
     float mo4[4];
     mask_rows<EP>(p, mw0, lane, mo4);
     float4 rres[PF + 1][4];
@@ -1416,11 +1416,80 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
         constexpr int t = decltype(tc)::value;
         if constexpr (t < NT) resid_prefetch<EP>(p, mw0, t * 32, lane, rres[t]);
     });
-    static_for<0, NT>([&](auto tc) {
-        constexpr int nt = decltype(tc)::value;
-        if constexpr (nt + PF < NT) resid_prefetch<EP>(p, mw0, (nt + PF) * 32, lane, rres[(nt + PF) % (PF + 1)]);
-        store_rows_f32<EP>(p, stage, mw0, nt * 32, acc2[nt], mk, lane, nullptr, rres[nt % (PF + 1)], mo4);
-    });
+    if constexpr (!LN) {
+        static_for<0, NT>([&](auto tc) {
+            constexpr int nt = decltype(tc)::value;
+            if constexpr (nt + PF < NT) resid_prefetch<EP>(p, mw0, (nt + PF) * 32, lane, rres[(nt + PF) % (PF + 1)]);
+            store_rows_f32<EP>(p, stage, mw0, nt * 32, acc2[nt], mk, lane, nullptr, rres[nt % (PF + 1)], mo4);
+        });
+    } else {
+        // + LayerNorm of the finished rows for the next Linear (normalization.py:20-27; transformer.py:79 of the next
+        // layer, or :205-206 after the last): a wave holds ALL D features of its 32 rows, so the statistics need no LDS
+        // or barrier - two passes in fp32 over the final values kept in registers (D/32 x 4 float4, the accumulators
+        // they replace die tile by tile), reduced over the 8 lanes that share a row.  Saves the separate LayerNorm
+        // launch and its 50-MB re-read of the residual stream per decoder layer.
+        float4 yv[NT][4];
+        float rs[4] = {0.f, 0.f, 0.f, 0.f};
+        static_for<0, NT>([&](auto tc) {
+            constexpr int nt = decltype(tc)::value;
+            if constexpr (nt + PF < NT) resid_prefetch<EP>(p, mw0, (nt + PF) * 32, lane, rres[(nt + PF) % (PF + 1)]);
+            store_rows_f32<EP>(p, stage, mw0, nt * 32, acc2[nt], mk, lane, yv[nt], rres[nt % (PF + 1)], mo4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[i] += (yv[nt][i].x + yv[nt][i].y) + (yv[nt][i].z + yv[nt][i].w);
+        });
+        auto row_total = [&](float (&v)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] += __shfl_xor(v[i], 1, 64);
+                v[i] += __shfl_xor(v[i], 2, 64);
+                v[i] += __shfl_xor(v[i], 4, 64);
+            }
+        };
+        row_total(rs);
+        float mean[4], qs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mean[i] = rs[i] * (1.0f / (float)D);
+            qs[i] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = yv[t][i].x - mean[i], b = yv[t][i].y - mean[i], c = yv[t][i].z - mean[i],
+                            d = yv[t][i].w - mean[i];
+                qs[i] += (a * a + b * b) + (c * c + d * d);
+            }
+        row_total(qs);
+        const int c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int mr = mw0 + 8 * i + (lane >> 3);
+            if (mr >= p.M) continue;
+            const float rstd = 1.0f / sqrtf(qs[i] * (1.0f / (float)D) + p.ln_eps);
+            const float mo = ((p.ln_flags & 1u) && p.mask) ? (p.mask[mr] ? 1.0f : 0.0f) : 1.0f;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int n = t * 32 + c4;
+                const float4 g = *reinterpret_cast<const float4*>(p.ln_gamma + n);
+                const float4 be = *reinterpret_cast<const float4*>(p.ln_beta + n);
+                float4 o;
+                o.x = ((yv[t][i].x - mean[i]) * rstd * g.x + be.x) * mo;
+                o.y = ((yv[t][i].y - mean[i]) * rstd * g.y + be.y) * mo;
+                o.z = ((yv[t][i].z - mean[i]) * rstd * g.z + be.z) * mo;
+                o.w = ((yv[t][i].w - mean[i]) * rstd * g.w + be.w) * mo;
+                const int64_t off = (int64_t)mr * p.ln_ld + n;
+                if (p.ln_flags & 2u) {
+                    uint2 pk;
+                    pk.x = pack_bf16x2(o.x, o.y);
+                    pk.y = pack_bf16x2(o.z, o.w);
+                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.ln_out) + off) = pk;
+                } else {
+                    *reinterpret_cast<float4*>(static_cast<float*>(p.ln_out) + off) = o;
+                }
+            }
+        }
+    }
     if constexpr (ST) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         tsum[4] = __builtin_readcyclecounter() - tk0;
@@ -1453,10 +1522,19 @@ extern "C" int32_t ispk_ffn_pack_w2_bf16(const uint16_t* W2, int64_t ldw2, int32
     return ispk_launch_status();
 }
 
-extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
-                                 const uint16_t* W2, int64_t ldw2, const float* bias2, const float* resid, int64_t ldr,
-                                 const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F,
-                                 uint32_t flags, ispk_stream_t stream) {
+namespace {
+struct FfnLn {   // optional LayerNorm of the result (ispk_ffn_bf16_ln)
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float eps = 0.f;
+    void* out = nullptr;
+    int64_t ld = 0;
+    uint32_t flags = 0;
+};
+int32_t ffn_launch(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
+                   const uint16_t* W2, int64_t ldw2, const float* bias2, const float* resid, int64_t ldr,
+                   const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F, uint32_t flags,
+                   const FfnLn* ln, ispk_stream_t stream) {
     ISPK_REQUIRE(x && W1 && W2 && out, ISPK_E_NULL, "ffn: null pointer");
     ISPK_REQUIRE(D == 384 || D == 256, ISPK_E_UNSUPPORTED, "ffn: dim %d (built for 256 / 384)", D);
     ISPK_REQUIRE(rows >= 0 && F >= 64 && F % 32 == 0, ISPK_E_SHAPE, "ffn: bad shape rows=%d inner=%d", rows, F);
@@ -1477,10 +1555,20 @@ extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t*
     constexpr int kHot = ISPK_EP_MASK_OUT | kEpResid;   // the transformer layer's call (transformer.py:105-110), no bias2
     const bool hot = ep_key(p) == kHot && getenv("ISPK_EP_DYN") == nullptr;
     const bool packed = ldw2 == 0;   // W2 laid out by ispk_ffn_pack_w2_bf16
+    if (ln) {
+        ISPK_REQUIRE(ln->gamma && ln->beta && ln->out, ISPK_E_NULL, "ffn_ln: null LayerNorm argument");
+        ISPK_REQUIRE(ln->ld % 4 == 0 && ln->ld >= D && ispk_aligned(ln->out, (ln->flags & 2u) ? 8 : 16) &&
+                         ispk_aligned(ln->gamma, 16) && ispk_aligned(ln->beta, 16),
+                     ISPK_E_ALIGN, "ffn_ln: LayerNorm buffers must be 16-byte aligned, ln_ld a multiple of 4");
+        ISPK_REQUIRE(!((ln->flags & 1u) && !mask), ISPK_E_NULL, "ffn_ln: ln mask flag set but mask is NULL");
+        ISPK_REQUIRE(packed && !bias1, ISPK_E_UNSUPPORTED, "ffn_ln: needs the packed W2 image and no first-Linear bias");
+        p.ln_gamma = ln->gamma; p.ln_beta = ln->beta; p.ln_out = ln->out; p.ln_ld = ln->ld; p.ln_eps = ln->eps;
+        p.ln_flags = ln->flags;
+    }
     void* stamp = nullptr;
     if (const char* e = getenv("ISPK_FFN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][3]
         stamp = reinterpret_cast<void*>(strtoull(e, nullptr, 16));
-        ISPK_REQUIRE(D == 384 && packed && !bias1 && hot, ISPK_E_UNSUPPORTED, "ffn stamps: the hot instance only");
+        ISPK_REQUIRE(D == 384 && packed && !bias1 && hot && !ln, ISPK_E_UNSUPPORTED, "ffn stamps: the hot instance only");
         p.ln_out = stamp;
     }
 #define ISPK_FFN_GO(KC_, B1_, PK_, EP_, ST_)                                                                          \
@@ -1490,8 +1578,18 @@ extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t*
         hipLaunchKernelGGL((ffn_bf16_kernel<KC_, B1_, PK_, EP_, ST_>), grid, dim3(256), lds, s, p, W2, ldw2, bias1, F); \
         return ispk_launch_status();                                                                                  \
     } while (0)
+#define ISPK_FFN_GO_LN(KC_, EP_)                                                                                      \
+    do {                                                                                                              \
+        constexpr size_t lds = (size_t)(2 * 32 * (64 * KC_ + 8) + 2 * 64 * KC_ * 40) * 2 + 4 * kStageBytes;             \
+        ISPK_RESERVE_LDS((&ffn_bf16_kernel<KC_, false, true, EP_, false, true>), lds, "ffn");                         \
+        hipLaunchKernelGGL((ffn_bf16_kernel<KC_, false, true, EP_, false, true>), grid, dim3(256), lds, s, p, W2, ldw2, \
+                           bias1, F);                                                                                 \
+        return ispk_launch_status();                                                                                  \
+    } while (0)
 #define ISPK_FFN_KC(KC_)                                                   \
     do {                                                                   \
+        if (ln && hot) ISPK_FFN_GO_LN(KC_, kHot);                          \
+        if (ln) ISPK_FFN_GO_LN(KC_, kEpDyn);                               \
         if (stamp) ISPK_FFN_GO(6, false, true, kHot, true);                \
         if (!bias1 && packed && hot) ISPK_FFN_GO(KC_, false, true, kHot, false);  \
         if (!bias1 && packed) ISPK_FFN_GO(KC_, false, true, kEpDyn, false);  \
@@ -1501,8 +1599,27 @@ extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t*
     } while (0)
     if (D == 384) ISPK_FFN_KC(6); else ISPK_FFN_KC(4);
 #undef ISPK_FFN_KC
+#undef ISPK_FFN_GO_LN
 #undef ISPK_FFN_GO
     return ispk_launch_status();
+}
+}  // namespace
+
+extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
+                                 const uint16_t* W2, int64_t ldw2, const float* bias2, const float* resid, int64_t ldr,
+                                 const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F,
+                                 uint32_t flags, ispk_stream_t stream) {
+    return ffn_launch(x, ldx, W1, ldw1, bias1, W2, ldw2, bias2, resid, ldr, mask, out, ldo, rows, D, F, flags, nullptr, stream);
+}
+
+extern "C" int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
+                                    const uint16_t* W2_packed, const float* bias2, const float* resid, int64_t ldr,
+                                    const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F,
+                                    uint32_t flags, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                    void* ln_out, int64_t ln_ld, uint32_t ln_flags, ispk_stream_t stream) {
+    FfnLn ln{ln_gamma, ln_beta, ln_eps, ln_out, ln_ld, ln_flags};
+    return ffn_launch(x, ldx, W1, ldw1, nullptr, W2_packed, 0, bias2, resid, ldr, mask, out, ldo, rows, D, F, flags, &ln,
+                      stream);
 }
 
 extern "C" int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc,

@@ -61,6 +61,25 @@ class FeedForward(nn.Module, Constructor):
             self._cache["w2p"] = runtime.ffn_pack_w2(self._cache["w2"])
         return self._cache["w2p"]
 
+    def fused_with_norm_ok(self, x: Tensor) -> bool:
+        """Can `forward_with_norm` emit the next LayerNorm from the fused kernel's epilogue for this input?"""
+        rows = x.numel() // x.shape[-1]
+        return (self.compute_dtype == torch.bfloat16 and self.act_flag == runtime.EP_GELU and x.shape[-1] in (256, 384)
+                and rows >= self.fused_min_rows and self.net[0].bias is None
+                and not (self.training and self.dropout_p > 0))
+
+    def forward_with_norm(self, x: Tensor, next_norm: tuple, *, residual: Optional[Tensor] = None,
+                          mask: Optional[Tensor] = None):
+        """(y, LN_next(y)): the fused FFN kernel with the LayerNorm that consumes its output in its epilogue
+        (`next_norm` = (weight, bias, eps, apply_mask, dtype)).  Only when `fused_with_norm_ok(x)`."""
+        w1, _ = self._staged(torch.bfloat16)
+        if x.dtype != torch.bfloat16:
+            x = runtime.cast_bf16(x)
+        nw, nb, neps, nmask, ndtype = next_norm
+        return runtime.ffn_fused_ln(x, w1, self._packed_w2(), nw, nb, resid=residual, mask=mask, bias2=self.net[3].bias,
+                                    flags=runtime.EP_MASK_OUT if mask is not None else 0, ln_mask=nmask, ln_dtype=ndtype,
+                                    ln_eps=neps)
+
     def forward(self, x: Tensor, *, residual: Optional[Tensor] = None, mask: Optional[Tensor] = None) -> Tensor:
         if self.training and self.dropout_p > 0:
             raise NotImplementedError("feed-forward dropout (training) is outside the forward-path scope")

@@ -35,6 +35,7 @@ class TransformerLayerOutput(NamedTuple):
     out: Tensor
     intermediates: Optional[TransformerLayerIntermediates] = None
     shared_intermediates: Optional[AttentionSharedIntermediates] = None
+    next_normed: Optional[Tensor] = None   # LN_next(out) when the feed-forward kernel produced it (not in the reference)
 
 
 @dataclass
@@ -65,7 +66,10 @@ class TransformerLayer(nn.Module, Constructor):
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 adaptive_condition: Optional[Tensor] = None, cache: Optional[TransformerLayerIntermediates] = None,
                 shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None,
-                ada: Optional[tuple] = None):
+                ada: Optional[tuple] = None, normed: Optional[Tensor] = None, next_norm: Optional[tuple] = None):
+        """`normed`: attention_norm(x) when the previous layer's feed-forward kernel already produced it; `next_norm`
+        = (weight, bias, eps, apply_mask, dtype) of the norm that will consume this layer's output - if the fused
+        feed-forward kernel can emit it, the output carries it in `next_normed` (bf16 path, decoder-sized batches)."""
         assert not self.adaptive_norm or adaptive_condition is not None or ada is not None, \
             "`adaptive_condition` should be provided for AdaptiveLayerNorm"
         if cache is not None:
@@ -76,13 +80,17 @@ class TransformerLayer(nn.Module, Constructor):
             key_len = mask.sum(dim=1)
         kw1 = {"scale_shift": ada[0]} if ada is not None else {}
         kw2 = {"scale_shift": ada[1]} if ada is not None else {}
-        h = self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
+        h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
         x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
                                            attention_mask=attention_mask, key_len=key_len, residual=x)
         h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt, **kw2)
-        y = self.feed_forward(h2, residual=x1, mask=mask)
+        hn = None
+        if next_norm is not None and self.feed_forward.fused_with_norm_ok(h2):
+            y, hn = self.feed_forward.forward_with_norm(h2, next_norm, residual=x1, mask=mask)
+        else:
+            y = self.feed_forward(h2, residual=x1, mask=mask)
         return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
-                                      shared_intermediates=shared)
+                                      shared_intermediates=shared, next_normed=hn)
 
 
     def forward_fused(self, x: Tensor, h: Tensor, mask: Optional[Tensor], key_len: Optional[Tensor], next_norm: tuple):
@@ -170,6 +178,11 @@ class Transformer(nn.Module, Constructor):
     # (residual in, fp32 + bf16 rows out) overlaps with no MFMA work, and its 64-row variant under-fills the chip on the
     # 6,400-row encoder.  Kept for the next round (needs an epilogue that overlaps with the following tile's K loop).
     fuse_layernorm = False
+    # LayerNorm of a layer's output in the epilogue of its fused feed-forward kernel (ispk_ffn_bf16_ln: each wave of that
+    # kernel owns whole rows, so the statistics need no extra pass).  Parity-tested, opt-in: at the benchmark shape the
+    # kernel gets 13 us slower per layer (its 256 workgroups reach the epilogue together, nothing overlaps the extra
+    # work) while the removed LayerNorm launch saved 17 us - 2.94 vs 2.98 ms per step, within run-to-run noise.
+    chain_layernorm = False
 
     def _fusable(self, context, context_mask, attention_mask) -> bool:
         att = self.layers[0].attention
@@ -218,12 +231,28 @@ class Transformer(nn.Module, Constructor):
                     intermediates.append(TransformerLayerIntermediates(attention=inter))
             return TransformerOutput(out=h, intermediates=intermediates)
         ada = self._ada_all(adaptive_condition) if (self.adaptive_norm and adaptive_condition is not None) else None
+        # bf16, plain LayerNorm: a layer's fused feed-forward kernel also emits the LayerNorm that consumes its output
+        # (the next layer's attention_norm, or the final norm) when the batch is large enough for that kernel
+        chain = self.chain_layernorm and not self.adaptive_norm and self.layers[0].attention.compute_dtype == torch.bfloat16
+        cdt = self.layers[0].attention.compute_dtype
+        normed = None
         for li, layer in enumerate(self.layers):
+            nxt = None
+            if chain:
+                if li + 1 < len(self.layers):
+                    nn_ = self.layers[li + 1].attention_norm
+                    nxt = (nn_.weight, nn_.bias, nn_.eps, False, cdt)
+                else:
+                    nxt = (self.norm.weight, self.norm.bias, self.norm.eps, mask is not None, out_dtype)
+                if nxt[0] is None or nxt[1] is None:
+                    nxt = None
             res = layer(out, mask=mask, context=context, context_mask=context_mask, attention_mask=attention_mask,
-                        adaptive_condition=adaptive_condition, key_len=key_len, ada=None if ada is None else ada[li])
-            out = res.out
+                        adaptive_condition=adaptive_condition, key_len=key_len, ada=None if ada is None else ada[li],
+                        normed=normed, next_norm=nxt)
+            out, normed = res.out, res.next_normed
             if return_intermediates:
                 intermediates.append(res.intermediates)
-        out = runtime.layernorm(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps,
-                                out_dtype=out_dtype)
-        return TransformerOutput(out=out, intermediates=intermediates)
+        if normed is None:
+            normed = runtime.layernorm(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps,
+                                       out_dtype=out_dtype)
+        return TransformerOutput(out=normed, intermediates=intermediates)

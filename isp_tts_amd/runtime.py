@@ -37,6 +37,8 @@ SIGNATURES = {
                           _P],
     "ispk_ffn_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_ffn_pack_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
+    "ispk_ffn_bf16_ln": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64,
+                         _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -302,6 +304,31 @@ def ffn_fused(x: Tensor, w1: Tensor, w2: Tensor, resid: Optional[Tensor] = None,
             w1.data_ptr(), w1.stride(0), _ptr(bias1), w2.data_ptr(), 0 if packed else w2.stride(0), _ptr(bias2), _ptr(r2),
             r2.stride(0) if r2 is not None else 0, _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, _stream())
     return out
+
+
+def ffn_fused_ln(x: Tensor, w1: Tensor, w2p: Tensor, ln_weight: Tensor, ln_bias: Tensor, resid: Optional[Tensor] = None,
+                 mask: Optional[Tensor] = None, bias2: Optional[Tensor] = None, flags: int = 0, ln_mask: bool = False,
+                 ln_dtype: torch.dtype = torch.bfloat16, ln_eps: float = 1e-5):
+    """ispk_ffn_bf16_ln: (out fp32 [..., D], LN(out) [..., D] in ln_dtype); w2p = the packed image from `ffn_pack_w2`."""
+    _dev(x, w1, w2p, ln_weight, ln_bias, resid, mask, bias2)
+    assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2p.dtype == torch.bfloat16
+    x2 = _rows2d(x)
+    R, D = x2.shape
+    Fi = w1.shape[0]
+    assert w1.shape == (Fi, D) and w1.stride(1) == 1 and w2p.shape == (Fi // 32, D, 32) and w2p.is_contiguous()
+    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
+    ln_out = torch.empty((*x.shape[:-1], D), dtype=ln_dtype, device=x.device)
+    r2 = _rows2d(resid) if resid is not None else None
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+    lnf = (1 if (ln_mask and mask is not None) else 0) | (2 if ln_dtype == torch.bfloat16 else 0)
+    nb = x2.numel() * 2 + (w1.numel() + w2p.numel()) * 2 + out.numel() * 4 + ln_out.numel() * ln_out.element_size() + \
+        (r2.numel() * 4 if r2 is not None else 0)
+    _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_ln, x2.data_ptr(), x2.stride(0),
+            w1.data_ptr(), w1.stride(0), w2p.data_ptr(), _ptr(bias2), _ptr(r2), r2.stride(0) if r2 is not None else 0,
+            _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, ln_weight.data_ptr(), ln_bias.data_ptr(), ln_eps,
+            ln_out.data_ptr(), D, lnf, _stream())
+    return out, ln_out
 
 
 def _gemm_label(bf16: bool, M: int, N: int, K: int) -> str:

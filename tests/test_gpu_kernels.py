@@ -334,6 +334,29 @@ def test_attention_bf16(B, N, H, lens):
     assert err < 1.5e-2, err
 
 
+@pytest.mark.parametrize("R,D,Fi,ln_dtype", [(777, 384, 1536, torch.bfloat16), (16500, 384, 1536, torch.bfloat16),
+                                             (300, 256, 1024, torch.float32)])
+def test_fused_ffn_with_layernorm_epilogue(R, D, Fi, ln_dtype):
+    """ispk_ffn_bf16_ln: `out` is bit-identical to ispk_ffn_bf16's, and ln_out equals the LayerNorm kernel applied to it
+    (both two-pass fp32; only the reduction tree differs), including the row mask on ln_out."""
+    x = _bf(synth._normal(f"t/ffnln/x{R}", (R, D)))
+    w1, w2 = _bf(synth._normal(f"t/ffnln/w1{D}", (Fi, D), D ** -0.5)), _bf(synth._normal(f"t/ffnln/w2{D}", (D, Fi), Fi ** -0.5))
+    resid = synth._normal("t/ffnln/r", (R, D), 1.0, 0.3)
+    g, b = synth._normal("t/ffnln/g", (D,), 0.1, 1.0), synth._normal("t/ffnln/b", (D,), 0.1)
+    mask = torch.arange(R) % 7 != 3
+    d = lambda t: t.to(DEV)  # noqa: E731
+    w2p = runtime.ffn_pack_w2(d(w2))
+    base = runtime.ffn_fused(d(x), d(w1), w2p, resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT)
+    for ln_mask in (False, True):
+        out, ln = runtime.ffn_fused_ln(d(x), d(w1), w2p, d(g), d(b), resid=d(resid), mask=d(mask),
+                                       flags=runtime.EP_MASK_OUT, ln_mask=ln_mask, ln_dtype=ln_dtype)
+        assert torch.equal(out, base)
+        ref = runtime.layernorm(base, d(g), d(b), row_mask=d(mask) if ln_mask else None, out_dtype=ln_dtype)
+        assert ln.dtype == ln_dtype
+        tol = 2 ** -6 if ln_dtype == torch.bfloat16 else 2e-5     # bf16: one ulp at |value| <= 4
+        assert (ln.float() - ref.float()).abs().max().item() <= tol
+
+
 def test_attention_bf16_several_query_tiles_per_workgroup(monkeypatch):
     """With the whole key range resident in LDS a workgroup serves several 64-query tiles off one K/V fetch (the launcher
     does this by itself only for large batches; forced here).  Same values as one tile per workgroup, bit for bit."""

@@ -194,6 +194,30 @@ def test_bf16_fused_ffn_matches_two_gemm_path_at_full_size(gpu_model):
     assert (fused * ~mask[..., None]).abs().max() == 0
 
 
+def test_bf16_chained_layernorm_matches_separate_layernorm_at_full_size(gpu_model):
+    """Decoder stack at the benchmark shape with every LayerNorm after a feed-forward emitted by the fused FFN kernel's
+    epilogue (`Transformer.chain_layernorm`, opt-in) against the same stack with separate LayerNorm launches: the
+    same fp32 two-pass statistics on the same values, so only 1-ulp bf16 roundings of the normalised rows differ (an ulp
+    is 2^-7 at |value| in [1, 2)); through 6 layers they stay a fraction of an ulp in RMS."""
+    x = synth._normal("t/chain/x", (64, 512, 384)).to(DEV)
+    lens = torch.full((64,), 512, device=DEV)
+    lens[2::5] = 211
+    mask = torch.arange(512, device=DEV)[None] < lens[:, None]
+    dec = gpu_model.decoder
+    try:
+        dec.set_compute_dtype(torch.bfloat16)
+        plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+        dec.chain_layernorm = True
+        chained = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+    finally:
+        dec.chain_layernorm = False
+        dec.set_compute_dtype(torch.float32)
+    assert chained.dtype == torch.bfloat16
+    diff = (chained.float() - plain.float()).abs()
+    assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
+    assert (chained.float() * ~mask[..., None]).abs().max() == 0
+
+
 def test_config2_encoder_decoder_scope_fp32(gpu_model, state_dict):
     """BASELINE config 2 scope (TextEncoder + MelDecoder + to_mel on given activations, fp32) against the oracle."""
     tok = synth._normal("t/c2/tok", (4, 100, 384))

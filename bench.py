@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 from isp_tts_amd import runtime, synth  # noqa: E402
 from isp_tts_amd.acoustic import AcousticModel  # noqa: E402
 from isp_tts_amd.config import AcousticDims  # noqa: E402
-from isp_tts_amd.dist import all_gather_mel  # noqa: E402
+from isp_tts_amd.dist import MelGatherPipeline  # noqa: E402
 from isp_tts_amd.graph import GraphedForward  # noqa: E402
 
 # gfx950 peaks from /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters", dense, no sparsity)
@@ -191,13 +191,17 @@ def main():
         graphed = GraphedForward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
                                  d["flow_x0"], d["flow_t"])
 
+    gather = MelGatherPipeline(B, AcousticDims().mel_dim, M, dev) if use_dist else None
+
     def step():
         out = graphed.replay() if graphed is not None else eager_step()
-        if use_dist:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather)
-            all_gather_mel(out.mel, out.adaptor_output.dec_lengths, max_frames=M, max_batch=B)
+        if use_dist:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather), overlapped with the next step
+            gather.submit(out.mel, out.adaptor_output.dec_lengths)
         return out
 
     def fence():
+        if use_dist:
+            gather.wait()          # every submitted gather has completed
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
@@ -245,7 +249,7 @@ def main():
                                    "1 flow eval + MelDecoder + to_mel), fixed-length synthetic random-phoneme batch, "
                                    "random-init weights of the recipe architecture (23.2 M params)",
                        "batch_per_gpu": B, "global_batch": world * B, "text_len": L, "mel_len": M,
-                       "parallelism": f"dp{world} (utterances sharded, RCCL all-gather of mel)" if world > 1 else "single GPU",
+                       "parallelism": f"dp{world} (utterances sharded, RCCL all-gather of mel overlapped with the next step)" if world > 1 else "single GPU",
                        "device": name, "compute_units": cus,
                        "launch": "eager" if graphed is None else "HIP graph replay"},
             "model_TFLOPs": round(value * FLOP_PER_FRAME / 1e12, 2),

@@ -62,6 +62,53 @@ def all_gather_mel(mel: Tensor, dec_len: Tensor, group: Optional[dist.ProcessGro
     return out.view(world, max_batch, C, max_frames), lens.view(world, max_batch)
 
 
+class MelGatherPipeline:
+    """The same exchange for a stream of fixed-shape batches, overlapped with compute: batch i's gather runs on the
+    process group's communication stream while batch i+1 is being computed (xGMI and the CUs work at the same time; a
+    blocking all-gather of 8 x 10.5 MB per step would add its full ring time to every step).
+
+    `submit(mel, dec_len)` copies the step's outputs into one of two staging buffers (the model's output buffers are
+    overwritten by the next step, e.g. by a HIP-graph replay) and starts an asynchronous all-gather from it; it only
+    blocks when that staging buffer's previous gather (two batches back) is still in flight.  `wait()` drains the
+    pipeline and returns the latest (mel [world, B, C, M], dec_len [world, B])."""
+
+    def __init__(self, batch: int, channels: int, frames: int, device, dtype: torch.dtype = torch.float32,
+                 group: Optional[dist.ProcessGroup] = None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.shape = (batch, channels, frames)
+        self.stage = [torch.empty(self.shape, dtype=dtype, device=device) for _ in range(2)]
+        self.stage_len = [torch.empty((batch,), dtype=torch.int64, device=device) for _ in range(2)]
+        self.out = [torch.empty((self.world * batch, channels, frames), dtype=dtype, device=device) for _ in range(2)]
+        self.out_len = [torch.empty((self.world * batch,), dtype=torch.int64, device=device) for _ in range(2)]
+        self.work: list = [None, None]
+        self.count = 0
+
+    def submit(self, mel: Tensor, dec_len: Tensor) -> None:
+        assert tuple(mel.shape) == self.shape, "MelGatherPipeline is for fixed-shape batches (pad to the agreed shape)"
+        k = self.count & 1
+        if self.work[k] is not None:          # this staging pair is being read by the gather of two batches ago
+            for w in self.work[k]:
+                w.wait()
+        self.stage[k].copy_(mel)
+        self.stage_len[k].copy_(dec_len)
+        self.work[k] = [dist.all_gather_into_tensor(self.out[k], self.stage[k], group=self.group, async_op=True),
+                        dist.all_gather_into_tensor(self.out_len[k], self.stage_len[k], group=self.group, async_op=True)]
+        self.count += 1
+
+    def wait(self):
+        for ws in self.work:
+            if ws is not None:
+                for w in ws:
+                    w.wait()
+        self.work = [None, None]
+        if self.count == 0:
+            return None
+        k = (self.count - 1) & 1
+        b, c, m = self.shape
+        return self.out[k].view(self.world, b, c, m), self.out_len[k].view(self.world, b)
+
+
 def unshard(gathered: Tensor, lens: Tensor, shards: list[list[int]]):
     """Restores the original utterance order after `shard_by_cost` + `all_gather_mel`.
     -> (mel [N, C, max_frames], dec_len [N])."""

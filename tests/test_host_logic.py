@@ -132,6 +132,18 @@ def _rank_main(rank, world, port, q):
         # fixed-shape fast path (no MAX all-reduce), as bench.py uses it
         g2, l2 = idist.all_gather_mel(want[:2] + rank, mel_len[:2], max_frames=want.shape[2], max_batch=2)
         ok = ok and all(torch.equal(g2[r], want[:2] + r) for r in range(world))
+        # the overlapped pipeline bench.py uses for N > 1: the source buffer is overwritten right after each submit (as a
+        # HIP-graph replay would), three batches through two staging buffers, the last one is what wait() returns
+        pipe = idist.MelGatherPipeline(2, 80, want.shape[2], "cpu")
+        src, src_len = torch.empty_like(want[:2]), torch.empty(2, dtype=torch.int64)
+        for step in range(3):
+            src.copy_(want[:2] + rank + 10 * step)
+            src_len.copy_(mel_len[:2] + step)
+            pipe.submit(src, src_len)
+            src.fill_(-1.0)
+        g3, l3 = pipe.wait()
+        ok = ok and all(torch.equal(g3[r], want[:2] + r + 20) for r in range(world))
+        ok = ok and all(torch.equal(l3[r], mel_len[:2] + 2) for r in range(world))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

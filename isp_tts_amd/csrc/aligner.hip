@@ -40,6 +40,31 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
     put<OutT>(out + idx, v);
 }
 
+// Channel-first input ([B][C][T], time contiguous: the collator's mel layout): a 32 x 32 tile transposed through LDS so
+// that both the reads (along t) and the writes (along c) are coalesced; the element-wise kernel above reads such an
+// input with a stride of T floats between neighbouring threads.  grid (ceil((T+4)/32), ceil(C/32), B), block (32, 8).
+template <typename OutT>
+__global__ __launch_bounds__(256) void pad_rows_cf_kernel(const float* __restrict__ x, int64_t sb, int64_t sc,
+                                                          const int64_t* __restrict__ len, OutT* __restrict__ out, int T,
+                                                          int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x, ty = threadIdx.y, b = blockIdx.z;
+    const int tp0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    int n = (int)len[b];
+    n = n < T ? n : T;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, t = tp0 + tx - 2;
+        tile[ty + 8 * k][tx] = (c < C && t >= 0 && t < n) ? x[b * sb + c * sc + t] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int tp = tp0 + ty + 8 * k, c = c0 + tx;
+        if (tp < T + 4 && c < C) put<OutT>(out + ((int64_t)b * (T + 4) + tp) * C + c, tile[tx][ty + 8 * k]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ masked instance norm
 // grid (ceil(C/64), B), 1024 threads = 16 time lanes x 64 channels (256-B coalesced rows).  y: [B][T+4][C] conv output
 // (row r = b*(T+4) + t is frame t); out: next padded buffer, frame t at row t+2.  Two passes like the reference
@@ -330,6 +355,16 @@ extern "C" int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t s
     const int64_t total = (int64_t)B * (T + 4) * C;
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (stride_t == 1 && stride_c > 1 && B <= 65535) {   // channel-first: transposing tile kernel
+        dim3 gcf((T + 4 + 31) / 32, (C + 31) / 32, B), bcf(32, 8);
+        if (out_bf16)
+            hipLaunchKernelGGL(pad_rows_cf_kernel<uint16_t>, gcf, bcf, 0, s, x, stride_b, stride_c, len,
+                               static_cast<uint16_t*>(out), T, C);
+        else
+            hipLaunchKernelGGL(pad_rows_cf_kernel<float>, gcf, bcf, 0, s, x, stride_b, stride_c, len,
+                               static_cast<float*>(out), T, C);
+        return ispk_launch_status();
+    }
     if (out_bf16)
         hipLaunchKernelGGL(pad_rows_kernel<uint16_t>, grid, dim3(256), 0, s, x, stride_b, stride_t, stride_c, len,
                            static_cast<uint16_t*>(out), T, C, total);

@@ -381,6 +381,23 @@ def test_layernorm_bf16_output_and_cast():
 
 
 # ------------------------------------------------------------------------------------------------ aligner front-end
+@pytest.mark.parametrize("B,T,C", [(3, 203, 80), (2, 512, 384), (4, 33, 5)])
+@pytest.mark.parametrize("channel_first", [False, True])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pad_rows(B, T, C, channel_first, dtype):
+    """ispk_pad_rows_f32: masked, zero-padded channel-last [B, T+4, C] from [B,T,C] or channel-first [B,C,T] input (the
+    latter through the tile-transposing kernel) - exact (a copy, plus bf16 rounding)."""
+    x = synth._normal(f"t/pad/x{T}", (B, C, T) if channel_first else (B, T, C))
+    lens = torch.tensor([T, max(1, T // 3), 1, T - 1][:B])
+    out = runtime.pad_rows(x.to(DEV), lens.to(DEV), channel_first=channel_first, out_dtype=dtype).cpu()
+    xt = x.transpose(1, 2) if channel_first else x
+    ref = torch.zeros(B, T + 4, C)
+    for b in range(B):
+        ref[b, 2:2 + int(lens[b])] = xt[b, :int(lens[b])]
+    assert out.shape == (B, T + 4, C) and out.dtype == dtype
+    assert torch.equal(out.float(), ref.to(dtype).float())
+
+
 @pytest.mark.parametrize("B,M,L", [(2, 512, 100), (3, 203, 37), (2, 64, 9), (1, 700, 300)])
 def test_conv_attention_front_end_matches_oracle(state_dict, B, M, L):
     """Product ConvAttention (pad -> conv-as-GEMM -> masked instance norm -> fused scores) vs the oracle's

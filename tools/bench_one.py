@@ -20,7 +20,11 @@ klen = torch.full((64,), 512, dtype=torch.int64, device=dev)
 x6k = synth._normal("b/x6k", (6400, 1536)).to(dev).to(dt)
 r6k = synth._normal("b/r6k", (6400, 384)).to(dev)
 m6k = torch.ones(6400, dtype=torch.bool, device=dev)
+x6k384 = synth._normal("b/x6k384", (6400, 384)).to(dev).to(dt)
 cases = {
+    "small panel 6400x384->1536 gelu": (lambda: runtime.gemm(x6k384, w1, flags=runtime.EP_GELU), 2.0 * 6400 * 384 * 1536),
+    "small panel 6400x384->512": (lambda: runtime.gemm(x6k384, wqkv), 2.0 * 6400 * 384 * 512),
+    "small panel 6400x384->384 f32+resid": (lambda: runtime.gemm(x6k384, wo, resid=r6k, mask=m6k, flags=runtime.EP_MASK_ACC, out_dtype=torch.float32), 2.0 * 6400 * 384 * 384),
     "wide 6400x1536->384 f32+resid": (lambda: runtime.gemm(x6k, w2, resid=r6k, mask=m6k, flags=runtime.EP_MASK_OUT, out_dtype=torch.float32), 2.0 * 6400 * 384 * 1536),
     "attn B64 T512 H6": (lambda: runtime.alibi_mqa_attention(qkv, 6, slopes, klen), 256.0 * 64 * 512 * 512 * 6),
     "attn B64 T100 H6": (lambda: runtime.alibi_mqa_attention(qkv100, 6, slopes, None), 256.0 * 64 * 100 * 100 * 6),

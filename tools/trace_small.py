@@ -15,9 +15,11 @@ rec = []
 orig = runtime._launch
 want = sys.argv[1] if len(sys.argv) > 1 else "linear_small"
 def spy(label, flops, nbytes, fn, *args):
-    if want in label:
+    if want in label or (want == "gemm" and label == "gemm_bf16_kernel"):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(); orig(label, flops, nbytes, fn, *args); e1.record()
+        if label == "gemm_bf16_kernel":
+            label = f"gemm variant {runtime.lib().ispk_gemm_bf16_last_variant()}"
         rec.append((label, [a for a in args if isinstance(a, int) and 0 < a < 10**7], e0, e1))
     else:
         orig(label, flops, nbytes, fn, *args)

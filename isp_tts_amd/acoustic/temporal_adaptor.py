@@ -39,10 +39,11 @@ class TransformerTemporalModule(nn.Module, Constructor):
             self._cache = {"key": key, "w": w.detach().to(dtype).contiguous()}
         return self._cache["w"]
 
-    def forward(self, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None, *, key_len: Optional[Tensor] = None) -> Tensor:
+        """`key_len` (= mask.sum(1), when the caller already has the lengths) saves the reduction launch."""
         m2 = mask[..., 0] if mask is not None else None
         cdt = self.transformer.layers[0].attention.compute_dtype   # bf16 path: the output Linear is an MFMA GEMM too
-        out = self.transformer(x, mask=m2, out_dtype=cdt).out
+        out = self.transformer(x, mask=m2, out_dtype=cdt, key_len=key_len if m2 is not None else None).out
         flags = runtime.EP_MASK_OUT if m2 is not None else 0
         return runtime.gemm(out, self._weight(cdt), bias=self.linear_layer.bias, mask=m2, flags=flags,
                             out_dtype=torch.float32)
@@ -86,8 +87,9 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         return runtime.gemm(c, self._cond_weight(cdt), bias=self.transformer.project_emb.bias, out_dtype=torch.float32)
 
     def forward(self, x: Tensor, targets: Tensor, mask: Optional[Tensor] = None, *, noise: Optional[Tensor] = None,
-                time_steps: Optional[Tensor] = None):
+                time_steps: Optional[Tensor] = None, key_len: Optional[Tensor] = None):
         cond = x
+        have_mask = mask is not None
         if mask is None:
             mask = torch.ones(x.shape[:2], dtype=torch.bool, device=x.device)
         elif mask.ndim == 3:
@@ -100,7 +102,8 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         x_t = (1 - (1 - self.sigma) * tt) * x0 + tt * x1
         flow = x1 - (1 - self.sigma) * x0
         proj = self._project(x_t, self._cond_projection(cond))
-        out = self.transformer(None, mask=mask, adaptive_condition=time_emb, projected=proj).out
+        out = self.transformer(None, mask=mask, adaptive_condition=time_emb, projected=proj,
+                               key_len=key_len if have_mask else None).out
         m3 = mask[..., None].expand(-1, -1, self.output_dim)
         pred_flow = runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias) * m3
         loss = masked_mean(F.mse_loss(pred_flow, flow, reduction="none"), m3)
@@ -213,11 +216,11 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
             enc_len = enc_mask.sum(dim=1)
         targets = runtime.soft_average(alignment, pitch_target_dense, energy_target_dense, duration_target, enc_len)
         pitch_target, energy_target = targets[..., 1:2], targets[..., 2:3]
-        pred, losses = self.predictor(enc_out, targets, m3, noise=noise, time_steps=time_steps)
+        pred, losses = self.predictor(enc_out, targets, m3, noise=noise, time_steps=time_steps, key_len=enc_len)
         log_duration_pred = pred[..., 0]
         duration_pred = torch.clamp(torch.exp(log_duration_pred) - 1, min=0)
         features = torch.cat([pitch_target, energy_target], dim=-1)
-        enc_out = enc_out + self.embedding(features, mask=m3)
+        enc_out = enc_out + self.embedding(features, mask=m3, key_len=enc_len)
         enc_out, dec_lens = self.length_regulator(enc_out, duration_target, max_len=max_dec_len, alignment=alignment)
         return TemporalAdaptorOutput(enc_out=enc_out, log_duration=log_duration_pred, duration=duration_pred,
                                      dec_lengths=dec_lens, pitch=pred[..., 1], energy=pred[..., 2],

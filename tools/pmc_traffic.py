@@ -10,6 +10,7 @@ import collections
 import csv
 import glob
 import json
+import os
 import re
 import sys
 
@@ -28,7 +29,7 @@ def label_of(kernel_name: str):
 
 
 def per_kernel(d, counter):
-    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
+    f = max(glob.glob(f"{d}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)   # newest run
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Which Python lines launch the PyTorch (non-libispk) kernels of one benchmark-shape forward: torch.profiler with stacks."""
-import collections, os, sys, torch
+"""Lists every ATen op one benchmark-shape forward dispatches (the PyTorch "glue" between libispk launches) with the
+isp_tts_amd source line that issued it.  TorchDispatchMode, GPU box."""
+import collections, os, sys, traceback, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from torch.utils._python_dispatch import TorchDispatchMode
 from isp_tts_amd import synth
 from isp_tts_amd.acoustic.model import AcousticModel
 from isp_tts_amd.config import AcousticDims
@@ -16,17 +18,30 @@ def step():
         return model(d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"], flow_noise=d["flow_x0"],
                      flow_time=d["flow_t"])
 step(); step(); torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    step(); torch.cuda.synchronize()
-agg = collections.Counter(); cnt = collections.Counter()
-for ka in prof.key_averages(group_by_stack_n=12):
-    t = getattr(ka, "self_device_time_total", 0) or 0
-    if t <= 0:
-        continue
-    frames = [f for f in (ka.stack or []) if "isp_tts_amd" in f and "runtime.py" not in f]
-    where = frames[0].split("isp_tts_amd/")[-1] if frames else (ka.stack[0] if ka.stack else "?")
-    agg[(where, ka.key)] += t
-    cnt[(where, ka.key)] += ka.count
-for (where, name), t in agg.most_common(70):
-    print(f"{t:8.1f} us  x{cnt[(where, name)]:3d}  {name[:36]:36s} {where[:100]}")
+SKIP = ("aten.view", "aten.empty", "aten._unsafe_view", "aten.transpose", "aten.slice", "aten.select", "aten.unsqueeze",
+        "aten.expand", "aten.detach", "aten.alias", "aten.t.", "aten.permute", "aten.squeeze", "aten.reshape",
+        "aten.as_strided", "aten.is_", "aten.size", "aten.stride", "aten.lift_fresh", "aten._reshape_alias", "aten.split",
+        "aten.unbind", "aten.sym_", "aten.empty_like", "aten.new_empty")
+log = collections.Counter()
+class Spy(TorchDispatchMode):
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = str(func)
+        if not name.startswith(SKIP):
+            where = "?"
+            for fr in reversed(traceback.extract_stack()):
+                if "isp_tts_amd" in fr.filename and "runtime.py" not in fr.filename:
+                    where = f"{fr.filename.split('isp_tts_amd/')[-1]}:{fr.lineno}"
+                    break
+            else:
+                for fr in reversed(traceback.extract_stack()):
+                    if "runtime.py" in fr.filename:
+                        where = f"runtime.py:{fr.lineno}"
+                        break
+            log[(where, name)] += 1
+        return func(*args, **(kwargs or {}))
+with Spy():
+    step()
+torch.cuda.synchronize()
+for (where, name), n in sorted(log.items()):
+    print(f"{n:3d}  {name:40s} {where}")
+print("total dispatched (non-view) ops:", sum(log.values()))

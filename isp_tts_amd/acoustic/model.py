@@ -103,11 +103,18 @@ class AcousticModel(nn.Module, Constructor):
             enc_out=enc_out, enc_mask=enc_mask, max_dec_len=mel.size(2),
             duration_target=aligner_output.attn_hard_duration, alignment=aligner_output.attn_soft,
             pitch_target_dense=pitch, energy_target_dense=energy, noise=flow_noise, time_steps=flow_time,
-            enc_len=text_len)
+            enc_len=text_len, predictor_stream=side if q_proj is not None else None)
         dec_len = adaptor_output.dec_lengths
         dec_mask = get_mask_from_lengths(dec_len, adaptor_output.enc_out.shape[1])
         dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, key_len=dec_len, out_dtype=self.compute_dtype).out
         mel_out = self._to_mel(dec_out, dec_mask)
+        if q_proj is not None:
+            # join the flow-predictor branch (it ran beside the embedding stack and the decoder) before handing out its tensors
+            main.wait_stream(side)
+            for t in (adaptor_output.log_duration, adaptor_output.duration, adaptor_output.pitch, adaptor_output.energy,
+                      *(adaptor_output.losses or {}).values()):
+                if isinstance(t, Tensor):
+                    t.record_stream(main)
         return AcousticModelOutput(mel=mel_out, adaptor_output=adaptor_output, aligner_output=aligner_output)
 
     @torch.no_grad()

@@ -206,9 +206,16 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
     def forward(self, enc_out: Tensor, enc_mask: Tensor, max_dec_len: int, duration_target: Optional[Tensor] = None,
                 alignment: Optional[Tensor] = None, pitch_target_dense: Optional[Tensor] = None,
                 energy_target_dense: Optional[Tensor] = None, *, noise: Optional[Tensor] = None,
-                time_steps: Optional[Tensor] = None, enc_len: Optional[Tensor] = None) -> TemporalAdaptorOutput:
+                time_steps: Optional[Tensor] = None, enc_len: Optional[Tensor] = None,
+                predictor_stream=None) -> TemporalAdaptorOutput:
         """temporal_adaptor.py:238-312 (teacher-forced: the decoder input uses the TARGET pitch/energy, :284,:292).
-        The three flow targets (log1p duration, soft-averaged pitch and energy, :257-269) come from ONE kernel."""
+        The three flow targets (log1p duration, soft-averaged pitch and energy, :257-269) come from ONE kernel.
+
+        `predictor_stream`: in the teacher-forced forward the flow predictor's outputs (predicted duration / pitch /
+        energy, flow loss) feed nothing downstream - the decoder input is built from the TARGETS - so that whole branch
+        (a 2-layer AdaLN stack on 6,400 rows: small, latency-bound launches) can run on this second stream beside the
+        embedding stack, the length regulator and the decoder.  The CALLER joins the stream before using those outputs
+        (`AcousticModel.forward` does, just before returning)."""
         assert alignment is not None and duration_target is not None
         assert pitch_target_dense is not None and energy_target_dense is not None
         m3 = enc_mask[..., None]
@@ -216,9 +223,17 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
             enc_len = enc_mask.sum(dim=1)
         targets = runtime.soft_average(alignment, pitch_target_dense, energy_target_dense, duration_target, enc_len)
         pitch_target, energy_target = targets[..., 1:2], targets[..., 2:3]
-        pred, losses = self.predictor(enc_out, targets, m3, noise=noise, time_steps=time_steps, key_len=enc_len)
+        def predict():
+            pred_, losses_ = self.predictor(enc_out, targets, m3, noise=noise, time_steps=time_steps, key_len=enc_len)
+            return pred_, losses_, torch.clamp(torch.exp(pred_[..., 0]) - 1, min=0)
+
+        if predictor_stream is not None and enc_out.is_cuda:
+            predictor_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(predictor_stream):
+                pred, losses, duration_pred = predict()
+        else:
+            pred, losses, duration_pred = predict()
         log_duration_pred = pred[..., 0]
-        duration_pred = torch.clamp(torch.exp(log_duration_pred) - 1, min=0)
         features = torch.cat([pitch_target, energy_target], dim=-1)
         enc_out = enc_out + self.embedding(features, mask=m3, key_len=enc_len)
         enc_out, dec_lens = self.length_regulator(enc_out, duration_target, max_len=max_dec_len, alignment=alignment)

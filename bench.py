@@ -35,7 +35,7 @@ from isp_tts_amd import runtime, synth  # noqa: E402
 from isp_tts_amd.acoustic import AcousticModel  # noqa: E402
 from isp_tts_amd.config import AcousticDims  # noqa: E402
 from isp_tts_amd.dist import MelGatherPipeline  # noqa: E402
-from isp_tts_amd.graph import GraphedForward  # noqa: E402
+from isp_tts_amd.graph import GraphedForward, GraphedForwardLanes  # noqa: E402
 
 # gfx950 peaks from /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters", dense, no sparsity)
 PEAK = {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3, "mfma_bf16_TFs": 2500.0}
@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="batches in flight per GPU: consecutive steps alternate between this many HIP-graph instances on "
+                         "their own streams, so one batch's small text-side launches overlap another's decoder (1 = serial)")
     ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=5)
     return ap.parse_args()
@@ -187,15 +190,27 @@ def main():
                      flow_noise=d["flow_x0"], flow_time=d["flow_t"])
 
     graphed = None
+    lanes = None
     if not args.no_graph:   # the whole forward as one HIP graph: ~300 launches per step would otherwise be host-bound
-        graphed = GraphedForward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
-                                 d["flow_x0"], d["flow_t"])
+        # `--in-flight` graph instances (own static buffers, own stream): step k replays instance k % n, so consecutive
+        # batches overlap on the GPU - every step still runs the complete forward on its own batch of B utterances
+        lanes = GraphedForwardLanes(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
+                                    d["flow_x0"], d["flow_t"], lanes=args.in_flight)
+        graphed = lanes.lanes[0][0]
 
     gather = MelGatherPipeline(B, AcousticDims().mel_dim, M, dev) if use_dist else None
 
     def step():
-        out = graphed.replay() if graphed is not None else eager_step()
-        if use_dist:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather), overlapped with the next step
+        if lanes is not None:
+            g, stream = lanes.next_lane()
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                out = g.replay()
+                if use_dist:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather), overlapped too
+                    gather.submit(out.mel, out.adaptor_output.dec_lengths)
+            return out
+        out = eager_step()
+        if use_dist:
             gather.submit(out.mel, out.adaptor_output.dec_lengths)
         return out
 
@@ -251,7 +266,8 @@ def main():
                        "batch_per_gpu": B, "global_batch": world * B, "text_len": L, "mel_len": M,
                        "parallelism": f"dp{world} (utterances sharded, RCCL all-gather of mel overlapped with the next step)" if world > 1 else "single GPU",
                        "device": name, "compute_units": cus,
-                       "launch": "eager" if graphed is None else "HIP graph replay"},
+                       "launch": "eager" if graphed is None else "HIP graph replay",
+                       "batches_in_flight": len(lanes) if lanes is not None else 1},
             "model_TFLOPs": round(value * FLOP_PER_FRAME / 1e12, 2),
         }
         if prof is not None:

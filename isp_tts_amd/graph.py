@@ -50,3 +50,41 @@ class GraphedForward:
         for k, v in inputs.items():
             self.static[k].copy_(v)
         return self.replay()
+
+
+class GraphedForwardLanes:
+    """Several `GraphedForward` instances ("lanes": own static buffers, own stream) replayed round-robin, so consecutive
+    batches overlap on the GPU: while one batch is in its decoder (large, chip-filling launches) the next one runs its
+    text-side stacks, aligner and MAS (small, latency-bound launches that leave most CUs idle).  Every replay is a
+    complete forward on its own batch; only the latency of a single batch grows (about x 1.7 with two lanes) while
+    throughput rises by about 20 %.
+
+    HIP binds a stream to one of its few hardware queues at the stream's FIRST submission, round-robin.  The lanes'
+    streams are therefore used back to back at construction, before any other new stream (e.g. RCCL's) submits; with
+    another stream's first submission in between, two lanes were observed to share a queue and never overlap."""
+
+    def __init__(self, model, *inputs, lanes: int = 2, **kw):
+        dev = inputs[0].device
+        self.lanes = [(GraphedForward(model, *inputs, **kw), torch.cuda.Stream(device=dev)) for _ in range(max(1, lanes))]
+        for _, stream in self.lanes:
+            with torch.cuda.stream(stream):
+                torch.zeros(1, device=dev)
+        torch.cuda.synchronize()
+        self.count = 0
+
+    def __len__(self) -> int:
+        return len(self.lanes)
+
+    def next_lane(self):
+        """(GraphedForward, stream) of the next replay; the caller copies inputs / consumes outputs on that stream."""
+        lane = self.lanes[self.count % len(self.lanes)]
+        self.count += 1
+        return lane
+
+    def replay(self):
+        """Replays the next lane on its stream (ordered after the caller's current stream) and returns its outputs; they
+        are complete once that stream - or `torch.cuda.synchronize()` - has been waited for."""
+        g, stream = self.next_lane()
+        stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream):
+            return g.replay()

@@ -103,6 +103,11 @@ def set_profiler(p: Optional[LaunchProfiler]) -> None:
     _profiler = p
 
 
+# epilogue instances launch_panel() in csrc/gemm.hip compiles: qkv (bf16 out), FFN1 (bf16 out + GELU), out-projection
+# (mask-acc + residual), to_mel (ROWS_T + mask-out + bias)
+_PANEL_EPS = (64, 65, 4 | (1 << 17), 256 | 8 | (1 << 16))
+
+
 def _launch(label: str, flops: float, nbytes: float, fn, *args) -> None:
     if _profiler is None:
         _check(fn(*args), label)
@@ -114,8 +119,12 @@ def _launch(label: str, flops: float, nbytes: float, fn, *args) -> None:
     _check(rc, label)
     if label == "gemm_bf16_kernel":   # resolve to the instance the library actually dispatched
         v = lib().ispk_gemm_bf16_last_variant()
-        label = {1: f"gemm_bf16_panel_kernel<{v % 1000}>", 2: f"gemm_bf16_wide_kernel<{(v % 1000) // 10},{v % 10}>",
-                 3: f"gemm_bf16_kernel<{(v % 1000) // 10},{v % 10}>"}.get(v // 1000, label)
+        if v // 1000 == 1:   # panel kernel <KC, EP>: EP = the compile-time epilogue instance (-1: the generic one)
+            ep = (args[13] & 0xffff) | ((1 << 16) if args[6] else 0) | ((1 << 17) if args[7] else 0)
+            label = f"gemm_bf16_panel_kernel<{v % 1000},{ep if ep in _PANEL_EPS else -1}>"
+        else:
+            label = {2: f"gemm_bf16_wide_kernel<{(v % 1000) // 10},{v % 10}>",
+                     3: f"gemm_bf16_kernel<{(v % 1000) // 10},{v % 10}>"}.get(v // 1000, label)
     _profiler.records.append((label, flops, nbytes, e0, e1))
 
 

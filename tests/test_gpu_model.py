@@ -172,6 +172,33 @@ def test_bf16_forward_error_vs_reference(gpu_model):
     assert _maxdiff(out.mel, g["mel"]) < MEL_TOL
 
 
+def test_graph_lanes_reproduce_the_eager_forward(gpu_model):
+    """HIP-graph replay on two alternating lanes (isp_tts_amd/graph.py:GraphedForwardLanes, what bench.py times) gives
+    bit for bit the eager forward - including the side-stream branches, which become graph edges - and still does after
+    new inputs are copied into a lane's static buffers; MAS durations equal the reference golden."""
+    from isp_tts_amd.graph import GraphedForwardLanes
+    g = golden("forward.npz")
+    inp = {k: v.to(DEV) for k, v in _forward_inputs().items()}
+    eager = gpu_model(**inp)
+    torch.cuda.synchronize()
+    lanes = GraphedForwardLanes(gpu_model, inp["text"], inp["text_len"], inp["mel"], inp["mel_len"], inp["pitch"],
+                                inp["energy"], inp["flow_noise"], inp["flow_time"], lanes=2)
+    outs = [lanes.replay() for _ in range(4)]
+    torch.cuda.synchronize()
+    for out in outs[-2:]:
+        assert torch.equal(out.mel, eager.mel)
+        assert torch.equal(out.adaptor_output.duration, eager.adaptor_output.duration)
+        assert torch.equal(out.adaptor_output.losses["flow_loss"], eager.adaptor_output.losses["flow_loss"])
+        assert np.array_equal(out.adaptor_output.dec_lengths.cpu().numpy(), g["dec_lengths"])
+    # new inputs into lane 0's static buffers: utterance order swapped -> outputs swapped
+    g0, s0 = lanes.lanes[0]
+    with torch.cuda.stream(s0):
+        swapped = g0(**{k: inp[k].flip(0) for k in ("text", "text_len", "mel", "mel_len", "pitch", "energy", "flow_noise",
+                                                     "flow_time")})
+    torch.cuda.synchronize()
+    assert _maxdiff(swapped.mel.flip(0), eager.mel) < 1e-5
+
+
 def test_bf16_fused_ffn_matches_two_gemm_path_at_full_size(gpu_model):
     """Decoder stack at the benchmark shape (B=64 x 512 frames -> 32,768 rows, where FeedForward takes the fused
     ispk_ffn_bf16 kernel) against the same stack forced onto the two-GEMM path."""

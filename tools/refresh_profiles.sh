@@ -9,7 +9,8 @@ cd "$R"
 timeout -k 10 400 python3 bench.py > "$O/bench.json" 2> "$O/bench.err"
 echo "bench done"
 cd /tmp && export TMPDIR=/tmp
-B="$R/bench.py --no-kernel-events --no-cpu-baseline --no-f32-line"
+# per-kernel evidence is taken with ONE batch in flight (two overlapping graphs stretch each other's kernels in a trace)
+B="$R/bench.py --no-kernel-events --no-cpu-baseline --no-f32-line --in-flight 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_bf16" -- python3 $B --steps 10 --warmup 2 > "$O/trace_bf16.log" 2>&1
 echo "trace bf16 done"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_f32" -- python3 $B --steps 10 --warmup 2 --dtype f32 > "$O/trace_f32.log" 2>&1

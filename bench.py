@@ -275,6 +275,17 @@ def main():
             line["roofline"]["timing"] = ("HIP events around every launch of the timed region" if graphed is None else
                                           f"HIP events around every launch of {prof_steps} eager passes of the same step "
                                           "(the timed region replays them as one HIP graph)")
+        if world == 1 and lanes is not None and len(lanes) > 1:
+            # for transparency: the same step with ONE batch in flight (lane 0 replayed back to back) - the latency-oriented
+            # figure; `value` above is the throughput with len(lanes) batches in flight
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(10):
+                graphed.replay()
+            torch.cuda.synchronize()
+            ms1 = (time.perf_counter() - ts) / 10 * 1e3
+            line["one_batch_in_flight"] = {"value": round(B * M / ms1 * 1e3, 1), "unit": "mel-frames/s",
+                                           "ms_per_step": round(ms1, 3), "steps": 10}
         if world == 1 and not args.no_f32_line and args.dtype == "bf16":
             # the same step on the fp32 parity path (exact-fp32 MFMA; the path that holds mel L-inf < 1e-4), 5 replays
             model.set_compute_dtype(torch.float32)

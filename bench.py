@@ -267,7 +267,8 @@ def main():
                        "parallelism": f"dp{world} (utterances sharded, RCCL all-gather of mel overlapped with the next step)" if world > 1 else "single GPU",
                        "device": name, "compute_units": cus,
                        "launch": "eager" if graphed is None else "HIP graph replay",
-                       "batches_in_flight": len(lanes) if lanes is not None else 1},
+                       "batches_in_flight": len(lanes) if lanes is not None else 1,
+                       "lane_overlap_gain": None if lanes is None or lanes.overlap is None else round(lanes.overlap, 3)},
             "model_TFLOPs": round(value * FLOP_PER_FRAME / 1e12, 2),
         }
         if prof is not None:

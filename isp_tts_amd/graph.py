@@ -63,14 +63,39 @@ class GraphedForwardLanes:
     streams are therefore used back to back at construction, before any other new stream (e.g. RCCL's) submits; with
     another stream's first submission in between, two lanes were observed to share a queue and never overlap."""
 
-    def __init__(self, model, *inputs, lanes: int = 2, **kw):
-        dev = inputs[0].device
-        self.lanes = [(GraphedForward(model, *inputs, **kw), torch.cuda.Stream(device=dev)) for _ in range(max(1, lanes))]
+    def __init__(self, model, *inputs, lanes: int = 2, calibrate: bool = True, **kw):
+        self.dev = inputs[0].device
+        self.lanes = [(GraphedForward(model, *inputs, **kw), None) for _ in range(max(1, lanes))]
+        self.count = 0
+        self._new_streams()
+        # Which hardware queue a stream lands on cannot be chosen; so measure: alternating lanes must beat one lane
+        # replayed back to back.  If it does not (the lanes share a queue), take fresh streams and try again.
+        self.overlap = None
+        if calibrate and len(self.lanes) > 1:
+            for _ in range(6):
+                one, alt = self._time(False), self._time(True)
+                self.overlap = one / alt
+                if alt < 0.93 * one:
+                    break
+                self._new_streams()
+
+    def _new_streams(self) -> None:
+        self.lanes = [(g, torch.cuda.Stream(device=self.dev)) for g, _ in self.lanes]
         for _, stream in self.lanes:
             with torch.cuda.stream(stream):
-                torch.zeros(1, device=dev)
+                torch.zeros(1, device=self.dev)
         torch.cuda.synchronize()
-        self.count = 0
+
+    def _time(self, alternate: bool, n: int = 6) -> float:
+        import time
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(n):
+            g, stream = self.lanes[k % len(self.lanes) if alternate else 0]
+            with torch.cuda.stream(stream):
+                g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
 
     def __len__(self) -> int:
         return len(self.lanes)

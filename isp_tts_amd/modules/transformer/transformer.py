@@ -12,6 +12,8 @@ The residual stream (x, x1, y) is always fp32; with compute_dtype = bf16 the GEM
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import NamedTuple, Optional, Union
 
@@ -233,7 +235,9 @@ class Transformer(nn.Module, Constructor):
         ada = self._ada_all(adaptive_condition) if (self.adaptive_norm and adaptive_condition is not None) else None
         # bf16, plain LayerNorm: a layer's fused feed-forward kernel also emits the LayerNorm that consumes its output
         # (the next layer's attention_norm, or the final norm) when the batch is large enough for that kernel
-        chain = self.chain_layernorm and not self.adaptive_norm and self.layers[0].attention.compute_dtype == torch.bfloat16
+        # (ISPK_CHAIN_LN=1: experiments only - measured neutral with one and with two batches in flight)
+        chain = ((self.chain_layernorm or os.environ.get("ISPK_CHAIN_LN") == "1") and not self.adaptive_norm
+                 and self.layers[0].attention.compute_dtype == torch.bfloat16)
         cdt = self.layers[0].attention.compute_dtype
         normed = None
         for li, layer in enumerate(self.layers):

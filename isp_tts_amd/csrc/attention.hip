@@ -216,16 +216,14 @@ namespace {
 //   * Q: 4 fragments of 8 bf16 per lane (lane half h owns head dims 16ks + 8h .. +7);
 //   * the Pᵀ accumulator (fp32, register r = key (r&3) + 8(r>>2) + 4h) is packed pairwise to bf16 and used directly as
 //     the B operand of Oᵀ += Vᵀ·Pᵀ: registers 8s..8s+7 form k-step s, whose element j is key 16s + 8(j>>2) + 4h + (j&3)
-//     (guide §3 "An accumulator tile as the next MFMA's operand").  The A operand must present V in that same key order,
-//     V stays ROW-major in LDS ([key][d], staged with plain 16-byte stores like K) and is read with the transposing
-//     ds_read_b64_tr_b16 (guide T10): per 16-lane group a 4-key x 16-dim block comes back with one dim per lane and
-//     its 4 consecutive keys packed in 8 bytes - two such reads are one A fragment.  Rows are padded to 192 bytes:
-//     the 32 lanes of a half then touch every one of the 64 banks exactly once;
-//   * exp() runs as v_exp_f32 on log2-domain scores: s*log2(e)/8 - slope*log2(e)*|i-j| in one FMA.
-// Per 32x32 (key x query) block a wave issues 8 MFMAs (256 cycles) but ~16 exp + ~130 VALU ops, so this kernel is
-// VALU-bound, not MFMA-bound; 3 waves per SIMD overlap one wave's softmax with another's MFMAs.
-constexpr int kLdh = 72;  // padded row of the bf16 K tile (64 + 8 elements = 144 B)
-constexpr int kLdv = 96;  // padded row of the bf16 V tile (192 B, see above)
+//     (guide §3 "An accumulator tile as the next MFMA's operand").  The A operand must present V in that same key order:
+//     V stays ROW-major in LDS ([key][d]) and is read with the transposing ds_read_b64_tr_b16 (guide T10): per 16-lane
+//     group a 4-key x 16-dim block comes back with one dim per lane and its 4 consecutive keys packed in 8 bytes - two
+//     such reads are one A fragment (layout and swizzle: see the staging comment above the kernel);
+//   * exp() runs as v_exp_f32 on log2-domain scores; bias and reference maximum ride in the score MFMA's accumulator
+//     init (see the softmax comment in the kernel).
+// Per 32x32 (key x query) block a wave issues 8 MFMAs (256 cycles) and ~100 VALU instructions incl. 16 v_exp_f32: the
+// kernel is VALU-issue-bound, not MFMA-bound; 3 waves per SIMD overlap one wave's softmax with another's MFMAs.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <int OFF>
 __device__ __forceinline__ void lds_read_tr16_b64(u32x2& dst, uint32_t lds_byte_addr) {

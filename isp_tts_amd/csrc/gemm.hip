@@ -764,11 +764,11 @@ bool vec_epilogue_ok(const GemmParams& p) {
 // The generic tile loop above is latency-bound here: with K = 384 a 128x128 tile has six dependent
 // load -> barrier -> compute steps and then a scalar epilogue.  This kernel is built around the shape instead:
 //   * a wave owns 32 activation rows and keeps them, for the FULL K, as MFMA operand fragments in registers
-//     (K/16 fragments of 8 bf16: 96 VGPRs at K = 384), loaded by ONE burst of K/16 independent 16-B loads per lane —
-//     the activation matrix is read exactly once from HBM with all of a wave's loads in flight together;
-//   * weights stream through LDS as [64 out-features][K] tiles (50 KB, conflict-free padded rows), the next tile
-//     prefetched into registers while the current one feeds the MFMAs, so a step is 2 x K/16 MFMAs per wave with one
-//     ds_read_b128 per MFMA;
+//     (K/16 fragments of 8 bf16: 96 VGPRs at K = 384), fetched with coalesced 16-byte loads and re-shaped through a
+//     wave-private LDS patch (see the prologue) — the activation matrix is read once per N-split from HBM / L2;
+//   * weights stream through LDS as [64 out-features][K] tiles (50 KB, conflict-free padded rows) in two 32-row halves,
+//     the next half prefetched into registers ONE load per second MFMA gap while the current one feeds the MFMAs, so a
+//     step is 2 x K/16 MFMAs per wave with one ds_read_b128 per MFMA;
 //   * the tile is computed TRANSPOSED (D = W_tile · Xᵀ): the MFMA C/D fragment then has the activation row on the lane
 //     and 4 consecutive output features in consecutive registers, so bias / residual / output are 8- or 16-byte
 //     vector accesses (4 store instructions per 32x32 tile instead of 16 scalar ones);

@@ -231,6 +231,19 @@ int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const 
                               const int64_t* text_len, float* feats, int32_t B, int32_t M, int32_t L,
                               ispk_stream_t stream);
 
+/* Flow-matching algebra of the adaptor's predictor, FlowTransformerTemporalModule.forward (temporal_adaptor.py:120-147): [B][L][C]
+ * fp32 tensors (C = 3 flow channels), t [B].
+ * ispk_flow_mix_f32     x_t = (1 - (1 - sigma) t_b) x0 + t_b x1 ;  flow = x1 - (1 - sigma) x0      (:123-126; each operation
+ *                       rounded once, in the reference's order)
+ * ispk_flow_finish_f32  pf = pred_raw * mask ;  pred = (x0 + pf) * mask (:145) ;  duration = max(exp(pred[..., 0]) - 1, 0)
+ *                       (the adaptor's duration estimate, :221 of this repo's mirror / temporal_adaptor.py:276) ;
+ *                       loss_ratio[b] = sum over valid (l, c) of (pf - flow)^2 / max(C * valid_l, 1e-5): masked_mean of the
+ *                       MSE (:146, utils/functions.py:44-58) before its final mean over the batch.  mask uint8 [B][L]. */
+int32_t ispk_flow_mix_f32(const float* x0, const float* x1, const float* t, float sigma, float* x_t, float* flow, int32_t B,
+                          int32_t L, int32_t C, ispk_stream_t stream);
+int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow, const float* x0, const uint8_t* mask, float* pred,
+                             float* duration, float* loss_ratio, int32_t B, int32_t L, int32_t C, ispk_stream_t stream);
+
 /* fp32 -> bf16 conversion (round-to-nearest-even) of a [rows][cols] matrix; used to stage weights/activations. */
 int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int32_t rows, int32_t cols,
                            ispk_stream_t stream);

@@ -98,16 +98,15 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         x0 = torch.randn_like(x1) if noise is None else noise.to(x1)
         t = torch.rand((x1.shape[0],), dtype=x1.dtype, device=x1.device) if time_steps is None else time_steps.to(x1)
         time_emb = self.time_embedding(t)
-        tt = t[:, None, None]
-        x_t = (1 - (1 - self.sigma) * tt) * x0 + tt * x1
-        flow = x1 - (1 - self.sigma) * x0
+        x_t, flow = runtime.flow_mix(x0, x1, t, self.sigma)                     # :123-126, one launch
         proj = self._project(x_t, self._cond_projection(cond))
         out = self.transformer(None, mask=mask, adaptive_condition=time_emb, projected=proj,
                                key_len=key_len if have_mask else None).out
-        m3 = mask[..., None].expand(-1, -1, self.output_dim)
-        pred_flow = runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias) * m3
-        loss = masked_mean(F.mse_loss(pred_flow, flow, reduction="none"), m3)
-        return (x0 + pred_flow) * m3, {"flow_loss": loss}
+        raw = runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias)
+        # pred_flow = raw * m3 ; loss = masked_mean(mse(pred_flow, flow), m3) ; pred = (x0 + pred_flow) * m3 ;
+        # duration estimate = clamp(exp(pred[..., 0]) - 1, 0): one launch + the mean over the batch
+        pred, self._duration_estimate, ratio = runtime.flow_finish(raw, flow, x0, mask)
+        return pred, {"flow_loss": ratio.mean()}
 
     def euler_grid(self, steps: int, step_factor: float, device) -> Tensor:
         """temporal_adaptor.py:150-156 (steps=4, factor .75 -> [0, .3657, .6400, .8457, 1])."""
@@ -225,7 +224,7 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
         pitch_target, energy_target = targets[..., 1:2], targets[..., 2:3]
         def predict():
             pred_, losses_ = self.predictor(enc_out, targets, m3, noise=noise, time_steps=time_steps, key_len=enc_len)
-            return pred_, losses_, torch.clamp(torch.exp(pred_[..., 0]) - 1, min=0)
+            return pred_, losses_, self.predictor._duration_estimate   # = clamp(exp(pred[..., 0]) - 1, min=0)
 
         if predictor_stream is not None and enc_out.is_cuda:
             predictor_stream.wait_stream(torch.cuda.current_stream())

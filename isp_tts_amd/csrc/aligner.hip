@@ -344,6 +344,61 @@ __global__ __launch_bounds__(256) void soft_average_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ flow-matching algebra
+// (temporal_adaptor.py:120-147 of the reference; [B][L][C] tensors with C = 3: a dozen PyTorch element-wise launches each.)
+// flow_mix:  x_t = (1 - (1 - sigma) t_b) x0 + t_b x1 ;  flow = x1 - (1 - sigma) x0      one rounding per operation, in the
+//            reference's order (no FMA contraction), s = float(1 - sigma) as PyTorch wraps the Python scalar
+__global__ __launch_bounds__(256) void flow_mix_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                       const float* __restrict__ t, float s, float* __restrict__ xt,
+                                                       float* __restrict__ flow, int per_batch, int64_t total) {
+#pragma clang fp contract(off)   // HIP's __fmul_rn / __fadd_rn are plain operators and hipcc contracts them into FMAs by default
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float tb = t[i / per_batch], a = x0[i], b = x1[i];
+    const float w0 = 1.0f - s * tb;
+    const float p0 = w0 * a, p1 = tb * b;
+    xt[i] = p0 + p1;
+    const float sa = s * a;
+    flow[i] = b - sa;
+}
+
+// flow_finish (one workgroup per utterance):  pf = raw * m ;  pred = (x0 + pf) * m ;  dur = max(exp(pred[..., 0]) - 1, 0) ;
+//            ratio[b] = sum_{valid l, c} (pf - flow)^2 / max(C * #valid, 1e-5)     (utils.masked_mean before its .mean())
+__global__ __launch_bounds__(256) void flow_finish_kernel(const float* __restrict__ raw, const float* __restrict__ flow,
+                                                          const float* __restrict__ x0, const uint8_t* __restrict__ mask,
+                                                          float* __restrict__ pred, float* __restrict__ dur,
+                                                          float* __restrict__ ratio, int L, int C) {
+    __shared__ float red[2][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float num = 0.f, den = 0.f;
+    for (int e = tid; e < L * C; e += 256) {
+        const int l = e / C, c = e - l * C;
+        const int64_t i = (int64_t)b * L * C + e;
+        const bool m = mask[(int64_t)b * L + l] != 0;
+        const float pf = m ? raw[i] : 0.f;
+        const float pr = m ? x0[i] + pf : 0.f;
+        pred[i] = pr;
+        if (c == 0) dur[(int64_t)b * L + l] = fmaxf(expf(pr) - 1.0f, 0.f);
+        if (m) {
+            const float d = pf - flow[i];
+            num += d * d;
+            den += 1.0f;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        num += __shfl_xor(num, off, 64);
+        den += __shfl_xor(den, off, 64);
+    }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = num; red[1][tid >> 6] = den; }
+    __syncthreads();
+    if (tid == 0) {
+        const float n = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), d = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        ratio[b] = n / fmaxf(d, 1e-5f);
+    }
+}
+
 }  // namespace
 
 extern "C" int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_c,
@@ -435,5 +490,28 @@ extern "C" int32_t ispk_soft_average_f32(const float* attn_soft, const float* pi
     if (B == 0) return 0;
     hipLaunchKernelGGL(soft_average_kernel, dim3((L + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        attn_soft, pitch, energy, duration, text_len, feats, M, L);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_flow_mix_f32(const float* x0, const float* x1, const float* t, float sigma, float* x_t, float* flow,
+                                     int32_t B, int32_t L, int32_t C, ispk_stream_t stream) {
+    ISPK_REQUIRE(x0 && x1 && t && x_t && flow, ISPK_E_NULL, "flow_mix: null pointer");
+    ISPK_REQUIRE(B >= 0 && L >= 1 && C >= 1, ISPK_E_SHAPE, "flow_mix: bad shape B=%d L=%d C=%d", B, L, C);
+    if (B == 0) return 0;
+    const int64_t total = (int64_t)B * L * C;
+    const float s = (float)(1.0 - (double)sigma);
+    hipLaunchKernelGGL(flow_mix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x0, x1, t, s, x_t, flow, L * C, total);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow, const float* x0, const uint8_t* mask,
+                                        float* pred, float* duration, float* loss_ratio, int32_t B, int32_t L, int32_t C,
+                                        ispk_stream_t stream) {
+    ISPK_REQUIRE(pred_raw && flow && x0 && mask && pred && duration && loss_ratio, ISPK_E_NULL, "flow_finish: null pointer");
+    ISPK_REQUIRE(B >= 0 && L >= 1 && C >= 1 && B <= 65535, ISPK_E_SHAPE, "flow_finish: bad shape B=%d L=%d C=%d", B, L, C);
+    if (B == 0) return 0;
+    hipLaunchKernelGGL(flow_finish_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred_raw, flow, x0,
+                       mask, pred, duration, loss_ratio, L, C);
     return ispk_launch_status();
 }

@@ -43,6 +43,8 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_cast_f32_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
+    "ispk_flow_mix_f32": [_P, _P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_flow_finish_f32": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F32, _P],
     "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
@@ -510,6 +512,31 @@ def soft_average(attn_soft: Tensor, pitch: Tensor, energy: Tensor, duration: Ten
             pitch.contiguous().data_ptr(), energy.contiguous().data_ptr(), duration.to(torch.int64).contiguous().data_ptr(),
             text_len.to(torch.int64).contiguous().data_ptr(), feats.data_ptr(), B, M, L, _stream())
     return feats
+
+
+def flow_mix(x0: Tensor, x1: Tensor, t: Tensor, sigma: float):
+    """ispk_flow_mix_f32 -> (x_t, flow), both [B, L, C] fp32."""
+    _dev(x0, x1, t)
+    B, L, C = x1.shape
+    x0c, x1c, tc = x0.float().contiguous(), x1.float().contiguous(), t.float().contiguous()
+    xt, flow = torch.empty_like(x1c), torch.empty_like(x1c)
+    _launch("flow_mix_kernel", 0.0, 16.0 * B * L * C, lib().ispk_flow_mix_f32, x0c.data_ptr(), x1c.data_ptr(), tc.data_ptr(),
+            float(sigma), xt.data_ptr(), flow.data_ptr(), B, L, C, _stream())
+    return xt, flow
+
+
+def flow_finish(pred_raw: Tensor, flow: Tensor, x0: Tensor, mask: Tensor):
+    """ispk_flow_finish_f32 -> (pred [B,L,C], duration [B,L], loss_ratio [B])."""
+    _dev(pred_raw, flow, x0, mask)
+    B, L, C = pred_raw.shape
+    assert mask.dtype == torch.bool and mask.shape == (B, L)
+    pr, fl, x0c, mk = pred_raw.float().contiguous(), flow.contiguous(), x0.float().contiguous(), mask.contiguous()
+    pred = torch.empty_like(pr)
+    dur = torch.empty((B, L), dtype=torch.float32, device=pr.device)
+    ratio = torch.empty((B,), dtype=torch.float32, device=pr.device)
+    _launch("flow_finish_kernel", 0.0, 20.0 * B * L * C, lib().ispk_flow_finish_f32, pr.data_ptr(), fl.data_ptr(),
+            x0c.data_ptr(), mk.data_ptr(), pred.data_ptr(), dur.data_ptr(), ratio.data_ptr(), B, L, C, _stream())
+    return pred, dur, ratio
 
 
 def cast_bf16(x: Tensor) -> Tensor:

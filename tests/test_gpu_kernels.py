@@ -381,6 +381,31 @@ def test_layernorm_bf16_output_and_cast():
 
 
 # ------------------------------------------------------------------------------------------------ aligner front-end
+def test_flow_matching_algebra_kernels():
+    """ispk_flow_mix_f32 / ispk_flow_finish_f32 against the PyTorch expressions of the reference's
+    FlowTransformerTemporalModule.forward (temporal_adaptor.py:120-147) and utils.masked_mean: the mix is bit-exact (same
+    operations, one rounding each), the loss agrees to fp32 summation-order noise."""
+    from isp_tts_amd.utils import masked_mean
+    B, L, C, sigma = 5, 37, 3, 1e-5
+    x0, x1 = synth._normal("t/flow/x0", (B, L, C)), synth._normal("t/flow/x1", (B, L, C), 2.0, 0.3)
+    t = synth._normal("t/flow/t", (B,)).abs().clamp(max=1.0)
+    raw = synth._normal("t/flow/raw", (B, L, C))
+    mask = torch.arange(L)[None] < torch.tensor([L, 1, 20, L - 1, 7])[:, None]
+    tt = t[:, None, None]
+    xt_ref = (1 - (1 - sigma) * tt) * x0 + tt * x1
+    flow_ref = x1 - (1 - sigma) * x0
+    xt, flow = runtime.flow_mix(x0.to(DEV), x1.to(DEV), t.to(DEV), sigma)
+    assert torch.equal(xt.cpu(), xt_ref) and torch.equal(flow.cpu(), flow_ref)
+    m3 = mask[..., None].expand(-1, -1, C)
+    pf = raw * m3
+    pred_ref = (x0 + pf) * m3
+    loss_ref = masked_mean(F.mse_loss(pf, flow_ref, reduction="none"), m3)
+    pred, dur, ratio = runtime.flow_finish(raw.to(DEV), flow, x0.to(DEV), mask.to(DEV))
+    assert torch.equal(pred.cpu(), pred_ref)
+    assert (dur.cpu() - torch.clamp(torch.exp(pred_ref[..., 0]) - 1, min=0)).abs().max() < 1e-5
+    assert abs(float(ratio.mean()) - float(loss_ref)) < 1e-5 * max(1.0, float(loss_ref))
+
+
 @pytest.mark.parametrize("B,T,C", [(3, 203, 80), (2, 512, 384), (4, 33, 5)])
 @pytest.mark.parametrize("channel_first", [False, True])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

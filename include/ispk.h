@@ -150,12 +150,25 @@ int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_
  * Replaces: the block above plus normalization.py:20-27 as applied by the NEXT layer (transformer.py:79) or by the
  * stack's final norm (:205-206): the separate LayerNorm launch and its re-read of the residual stream disappear.
  * W2 must be the packed image (ispk_ffn_pack_w2_bf16); no first-Linear bias.  ln_flags: bit 0 = multiply ln_out by the
- * row mask, bit 1 = ln_out is bf16 (else fp32); ln_ld: leading stride of ln_out. */
+ * row mask, bit 1 = ln_out is bf16 (else fp32); ln_ld: leading stride of ln_out.
+ * bit 2 = statistics only: ln_out is float [rows][2] = (mean_i, rstd_i), ln_gamma / ln_beta / ln_ld unused - the
+ * consumer applies the LayerNorm while it stages its operand (ispk_gemm_bf16_lnin). */
 int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed,
                          const float* bias2, const float* resid, int64_t ldr, const uint8_t* mask, float* out, int64_t ldo,
                          int32_t rows, int32_t dim, int32_t inner, uint32_t flags, const float* ln_gamma,
                          const float* ln_beta, float ln_eps, void* ln_out, int64_t ln_ld, uint32_t ln_flags,
                          ispk_stream_t stream);
+
+/* Linear whose input is LayerNorm(x), with the row statistics supplied by the kernel that produced x:
+ *   C[i][n] = epilogue( sum_k bf16( (x[i][k] - mean_i) * rstd_i * ln_gamma[k] + ln_beta[k] ) * W[n][k] )
+ * Replaces: normalization.py:20-27 + the Linear that follows it (transformer.py:79-80, attention.py:63-64: attention_norm
+ * -> to_q / to_kv) on the bf16 path - the separate LayerNorm launch, its re-read of the fp32 residual stream and the
+ * bf16 copy it writes disappear.  x fp32 [M][K] (the residual stream), row_stats float [M][2] = (mean, rstd) from
+ * ispk_ffn_bf16_ln(ln_flags bit 2); K 256 or 384; flags / bias / resid / mask / C as ispk_gemm_bf16 (row-major outputs). */
+int32_t ispk_gemm_bf16_lnin(const float* x, int64_t ldx, const float* row_stats, const float* ln_gamma, const float* ln_beta,
+                            const uint16_t* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* resid,
+                            int64_t ldr, const uint8_t* mask, int32_t M, int32_t N, int32_t K, uint32_t flags,
+                            ispk_stream_t stream);
 
 /* One-time weight staging for ispk_ffn_bf16: W2 [dim][inner] (nn.Linear layout, feedforward.py:27) ->
  * packed [inner/32][dim][32], each chunk's 32 hidden units in MFMA accumulator-fragment order.  packed holds

@@ -773,7 +773,7 @@ bool vec_epilogue_ok(const GemmParams& p) {
 //     and 4 consecutive output features in consecutive registers, so bias / residual / output are 8- or 16-byte
 //     vector accesses (4 store instructions per 32x32 tile instead of 16 scalar ones);
 //   * the N range is split over blockIdx.x so that >= 512 workgroups exist (2 per CU).
-template <int KC, int EP = kEpDyn, bool ST = false>  // K = 64 * KC; EP: compile-time epilogue; ST: phase stamps (experiments)
+template <int KC, int EP = kEpDyn, bool ST = false, bool LNP = false>  // K = 64 * KC; EP: compile-time epilogue; ST: stamps; LNP: fp32 A + LayerNorm in the prologue
 __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, int tiles_per_wg, int nsplit, int mblocks) {
     [[maybe_unused]] uint64_t tsum[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, tA = 0, tB = 0, tC = 0, tD = 0;
     if constexpr (ST) t0 = __builtin_readcyclecounter();
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
     wload(wr0, nt0, 0);
     wload(wr1, nt0, 1);
     bf16x8 xf[KS];
-    {
+    if constexpr (!LNP) {
         char* xs = smem_raw + wave * (32 * XLD);
         const int mwave = mb * 128 + wave * 32;
         u32x4 t[2][XCH];   // both K-halves in flight at once: one memory round trip for the whole panel
@@ -859,6 +859,63 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
 #pragma unroll
             for (int ks = 0; ks < KS / 2; ++ks)
                 xf[half * (KS / 2) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLD + ks * 32 + h * 16);
+        }
+    } else {
+        // LayerNorm in the prologue (ispk_gemm_bf16_lnin): A is the fp32 residual stream; every row's (mean, rstd) comes
+        // from the kernel that produced it (p.ln_out, float [M][2]); this wave normalises its 32 rows x K while it turns
+        // them into fragments - (x - mean) * rstd * gamma + beta, rounded to bf16 - so the separate LayerNorm launch and
+        // its write + re-read of a bf16 copy disappear.  fp32 rows are twice as long: four K-quarters through the patch,
+        // two of them (one K-half) in flight at a time.  A lane meets only NG distinct 4-column groups per quarter
+        // (chunk = (lane + 64 j) % CPQ), so gamma / beta are 2 NG float4 registers per quarter.
+        constexpr int KQ = K / 4, CPQ = KQ / 4, XQ = 32 * CPQ / 64, XLQ = KQ * 2 + 16;   // per K-quarter; XLQ in bytes
+        constexpr int GC = (64 % CPQ == 0) ? CPQ : (CPQ == 24 ? 8 : 1), NG = CPQ / GC;       // gcd(64, CPQ); groups per lane
+        static_assert(K == 384 || K == 256, "quarter staging is laid out for K = 256 / 384");
+        const float* Af = static_cast<const float*>(p.A);
+        const float* stats = static_cast<const float*>(p.ln_out);
+        char* xs = smem_raw + wave * (32 * XLQ);
+        float* sst = reinterpret_cast<float*>(smem_raw + 4 * (32 * XLQ)) + wave * 64;      // this wave's 32 x (mean, rstd)
+        const int mwave = mb * 128 + wave * 32;
+        if (lane < 32) {
+            const int row = mwave + lane < p.M ? mwave + lane : p.M - 1;
+            const float2 ms = *reinterpret_cast<const float2*>(stats + 2 * (int64_t)row);
+            sst[2 * lane] = ms.x;
+            sst[2 * lane + 1] = ms.y;
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float4 t[2][XQ];
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                for (int j = 0; j < XQ; ++j) {
+                    const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                    const int row = mwave + r < p.M ? mwave + r : p.M - 1;
+                    t[qq][j] = *reinterpret_cast<const float4*>(Af + (int64_t)row * p.lda + (2 * half + qq) * KQ + c * 4);
+                }
+#pragma unroll
+            for (int qq = 0; qq < 2; ++qq) {
+                const int q = 2 * half + qq;
+                float4 g[NG], be[NG];
+#pragma unroll
+                for (int u = 0; u < NG; ++u) {
+                    const int c = (lane + 64 * u) % CPQ;
+                    g[u] = *reinterpret_cast<const float4*>(p.ln_gamma + q * KQ + c * 4);
+                    be[u] = *reinterpret_cast<const float4*>(p.ln_beta + q * KQ + c * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < XQ; ++j) {
+                    const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                    const float mean = sst[2 * r], rstd = sst[2 * r + 1];
+                    const float4 v = t[qq][j], gg = g[j % NG], bb = be[j % NG];
+                    uint2 o;
+                    o.x = pack_bf16x2((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y);
+                    o.y = pack_bf16x2((v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
+                    *reinterpret_cast<uint2*>(xs + r * XLQ + c * 8) = o;
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS / 4; ++ks)
+                    xf[q * (KS / 4) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLQ + ks * 32 + h * 16);
+            }
         }
     }
     __syncthreads();   // every wave has its fragments: the patches may be overwritten by the weight tile
@@ -991,6 +1048,18 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
         if (key == kQkv) ISPK_PANEL_GO(kQkv, true, q);
         if (key == kFfn1) ISPK_PANEL_GO(kFfn1, true, q);
         ISPK_PANEL_GO(kEpDyn, true, q);
+    }
+    if (p.ln_flags & 0x100u) {   // fp32 A + LayerNorm in the prologue (ispk_gemm_bf16_lnin)
+        ISPK_RESERVE_LDS((&gemm_bf16_panel_kernel<KC, kQkv, false, true>), lds, "gemm");
+        if (key == kQkv) {
+            hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC, kQkv, false, true>), dim3(mb8 * nsplit), dim3(256), lds, s, p, per,
+                               nsplit, mblocks);
+        } else {
+            ISPK_RESERVE_LDS((&gemm_bf16_panel_kernel<KC, kEpDyn, false, true>), lds, "gemm");
+            hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC, kEpDyn, false, true>), dim3(mb8 * nsplit), dim3(256), lds, s, p, per,
+                               nsplit, mblocks);
+        }
+        return ispk_launch_status();
     }
     if (getenv("ISPK_EP_DYN") == nullptr) {   // (set: experiments, forces the generic epilogue)
         if (key == kQkv) ISPK_PANEL_GO(kQkv, false, p);
@@ -1467,6 +1536,11 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
             const int mr = mw0 + 8 * i + (lane >> 3);
             if (mr >= p.M) continue;
             const float rstd = 1.0f / sqrtf(qs[i] * (1.0f / (float)D) + p.ln_eps);
+            if (p.ln_flags & 4u) {   // statistics only: the consumer GEMM normalises in its prologue (ispk_gemm_bf16_lnin)
+                if ((lane & 7) == 0)
+                    *reinterpret_cast<float2*>(static_cast<float*>(p.ln_out) + 2 * (int64_t)mr) = make_float2(mean[i], rstd);
+                continue;
+            }
             const float mo = ((p.ln_flags & 1u) && p.mask) ? (p.mask[mr] ? 1.0f : 0.0f) : 1.0f;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -1556,9 +1630,11 @@ int32_t ffn_launch(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t l
     const bool hot = ep_key(p) == kHot && getenv("ISPK_EP_DYN") == nullptr;
     const bool packed = ldw2 == 0;   // W2 laid out by ispk_ffn_pack_w2_bf16
     if (ln) {
-        ISPK_REQUIRE(ln->gamma && ln->beta && ln->out, ISPK_E_NULL, "ffn_ln: null LayerNorm argument");
-        ISPK_REQUIRE(ln->ld % 4 == 0 && ln->ld >= D && ispk_aligned(ln->out, (ln->flags & 2u) ? 8 : 16) &&
-                         ispk_aligned(ln->gamma, 16) && ispk_aligned(ln->beta, 16),
+        const bool stats_only = ln->flags & 4u;   // ln_out = float [rows][2] (mean, rstd); gamma / beta unused
+        ISPK_REQUIRE(ln->out && (stats_only || (ln->gamma && ln->beta)), ISPK_E_NULL, "ffn_ln: null LayerNorm argument");
+        ISPK_REQUIRE(stats_only ? ispk_aligned(ln->out, 8)
+                                : (ln->ld % 4 == 0 && ln->ld >= D && ispk_aligned(ln->out, (ln->flags & 2u) ? 8 : 16) &&
+                                   ispk_aligned(ln->gamma, 16) && ispk_aligned(ln->beta, 16)),
                      ISPK_E_ALIGN, "ffn_ln: LayerNorm buffers must be 16-byte aligned, ln_ld a multiple of 4");
         ISPK_REQUIRE(!((ln->flags & 1u) && !mask), ISPK_E_NULL, "ffn_ln: ln mask flag set but mask is NULL");
         ISPK_REQUIRE(packed && !bias1, ISPK_E_UNSUPPORTED, "ffn_ln: needs the packed W2 image and no first-Linear bias");
@@ -1640,4 +1716,24 @@ extern "C" int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint1
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (M >= 128 * 160) return N == 384 ? launch_wide<6, 4, true>(p, s) : launch_wide<4, 4, true>(p, s);
     return N == 384 ? launch_wide<6, 2, true>(p, s) : launch_wide<4, 2, true>(p, s);
+}
+
+extern "C" int32_t ispk_gemm_bf16_lnin(const float* x, int64_t ldx, const float* row_stats, const float* ln_gamma,
+                                       const float* ln_beta, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
+                                       const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M,
+                                       int32_t N, int32_t K, uint32_t flags, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && row_stats && ln_gamma && ln_beta && W && C, ISPK_E_NULL, "gemm_lnin: null pointer");
+    ISPK_REQUIRE(K == 256 || K == 384, ISPK_E_UNSUPPORTED, "gemm_lnin: K=%d (built for 256 / 384)", K);
+    ISPK_REQUIRE(M >= 0 && N >= 1, ISPK_E_SHAPE, "gemm_lnin: bad shape M=%d N=%d", M, N);
+    ISPK_REQUIRE(ldx % 4 == 0 && ldx >= K && ldw % 8 == 0 && ldw >= K && ispk_aligned(x, 16) && ispk_aligned(W, 16) &&
+                     ispk_aligned(row_stats, 8) && ispk_aligned(ln_gamma, 16) && ispk_aligned(ln_beta, 16),
+                 ISPK_E_ALIGN, "gemm_lnin: x / gamma / beta / W must be 16-byte aligned (ldx %% 4, ldw %% 8)");
+    GemmParams p{x, ldx, W, ldw, C, ldc, bias, resid, ldr, mask, M, N, K, flags, 0, 0};
+    ISPK_REQUIRE(!((flags & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT)) && !mask), ISPK_E_NULL, "gemm_lnin: mask flag without mask");
+    ISPK_REQUIRE(!(flags & (ISPK_EP_ROWS_T | ISPK_EP_BIAS_ROW | ISPK_EP_MASK_COL)) && vec_epilogue_ok(p) && rows_epilogue_ok(p),
+                 ISPK_E_UNSUPPORTED, "gemm_lnin: needs a row-major output with 16-byte aligned rows");
+    if (M == 0) return 0;
+    p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_out = const_cast<float*>(row_stats); p.ln_flags = 0x100u;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
 }

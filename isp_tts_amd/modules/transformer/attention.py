@@ -85,22 +85,28 @@ class Attention(nn.Module, Constructor):
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 cache: Optional[AttentionIntermediates] = None,
                 shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None,
-                residual: Optional[Tensor] = None):
+                residual: Optional[Tensor] = None, prenorm: Optional[tuple] = None):
         """x [B,N,dim] (fp32, or bf16 when compute_dtype is bf16); mask [B,N] bool, True = valid, a length mask.
         `key_len` (int64 [B]) may be passed to skip recomputing mask.sum(1); `residual` (fp32 [B,N,dim]) fuses
         `residual + mask * to_out(...)` into the output GEMM.  Returns (out, AttentionIntermediates,
-        AttentionSharedIntermediates) like the reference; `rel_pos_bias` is None because no bias tensor exists."""
+        AttentionSharedIntermediates) like the reference; `rel_pos_bias` is None because no bias tensor exists.
+        `prenorm` = (row_stats, weight, bias): x is the fp32 input of the LayerNorm that precedes this block and the
+        q/kv GEMM applies that LayerNorm while staging x (bf16 path; statistics from the producing kernel)."""
         if context is not None or context_mask is not None or attention_mask is not None or cache is not None:
             raise NotImplementedError("cross-attention, explicit attention masks and KV caches are not on the "
                                       "acoustic-model forward path and are not built")
         b, n, _ = x.shape
         dt = self.compute_dtype
         wqkv, wo, slopes = self._staged(dt)
-        if x.dtype != dt:
-            x = runtime.cast_bf16(x) if dt == torch.bfloat16 else x.float()
         if mask is not None and key_len is None:
             key_len = mask.sum(dim=1)
-        qkv = runtime.gemm(x, wqkv)                                            # [B,N,H*64+128]
+        if prenorm is not None:
+            assert dt == torch.bfloat16 and x.dtype == torch.float32
+            qkv = runtime.gemm_lnin(x, prenorm[0], prenorm[1], prenorm[2], wqkv)
+        else:
+            if x.dtype != dt:
+                x = runtime.cast_bf16(x) if dt == torch.bfloat16 else x.float()
+            qkv = runtime.gemm(x, wqkv)                                        # [B,N,H*64+128]
         o = runtime.alibi_mqa_attention(qkv, self.heads, slopes, key_len)      # [B,N,H*64]
         flags = runtime.EP_MASK_ACC if mask is not None else 0
         out = runtime.gemm(o, wo, resid=residual, mask=mask, flags=flags, out_dtype=torch.float32)

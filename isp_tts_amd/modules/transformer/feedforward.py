@@ -76,6 +76,9 @@ class FeedForward(nn.Module, Constructor):
         if x.dtype != torch.bfloat16:
             x = runtime.cast_bf16(x)
         nw, nb, neps, nmask, ndtype = next_norm
+        if ndtype == "stats":   # only the rows' (mean, rstd): the consumer GEMM normalises in its prologue
+            return runtime.ffn_fused_stats(x, w1, self._packed_w2(), resid=residual, mask=mask, bias2=self.net[3].bias,
+                                           flags=runtime.EP_MASK_OUT if mask is not None else 0, ln_eps=neps)
         return runtime.ffn_fused_ln(x, w1, self._packed_w2(), nw, nb, resid=residual, mask=mask, bias2=self.net[3].bias,
                                     flags=runtime.EP_MASK_OUT if mask is not None else 0, ln_mask=nmask, ln_dtype=ndtype,
                                     ln_eps=neps)

@@ -82,9 +82,14 @@ class TransformerLayer(nn.Module, Constructor):
             key_len = mask.sum(dim=1)
         kw1 = {"scale_shift": ada[0]} if ada is not None else {}
         kw2 = {"scale_shift": ada[1]} if ada is not None else {}
-        h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
-        x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
-                                           attention_mask=attention_mask, key_len=key_len, residual=x)
+        if normed is not None and normed.dtype == torch.float32 and normed.shape[-1] == 2 and cdt == torch.bfloat16:
+            # the previous layer handed over this norm's row statistics: the q/kv GEMM applies it while staging x
+            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x,
+                                               prenorm=(normed, self.attention_norm.weight, self.attention_norm.bias))
+        else:
+            h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
+            x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
+                                               attention_mask=attention_mask, key_len=key_len, residual=x)
         h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt, **kw2)
         hn = None
         if next_norm is not None and self.feed_forward.fused_with_norm_ok(h2):
@@ -185,6 +190,11 @@ class Transformer(nn.Module, Constructor):
     # kernel gets 13 us slower per layer (its 256 workgroups reach the epilogue together, nothing overlaps the extra
     # work) while the removed LayerNorm launch saved 17 us - 2.94 vs 2.98 ms per step, within run-to-run noise.
     chain_layernorm = False
+    # Variant of the above that moves only the STATISTICS: the fused feed-forward kernel writes (mean, rstd) per row and the
+    # next layer's q/kv GEMM (ispk_gemm_bf16_lnin) normalises while it stages its fp32 input - no normalised copy in HBM.
+    # ON: the feed-forward kernel is unchanged in time (106.6 us), q/kv goes 21.8 -> 26.6 us and the 15.0-us LayerNorm
+    # launch disappears: 2.636 -> 2.587 ms per step with one batch in flight, 2.162 -> 2.147 with two (ISPK_STATS_LN=0: off).
+    stats_layernorm = True
 
     def _fusable(self, context, context_mask, attention_mask) -> bool:
         att = self.layers[0].attention
@@ -239,16 +249,19 @@ class Transformer(nn.Module, Constructor):
         chain = ((self.chain_layernorm or os.environ.get("ISPK_CHAIN_LN") == "1") and not self.adaptive_norm
                  and self.layers[0].attention.compute_dtype == torch.bfloat16)
         cdt = self.layers[0].attention.compute_dtype
+        stats = (not chain and self.stats_layernorm and os.environ.get("ISPK_STATS_LN") != "0" and not self.adaptive_norm
+                 and cdt == torch.bfloat16 and context is None and attention_mask is None)
+        chain = chain or stats
         normed = None
         for li, layer in enumerate(self.layers):
             nxt = None
             if chain:
                 if li + 1 < len(self.layers):
                     nn_ = self.layers[li + 1].attention_norm
-                    nxt = (nn_.weight, nn_.bias, nn_.eps, False, cdt)
-                else:
+                    nxt = (nn_.weight, nn_.bias, nn_.eps, False, "stats" if stats else cdt)
+                elif not stats:
                     nxt = (self.norm.weight, self.norm.bias, self.norm.eps, mask is not None, out_dtype)
-                if nxt[0] is None or nxt[1] is None:
+                if nxt is not None and (nxt[0] is None or nxt[1] is None):
                     nxt = None
             res = layer(out, mask=mask, context=context, context_mask=context_mask, attention_mask=attention_mask,
                         adaptive_condition=adaptive_condition, key_len=key_len, ada=None if ada is None else ada[li],

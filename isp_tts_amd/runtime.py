@@ -39,6 +39,7 @@ SIGNATURES = {
     "ispk_ffn_pack_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
     "ispk_ffn_bf16_ln": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64,
                          _U32, _P],
+    "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -340,6 +341,51 @@ def ffn_fused_ln(x: Tensor, w1: Tensor, w2p: Tensor, ln_weight: Tensor, ln_bias:
             _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, ln_weight.data_ptr(), ln_bias.data_ptr(), ln_eps,
             ln_out.data_ptr(), D, lnf, _stream())
     return out, ln_out
+
+
+def ffn_fused_stats(x: Tensor, w1: Tensor, w2p: Tensor, resid: Optional[Tensor] = None, mask: Optional[Tensor] = None,
+                    bias2: Optional[Tensor] = None, flags: int = 0, ln_eps: float = 1e-5):
+    """ispk_ffn_bf16_ln with ln_flags bit 2: (out fp32 [..., D], row statistics fp32 [rows, 2] = (mean, rstd) of out) -
+    the LayerNorm itself is applied by the consumer (`gemm_lnin`)."""
+    _dev(x, w1, w2p, resid, mask, bias2)
+    assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2p.dtype == torch.bfloat16
+    x2 = _rows2d(x)
+    R, D = x2.shape
+    Fi = w1.shape[0]
+    assert w1.shape == (Fi, D) and w1.stride(1) == 1 and w2p.shape == (Fi // 32, D, 32) and w2p.is_contiguous()
+    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
+    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device)
+    r2 = _rows2d(resid) if resid is not None else None
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+    nb = x2.numel() * 2 + (w1.numel() + w2p.numel()) * 2 + out.numel() * 4 + stats.numel() * 4 + \
+        (r2.numel() * 4 if r2 is not None else 0)
+    _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_ln, x2.data_ptr(), x2.stride(0),
+            w1.data_ptr(), w1.stride(0), w2p.data_ptr(), _ptr(bias2), _ptr(r2), r2.stride(0) if r2 is not None else 0,
+            _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, 0, 0, ln_eps, stats.data_ptr(), 0, 4, _stream())
+    return out, stats
+
+
+def gemm_lnin(x: Tensor, stats: Tensor, ln_weight: Tensor, ln_bias: Tensor, w: Tensor, bias: Optional[Tensor] = None,
+              mask: Optional[Tensor] = None, flags: int = 0, out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
+    """ispk_gemm_bf16_lnin: C[..., N] = epilogue(bf16(LayerNorm(x)) @ w[N, K]^T) with x fp32 [..., K] and the rows'
+    (mean, rstd) in `stats` (from `ffn_fused_stats`)."""
+    _dev(x, stats, ln_weight, ln_bias, w, bias, mask)
+    assert x.dtype == torch.float32 and w.dtype == torch.bfloat16 and stats.dtype == torch.float32
+    x2 = _rows2d(x)
+    M, K = x2.shape
+    N = w.shape[0]
+    assert stats.shape == (M, 2) and stats.is_contiguous() and w.shape == (N, K) and w.stride(1) == 1
+    if out_dtype == torch.bfloat16:
+        flags |= EP_OUT_BF16
+    out = torch.empty((*x.shape[:-1], N), dtype=out_dtype, device=x.device)
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+    nb = x2.numel() * 4 + stats.numel() * 4 + w.numel() * 2 + out.numel() * out.element_size()
+    _launch(f"gemm_bf16_panel_kernel<{K // 64},lnin>", 2.0 * M * N * K, float(nb), lib().ispk_gemm_bf16_lnin, x2.data_ptr(),
+            x2.stride(0), stats.data_ptr(), ln_weight.data_ptr(), ln_bias.data_ptr(), w.data_ptr(), w.stride(0),
+            out.data_ptr(), N, _ptr(bias), 0, 0, _ptr(mask), M, N, K, flags, _stream())
+    return out
 
 
 def _gemm_label(bf16: bool, M: int, N: int, K: int) -> str:

@@ -357,6 +357,55 @@ def test_fused_ffn_with_layernorm_epilogue(R, D, Fi, ln_dtype):
         assert (ln.float() - ref.float()).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("R,D,N", [(5000, 384, 512), (777, 256, 384), (128 * 130, 384, 512), (31, 384, 192)])
+def test_linear_with_layernorm_prologue(R, D, N):
+    """ispk_gemm_bf16_lnin == LayerNorm kernel (bf16 out) followed by ispk_gemm_bf16, given the rows' (mean, rstd):
+    the normalised operand is rounded to bf16 exactly as the LayerNorm kernel rounds it, up to 1-ulp flips where the
+    two reduction trees leave the fp32 value on a rounding boundary."""
+    x = synth._normal(f"t/lnin/x{R}", (R, D), 2.0, 0.5)
+    g, b = synth._normal("t/lnin/g", (D,), 0.1, 1.0), synth._normal("t/lnin/b", (D,), 0.1)
+    w = _bf(synth._normal(f"t/lnin/w{D}", (N, D), D ** -0.5))
+    mean = x.double().mean(1)
+    rstd = 1.0 / torch.sqrt(x.double().var(1, unbiased=False) + 1e-5)
+    stats = torch.stack([mean, rstd], 1).float().contiguous()
+    d = lambda t: t.to(DEV)  # noqa: E731
+    out = runtime.gemm_lnin(d(x), d(stats), d(g), d(b), d(w)).cpu()
+    h = runtime.layernorm(d(x), d(g), d(b), out_dtype=torch.bfloat16)
+    ref = runtime.gemm(h, d(w)).cpu()
+    assert out.dtype == torch.bfloat16 and out.shape == (R, N)
+    err = (out.float() - ref.float()).abs()
+    assert err.max().item() <= 2 ** -5 and err.pow(2).mean().sqrt().item() <= 2e-3
+    # and against fp64 on the fp32-normalised operand: bounded by the bf16 operand rounding
+    hn = ((x.double() - mean[:, None]) * rstd[:, None] * g.double() + b.double())
+    ref64 = hn @ w.double().t()
+    assert (out.double() - ref64).abs().max().item() <= 0.08
+
+
+def test_fused_ffn_row_statistics_feed_the_next_linear():
+    """ispk_ffn_bf16_ln(ln_flags bit 2): `out` bit-identical to ispk_ffn_bf16, statistics = (mean, rstd) of `out`;
+    chained into ispk_gemm_bf16_lnin it reproduces FFN -> LayerNorm -> Linear."""
+    R, D, Fi, N = 128 * 9 + 17, 384, 1536, 512
+    x = _bf(synth._normal("t/ffnst/x", (R, D)))
+    w1, w2 = _bf(synth._normal("t/ffnst/w1", (Fi, D), D ** -0.5)), _bf(synth._normal("t/ffnst/w2", (D, Fi), Fi ** -0.5))
+    resid = synth._normal("t/ffnst/r", (R, D), 1.0, 0.3)
+    g, b = synth._normal("t/ffnst/g", (D,), 0.1, 1.0), synth._normal("t/ffnst/b", (D,), 0.1)
+    w = _bf(synth._normal("t/ffnst/w", (N, D), D ** -0.5))
+    mask = torch.arange(R) % 7 != 3
+    d = lambda t: t.to(DEV)  # noqa: E731
+    w2p = runtime.ffn_pack_w2(d(w2))
+    base = runtime.ffn_fused(d(x), d(w1), w2p, resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT)
+    out, stats = runtime.ffn_fused_stats(d(x), d(w1), w2p, resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT)
+    assert torch.equal(out, base) and stats.shape == (R, 2)
+    o64 = base.double().cpu()
+    assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
+    rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
+    assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
+    qkv = runtime.gemm_lnin(out, stats, d(g), d(b), d(w)).cpu()
+    ref = runtime.gemm(runtime.layernorm(base, d(g), d(b), out_dtype=torch.bfloat16), d(w)).cpu()
+    err = (qkv.float() - ref.float()).abs()
+    assert err.max().item() <= 2 ** -5 and err.pow(2).mean().sqrt().item() <= 2e-3
+
+
 def test_attention_bf16_several_query_tiles_per_workgroup(monkeypatch):
     """With the whole key range resident in LDS a workgroup serves several 64-query tiles off one K/V fetch (the launcher
     does this by itself only for large batches; forced here).  Same values as one tile per workgroup, bit for bit."""

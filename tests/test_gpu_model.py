@@ -233,7 +233,9 @@ def test_bf16_chained_layernorm_matches_separate_layernorm_at_full_size(gpu_mode
     dec = gpu_model.decoder
     try:
         dec.set_compute_dtype(torch.bfloat16)
+        dec.stats_layernorm = False
         plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+        del dec.stats_layernorm
         dec.chain_layernorm = True
         chained = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
     finally:
@@ -243,6 +245,29 @@ def test_bf16_chained_layernorm_matches_separate_layernorm_at_full_size(gpu_mode
     diff = (chained.float() - plain.float()).abs()
     assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
     assert (chained.float() * ~mask[..., None]).abs().max() == 0
+
+
+def test_bf16_layernorm_statistics_handoff_matches_separate_layernorm_at_full_size(gpu_model):
+    """Decoder stack at the benchmark shape with layers 2..6's attention LayerNorm applied inside the q/kv GEMM from the
+    previous feed-forward kernel's row statistics (`Transformer.stats_layernorm`) against separate LayerNorm launches:
+    same fp32 statistics up to the reduction tree, so only 1-ulp bf16 roundings of the normalised operand differ."""
+    x = synth._normal("t/chain/x", (64, 512, 384)).to(DEV)
+    lens = torch.full((64,), 512, device=DEV)
+    lens[2::5] = 211
+    mask = torch.arange(512, device=DEV)[None] < lens[:, None]
+    dec = gpu_model.decoder
+    try:
+        dec.set_compute_dtype(torch.bfloat16)
+        dec.stats_layernorm = False
+        plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+        dec.stats_layernorm = True
+        handed = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+    finally:
+        del dec.stats_layernorm              # back to the class default
+        dec.set_compute_dtype(torch.float32)
+    diff = (handed.float() - plain.float()).abs()
+    assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
+    assert (handed.float() * ~mask[..., None]).abs().max() == 0
 
 
 def test_config2_encoder_decoder_scope_fp32(gpu_model, state_dict):

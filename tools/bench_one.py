@@ -34,6 +34,13 @@ cases = {
     "panel 384->384 f32+resid": (lambda: runtime.gemm(x, wo, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT, out_dtype=torch.float32), 2.0 * R * 384 * 384),
     "wide 1536->384 f32+resid": (lambda: runtime.gemm(x1536, w2, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT, out_dtype=torch.float32), 2.0 * R * 384 * 1536),
 }
+gam, bet = torch.ones(384, device=dev), torch.zeros(384, device=dev)
+stats32 = torch.stack([resid.mean(1), 1.0 / torch.sqrt(resid.var(1, unbiased=False) + 1e-5)], 1).contiguous()
+cases.update({
+    "lnin panel 384->512 (fp32 x + stats)": (lambda: runtime.gemm_lnin(resid, stats32, gam, bet, wqkv), 2.0 * R * 384 * 512),
+    "layernorm 384 bf16 out": (lambda: runtime.layernorm(resid, gam, bet, out_dtype=dt), 0.0),
+    "ffn_fused + stats": (lambda: runtime.ffn_fused_stats(x, w1, w2p, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),
+})
 only = sys.argv[1:]
 graphs = {}
 for name, (fn, _) in cases.items():

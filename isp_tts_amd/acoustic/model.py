@@ -8,6 +8,7 @@ all on the current stream, with no host synchronisation inside `forward` when `m
 """
 from __future__ import annotations
 
+import warnings
 from typing import NamedTuple, Optional
 
 import torch
@@ -147,6 +148,47 @@ class AcousticModel(nn.Module, Constructor):
             dec_mask = get_mask_from_lengths(adaptor_output.dec_lengths, adaptor_output.enc_out.shape[1])
         dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, out_dtype=self.compute_dtype).out
         return self._to_mel(dec_out, dec_mask), adaptor_output
+
+    # ---- checkpoint drop-in (tts/models/base.py:39-108 of the reference; trainer.py:361-372 writes the file) ----
+    @classmethod
+    def from_pretrained(cls, checkpoint_path: str, strict: bool = True) -> "AcousticModel":
+        """Builds the model from a checkpoint written by the reference's Trainer: a `torch.save`d dict whose
+        `["model"]["config"]` is the plain-container model config and `["model"]["state_dict"]` the weights
+        (base.py:39-56).  Keys the checkpoint lacks keep their initial values, as in the reference (:50-52)."""
+        checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+        model = cls.init(checkpoint["model"]["config"])
+        state_dict = dict(checkpoint["model"]["state_dict"])
+        for key, weight in model.state_dict().items():
+            if key not in state_dict:
+                state_dict[key] = weight
+        model.load_state_dict(state_dict, strict=strict)
+        return model
+
+    def load(self, state_dict: dict, ignore_layers: Optional[list] = None, ignore_mismatched_keys: bool = False):
+        """base.py:58-64 / `load_state_dict` :73-108: drops checkpoint keys the model lacks, keys matching
+        `ignore_layers` (substring) and - with `ignore_mismatched_keys` - keys whose shape differs; the rest is loaded
+        over the current weights."""
+        own = self.state_dict()
+        extra = [k for k in state_dict if k not in own]
+        if extra:
+            warnings.warn(f"checkpoint keys absent from the model are ignored: {extra}")
+        kept = {k: v for k, v in state_dict.items() if k in own}
+        ignored = []
+        if ignore_mismatched_keys:
+            ignored += [k for k, v in kept.items() if v.shape != own[k].shape]
+        if ignore_layers:
+            ignored += [k for k in kept if any(layer in k for layer in ignore_layers)]
+        kept = {k: v for k, v in kept.items() if k not in ignored}
+        own.update(kept)
+        self.load_state_dict(own)
+        return self
+
+    def freeze(self, exception_list: Optional[list] = None):
+        """base.py:66-73: requires_grad only for parameters whose name starts with an entry of `exception_list`."""
+        exception_list = exception_list or []
+        for name, param in self.named_parameters():
+            param.requires_grad = any(name.startswith(layer) for layer in exception_list)
+        return self
 
     def prepare_inputs(self, inputs: dict) -> dict:
         """model.py:244-259 (collator field names -> forward kwargs)."""

@@ -162,3 +162,45 @@ def test_shard_gather_unshard_world_size_2_gloo():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert res == [(0, True), (1, True)]
+
+
+def test_from_pretrained_reads_the_reference_checkpoint_layout(tmp_path):
+    """A file laid out as the reference's Trainer writes it (trainer.py:361-372: checkpoint["model"] = {"config",
+    "state_dict"}) restores the same weights (base.py:39-56); keys the file lacks keep their initial value."""
+    import torch
+    cfg = AcousticDims().model_config()
+    src = AcousticModel.init(cfg)
+    with torch.no_grad():
+        for i, p in enumerate(src.parameters()):
+            p.add_(0.01 * ((i % 7) - 3))
+    sd = {k: v.clone() for k, v in src.state_dict().items()}
+    dropped = "decoder.norm.bias"
+    del sd[dropped]
+    path = tmp_path / "ckpt.pt"
+    torch.save({"epoch": 3, "iteration": 1000, "model": {"config": cfg, "state_dict": sd}, "optimizer": None}, path)
+    model = AcousticModel.from_pretrained(str(path))
+    got = model.state_dict()
+    assert set(got) == set(src.state_dict())
+    for k, v in src.state_dict().items():
+        if k != dropped:
+            assert torch.equal(got[k], v), k
+    assert torch.equal(got[dropped], torch.zeros_like(got[dropped]))       # nn.LayerNorm's initial bias
+
+
+def test_load_filters_keys_like_the_reference_and_freeze_sets_requires_grad():
+    import torch
+    model = AcousticModel.init(AcousticDims().model_config())
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    sd = {k: v + 1.0 if v.is_floating_point() else v for k, v in before.items()}
+    sd["not.a.key"] = torch.zeros(3)
+    sd["to_mel.weight"] = torch.zeros(81, 384)                             # wrong shape
+    with pytest.warns(UserWarning, match="not.a.key"):
+        model.load(sd, ignore_layers=["text_embedding"], ignore_mismatched_keys=True)
+    after = model.state_dict()
+    assert torch.equal(after["to_mel.weight"], before["to_mel.weight"])                      # mismatched: kept
+    assert torch.equal(after["text_embedding.weight"], before["text_embedding.weight"])      # ignored layer: kept
+    assert torch.equal(after["to_mel.bias"], before["to_mel.bias"] + 1.0)                    # everything else: loaded
+    model.freeze(exception_list=["decoder.layers.5", "to_mel"])
+    trainable = {n for n, p in model.named_parameters() if p.requires_grad}
+    assert trainable and all(n.startswith(("decoder.layers.5", "to_mel")) for n in trainable)
+    assert any(n.startswith("to_mel") for n in trainable)

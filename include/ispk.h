@@ -159,6 +159,20 @@ int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16_t* W1, int
                          const float* ln_beta, float ln_eps, void* ln_out, int64_t ln_ld, uint32_t ln_flags,
                          ispk_stream_t stream);
 
+/* The pre-norm feed-forward block of a transformer layer in one kernel, LayerNorm included:
+ *   out[i][:] = [mask[i]] * ( x[i][:] + gelu_erf( LN(x[i][:])·W1ᵀ )·W2ᵀ + bias2 ),   LN = (x - mean_i) * rstd_i * gamma + beta
+ * Replaces: transformer.py:101-110 (feed_forward_norm -> feed_forward -> residual add -> mask) = normalization.py:20-27 +
+ * feedforward.py:33-40: the separate LayerNorm launch, its bf16 copy of the rows and that copy's re-read disappear.
+ * x fp32 [rows][dim] is both the LayerNorm input and the residual; a wave owns whole rows and computes their statistics
+ * itself (two-pass fp32, fixed summation order).  The reference also multiplies LN(x) by the row mask (:102); with the
+ * same mask applied to the output (flags: ISPK_EP_MASK_OUT / ISPK_EP_MASK_ACC) that product cannot reach any kept value
+ * and is skipped.  W2 packed (ispk_ffn_pack_w2_bf16), no first-Linear bias.  row_stats (optional): float [rows][2] =
+ * (mean, rstd with stats_eps) of the OUTPUT rows for ispk_gemm_bf16_lnin, as ispk_ffn_bf16_ln(ln_flags bit 2). */
+int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                              const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed, const float* bias2,
+                              const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner,
+                              uint32_t flags, float* row_stats, float stats_eps, ispk_stream_t stream);
+
 /* Linear whose input is LayerNorm(x), with the row statistics supplied by the kernel that produced x:
  *   C[i][n] = epilogue( sum_k bf16( (x[i][k] - mean_i) * rstd_i * ln_gamma[k] + ln_beta[k] ) * W[n][k] )
  * Replaces: normalization.py:20-27 + the Linear that follows it (transformer.py:79-80, attention.py:63-64: attention_norm

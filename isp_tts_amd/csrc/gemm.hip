@@ -44,6 +44,10 @@ struct GemmParams {
     int64_t ln_ld = 0;
     float ln_eps = 1e-5f;
     uint32_t ln_flags = 0;
+    // LayerNorm of the INPUT rows computed by the kernel itself (fused feed-forward, ispk_ffn_bf16_prenorm): A is fp32
+    const float* lx_gamma = nullptr;
+    const float* lx_beta = nullptr;
+    float lx_eps = 1e-5f;
 };
 
 constexpr int kLdt = 36;  // padded LDS row length in dwords (32 + 4)
@@ -1219,7 +1223,8 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
 //     burst of 12 loads blocks the wave's issue for 12 x 16 cycles x 4 waves on the CU's one address path).
 // The operand reads of both phases run as ONE stream through an RD-deep ring of opaque asm reads.  One barrier per chunk.
 // Epilogue: the row-coalescing transpose (store_rows_f32) with residual and mask.
-template <int KC, bool B1, bool PK, int EP = kEpDyn, bool ST = false, bool LN = false>  // D = 64 KC; B1: Linear 1 bias; PK: packed W2; LN: + LayerNorm of the result
+// LX: the input is the fp32 residual stream and the kernel applies the LayerNorm that precedes the block itself.
+template <int KC, bool B1, bool PK, int EP = kEpDyn, bool ST = false, bool LN = false, bool LX = false>  // D = 64 KC; B1: Linear 1 bias; PK: packed W2; LN: + LayerNorm of the result
 __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const uint16_t* __restrict__ W2, int64_t ldw2,
                                                           const float* __restrict__ bias1, int F) {
     [[maybe_unused]] uint64_t tk0 = 0;
@@ -1238,7 +1243,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
     const int l31 = lane & 31, h = lane >> 5;
     const int mw0 = blockIdx.x * 128 + wave * 32;
     const int m = mw0 + l31;
-    const uint16_t* X = static_cast<const uint16_t*>(p.A);
+    [[maybe_unused]] const uint16_t* X = static_cast<const uint16_t*>(p.A);
     const uint16_t* W1 = static_cast<const uint16_t*>(p.W);
     const int nchunks = F / HC;
 
@@ -1296,7 +1301,82 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
 #pragma unroll
     for (int i = 0; i < C; ++i) load1(i, 0);
     bf16x8 xf[KS];
-    {
+    if constexpr (LX) {
+        // Pre-norm in the prologue (ispk_ffn_bf16_prenorm; transformer.py:101-105: feed_forward(feed_forward_norm(x))):
+        // a wave owns whole rows, so it computes their LayerNorm statistics itself - the 32 rows x D fp32 stay in
+        // registers (D/2 VGPRs; the accumulators are not live yet) through two passes in fixed summation order (each
+        // lane's float4 partial -> a wave-private LDS table -> one lane per row half adds them up: deterministic), then
+        // (x - mean) * rstd * gamma + beta is rounded to bf16 on the way into the fragment patch, a K-quarter at a time.
+        constexpr int KQ = D / 4, CPQ = KQ / 4, XQ = 32 * CPQ / 64, XLQ = KQ * 2 + 16;     // per K-quarter; XLQ in bytes
+        constexpr int GC = (64 % CPQ == 0) ? CPQ : (CPQ == 24 ? 8 : 1), NG = CPQ / GC;       // gcd(64, CPQ); groups per lane
+        constexpr int PLD = 4 * CPQ + 1;                                                     // partials per row, padded
+        static_assert(4 * 32 * XLQ + 4 * 32 * PLD * 4 + 4 * 64 * 4 <= (2 * HC * LD1 + 2 * D * LD2) * 2,
+                      "pre-norm staging aliases the weight buffers");
+        const float* Xf = static_cast<const float*>(p.A);
+        char* xs = smem_raw + wave * (32 * XLQ);
+        float* part = reinterpret_cast<float*>(smem_raw + 4 * (32 * XLQ)) + wave * (32 * PLD);
+        float* sst = reinterpret_cast<float*>(smem_raw + 4 * (32 * XLQ) + 4 * 32 * PLD * 4) + wave * 64;
+        float4 t[4][XQ];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < XQ; ++j) {
+                const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                const int row = mw0 + r < p.M ? mw0 + r : p.M - 1;
+                t[q][j] = *reinterpret_cast<const float4*>(Xf + (int64_t)row * p.lda + q * KQ + c * 4);
+            }
+        auto row_total = [&]() {   // sum of this lane's row (l31) over the partial table; both halves end with the total
+            float a = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2 * CPQ; ++i) a += part[l31 * PLD + h * (2 * CPQ) + i];
+            return a + __shfl_xor(a, 32, 64);
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < XQ; ++j) {
+                const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                const float4 v = t[q][j];
+                part[r * PLD + q * CPQ + c] = (v.x + v.y) + (v.z + v.w);
+            }
+        const float mean_l = row_total() * (1.0f / (float)D);
+        if (h == 0) sst[2 * l31] = mean_l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < XQ; ++j) {
+                const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                const float mu = sst[2 * r];
+                const float4 v = t[q][j];
+                const float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
+                part[r * PLD + q * CPQ + c] = (a * a + b * b) + (cc * cc + d * d);
+            }
+        const float rstd_l = 1.0f / sqrtf(row_total() * (1.0f / (float)D) + p.lx_eps);
+        if (h == 0) sst[2 * l31 + 1] = rstd_l;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 g[NG], be[NG];
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const int c = (lane + 64 * u) % CPQ;
+                g[u] = *reinterpret_cast<const float4*>(p.lx_gamma + q * KQ + c * 4);
+                be[u] = *reinterpret_cast<const float4*>(p.lx_beta + q * KQ + c * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < XQ; ++j) {
+                const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                const float mean = sst[2 * r], rstd = sst[2 * r + 1];
+                const float4 v = t[q][j], gg = g[j % NG], bb = be[j % NG];
+                uint2 o;
+                o.x = pack_bf16x2((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y);
+                o.y = pack_bf16x2((v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
+                *reinterpret_cast<uint2*>(xs + r * XLQ + c * 8) = o;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS / 4; ++ks)
+                xf[q * (KS / 4) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLQ + ks * 32 + h * 16);
+        }
+    } else {
         constexpr int KH = D / 2, CPH = KH / 8, XCH = 32 * CPH / 64, XLD = KH * 2 + 16;
         static_assert(4 * 32 * XLD <= (2 * HC * LD1 + 2 * D * LD2) * 2, "x staging patches alias the weight buffers");
         char* xs = smem_raw + wave * (32 * XLD);
@@ -1605,16 +1685,21 @@ struct FfnLn {   // optional LayerNorm of the result (ispk_ffn_bf16_ln)
     int64_t ld = 0;
     uint32_t flags = 0;
 };
-int32_t ffn_launch(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
+struct FfnLx {   // LayerNorm applied to the (fp32) input in the prologue
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float eps = 1e-5f;
+};
+int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
                    const uint16_t* W2, int64_t ldw2, const float* bias2, const float* resid, int64_t ldr,
                    const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F, uint32_t flags,
-                   const FfnLn* ln, ispk_stream_t stream) {
+                   const FfnLn* ln, ispk_stream_t stream, const FfnLx* lx = nullptr) {
     ISPK_REQUIRE(x && W1 && W2 && out, ISPK_E_NULL, "ffn: null pointer");
     ISPK_REQUIRE(D == 384 || D == 256, ISPK_E_UNSUPPORTED, "ffn: dim %d (built for 256 / 384)", D);
     ISPK_REQUIRE(rows >= 0 && F >= 64 && F % 32 == 0, ISPK_E_SHAPE, "ffn: bad shape rows=%d inner=%d", rows, F);
     ISPK_REQUIRE((flags & ~(ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) == 0, ISPK_E_UNSUPPORTED, "ffn: unsupported flags");
     ISPK_REQUIRE(!((flags & (ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) && !mask), ISPK_E_NULL, "ffn: mask flag without mask");
-    ISPK_REQUIRE(ldx % 8 == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0 && ldo % 4 == 0 && (!resid || ldr % 4 == 0) && ldx >= D &&
+    ISPK_REQUIRE(ldx % (lx ? 4 : 8) == 0 && ldw1 % 8 == 0 && ldw2 % 8 == 0 && ldo % 4 == 0 && (!resid || ldr % 4 == 0) && ldx >= D &&
                      ldw1 >= D && (ldw2 >= F || ldw2 == 0) && ldo >= D,
                  ISPK_E_ALIGN, "ffn: leading strides must be multiples of 8 (bf16) / 4 (fp32)");
     ISPK_REQUIRE(ispk_aligned(x, 16) && ispk_aligned(W1, 16) && ispk_aligned(W2, 16) && ispk_aligned(out, 16) &&
@@ -1641,10 +1726,17 @@ int32_t ffn_launch(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t l
         p.ln_gamma = ln->gamma; p.ln_beta = ln->beta; p.ln_out = ln->out; p.ln_ld = ln->ld; p.ln_eps = ln->eps;
         p.ln_flags = ln->flags;
     }
+    if (lx) {
+        ISPK_REQUIRE(lx->gamma && lx->beta, ISPK_E_NULL, "ffn_prenorm: null LayerNorm argument");
+        ISPK_REQUIRE(ispk_aligned(lx->gamma, 16) && ispk_aligned(lx->beta, 16), ISPK_E_ALIGN,
+                     "ffn_prenorm: gamma / beta must be 16-byte aligned");
+        ISPK_REQUIRE(packed && !bias1, ISPK_E_UNSUPPORTED, "ffn_prenorm: needs the packed W2 image and no first-Linear bias");
+        p.lx_gamma = lx->gamma; p.lx_beta = lx->beta; p.lx_eps = lx->eps;
+    }
     void* stamp = nullptr;
     if (const char* e = getenv("ISPK_FFN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][3]
         stamp = reinterpret_cast<void*>(strtoull(e, nullptr, 16));
-        ISPK_REQUIRE(D == 384 && packed && !bias1 && hot && !ln, ISPK_E_UNSUPPORTED, "ffn stamps: the hot instance only");
+        ISPK_REQUIRE(D == 384 && packed && !bias1 && hot && !ln && !lx, ISPK_E_UNSUPPORTED, "ffn stamps: the hot instance only");
         p.ln_out = stamp;
     }
 #define ISPK_FFN_GO(KC_, B1_, PK_, EP_, ST_)                                                                          \
@@ -1662,8 +1754,20 @@ int32_t ffn_launch(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t l
                            bias1, F);                                                                                 \
         return ispk_launch_status();                                                                                  \
     } while (0)
+#define ISPK_FFN_GO_LX(KC_, EP_, LN_)                                                                                 \
+    do {                                                                                                              \
+        constexpr size_t lds = (size_t)(2 * 32 * (64 * KC_ + 8) + 2 * 64 * KC_ * 40) * 2 + 4 * kStageBytes;             \
+        ISPK_RESERVE_LDS((&ffn_bf16_kernel<KC_, false, true, EP_, false, LN_, true>), lds, "ffn");                    \
+        hipLaunchKernelGGL((ffn_bf16_kernel<KC_, false, true, EP_, false, LN_, true>), grid, dim3(256), lds, s, p, W2,  \
+                           ldw2, bias1, F);                                                                           \
+        return ispk_launch_status();                                                                                  \
+    } while (0)
 #define ISPK_FFN_KC(KC_)                                                   \
     do {                                                                   \
+        if (lx && ln && hot) ISPK_FFN_GO_LX(KC_, kHot, true);              \
+        if (lx && ln) ISPK_FFN_GO_LX(KC_, kEpDyn, true);                   \
+        if (lx && hot) ISPK_FFN_GO_LX(KC_, kHot, false);                   \
+        if (lx) ISPK_FFN_GO_LX(KC_, kEpDyn, false);                        \
         if (ln && hot) ISPK_FFN_GO_LN(KC_, kHot);                          \
         if (ln) ISPK_FFN_GO_LN(KC_, kEpDyn);                               \
         if (stamp) ISPK_FFN_GO(6, false, true, kHot, true);                \
@@ -1675,6 +1779,7 @@ int32_t ffn_launch(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t l
     } while (0)
     if (D == 384) ISPK_FFN_KC(6); else ISPK_FFN_KC(4);
 #undef ISPK_FFN_KC
+#undef ISPK_FFN_GO_LX
 #undef ISPK_FFN_GO_LN
 #undef ISPK_FFN_GO
     return ispk_launch_status();
@@ -1736,4 +1841,16 @@ extern "C" int32_t ispk_gemm_bf16_lnin(const float* x, int64_t ldx, const float*
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_out = const_cast<float*>(row_stats); p.ln_flags = 0x100u;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
+}
+
+extern "C" int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta,
+                                         float norm_eps, const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed,
+                                         const float* bias2, const uint8_t* mask, float* out, int64_t ldo, int32_t rows,
+                                         int32_t D, int32_t F, uint32_t flags, float* row_stats, float stats_eps,
+                                         ispk_stream_t stream) {
+    ISPK_REQUIRE(x && ispk_aligned(x, 16), ISPK_E_ALIGN, "ffn_prenorm: x must be a 16-byte aligned fp32 pointer");
+    FfnLx lx{norm_gamma, norm_beta, norm_eps};
+    FfnLn ln{nullptr, nullptr, stats_eps, row_stats, 0, 4u};
+    return ffn_launch(x, ldx, W1, ldw1, nullptr, W2_packed, 0, bias2, x, ldx, mask, out, ldo, rows, D, F, flags,
+                      row_stats ? &ln : nullptr, stream, &lx);
 }

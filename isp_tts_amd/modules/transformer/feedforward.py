@@ -5,6 +5,7 @@ carry the residual add and row mask of transformer.py:105,110.  Dropout is ident
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -45,6 +46,7 @@ class FeedForward(nn.Module, Constructor):
         # the fused kernel gives a workgroup 128 rows: below ~256 workgroups it under-fills the chip and the two-GEMM
         # path (which splits the feature axis as well) is faster
         self.fused_min_rows = 128 * 128
+        self.prenorm_fused = True            # norm -> feed-forward -> residual as one kernel when a caller offers it
         self._cache: dict = {}
 
     def _staged(self, dtype: torch.dtype):
@@ -82,6 +84,25 @@ class FeedForward(nn.Module, Constructor):
         return runtime.ffn_fused_ln(x, w1, self._packed_w2(), nw, nb, resid=residual, mask=mask, bias2=self.net[3].bias,
                                     flags=runtime.EP_MASK_OUT if mask is not None else 0, ln_mask=nmask, ln_dtype=ndtype,
                                     ln_eps=neps)
+
+    def prenorm_ok(self, x: Tensor, norm) -> bool:
+        """Can `forward_prenorm` run the block (norm -> feed-forward -> residual) as one kernel for this input?"""
+        rows = x.numel() // x.shape[-1]
+        return (self.prenorm_fused and os.environ.get("ISPK_FFN_PRENORM") != "0" and isinstance(norm, nn.LayerNorm)
+                and norm.weight is not None and norm.bias is not None and x.dtype == torch.float32
+                and self.compute_dtype == torch.bfloat16 and self.act_flag == runtime.EP_GELU and x.shape[-1] in (256, 384)
+                and rows >= self.fused_min_rows and self.net[0].bias is None
+                and not (self.training and self.dropout_p > 0))
+
+    def forward_prenorm(self, x: Tensor, norm, *, mask: Optional[Tensor] = None, next_norm: Optional[tuple] = None):
+        """y = [mask] * (x + feed_forward(norm(x))) in one kernel (ispk_ffn_bf16_prenorm), x fp32; with `next_norm` =
+        (.., eps, .., "stats") also the output rows' (mean, rstd) for the next layer's q/kv GEMM.  Returns (y, stats)."""
+        w1, _ = self._staged(torch.bfloat16)
+        want = next_norm is not None and next_norm[4] == "stats"
+        res = runtime.ffn_prenorm(x, norm.weight, norm.bias, w1, self._packed_w2(), mask=mask, bias2=self.net[3].bias,
+                                  flags=runtime.EP_MASK_OUT if mask is not None else 0, norm_eps=norm.eps,
+                                  want_stats=want, stats_eps=next_norm[2] if want else 1e-5)
+        return res if want else (res, None)
 
     def forward(self, x: Tensor, *, residual: Optional[Tensor] = None, mask: Optional[Tensor] = None) -> Tensor:
         if self.training and self.dropout_p > 0:

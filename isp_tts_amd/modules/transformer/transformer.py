@@ -90,8 +90,15 @@ class TransformerLayer(nn.Module, Constructor):
             h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
             x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
                                                attention_mask=attention_mask, key_len=key_len, residual=x)
-        h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt, **kw2)
         hn = None
+        if (ada is None and (next_norm is None or next_norm[4] == "stats")
+                and self.feed_forward.prenorm_ok(x1, self.feed_forward_norm)):
+            # feed_forward_norm inside the fused feed-forward kernel (its waves own whole rows); the `* mask` of :102
+            # cannot reach a kept value because the same mask multiplies the block's output (:110)
+            y, hn = self.feed_forward.forward_prenorm(x1, self.feed_forward_norm, mask=mask, next_norm=next_norm)
+            return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
+                                          shared_intermediates=shared, next_normed=hn)
+        h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt, **kw2)
         if next_norm is not None and self.feed_forward.fused_with_norm_ok(h2):
             y, hn = self.feed_forward.forward_with_norm(h2, next_norm, residual=x1, mask=mask)
         else:

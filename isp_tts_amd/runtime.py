@@ -39,6 +39,7 @@ SIGNATURES = {
     "ispk_ffn_pack_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
     "ispk_ffn_bf16_ln": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64,
                          _U32, _P],
+    "ispk_ffn_bf16_prenorm": [_P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
     "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -364,6 +365,28 @@ def ffn_fused_stats(x: Tensor, w1: Tensor, w2p: Tensor, resid: Optional[Tensor] 
             w1.data_ptr(), w1.stride(0), w2p.data_ptr(), _ptr(bias2), _ptr(r2), r2.stride(0) if r2 is not None else 0,
             _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, 0, 0, ln_eps, stats.data_ptr(), 0, 4, _stream())
     return out, stats
+
+
+def ffn_prenorm(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2p: Tensor, mask: Optional[Tensor] = None,
+                bias2: Optional[Tensor] = None, flags: int = 0, norm_eps: float = 1e-5, want_stats: bool = False,
+                stats_eps: float = 1e-5):
+    """ispk_ffn_bf16_prenorm: out fp32 [..., D] = [mask] * (x + gelu(LN(x) @ w1^T) @ w2^T + bias2) from the fp32 rows x
+    (LayerNorm input AND residual); with `want_stats` also the (mean, rstd) of the output rows, fp32 [rows, 2]."""
+    _dev(x, norm_weight, norm_bias, w1, w2p, mask, bias2)
+    assert x.dtype == torch.float32 and w1.dtype == torch.bfloat16 and w2p.dtype == torch.bfloat16
+    x2 = _rows2d(x)
+    R, D = x2.shape
+    Fi = w1.shape[0]
+    assert w1.shape == (Fi, D) and w1.stride(1) == 1 and w2p.shape == (Fi // 32, D, 32) and w2p.is_contiguous()
+    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
+    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+    nb = x2.numel() * 8 + (w1.numel() + w2p.numel()) * 2 + out.numel() * 4 + (R * 8 if want_stats else 0)
+    _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_prenorm, x2.data_ptr(),
+            x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w1.stride(0),
+            w2p.data_ptr(), _ptr(bias2), _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())
+    return (out, stats) if want_stats else out
 
 
 def gemm_lnin(x: Tensor, stats: Tensor, ln_weight: Tensor, ln_bias: Tensor, w: Tensor, bias: Optional[Tensor] = None,

@@ -406,6 +406,42 @@ def test_fused_ffn_row_statistics_feed_the_next_linear():
     assert err.max().item() <= 2 ** -5 and err.pow(2).mean().sqrt().item() <= 2e-3
 
 
+@pytest.mark.parametrize("R,D,Fi,masked", [(128 * 9 + 17, 384, 1536, True), (300, 256, 1024, True), (128 * 3, 384, 1536, False)])
+def test_fused_ffn_with_layernorm_prologue(R, D, Fi, masked):
+    """ispk_ffn_bf16_prenorm == LayerNorm kernel (bf16 out, row mask) -> ispk_ffn_bf16 with the fp32 rows as residual:
+    two-pass fp32 statistics on the same values (another summation order), so the normalised operand differs by 1-ulp
+    bf16 flips only; masked rows are exactly zero; the optional statistics describe the output rows."""
+    x = synth._normal(f"t/ffnpre/x{R}", (R, D), 1.5, 0.4)
+    w1, w2 = _bf(synth._normal(f"t/ffnpre/w1{D}", (Fi, D), D ** -0.5)), _bf(synth._normal(f"t/ffnpre/w2{D}", (D, Fi), Fi ** -0.5))
+    g, b = synth._normal("t/ffnpre/g", (D,), 0.1, 1.0), synth._normal("t/ffnpre/b", (D,), 0.1)
+    mask = (torch.arange(R) % 7 != 3) if masked else None
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    w2p = runtime.ffn_pack_w2(d(w2))
+    fl = runtime.EP_MASK_OUT if masked else 0
+    h = runtime.layernorm(d(x), d(g), d(b), row_mask=d(mask), out_dtype=torch.bfloat16)
+    ref = runtime.ffn_fused(h, d(w1), w2p, resid=d(x), mask=d(mask), flags=fl).cpu()
+    out = runtime.ffn_prenorm(d(x), d(g), d(b), d(w1), w2p, mask=d(mask), flags=fl)
+    out2, stats = runtime.ffn_prenorm(d(x), d(g), d(b), d(w1), w2p, mask=d(mask), flags=fl, want_stats=True)
+    assert torch.equal(out, out2)                       # deterministic, and the statistics epilogue leaves `out` alone
+    assert torch.equal(out, runtime.ffn_prenorm(d(x), d(g), d(b), d(w1), w2p, mask=d(mask), flags=fl))
+    out = out.cpu()
+    err = (out - ref).abs()
+    assert err.max().item() <= 2e-2 and err.pow(2).mean().sqrt().item() <= 1e-3
+    if masked:
+        assert out[~mask].abs().max().item() == 0.0
+    # against float64 on the un-rounded LayerNorm: bounded by the bf16 operand / hidden roundings
+    x64 = x.double()
+    hn = (x64 - x64.mean(1, keepdim=True)) / torch.sqrt(x64.var(1, unbiased=False, keepdim=True) + 1e-5) * g.double() + b.double()
+    ref64 = x64 + F.gelu(hn @ w1.double().t()) @ w2.double().t()
+    if masked:
+        ref64 = ref64 * mask[:, None]
+    assert (out.double() - ref64).abs().max().item() <= 0.06
+    o64 = out.double()
+    assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
+    rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
+    assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
+
+
 def test_attention_bf16_several_query_tiles_per_workgroup(monkeypatch):
     """With the whole key range resident in LDS a workgroup serves several 64-query tiles off one K/V fetch (the launcher
     does this by itself only for large batches; forced here).  Same values as one tile per workgroup, bit for bit."""

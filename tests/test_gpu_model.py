@@ -247,10 +247,11 @@ def test_bf16_chained_layernorm_matches_separate_layernorm_at_full_size(gpu_mode
     assert (chained.float() * ~mask[..., None]).abs().max() == 0
 
 
-def test_bf16_layernorm_statistics_handoff_matches_separate_layernorm_at_full_size(gpu_model):
+def test_bf16_layernorm_statistics_handoff_matches_separate_layernorm_at_full_size(gpu_model, monkeypatch):
     """Decoder stack at the benchmark shape with layers 2..6's attention LayerNorm applied inside the q/kv GEMM from the
     previous feed-forward kernel's row statistics (`Transformer.stats_layernorm`) against separate LayerNorm launches:
     same fp32 statistics up to the reduction tree, so only 1-ulp bf16 roundings of the normalised operand differ."""
+    monkeypatch.setenv("ISPK_FFN_PRENORM", "0")          # isolate the hand-off (ispk_ffn_bf16_ln -> ispk_gemm_bf16_lnin)
     x = synth._normal("t/chain/x", (64, 512, 384)).to(DEV)
     lens = torch.full((64,), 512, device=DEV)
     lens[2::5] = 211
@@ -268,6 +269,27 @@ def test_bf16_layernorm_statistics_handoff_matches_separate_layernorm_at_full_si
     diff = (handed.float() - plain.float()).abs()
     assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
     assert (handed.float() * ~mask[..., None]).abs().max() == 0
+
+
+def test_bf16_prenorm_feed_forward_matches_separate_layernorm_at_full_size(gpu_model, monkeypatch):
+    """Decoder stack at the benchmark shape with feed_forward_norm computed inside the fused feed-forward kernel
+    (ispk_ffn_bf16_prenorm, the default) against separate LayerNorm launches (ISPK_FFN_PRENORM=0)."""
+    x = synth._normal("t/chain/x", (64, 512, 384)).to(DEV)
+    lens = torch.full((64,), 512, device=DEV)
+    lens[2::5] = 211
+    mask = torch.arange(512, device=DEV)[None] < lens[:, None]
+    dec = gpu_model.decoder
+    try:
+        dec.set_compute_dtype(torch.bfloat16)
+        fused = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+        monkeypatch.setenv("ISPK_FFN_PRENORM", "0")
+        monkeypatch.setenv("ISPK_STATS_LN", "0")
+        plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+    finally:
+        dec.set_compute_dtype(torch.float32)
+    diff = (fused.float() - plain.float()).abs()
+    assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
+    assert (fused.float() * ~mask[..., None]).abs().max() == 0
 
 
 def test_config2_encoder_decoder_scope_fp32(gpu_model, state_dict):

@@ -39,6 +39,8 @@ stats32 = torch.stack([resid.mean(1), 1.0 / torch.sqrt(resid.var(1, unbiased=Fal
 cases.update({
     "lnin panel 384->512 (fp32 x + stats)": (lambda: runtime.gemm_lnin(resid, stats32, gam, bet, wqkv), 2.0 * R * 384 * 512),
     "layernorm 384 bf16 out": (lambda: runtime.layernorm(resid, gam, bet, out_dtype=dt), 0.0),
+    "ffn_prenorm (fp32 x, own LN)": (lambda: runtime.ffn_prenorm(resid, gam, bet, w1, w2p, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),
+    "ffn_prenorm + stats": (lambda: runtime.ffn_prenorm(resid, gam, bet, w1, w2p, mask=mask, flags=runtime.EP_MASK_OUT, want_stats=True), 4.0 * R * 384 * 1536),
     "ffn_fused + stats": (lambda: runtime.ffn_fused_stats(x, w1, w2p, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),
 })
 only = sys.argv[1:]

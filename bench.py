@@ -198,7 +198,9 @@ def main():
                                     d["flow_x0"], d["flow_t"], lanes=args.in_flight)
         graphed = lanes.lanes[0][0]
 
-    gather = MelGatherPipeline(B, AcousticDims().mel_dim, M, dev) if use_dist else None
+    # the one exchange of the path: every rank's mel outputs gathered on rank 0 (ISPK_BENCH_ALLGATHER=1: on every rank)
+    gather_root = None if os.environ.get("ISPK_BENCH_ALLGATHER") == "1" else 0
+    gather = MelGatherPipeline(B, AcousticDims().mel_dim, M, dev, root=gather_root) if use_dist else None
 
     def step():
         if lanes is not None:
@@ -206,7 +208,7 @@ def main():
             stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(stream):
                 out = g.replay()
-                if use_dist:   # the one exchange of the path: mel outputs over xGMI (RCCL all-gather), overlapped too
+                if use_dist:   # the one exchange of the path: mel outputs over xGMI (RCCL gather), overlapped too
                     gather.submit(out.mel, out.adaptor_output.dec_lengths)
             return out
         out = eager_step()
@@ -264,7 +266,7 @@ def main():
                                    "1 flow eval + MelDecoder + to_mel), fixed-length synthetic random-phoneme batch, "
                                    "random-init weights of the recipe architecture (23.2 M params)",
                        "batch_per_gpu": B, "global_batch": world * B, "text_len": L, "mel_len": M,
-                       "parallelism": f"dp{world} (utterances sharded, RCCL all-gather of mel overlapped with the next step)" if world > 1 else "single GPU",
+                       "parallelism": f"dp{world} (utterances sharded, RCCL {'all-gather' if gather_root is None else 'gather to rank 0'} of mel overlapped with the next step)" if world > 1 else "single GPU",
                        "device": name, "compute_units": cus,
                        "launch": "eager" if graphed is None else "HIP graph replay",
                        "batches_in_flight": len(lanes) if lanes is not None else 1,

@@ -2,9 +2,10 @@
 
 Utterances are independent end to end (no cross-utterance op on the forward path), so data parallelism
 needs no collective inside the model: weights are replicated (92.5 MB fp32), each rank (one process per GPU) runs its
-shard, and the mel outputs are gathered once — `torch.distributed` all-gather, which is RCCL over xGMI with the "nccl"
-backend on ROCm.  Message sizes are small (B_local * 80 * M * 4 B: 10.5 MB per rank at 64 x 512 frames), so the
-exchange is one all-gather of equal-sized, padded blocks rather than a ring of bucketed pieces.
+shard, and the mel outputs are gathered once — a `torch.distributed` gather to one rank (or an all-gather when every
+rank wants every utterance), which is RCCL over xGMI with the "nccl" backend on ROCm.  Message sizes are small
+(B_local * 80 * M * 4 B: 10.5 MB per rank at 64 x 512 frames), so the exchange is one message of equal-sized, padded
+blocks per rank rather than a ring of bucketed pieces.
 
 Everything here is backend-agnostic (the CPU test suite runs it over gloo with world_size 2).
 """
@@ -65,48 +66,62 @@ def all_gather_mel(mel: Tensor, dec_len: Tensor, group: Optional[dist.ProcessGro
 class MelGatherPipeline:
     """The same exchange for a stream of fixed-shape batches, overlapped with compute: batch i's gather runs on the
     process group's communication stream while batch i+1 is being computed (xGMI and the CUs work at the same time; a
-    blocking all-gather of 8 x 10.5 MB per step would add its full ring time to every step).
+    blocking exchange of 8 x 10.5 MB per step would add its full transfer time to every step).
+
+    `root` = rank that collects (the "RCCL gather of mel outputs" of the north star: every other rank SENDS its 10.5 MB
+    over its direct xGMI link to the root and receives nothing - one grouped send/recv, the root's seven links work in
+    parallel), or None for an all-gather (every rank ends up with every utterance; 8 x the fabric traffic).  mel and
+    dec_len travel as ONE packed message per step.
 
     `submit(mel, dec_len)` copies the step's outputs into one of two staging buffers (the model's output buffers are
-    overwritten by the next step, e.g. by a HIP-graph replay) and starts an asynchronous all-gather from it; it only
-    blocks when that staging buffer's previous gather (two batches back) is still in flight.  `wait()` drains the
-    pipeline and returns the latest (mel [world, B, C, M], dec_len [world, B])."""
+    overwritten by the next step, e.g. by a HIP-graph replay) and starts the asynchronous exchange from it; it only
+    blocks when that staging buffer's previous exchange (two batches back) is still in flight.  `wait()` drains the
+    pipeline and returns the latest (mel [world, B, C, M], dec_len [world, B]) - on the root only when `root` is set
+    (None elsewhere)."""
 
     def __init__(self, batch: int, channels: int, frames: int, device, dtype: torch.dtype = torch.float32,
-                 group: Optional[dist.ProcessGroup] = None):
-        self.group = group
-        self.world = dist.get_world_size(group)
+                 group: Optional[dist.ProcessGroup] = None, root: Optional[int] = None):
+        assert dtype == torch.float32, "the packed message carries int64 lengths behind fp32 mel values"
+        self.group, self.root = group, root
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.shape = (batch, channels, frames)
-        self.stage = [torch.empty(self.shape, dtype=dtype, device=device) for _ in range(2)]
-        self.stage_len = [torch.empty((batch,), dtype=torch.int64, device=device) for _ in range(2)]
-        self.out = [torch.empty((self.world * batch, channels, frames), dtype=dtype, device=device) for _ in range(2)]
-        self.out_len = [torch.empty((self.world * batch,), dtype=torch.int64, device=device) for _ in range(2)]
+        self.n_mel = batch * channels * frames                     # fp32 elements; the int64 lengths follow (8-byte aligned)
+        assert self.n_mel % 2 == 0
+        self.n_msg = self.n_mel + 2 * batch
+        self.stage = [torch.empty((self.n_msg,), dtype=dtype, device=device) for _ in range(2)]
+        self.receives = root is None or self.rank == root
+        self.out = [torch.empty((self.world, self.n_msg), dtype=dtype, device=device) if self.receives else None
+                    for _ in range(2)]
         self.work: list = [None, None]
         self.count = 0
 
     def submit(self, mel: Tensor, dec_len: Tensor) -> None:
         assert tuple(mel.shape) == self.shape, "MelGatherPipeline is for fixed-shape batches (pad to the agreed shape)"
         k = self.count & 1
-        if self.work[k] is not None:          # this staging pair is being read by the gather of two batches ago
-            for w in self.work[k]:
-                w.wait()
-        self.stage[k].copy_(mel)
-        self.stage_len[k].copy_(dec_len)
-        self.work[k] = [dist.all_gather_into_tensor(self.out[k], self.stage[k], group=self.group, async_op=True),
-                        dist.all_gather_into_tensor(self.out_len[k], self.stage_len[k], group=self.group, async_op=True)]
+        if self.work[k] is not None:          # this staging buffer is being read by the exchange of two batches ago
+            self.work[k].wait()
+        self.stage[k][: self.n_mel].view(self.shape).copy_(mel)
+        self.stage[k][self.n_mel:].view(torch.int64).copy_(dec_len)
+        if self.root is None:
+            self.work[k] = dist.all_gather_into_tensor(self.out[k].view(-1), self.stage[k], group=self.group, async_op=True)
+        else:
+            rows = list(self.out[k].unbind(0)) if self.receives else None
+            dst = self.root if self.group is None else dist.get_global_rank(self.group, self.root)
+            self.work[k] = dist.gather(self.stage[k], rows, dst=dst, group=self.group, async_op=True)
         self.count += 1
 
     def wait(self):
-        for ws in self.work:
-            if ws is not None:
-                for w in ws:
-                    w.wait()
+        for w in self.work:
+            if w is not None:
+                w.wait()
         self.work = [None, None]
-        if self.count == 0:
+        if self.count == 0 or not self.receives:
             return None
         k = (self.count - 1) & 1
         b, c, m = self.shape
-        return self.out[k].view(self.world, b, c, m), self.out_len[k].view(self.world, b)
+        out = self.out[k]
+        return (out[:, : self.n_mel].reshape(self.world, b, c, m),
+                out[:, self.n_mel:].contiguous().view(torch.int64).view(self.world, b))
 
 
 def unshard(gathered: Tensor, lens: Tensor, shards: list[list[int]]):

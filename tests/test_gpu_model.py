@@ -323,5 +323,16 @@ def test_rccl_all_gather_of_mel_single_rank():
         assert torch.equal(g2[0], mel)
         full, dec = idist.unshard(g, l, [[3, 0, 4, 1, 2]])
         assert torch.equal(full[3], mel[0]) and int(dec[2]) == 1
+        # the overlapped pipeline of bench.py, as a gather to rank 0 (default) and as an all-gather
+        for root in (0, None):
+            pipe = idist.MelGatherPipeline(5, 80, 64, DEV, root=root)
+            src, src_len = torch.empty_like(mel), torch.empty_like(lens)
+            for step in range(3):
+                src.copy_(mel + step)
+                src_len.copy_(lens + step)
+                pipe.submit(src, src_len)
+                src.fill_(-1.0)
+            g3, l3 = pipe.wait()
+            assert torch.equal(g3[0], mel + 2) and torch.equal(l3[0], lens + 2)
     finally:
         dist.destroy_process_group()

@@ -144,6 +144,19 @@ def _rank_main(rank, world, port, q):
         g3, l3 = pipe.wait()
         ok = ok and all(torch.equal(g3[r], want[:2] + r + 20) for r in range(world))
         ok = ok and all(torch.equal(l3[r], mel_len[:2] + 2) for r in range(world))
+        # ... and as a gather to one rank (bench.py's default: the north star's "RCCL gather of mel outputs")
+        pipe = idist.MelGatherPipeline(2, 80, want.shape[2], "cpu", root=1)
+        for step in range(3):
+            src.copy_(want[:2] + rank + 10 * step)
+            src_len.copy_(mel_len[:2] + step)
+            pipe.submit(src, src_len)
+            src.fill_(-1.0)
+        res = pipe.wait()
+        if rank == 1:
+            ok = ok and all(torch.equal(res[0][r], want[:2] + r + 20) for r in range(world))
+            ok = ok and all(torch.equal(res[1][r], mel_len[:2] + 2) for r in range(world))
+        else:
+            ok = ok and res is None
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -178,9 +178,12 @@ int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const float* norm_gam
  * Replaces: normalization.py:20-27 + the Linear that follows it (transformer.py:79-80, attention.py:63-64: attention_norm
  * -> to_q / to_kv) on the bf16 path - the separate LayerNorm launch, its re-read of the fp32 residual stream and the
  * bf16 copy it writes disappear.  x fp32 [M][K] (the residual stream), row_stats float [M][2] = (mean, rstd) from
- * ispk_ffn_bf16_ln(ln_flags bit 2); K 256 or 384; flags / bias / resid / mask / C as ispk_gemm_bf16 (row-major outputs). */
+ * ispk_ffn_bf16_ln(ln_flags bit 2) / ispk_ffn_bf16_prenorm, or NULL: the kernel computes the statistics itself (its waves
+ * own whole rows; two-pass fp32 with ln_eps, fixed summation order) - then any LayerNorm -> Linear pair qualifies
+ * (transformer.py:79-80 of a stack's first layer, :101-105 + feedforward.py:33 on the unfused path).
+ * K 256 or 384; flags / bias / resid / mask / C as ispk_gemm_bf16 (row-major outputs). */
 int32_t ispk_gemm_bf16_lnin(const float* x, int64_t ldx, const float* row_stats, const float* ln_gamma, const float* ln_beta,
-                            const uint16_t* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* resid,
+                            float ln_eps, const uint16_t* W, int64_t ldw, void* C, int64_t ldc, const float* bias, const void* resid,
                             int64_t ldr, const uint8_t* mask, int32_t M, int32_t N, int32_t K, uint32_t flags,
                             ispk_stream_t stream);
 

@@ -777,7 +777,8 @@ bool vec_epilogue_ok(const GemmParams& p) {
 //     and 4 consecutive output features in consecutive registers, so bias / residual / output are 8- or 16-byte
 //     vector accesses (4 store instructions per 32x32 tile instead of 16 scalar ones);
 //   * the N range is split over blockIdx.x so that >= 512 workgroups exist (2 per CU).
-template <int KC, int EP = kEpDyn, bool ST = false, bool LNP = false>  // K = 64 * KC; EP: compile-time epilogue; ST: stamps; LNP: fp32 A + LayerNorm in the prologue
+// LNP: fp32 A + LayerNorm in the prologue - 1: the rows' (mean, rstd) are given, 2: the wave computes them itself
+template <int KC, int EP = kEpDyn, bool ST = false, int LNP = 0>  // K = 64 * KC; EP: compile-time epilogue; ST: stamps
 __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, int tiles_per_wg, int nsplit, int mblocks) {
     [[maybe_unused]] uint64_t tsum[6] = {0, 0, 0, 0, 0, 0}, t0 = 0, tA = 0, tB = 0, tC = 0, tD = 0;
     if constexpr (ST) t0 = __builtin_readcyclecounter();
@@ -838,8 +839,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
     // made this prologue as long as four weight tiles.)  The patches alias the weight-tile area, hence the barrier.
     constexpr int KH = K / 2, CPH = KH / 8, XCH = 32 * CPH / 64, XLD = KH * 2 + 16;   // per K-half; XLD in bytes
     static_assert(4 * 32 * XLD <= 64 * LDW * 2 + 4 * kStageBytes, "x staging patches must fit the workgroup's LDS");
-    wload(wr0, nt0, 0);
-    wload(wr1, nt0, 1);
+    if constexpr (LNP != 2) {   // (the self-statistics prologue holds the whole fp32 panel in registers: loads these later)
+        wload(wr0, nt0, 0);
+        wload(wr1, nt0, 1);
+    }
     bf16x8 xf[KS];
     if constexpr (!LNP) {
         char* xs = smem_raw + wave * (32 * XLD);
@@ -863,6 +866,87 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
 #pragma unroll
             for (int ks = 0; ks < KS / 2; ++ks)
                 xf[half * (KS / 2) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLD + ks * 32 + h * 16);
+        }
+    } else if constexpr (LNP == 2) {
+        // LayerNorm in the prologue with NO producer hand-off (ispk_gemm_bf16_lnin, row_stats == NULL): a wave owns whole
+        // rows, so it computes their statistics itself, exactly as the fused feed-forward kernel does for its pre-norm
+        // (ffn_bf16_kernel, LX): the 32 rows x K fp32 stay in registers (K/2 VGPRs; no accumulator is live yet) through two
+        // passes - per-lane float4 partials of one K-quarter -> a wave-private LDS table -> one lane per row half adds
+        // them in fixed order - then (x - mean) * rstd * gamma + beta is rounded to bf16 on the way into the fragment
+        // patch.  With N split over several workgroups each of them repeats the statistics (a few hundred cycles).
+        constexpr int KQ = K / 4, CPQ = KQ / 4, XQ = 32 * CPQ / 64, XLQ = KQ * 2 + 16;   // per K-quarter; XLQ in bytes
+        constexpr int GC = (64 % CPQ == 0) ? CPQ : (CPQ == 24 ? 8 : 1), NG = CPQ / GC;       // gcd(64, CPQ); groups per lane
+        constexpr int PLD = CPQ + 1;                                                         // one quarter's partials per row
+        static_assert(K == 384 || K == 256, "quarter staging is laid out for K = 256 / 384");
+        static_assert(4 * 32 * XLQ + 4 * 32 * PLD * 4 + 4 * 64 * 4 <= 64 * (K + 8) * 2, "pre-norm staging aliases the weight tile");
+        const float* Af = static_cast<const float*>(p.A);
+        char* xs = smem_raw + wave * (32 * XLQ);
+        float* part = reinterpret_cast<float*>(smem_raw + 4 * (32 * XLQ)) + wave * (32 * PLD);
+        float* sst = reinterpret_cast<float*>(smem_raw + 4 * (32 * XLQ) + 4 * 32 * PLD * 4) + wave * 64;
+        const int mwave = mb * 128 + wave * 32;
+        float4 t[4][XQ];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < XQ; ++j) {
+                const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                const int row = mwave + r < p.M ? mwave + r : p.M - 1;
+                t[q][j] = *reinterpret_cast<const float4*>(Af + (int64_t)row * p.lda + q * KQ + c * 4);
+            }
+        float tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < XQ; ++j) {
+                const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                const float4 v = t[q][j];
+                part[r * PLD + c] = (v.x + v.y) + (v.z + v.w);
+            }
+#pragma unroll
+            for (int i = 0; i < CPQ / 2; ++i) tot += part[l31 * PLD + h * (CPQ / 2) + i];
+        }
+        tot += __shfl_xor(tot, 32, 64);
+        if (h == 0) sst[2 * l31] = tot * (1.0f / (float)K);
+        tot = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int j = 0; j < XQ; ++j) {
+                const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                const float mu = sst[2 * r];
+                const float4 v = t[q][j];
+                const float a = v.x - mu, b = v.y - mu, cc = v.z - mu, d = v.w - mu;
+                part[r * PLD + c] = (a * a + b * b) + (cc * cc + d * d);
+            }
+#pragma unroll
+            for (int i = 0; i < CPQ / 2; ++i) tot += part[l31 * PLD + h * (CPQ / 2) + i];
+        }
+        tot += __shfl_xor(tot, 32, 64);
+        if (h == 0) sst[2 * l31 + 1] = 1.0f / sqrtf(tot * (1.0f / (float)K) + p.ln_eps);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q == 2) wload(wr0, nt0, 0);   // registers of the first two quarters are free again
+            if (q == 3) wload(wr1, nt0, 1);
+            float4 g[NG], be[NG];
+#pragma unroll
+            for (int u = 0; u < NG; ++u) {
+                const int c = (lane + 64 * u) % CPQ;
+                g[u] = *reinterpret_cast<const float4*>(p.ln_gamma + q * KQ + c * 4);
+                be[u] = *reinterpret_cast<const float4*>(p.ln_beta + q * KQ + c * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < XQ; ++j) {
+                const int id = lane + 64 * j, r = id / CPQ, c = id - r * CPQ;
+                const float mean = sst[2 * r], rstd = sst[2 * r + 1];
+                const float4 v = t[q][j], gg = g[j % NG], bb = be[j % NG];
+                uint2 o;
+                o.x = pack_bf16x2((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y);
+                o.y = pack_bf16x2((v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
+                *reinterpret_cast<uint2*>(xs + r * XLQ + c * 8) = o;
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS / 4; ++ks)
+                xf[q * (KS / 4) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLQ + ks * 32 + h * 16);
         }
     } else {
         // LayerNorm in the prologue (ispk_gemm_bf16_lnin): A is the fp32 residual stream; every row's (mean, rstd) comes
@@ -1054,16 +1138,21 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
         ISPK_PANEL_GO(kEpDyn, true, q);
     }
     if (p.ln_flags & 0x100u) {   // fp32 A + LayerNorm in the prologue (ispk_gemm_bf16_lnin)
-        ISPK_RESERVE_LDS((&gemm_bf16_panel_kernel<KC, kQkv, false, true>), lds, "gemm");
-        if (key == kQkv) {
-            hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC, kQkv, false, true>), dim3(mb8 * nsplit), dim3(256), lds, s, p, per,
-                               nsplit, mblocks);
-        } else {
-            ISPK_RESERVE_LDS((&gemm_bf16_panel_kernel<KC, kEpDyn, false, true>), lds, "gemm");
-            hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC, kEpDyn, false, true>), dim3(mb8 * nsplit), dim3(256), lds, s, p, per,
-                               nsplit, mblocks);
+#define ISPK_PANEL_GO_LN(EP_, LNP_)                                                                                     \
+    do {                                                                                                               \
+        ISPK_RESERVE_LDS((&gemm_bf16_panel_kernel<KC, EP_, false, LNP_>), lds, "gemm");                               \
+        hipLaunchKernelGGL((gemm_bf16_panel_kernel<KC, EP_, false, LNP_>), dim3(mb8 * nsplit), dim3(256), lds, s, p, per,  \
+                           nsplit, mblocks);                                                                           \
+        return ispk_launch_status();                                                                                   \
+    } while (0)
+        if (p.ln_out) {   // the rows' statistics are given (decoder layers 2..: from the fused feed-forward kernel)
+            if (key == kQkv) ISPK_PANEL_GO_LN(kQkv, 1);
+            ISPK_PANEL_GO_LN(kEpDyn, 1);
         }
-        return ispk_launch_status();
+        if (key == kQkv) ISPK_PANEL_GO_LN(kQkv, 2);
+        if (key == kFfn1) ISPK_PANEL_GO_LN(kFfn1, 2);
+        ISPK_PANEL_GO_LN(kEpDyn, 2);
+#undef ISPK_PANEL_GO_LN
     }
     if (getenv("ISPK_EP_DYN") == nullptr) {   // (set: experiments, forces the generic epilogue)
         if (key == kQkv) ISPK_PANEL_GO(kQkv, false, p);
@@ -1824,10 +1913,10 @@ extern "C" int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint1
 }
 
 extern "C" int32_t ispk_gemm_bf16_lnin(const float* x, int64_t ldx, const float* row_stats, const float* ln_gamma,
-                                       const float* ln_beta, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
+                                       const float* ln_beta, float ln_eps, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
                                        const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M,
                                        int32_t N, int32_t K, uint32_t flags, ispk_stream_t stream) {
-    ISPK_REQUIRE(x && row_stats && ln_gamma && ln_beta && W && C, ISPK_E_NULL, "gemm_lnin: null pointer");
+    ISPK_REQUIRE(x && ln_gamma && ln_beta && W && C, ISPK_E_NULL, "gemm_lnin: null pointer");
     ISPK_REQUIRE(K == 256 || K == 384, ISPK_E_UNSUPPORTED, "gemm_lnin: K=%d (built for 256 / 384)", K);
     ISPK_REQUIRE(M >= 0 && N >= 1, ISPK_E_SHAPE, "gemm_lnin: bad shape M=%d N=%d", M, N);
     ISPK_REQUIRE(ldx % 4 == 0 && ldx >= K && ldw % 8 == 0 && ldw >= K && ispk_aligned(x, 16) && ispk_aligned(W, 16) &&
@@ -1839,6 +1928,7 @@ extern "C" int32_t ispk_gemm_bf16_lnin(const float* x, int64_t ldx, const float*
                  ISPK_E_UNSUPPORTED, "gemm_lnin: needs a row-major output with 16-byte aligned rows");
     if (M == 0) return 0;
     p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_out = const_cast<float*>(row_stats); p.ln_flags = 0x100u;
+    p.ln_eps = ln_eps;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
 }

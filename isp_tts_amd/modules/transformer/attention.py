@@ -90,8 +90,9 @@ class Attention(nn.Module, Constructor):
         `key_len` (int64 [B]) may be passed to skip recomputing mask.sum(1); `residual` (fp32 [B,N,dim]) fuses
         `residual + mask * to_out(...)` into the output GEMM.  Returns (out, AttentionIntermediates,
         AttentionSharedIntermediates) like the reference; `rel_pos_bias` is None because no bias tensor exists.
-        `prenorm` = (row_stats, weight, bias): x is the fp32 input of the LayerNorm that precedes this block and the
-        q/kv GEMM applies that LayerNorm while staging x (bf16 path; statistics from the producing kernel)."""
+        `prenorm` = (row_stats | None, weight, bias, eps): x is the fp32 input of the LayerNorm that precedes this block
+        and the q/kv GEMM applies that LayerNorm while staging x (bf16 path; statistics from the producing kernel, or
+        computed by the GEMM's own waves when None)."""
         if context is not None or context_mask is not None or attention_mask is not None or cache is not None:
             raise NotImplementedError("cross-attention, explicit attention masks and KV caches are not on the "
                                       "acoustic-model forward path and are not built")
@@ -102,7 +103,7 @@ class Attention(nn.Module, Constructor):
             key_len = mask.sum(dim=1)
         if prenorm is not None:
             assert dt == torch.bfloat16 and x.dtype == torch.float32
-            qkv = runtime.gemm_lnin(x, prenorm[0], prenorm[1], prenorm[2], wqkv)
+            qkv = runtime.gemm_lnin(x, prenorm[0], prenorm[1], prenorm[2], wqkv, ln_eps=prenorm[3])
         else:
             if x.dtype != dt:
                 x = runtime.cast_bf16(x) if dt == torch.bfloat16 else x.float()

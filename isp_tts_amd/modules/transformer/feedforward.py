@@ -94,6 +94,24 @@ class FeedForward(nn.Module, Constructor):
                 and rows >= self.fused_min_rows and self.net[0].bias is None
                 and not (self.training and self.dropout_p > 0))
 
+    def prenorm_unfused_ok(self, x: Tensor, norm) -> bool:
+        """Two-GEMM path (e.g. an activation the fused kernel lacks): can the first Linear's GEMM apply `norm` itself?
+        Only from decoder-sized batches on - below, the separate LayerNorm launch is cheaper (28.8 vs 19.4 + 4.9 us at
+        6,400 rows: every workgroup of the split output repeats the fp32 staging)."""
+        return (os.environ.get("ISPK_LNIN_SELF") != "0" and isinstance(norm, nn.LayerNorm) and norm.weight is not None
+                and norm.bias is not None and x.dtype == torch.float32 and self.compute_dtype == torch.bfloat16
+                and x.shape[-1] in (256, 384) and x.numel() // x.shape[-1] >= self.fused_min_rows
+                and not (self.training and self.dropout_p > 0))
+
+    def forward_prenorm_unfused(self, x: Tensor, norm, *, mask: Optional[Tensor] = None) -> Tensor:
+        """y = [mask] * (x + W2 act(W1 norm(x))) as two GEMMs, the LayerNorm applied by the first one while it stages x
+        (ispk_gemm_bf16_lnin, statistics by its own waves); the `* mask` of transformer.py:102 is dead under the output mask."""
+        w1, w2 = self._staged(torch.bfloat16)
+        hidden = runtime.gemm_lnin(x, None, norm.weight, norm.bias, w1, bias=self.net[0].bias, flags=self.act_flag,
+                                   ln_eps=norm.eps)
+        return runtime.gemm(hidden, w2, bias=self.net[3].bias, resid=x, mask=mask,
+                            flags=runtime.EP_MASK_OUT if mask is not None else 0, out_dtype=torch.float32)
+
     def forward_prenorm(self, x: Tensor, norm, *, mask: Optional[Tensor] = None, next_norm: Optional[tuple] = None):
         """y = [mask] * (x + feed_forward(norm(x))) in one kernel (ispk_ffn_bf16_prenorm), x fp32; with `next_norm` =
         (.., eps, .., "stats") also the output rows' (mean, rstd) for the next layer's q/kv GEMM.  Returns (y, stats)."""

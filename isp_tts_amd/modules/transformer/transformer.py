@@ -58,6 +58,10 @@ class TransformerLayer(nn.Module, Constructor):
             raise NotImplementedError("post-norm layers are unused by the recipes and not built")
         assert not adaptive_norm or condition_dim is not None
         self.pre_norm, self.adaptive_norm = pre_norm, adaptive_norm
+        # LayerNorm inside the consuming GEMM with statistics computed by the GEMM's own waves: pays from decoder-sized
+        # batches on (33.0 vs 22.1 + 15.0 us at 32,768 rows); at 6,400 rows the output is split over many workgroups that
+        # each repeat the fp32 staging, and the separate 4.9-us LayerNorm is cheaper (18.6 vs 9.4 + 4.9 us)
+        self.lnin_self_min_rows = 128 * 128
         norm = (lambda: AdaptiveLayerNorm(dim, condition_dim=condition_dim)) if adaptive_norm else (lambda: LayerNorm(dim))
         self.attention_norm = norm()
         self.attention = Attention.init(attention if attention is not None else AttentionConfig(), dim=dim)
@@ -82,10 +86,17 @@ class TransformerLayer(nn.Module, Constructor):
             key_len = mask.sum(dim=1)
         kw1 = {"scale_shift": ada[0]} if ada is not None else {}
         kw2 = {"scale_shift": ada[1]} if ada is not None else {}
-        if normed is not None and normed.dtype == torch.float32 and normed.shape[-1] == 2 and cdt == torch.bfloat16:
-            # the previous layer handed over this norm's row statistics: the q/kv GEMM applies it while staging x
+        handed = normed is not None and normed.dtype == torch.float32 and normed.shape[-1] == 2
+        own = (normed is None and ada is None and isinstance(self.attention_norm, nn.LayerNorm) and context is None
+               and attention_mask is None and x.shape[-1] in (256, 384) and self.attention_norm.weight is not None
+               and self.attention_norm.bias is not None and os.environ.get("ISPK_LNIN_SELF") != "0"
+               and x.numel() // x.shape[-1] >= self.lnin_self_min_rows)
+        if cdt == torch.bfloat16 and (handed or own):
+            # attention_norm inside the q/kv GEMM, applied while it stages x: with the row statistics the previous layer's
+            # feed-forward kernel handed over, or (first layer of a stack) computed by the GEMM's own waves
+            an = self.attention_norm
             x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x,
-                                               prenorm=(normed, self.attention_norm.weight, self.attention_norm.bias))
+                                               prenorm=(normed if handed else None, an.weight, an.bias, an.eps))
         else:
             h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
             x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
@@ -98,6 +109,12 @@ class TransformerLayer(nn.Module, Constructor):
             y, hn = self.feed_forward.forward_prenorm(x1, self.feed_forward_norm, mask=mask, next_norm=next_norm)
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                           shared_intermediates=shared, next_normed=hn)
+        if (ada is None and (next_norm is None or next_norm[4] == "stats")
+                and self.feed_forward.prenorm_unfused_ok(x1, self.feed_forward_norm)):
+            # small batches (two-GEMM feed-forward): feed_forward_norm inside the first Linear's GEMM
+            y = self.feed_forward.forward_prenorm_unfused(x1, self.feed_forward_norm, mask=mask)
+            return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
+                                          shared_intermediates=shared, next_normed=None)
         h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt, **kw2)
         if next_norm is not None and self.feed_forward.fused_with_norm_ok(h2):
             y, hn = self.feed_forward.forward_with_norm(h2, next_norm, residual=x1, mask=mask)

@@ -40,7 +40,7 @@ SIGNATURES = {
     "ispk_ffn_bf16_ln": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64,
                          _U32, _P],
     "ispk_ffn_bf16_prenorm": [_P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
-    "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
+    "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _F32, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -389,24 +389,27 @@ def ffn_prenorm(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w
     return (out, stats) if want_stats else out
 
 
-def gemm_lnin(x: Tensor, stats: Tensor, ln_weight: Tensor, ln_bias: Tensor, w: Tensor, bias: Optional[Tensor] = None,
-              mask: Optional[Tensor] = None, flags: int = 0, out_dtype: torch.dtype = torch.bfloat16) -> Tensor:
-    """ispk_gemm_bf16_lnin: C[..., N] = epilogue(bf16(LayerNorm(x)) @ w[N, K]^T) with x fp32 [..., K] and the rows'
-    (mean, rstd) in `stats` (from `ffn_fused_stats`)."""
+def gemm_lnin(x: Tensor, stats: Optional[Tensor], ln_weight: Tensor, ln_bias: Tensor, w: Tensor,
+              bias: Optional[Tensor] = None, mask: Optional[Tensor] = None, flags: int = 0,
+              out_dtype: torch.dtype = torch.bfloat16, ln_eps: float = 1e-5) -> Tensor:
+    """ispk_gemm_bf16_lnin: C[..., N] = epilogue(bf16(LayerNorm(x)) @ w[N, K]^T) with x fp32 [..., K]; the rows'
+    (mean, rstd) come from `stats` (written by `ffn_fused_stats` / `ffn_prenorm`) or, with stats None, are computed by
+    the kernel itself."""
     _dev(x, stats, ln_weight, ln_bias, w, bias, mask)
-    assert x.dtype == torch.float32 and w.dtype == torch.bfloat16 and stats.dtype == torch.float32
+    assert x.dtype == torch.float32 and w.dtype == torch.bfloat16
     x2 = _rows2d(x)
     M, K = x2.shape
     N = w.shape[0]
-    assert stats.shape == (M, 2) and stats.is_contiguous() and w.shape == (N, K) and w.stride(1) == 1
+    assert w.shape == (N, K) and w.stride(1) == 1
+    assert stats is None or (stats.dtype == torch.float32 and stats.shape == (M, 2) and stats.is_contiguous())
     if out_dtype == torch.bfloat16:
         flags |= EP_OUT_BF16
     out = torch.empty((*x.shape[:-1], N), dtype=out_dtype, device=x.device)
     if mask is not None:
         mask = mask.reshape(-1).contiguous()
-    nb = x2.numel() * 4 + stats.numel() * 4 + w.numel() * 2 + out.numel() * out.element_size()
+    nb = x2.numel() * 4 + (stats.numel() * 4 if stats is not None else 0) + w.numel() * 2 + out.numel() * out.element_size()
     _launch(f"gemm_bf16_panel_kernel<{K // 64},lnin>", 2.0 * M * N * K, float(nb), lib().ispk_gemm_bf16_lnin, x2.data_ptr(),
-            x2.stride(0), stats.data_ptr(), ln_weight.data_ptr(), ln_bias.data_ptr(), w.data_ptr(), w.stride(0),
+            x2.stride(0), _ptr(stats), ln_weight.data_ptr(), ln_bias.data_ptr(), ln_eps, w.data_ptr(), w.stride(0),
             out.data_ptr(), N, _ptr(bias), 0, 0, _ptr(mask), M, N, K, flags, _stream())
     return out
 

@@ -379,6 +379,16 @@ def test_linear_with_layernorm_prologue(R, D, N):
     hn = ((x.double() - mean[:, None]) * rstd[:, None] * g.double() + b.double())
     ref64 = hn @ w.double().t()
     assert (out.double() - ref64).abs().max().item() <= 0.08
+    # row_stats NULL: the kernel's waves compute the statistics themselves (deterministic), also under other epilogues
+    own = runtime.gemm_lnin(d(x), None, d(g), d(b), d(w))
+    assert torch.equal(own, runtime.gemm_lnin(d(x), None, d(g), d(b), d(w)))
+    err = (own.cpu().float() - ref.float()).abs()
+    assert err.max().item() <= 2 ** -5 and err.pow(2).mean().sqrt().item() <= 2e-3
+    gel = runtime.gemm_lnin(d(x), None, d(g), d(b), d(w), flags=runtime.EP_GELU).cpu()
+    gref = runtime.gemm(h, d(w), flags=runtime.EP_GELU).cpu()
+    assert (gel.float() - gref.float()).abs().max().item() <= 2 ** -5
+    f32 = runtime.gemm_lnin(d(x), None, d(g), d(b), d(w), out_dtype=torch.float32).cpu()
+    assert (f32.double() - ref64).abs().max().item() <= 0.08
 
 
 def test_fused_ffn_row_statistics_feed_the_next_linear():

@@ -284,12 +284,40 @@ def test_bf16_prenorm_feed_forward_matches_separate_layernorm_at_full_size(gpu_m
         fused = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
         monkeypatch.setenv("ISPK_FFN_PRENORM", "0")
         monkeypatch.setenv("ISPK_STATS_LN", "0")
+        monkeypatch.setenv("ISPK_LNIN_SELF", "0")
         plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
     finally:
         dec.set_compute_dtype(torch.float32)
     diff = (fused.float() - plain.float()).abs()
     assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
     assert (fused.float() * ~mask[..., None]).abs().max() == 0
+
+
+def test_bf16_encoder_with_layernorms_inside_the_gemms_matches_separate_layernorms(gpu_model, monkeypatch):
+    """Encoder-sized stack (two-GEMM feed-forward): attention_norm inside the q/kv GEMM and feed_forward_norm inside the
+    first feed-forward GEMM (ispk_gemm_bf16_lnin, statistics by the GEMM's own waves) against separate LayerNorm launches."""
+    x = synth._normal("t/lnself/x", (16, 100, 384)).to(DEV)
+    lens = torch.full((16,), 100, device=DEV)
+    lens[1::3] = 37
+    mask = torch.arange(100, device=DEV)[None] < lens[:, None]
+    enc = gpu_model.encoder
+    saved = [(l.lnin_self_min_rows, l.feed_forward.fused_min_rows) for l in enc.layers]
+    try:
+        enc.set_compute_dtype(torch.bfloat16)
+        for l in enc.layers:                 # (by default only decoder-sized batches take these paths)
+            l.lnin_self_min_rows = 0
+            l.feed_forward.fused_min_rows = 0
+            l.feed_forward.prenorm_fused = False
+        fused = enc(x, mask=mask, key_len=lens).out
+        monkeypatch.setenv("ISPK_LNIN_SELF", "0")
+        plain = enc(x, mask=mask, key_len=lens).out
+    finally:
+        for l, (a, b) in zip(enc.layers, saved):
+            l.lnin_self_min_rows, l.feed_forward.fused_min_rows, l.feed_forward.prenorm_fused = a, b, True
+        enc.set_compute_dtype(torch.float32)
+    diff = (fused - plain).abs()
+    assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
+    assert (fused * ~mask[..., None]).abs().max() == 0
 
 
 def test_config2_encoder_decoder_scope_fp32(gpu_model, state_dict):

@@ -38,6 +38,10 @@ gam, bet = torch.ones(384, device=dev), torch.zeros(384, device=dev)
 stats32 = torch.stack([resid.mean(1), 1.0 / torch.sqrt(resid.var(1, unbiased=False) + 1e-5)], 1).contiguous()
 cases.update({
     "lnin panel 384->512 (fp32 x + stats)": (lambda: runtime.gemm_lnin(resid, stats32, gam, bet, wqkv), 2.0 * R * 384 * 512),
+    "lnin panel 384->512 (own stats)": (lambda: runtime.gemm_lnin(resid, None, gam, bet, wqkv), 2.0 * R * 384 * 512),
+    "lnin small 6400x384->512 (own stats)": (lambda: runtime.gemm_lnin(r6k, None, gam, bet, wqkv), 2.0 * 6400 * 384 * 512),
+    "lnin small 6400x384->1536 gelu (own)": (lambda: runtime.gemm_lnin(r6k, None, gam, bet, w1, flags=runtime.EP_GELU), 2.0 * 6400 * 384 * 1536),
+    "layernorm 6400x384 bf16 out": (lambda: runtime.layernorm(r6k, gam, bet, out_dtype=dt), 0.0),
     "layernorm 384 bf16 out": (lambda: runtime.layernorm(resid, gam, bet, out_dtype=dt), 0.0),
     "ffn_prenorm (fp32 x, own LN)": (lambda: runtime.ffn_prenorm(resid, gam, bet, w1, w2p, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),
     "ffn_prenorm + stats": (lambda: runtime.ffn_prenorm(resid, gam, bet, w1, w2p, mask=mask, flags=runtime.EP_MASK_OUT, want_stats=True), 4.0 * R * 384 * 1536),

@@ -24,7 +24,7 @@ def label_of(kernel_name: str):
     name, targs = m.group(1), [a.strip() for a in (m.group(2) or "").split(",") if a.strip()]
     if not targs:
         return name
-    if name == "gemm_bf16_panel_kernel" and len(targs) >= 4 and targs[3] == "true":
+    if name == "gemm_bf16_panel_kernel" and len(targs) >= 4 and targs[3] not in ("0", "false"):
         return f"{name}<{targs[0]},lnin>"          # the LayerNorm-prologue instances (ispk_gemm_bf16_lnin)
     n = 2 if name in ("gemm_bf16_wide_kernel", "gemm_bf16_kernel", "gemm_f32_kernel", "gemm_bf16_panel_kernel") else 1
     return f"{name}<{','.join(targs[:n])}>"

@@ -148,10 +148,13 @@ constexpr int kAD = 128;        // attention_dim of the aligner
 // same chunk of 16 different rows, land on 16 different 4-bank slots.
 __device__ __forceinline__ int ks_off(int row, int chunk) { return row * kAD + ((chunk ^ (row & 31)) << 2); }
 
-// grid (ceil(M/128), B), 256 threads: wave w owns mel rows blockIdx.x*128 + w*32 .. +31.
+// grid (ceil(M/64), B), 128 threads: wave w owns mel rows blockIdx.x*64 + w*32 .. +31.  Two waves per workgroup, so that
+// two workgroups share a CU at L_max <= 160 (64 KB of keys each) and one's load / MFMA / transcendental / store phases
+// overlap the other's (one 4-wave workgroup per CU ran them strictly one after the other: 56 us at B=64 x 512 x 100).
 // NB = ceil(L_max / 32) 32-key blocks held in registers (NB <= 10: L_max <= 320).
+constexpr int kAsWaves = 2;
 template <int NB>
-__global__ __launch_bounds__(256) void aligner_scores_kernel(const float* __restrict__ qe, int64_t q_stride_b,
+__global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const float* __restrict__ qe, int64_t q_stride_b,
                                                              const float* __restrict__ ke, int64_t k_stride_b,
                                                              const int64_t* __restrict__ text_len,
                                                              const int64_t* __restrict__ mel_len,
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256) void aligner_scores_kernel(const float* __rest
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
-    const int m0 = blockIdx.x * 128 + wave * 32;
+    const int m0 = blockIdx.x * (32 * kAsWaves) + wave * 32;
     int tl = (int)text_len[b], ml = (int)mel_len[b];
     tl = tl < 1 ? 1 : (tl > L ? L : tl);
     ml = ml < 1 ? 1 : (ml > M ? M : ml);
@@ -172,11 +175,25 @@ __global__ __launch_bounds__(256) void aligner_scores_kernel(const float* __rest
 
     // stage the encoded keys of this utterance (rows >= L zero-filled)
     const float* kb = ke + (int64_t)b * k_stride_b;
-    for (int idx = tid; idx < NB * 32 * (kAD / 4); idx += 256) {
-        const int row = idx / (kAD / 4), c4 = (idx - row * (kAD / 4)) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row < L) v = *reinterpret_cast<const float4*>(kb + (int64_t)row * kAD + c4);
-        *reinterpret_cast<float4*>(Ks + ks_off(row, c4 >> 2)) = v;
+    {   // 8 loads in flight per thread (a load -> store loop left as is runs one L2 round trip per 16 bytes)
+        constexpr int kPieces = NB * 32 * (kAD / 4) / (64 * kAsWaves), kBatch = 8;
+        static_assert(kPieces % kBatch == 0, "key tile pieces per thread");
+        for (int i0 = 0; i0 < kPieces; i0 += kBatch) {
+            float4 v[kBatch];
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int idx = tid + (i0 + u) * (64 * kAsWaves);
+                const int row = idx / (kAD / 4), c4 = (idx - row * (kAD / 4)) * 4;
+                const int rr = row < L ? row : L - 1;                       // clamped: unconditional loads
+                v[u] = *reinterpret_cast<const float4*>(kb + (int64_t)rr * kAD + c4);
+            }
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u) {
+                const int idx = tid + (i0 + u) * (64 * kAsWaves);
+                const int row = idx / (kAD / 4), c4 = (idx - row * (kAD / 4)) * 4;
+                *reinterpret_cast<float4*>(Ks + ks_off(row, c4 >> 2)) = row < L ? v[u] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
     }
     // this lane's mel row as the MFMA B operand: half h owns dims 64h .. 64h+63
     const int m = m0 + l31;
@@ -220,6 +237,7 @@ __global__ __launch_bounds__(256) void aligner_scores_kernel(const float* __rest
     rmax = fmaxf(rmax, __shfl_xor(rmax, 32, 64));
     float rsum = 0.f, psum = 0.f;
     const float mq = (float)m / (float)ml;
+    float pe[NB][16];   // the un-normalised prior, kept for the second pass (an expf and a division per element)
 #pragma unroll
     for (int kb_ = 0; kb_ < NB; ++kb_)
 #pragma unroll
@@ -227,9 +245,11 @@ __global__ __launch_bounds__(256) void aligner_scores_kernel(const float* __rest
             const int key = kb_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             rsum += expf(s[kb_][r] - rmax);  // exp(-inf) = 0 for key >= L
             // un-normalised diagonal prior (alignment.py:22-32): exp(-(t/T - m/M)^2 / (2 * 0.1^2)), 0 outside the lengths
+            pe[kb_][r] = 0.f;
             if (key < tl && m < ml) {
                 const float g = (float)key / (float)tl - mq;
-                psum += expf(-(g * g) / (2.0f * 0.1f * 0.1f));
+                pe[kb_][r] = expf(-(g * g) / (2.0f * 0.1f * 0.1f));
+                psum += pe[kb_][r];
             }
         }
     rsum += __shfl_xor(rsum, 32, 64);
@@ -246,8 +266,7 @@ __global__ __launch_bounds__(256) void aligner_scores_kernel(const float* __rest
             const int key = kb_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
             float pr = 0.f;
             if (key < tl && m < ml) {
-                const float g = (float)key / (float)tl - mq;
-                pr = expf(-(g * g) / (2.0f * 0.1f * 0.1f)) * pinv;
+                pr = pe[kb_][r] * pinv;
                 pr = pr < 1e-4f ? 0.f : pr;
             }
             const float lg = (s[kb_][r] - lse) + logf(pr + 1e-6f);
@@ -309,33 +328,58 @@ __global__ __launch_bounds__(256) void aligner_scores_kernel(const float* __rest
 // ------------------------------------------------------------------------------------------------ soft averages
 // TemporalAverager, soft branch (temporal_adaptor.py:446-449), for pitch and energy at once, plus log1p(duration):
 // feats[b][l][0] = log1p(dur[b][l]); feats[b][l][1+f] = mask * sum_m x_f[b][m] A[b][m][l] / (sum_m A[b][m][l] + 1e-5)
-// grid (ceil(L/64), B), 256 threads = 4 frame lanes x 64 text columns.
-__global__ __launch_bounds__(256) void soft_average_kernel(const float* __restrict__ attn, const float* __restrict__ pitch,
-                                                           const float* __restrict__ energy,
-                                                           const int64_t* __restrict__ dur,
-                                                           const int64_t* __restrict__ text_len, float* __restrict__ feats,
-                                                           int M, int L) {
-    __shared__ float red[3][4][64];
-    const int b = blockIdx.y, l = blockIdx.x * 64 + (threadIdx.x & 63), ml = threadIdx.x >> 6;
+// grid (ceil(L/64), B), 1024 threads = 16 frame lanes x 64 text columns (only 2 x B workgroups exist, so each carries as
+// many loads in flight as a workgroup can: 8 independent frames per thread and trip).
+constexpr int kSaLanes = 16;
+__global__ __launch_bounds__(64 * kSaLanes) void soft_average_kernel(const float* __restrict__ attn,
+                                                                     const float* __restrict__ pitch,
+                                                                     const float* __restrict__ energy,
+                                                                     const int64_t* __restrict__ dur,
+                                                                     const int64_t* __restrict__ text_len,
+                                                                     float* __restrict__ feats, int M, int L) {
+    __shared__ float red[3][kSaLanes][64];
+    const int b = blockIdx.y, j = threadIdx.x & 63, l = blockIdx.x * 64 + j, ml = threadIdx.x >> 6;
     const bool ok = l < L;
     const float* ab = attn + (int64_t)b * M * L;
+    const float* pb = pitch + (int64_t)b * M;
+    const float* eb = energy + (int64_t)b * M;
     float sa = 0.f, sp = 0.f, se = 0.f;
-    if (ok)
-        for (int mm = ml; mm < M; mm += 4) {
+    if (ok) {
+        int mm = ml;
+        for (; mm + 7 * kSaLanes < M; mm += 8 * kSaLanes) {
+            float a[8], pv[8], ev[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                a[u] = ab[(int64_t)(mm + u * kSaLanes) * L + l];
+                pv[u] = pb[mm + u * kSaLanes];
+                ev[u] = eb[mm + u * kSaLanes];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                sa += a[u];
+                sp = fmaf(pv[u], a[u], sp);
+                se = fmaf(ev[u], a[u], se);
+            }
+        }
+        for (; mm < M; mm += kSaLanes) {
             const float a = ab[(int64_t)mm * L + l];
             sa += a;
-            sp = fmaf(pitch[(int64_t)b * M + mm], a, sp);
-            se = fmaf(energy[(int64_t)b * M + mm], a, se);
+            sp = fmaf(pb[mm], a, sp);
+            se = fmaf(eb[mm], a, se);
         }
-    red[0][ml][threadIdx.x & 63] = sa;
-    red[1][ml][threadIdx.x & 63] = sp;
-    red[2][ml][threadIdx.x & 63] = se;
+    }
+    red[0][ml][j] = sa;
+    red[1][ml][j] = sp;
+    red[2][ml][j] = se;
     __syncthreads();
     if (ml == 0 && ok) {
-        const int j = threadIdx.x & 63;
-        const float a = red[0][0][j] + red[0][1][j] + red[0][2][j] + red[0][3][j];
-        const float pp = red[1][0][j] + red[1][1][j] + red[1][2][j] + red[1][3][j];
-        const float ee = red[2][0][j] + red[2][1][j] + red[2][2][j] + red[2][3][j];
+        float a = 0.f, pp = 0.f, ee = 0.f;
+#pragma unroll
+        for (int u = 0; u < kSaLanes; ++u) {
+            a += red[0][u][j];
+            pp += red[1][u][j];
+            ee += red[2][u][j];
+        }
         const float mk = l < (int)text_len[b] ? 1.0f : 0.0f;
         float* f = feats + ((int64_t)b * L + l) * 3;
         f[0] = log1pf((float)dur[(int64_t)b * L + l]);
@@ -463,9 +507,9 @@ extern "C" int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_
     if (B == 0) return 0;
     const int nb = (L + 31) / 32;
     size_t lds = (size_t)nb * 32 * kAD * 4;
-    if (lds < 4 * 32 * 144) lds = 4 * 32 * 144;
+    if (lds < kAsWaves * 32 * 144) lds = kAsWaves * 32 * 144;
     const float scale = 1.0f / sqrtf((float)D);
-    dim3 grid((M + 127) / 128, B), block(256);
+    dim3 grid((M + 32 * kAsWaves - 1) / (32 * kAsWaves), B), block(64 * kAsWaves);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define ISPK_AL_CASE(NB)                                                                                              \
     case NB:                                                                                                          \
@@ -488,7 +532,7 @@ extern "C" int32_t ispk_soft_average_f32(const float* attn_soft, const float* pi
     ISPK_REQUIRE(attn_soft && pitch && energy && duration && text_len && feats, ISPK_E_NULL, "soft_average: null pointer");
     ISPK_REQUIRE(B >= 0 && M >= 1 && L >= 1 && B <= 65535, ISPK_E_SHAPE, "soft_average: bad shape B=%d M=%d L=%d", B, M, L);
     if (B == 0) return 0;
-    hipLaunchKernelGGL(soft_average_kernel, dim3((L + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(soft_average_kernel, dim3((L + 63) / 64, B), dim3(64 * kSaLanes), 0, reinterpret_cast<hipStream_t>(stream),
                        attn_soft, pitch, energy, duration, text_len, feats, M, L);
     return ispk_launch_status();
 }

@@ -267,6 +267,20 @@ def test_abi_argument_errors_are_reported():
     with pytest.raises(runtime.IspkError, match="GPU tensors"):
         runtime.gemm(torch.zeros(8, 64), torch.zeros(16, 64))
     assert lib.ispk_mas_f32(None, None, None, None, None, None, 1, 1, 1, 1, 1, None) == -1
+    # the LayerNorm-in-GEMM entries: shapes they are not built for are refused, never silently served by another path
+    g128, w128 = torch.ones(128, device=DEV), torch.zeros(64, 128, device=DEV, dtype=torch.bfloat16)
+    with pytest.raises(runtime.IspkError, match="built for 256 / 384"):
+        runtime.gemm_lnin(torch.zeros(8, 128, device=DEV), None, g128, g128, w128)
+    g, w1 = torch.ones(384, device=DEV), torch.zeros(1536, 384, device=DEV, dtype=torch.bfloat16)
+    w2p = torch.zeros(48, 384, 32, device=DEV, dtype=torch.bfloat16)
+    assert lib.ispk_ffn_bf16_prenorm(None, 384, g.data_ptr(), g.data_ptr(), 1e-5, w1.data_ptr(), 384, w2p.data_ptr(), None,
+                                     None, None, 384, 8, 384, 1536, 0, None, 1e-5, None) < 0
+    assert "ffn" in lib.ispk_last_error_string().decode()
+    x = torch.zeros(8, 384, device=DEV)
+    assert lib.ispk_ffn_bf16_prenorm(x.data_ptr(), 384, None, g.data_ptr(), 1e-5, w1.data_ptr(), 384, w2p.data_ptr(), None,
+                                     None, x.data_ptr(), 384, 8, 384, 1536, 0, None, 1e-5, None) == -1   # ISPK_E_NULL
+    assert lib.ispk_ffn_bf16_prenorm(x.data_ptr(), 384, g.data_ptr(), g.data_ptr(), 1e-5, w1.data_ptr(), 384, w2p.data_ptr(),
+                                     None, None, x.data_ptr(), 384, 0, 384, 1536, 0, None, 1e-5, None) == 0   # zero rows: no launch
     name, cus = runtime.device_info()
     assert "gfx950" in name and cus >= 128
 

@@ -173,6 +173,24 @@ int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const float* norm_gam
                               const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner,
                               uint32_t flags, float* row_stats, float stats_eps, ispk_stream_t stream);
 
+/* The second half of a pre-norm transformer layer in one kernel - attention output projection, residual, mask,
+ * feed_forward_norm, feed-forward, residual, mask:
+ *   x1[i][:]  = x[i][:] + mask[i] * ( attn_out[i][:]·Woᵀ )                                  attention.py:168-172, transformer.py:91
+ *   out[i][:] = mask[i] * ( x1[i][:] + gelu_erf( LN(x1[i][:])·W1ᵀ )·W2ᵀ )                   transformer.py:101-110
+ * Replaces: ispk_gemm_bf16 (to_out + residual + mask) followed by ispk_ffn_bf16_prenorm - one launch less per layer, and
+ * x1 is written once and read once (as the epilogue's residual) instead of written once and read twice.  Parity-tested
+ * but NOT what the module mirror calls by default: measured on MI355X it is slower than the two launches (150 vs
+ * 32 + 114 us at 32,768 rows; the projection prologue is a plain loop).  attn_out bf16
+ * [rows][dim] (heads x 64 == dim), Wo bf16 [dim][dim] contiguous (nn.Linear layout), x fp32; x1: fp32 [rows][dim] buffer
+ * the kernel fills (it IS the layer's intermediate activation); mask required; no biases (the reference's attention and
+ * feed-forward Linears have none, attention.py:63-86, feedforward.py:27-36 with bias=False recipes); W2 packed.
+ * row_stats optional as in ispk_ffn_bf16_prenorm. */
+int32_t ispk_attn_out_ffn_bf16(const uint16_t* attn_out, int64_t ldao, const uint16_t* Wo, const float* x, int64_t ldx,
+                               const float* norm_gamma, const float* norm_beta, float norm_eps, const uint16_t* W1,
+                               int64_t ldw1, const uint16_t* W2_packed, const uint8_t* mask, float* x1, int64_t ldx1,
+                               float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, float* row_stats,
+                               float stats_eps, ispk_stream_t stream);
+
 /* Linear whose input is LayerNorm(x), with the row statistics supplied by the kernel that produced x:
  *   C[i][n] = epilogue( sum_k bf16( (x[i][k] - mean_i) * rstd_i * ln_gamma[k] + ln_beta[k] ) * W[n][k] )
  * Replaces: normalization.py:20-27 + the Linear that follows it (transformer.py:79-80, attention.py:63-64: attention_norm

@@ -48,6 +48,12 @@ struct GemmParams {
     const float* lx_gamma = nullptr;
     const float* lx_beta = nullptr;
     float lx_eps = 1e-5f;
+    // ... and the attention output projection in front of it (ispk_attn_out_ffn_bf16): x1 = pj_x + mask * (pj_o · pj_wᵀ)
+    const uint16_t* pj_o = nullptr;
+    int64_t pj_ldo = 0;
+    const uint16_t* pj_w = nullptr;
+    const float* pj_x = nullptr;
+    int64_t pj_ldx = 0;
 };
 
 constexpr int kLdt = 36;  // padded LDS row length in dwords (32 + 4)
@@ -1313,7 +1319,8 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
 // The operand reads of both phases run as ONE stream through an RD-deep ring of opaque asm reads.  One barrier per chunk.
 // Epilogue: the row-coalescing transpose (store_rows_f32) with residual and mask.
 // LX: the input is the fp32 residual stream and the kernel applies the LayerNorm that precedes the block itself.
-template <int KC, bool B1, bool PK, int EP = kEpDyn, bool ST = false, bool LN = false, bool LX = false>  // D = 64 KC; B1: Linear 1 bias; PK: packed W2; LN: + LayerNorm of the result
+// PJ (with LX): the rows it normalises are produced here too - x1 = x + mask * (attention output · Woᵀ), transformer.py:91.
+template <int KC, bool B1, bool PK, int EP = kEpDyn, bool ST = false, bool LN = false, bool LX = false, bool PJ = false>  // D = 64 KC; B1: Linear 1 bias; PK: packed W2; LN: + LayerNorm of the result
 __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const uint16_t* __restrict__ W2, int64_t ldw2,
                                                           const float* __restrict__ bias1, int F) {
     [[maybe_unused]] uint64_t tk0 = 0;
@@ -1387,10 +1394,133 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
 
     // ---- prologue: W1 chunk 0 on its way, then the wave's 32 rows x D as MFMA fragments through a wave-private LDS
     // patch (coalesced 16-byte loads; see gemm_bf16_panel_kernel), one D-half at a time
-#pragma unroll
-    for (int i = 0; i < C; ++i) load1(i, 0);
     bf16x8 xf[KS];
-    if constexpr (LX) {
+    if constexpr (PJ) {
+        // ---- the attention block's output projection, residual add and mask (attention.py:168-172, transformer.py:91) in
+        // front of the pre-norm: x1 = x + mask * (o · Woᵀ).  The wave's 32 rows of o become fragments like any bf16 input;
+        // Wo streams through the W1 buffers in 32-feature tiles (same shape as a W1 chunk) into the accumulators the main
+        // loop uses later; the finished rows go to HBM once (the epilogue re-reads them as the residual) and stay in
+        // registers in row layout for the LayerNorm statistics - the normalised bf16 rows reach the fragment patch
+        // without ever being read back.  One launch and 100 MB of traffic less per layer than out-projection + FFN.
+        const uint16_t* O = p.pj_o;
+        const uint16_t* Wo = p.pj_w;
+#pragma unroll
+        for (int i = 0; i < C; ++i) R[i] = *reinterpret_cast<const u32x4*>(Wo + i * 2048 + lane_off1);
+        {
+            constexpr int KH = D / 2, CPH = KH / 8, XCH = 32 * CPH / 64, XLD = KH * 2 + 16;
+            char* xs = smem_raw + wave * (32 * XLD);
+            u32x4 t[2][XCH];
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int j = 0; j < XCH; ++j) {
+                    const int id = lane + 64 * j, r = id / CPH, c = id - r * CPH;
+                    const int row = mw0 + r < p.M ? mw0 + r : p.M - 1;
+                    t[half][j] = *reinterpret_cast<const u32x4*>(O + (int64_t)row * p.pj_ldo + half * KH + c * 8);
+                }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                for (int j = 0; j < XCH; ++j) {
+                    const int id = lane + 64 * j, r = id / CPH, c = id - r * CPH;
+                    *reinterpret_cast<u32x4*>(xs + r * XLD + c * 16) = t[half][j];
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS / 2; ++ks)
+                    xf[half * (KS / 2) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLD + ks * 32 + h * 16);
+            }
+        }
+        __syncthreads();   // the patches alias the weight buffers
+#pragma unroll
+        for (int i = 0; i < C; ++i) store1(i, 0);
+        __syncthreads();
+        f32x16 accp[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accp[t][r] = 0.f;
+        // (plain loop: one tile of Wo ahead, a barrier per tile.  Measured 35 us - 288 MFMAs are 5 - which is why this
+        // entry point is not the default: it needs the main loop's hand-placed loads / ring reads to pay.)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            if (t + 1 < NT) {
+#pragma unroll
+                for (int i = 0; i < C; ++i)
+                    R[i] = *reinterpret_cast<const u32x4*>(Wo + ((int64_t)(t + 1) * step1 + i * 2048) + lane_off1);
+            }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8*>(W1s + (t & 1) * (HC * LD1) + l31 * LD1 + 8 * h + 16 * ks);
+                accp[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, xf[ks], accp[t], 0, 0, 0);
+            }
+            if (t + 1 < NT) {
+#pragma unroll
+                for (int i = 0; i < C; ++i) store1(i, (t + 1) & 1);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < C; ++i) load1(i, 0);   // W1 chunk 0 on its way
+        // x1 rows: to HBM (the residual of the epilogue) and, in row layout, into registers
+        GemmParams q = p;
+        q.C = const_cast<void*>(p.resid); q.ldc = p.ldr; q.resid = p.pj_x; q.ldr = p.pj_ldx; q.bias = nullptr; q.N = D;
+        q.flags = p.mask ? (uint32_t)ISPK_EP_MASK_ACC : 0u; q.cpb = 0;
+        const float mkp = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+        float4 yv[NT][4];
+        float rs[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            store_rows_f32<kEpDyn>(q, stage, mw0, nt * 32, accp[nt], mkp, lane, yv[nt]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[i] += (yv[nt][i].x + yv[nt][i].y) + (yv[nt][i].z + yv[nt][i].w);
+        }
+        auto row_total = [&](float (&v)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] += __shfl_xor(v[i], 1, 64);
+                v[i] += __shfl_xor(v[i], 2, 64);
+                v[i] += __shfl_xor(v[i], 4, 64);
+            }
+        };
+        row_total(rs);
+        float mean[4], qs[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            mean[i] = rs[i] * (1.0f / (float)D);
+            qs[i] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float a = yv[t][i].x - mean[i], b = yv[t][i].y - mean[i], c = yv[t][i].z - mean[i],
+                            d = yv[t][i].w - mean[i];
+                qs[i] += (a * a + b * b) + (c * c + d * d);
+            }
+        row_total(qs);
+        constexpr int XLP = D * 2 + 16;   // bytes per patch row: the whole normalised row in bf16
+        static_assert(4 * 32 * XLP <= (2 * HC * LD1 + 2 * D * LD2) * 2, "normalised-row patches alias the weight buffers");
+        char* xs = smem_raw + wave * (32 * XLP);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qs[i] = 1.0f / sqrtf(qs[i] * (1.0f / (float)D) + p.lx_eps);
+        const int c4 = (lane & 7) * 4;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const float4 g = *reinterpret_cast<const float4*>(p.lx_gamma + t * 32 + c4);
+            const float4 be = *reinterpret_cast<const float4*>(p.lx_beta + t * 32 + c4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                uint2 o;
+                o.x = pack_bf16x2((yv[t][i].x - mean[i]) * qs[i] * g.x + be.x, (yv[t][i].y - mean[i]) * qs[i] * g.y + be.y);
+                o.y = pack_bf16x2((yv[t][i].z - mean[i]) * qs[i] * g.z + be.z, (yv[t][i].w - mean[i]) * qs[i] * g.w + be.w);
+                *reinterpret_cast<uint2*>(xs + (8 * i + (lane >> 3)) * XLP + (t * 32 + c4) * 2) = o;
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLP + ks * 32 + h * 16);
+    } else if constexpr (LX) {
+#pragma unroll
+        for (int i = 0; i < C; ++i) load1(i, 0);
         // Pre-norm in the prologue (ispk_ffn_bf16_prenorm; transformer.py:101-105: feed_forward(feed_forward_norm(x))):
         // a wave owns whole rows, so it computes their LayerNorm statistics itself - the 32 rows x D fp32 stay in
         // registers (D/2 VGPRs; the accumulators are not live yet) through two passes in fixed summation order (each
@@ -1466,6 +1596,8 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
                 xf[q * (KS / 4) + ks] = *reinterpret_cast<const bf16x8*>(xs + l31 * XLQ + ks * 32 + h * 16);
         }
     } else {
+#pragma unroll
+        for (int i = 0; i < C; ++i) load1(i, 0);
         constexpr int KH = D / 2, CPH = KH / 8, XCH = 32 * CPH / 64, XLD = KH * 2 + 16;
         static_assert(4 * 32 * XLD <= (2 * HC * LD1 + 2 * D * LD2) * 2, "x staging patches alias the weight buffers");
         char* xs = smem_raw + wave * (32 * XLD);
@@ -1774,6 +1906,13 @@ struct FfnLn {   // optional LayerNorm of the result (ispk_ffn_bf16_ln)
     int64_t ld = 0;
     uint32_t flags = 0;
 };
+struct FfnPj {   // attention output projection + residual + mask in front of the pre-norm
+    const uint16_t* o = nullptr;
+    int64_t ldo = 0;
+    const uint16_t* Wo = nullptr;
+    const float* x = nullptr;
+    int64_t ldx = 0;
+};
 struct FfnLx {   // LayerNorm applied to the (fp32) input in the prologue
     const float* gamma = nullptr;
     const float* beta = nullptr;
@@ -1782,7 +1921,7 @@ struct FfnLx {   // LayerNorm applied to the (fp32) input in the prologue
 int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const float* bias1,
                    const uint16_t* W2, int64_t ldw2, const float* bias2, const float* resid, int64_t ldr,
                    const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F, uint32_t flags,
-                   const FfnLn* ln, ispk_stream_t stream, const FfnLx* lx = nullptr) {
+                   const FfnLn* ln, ispk_stream_t stream, const FfnLx* lx = nullptr, const FfnPj* pj = nullptr) {
     ISPK_REQUIRE(x && W1 && W2 && out, ISPK_E_NULL, "ffn: null pointer");
     ISPK_REQUIRE(D == 384 || D == 256, ISPK_E_UNSUPPORTED, "ffn: dim %d (built for 256 / 384)", D);
     ISPK_REQUIRE(rows >= 0 && F >= 64 && F % 32 == 0, ISPK_E_SHAPE, "ffn: bad shape rows=%d inner=%d", rows, F);
@@ -1822,10 +1961,18 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
         ISPK_REQUIRE(packed && !bias1, ISPK_E_UNSUPPORTED, "ffn_prenorm: needs the packed W2 image and no first-Linear bias");
         p.lx_gamma = lx->gamma; p.lx_beta = lx->beta; p.lx_eps = lx->eps;
     }
+    if (pj) {
+        ISPK_REQUIRE(lx && pj->o && pj->Wo && pj->x && resid && mask, ISPK_E_NULL, "attn_out_ffn: null pointer");
+        ISPK_REQUIRE(pj->ldo % 8 == 0 && pj->ldo >= D && pj->ldx % 4 == 0 && pj->ldx >= D && ispk_aligned(pj->o, 16) &&
+                         ispk_aligned(pj->Wo, 16) && ispk_aligned(pj->x, 16),
+                     ISPK_E_ALIGN, "attn_out_ffn: attention output / Wo / x must be 16-byte aligned with strides %% 8 / %% 4");
+        ISPK_REQUIRE(hot, ISPK_E_UNSUPPORTED, "attn_out_ffn: built for the transformer layer's call (row mask, no biases)");
+        p.pj_o = pj->o; p.pj_ldo = pj->ldo; p.pj_w = pj->Wo; p.pj_x = pj->x; p.pj_ldx = pj->ldx;
+    }
     void* stamp = nullptr;
     if (const char* e = getenv("ISPK_FFN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][3]
         stamp = reinterpret_cast<void*>(strtoull(e, nullptr, 16));
-        ISPK_REQUIRE(D == 384 && packed && !bias1 && hot && !ln && !lx, ISPK_E_UNSUPPORTED, "ffn stamps: the hot instance only");
+        ISPK_REQUIRE(D == 384 && packed && !bias1 && hot && !ln && !lx && !pj, ISPK_E_UNSUPPORTED, "ffn stamps: the hot instance only");
         p.ln_out = stamp;
     }
 #define ISPK_FFN_GO(KC_, B1_, PK_, EP_, ST_)                                                                          \
@@ -1851,8 +1998,18 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
                            ldw2, bias1, F);                                                                           \
         return ispk_launch_status();                                                                                  \
     } while (0)
+#define ISPK_FFN_GO_PJ(KC_, LN_)                                                                                      \
+    do {                                                                                                              \
+        constexpr size_t lds = (size_t)(2 * 32 * (64 * KC_ + 8) + 2 * 64 * KC_ * 40) * 2 + 4 * kStageBytes;             \
+        ISPK_RESERVE_LDS((&ffn_bf16_kernel<KC_, false, true, kHot, false, LN_, true, true>), lds, "ffn");             \
+        hipLaunchKernelGGL((ffn_bf16_kernel<KC_, false, true, kHot, false, LN_, true, true>), grid, dim3(256), lds, s, p,  \
+                           W2, ldw2, bias1, F);                                                                       \
+        return ispk_launch_status();                                                                                  \
+    } while (0)
 #define ISPK_FFN_KC(KC_)                                                   \
     do {                                                                   \
+        if (pj && ln) ISPK_FFN_GO_PJ(KC_, true);                           \
+        if (pj) ISPK_FFN_GO_PJ(KC_, false);                                \
         if (lx && ln && hot) ISPK_FFN_GO_LX(KC_, kHot, true);              \
         if (lx && ln) ISPK_FFN_GO_LX(KC_, kEpDyn, true);                   \
         if (lx && hot) ISPK_FFN_GO_LX(KC_, kHot, false);                   \
@@ -1868,6 +2025,7 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
     } while (0)
     if (D == 384) ISPK_FFN_KC(6); else ISPK_FFN_KC(4);
 #undef ISPK_FFN_KC
+#undef ISPK_FFN_GO_PJ
 #undef ISPK_FFN_GO_LX
 #undef ISPK_FFN_GO_LN
 #undef ISPK_FFN_GO
@@ -1943,4 +2101,19 @@ extern "C" int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const floa
     FfnLn ln{nullptr, nullptr, stats_eps, row_stats, 0, 4u};
     return ffn_launch(x, ldx, W1, ldw1, nullptr, W2_packed, 0, bias2, x, ldx, mask, out, ldo, rows, D, F, flags,
                       row_stats ? &ln : nullptr, stream, &lx);
+}
+
+extern "C" int32_t ispk_attn_out_ffn_bf16(const uint16_t* attn_out, int64_t ldao, const uint16_t* Wo, const float* x,
+                                          int64_t ldx, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                                          const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed, const uint8_t* mask,
+                                          float* x1, int64_t ldx1, float* out, int64_t ldo, int32_t rows, int32_t D,
+                                          int32_t F, float* row_stats, float stats_eps, ispk_stream_t stream) {
+    ISPK_REQUIRE(x1 && ispk_aligned(x1, 16) && ldx1 % 4 == 0 && ldx1 >= D, ISPK_E_ALIGN,
+                 "attn_out_ffn: x1 must be a 16-byte aligned fp32 buffer [rows][dim]");
+    FfnPj pj{attn_out, ldao, Wo, x, ldx};
+    FfnLx lx{norm_gamma, norm_beta, norm_eps};
+    FfnLn ln{nullptr, nullptr, stats_eps, row_stats, 0, 4u};
+    // the kernel writes x1 in its prologue and re-reads it as the residual of its epilogue
+    return ffn_launch(x1, ldx1, W1, ldw1, nullptr, W2_packed, 0, nullptr, x1, ldx1, mask, out, ldo, rows, D, F,
+                      ISPK_EP_MASK_OUT, row_stats ? &ln : nullptr, stream, &lx, &pj);
 }

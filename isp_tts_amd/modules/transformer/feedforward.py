@@ -112,6 +112,16 @@ class FeedForward(nn.Module, Constructor):
         return runtime.gemm(hidden, w2, bias=self.net[3].bias, resid=x, mask=mask,
                             flags=runtime.EP_MASK_OUT if mask is not None else 0, out_dtype=torch.float32)
 
+    def forward_attn_out_prenorm(self, o: Tensor, wo: Tensor, x: Tensor, norm, *, mask: Tensor,
+                                 next_norm: Optional[tuple] = None):
+        """The layer's second half in one kernel (ispk_attn_out_ffn_bf16): x1 = x + mask * to_out(o);
+        y = mask * (x1 + feed_forward(norm(x1))).  Returns (y, stats | None)."""
+        w1, _ = self._staged(torch.bfloat16)
+        want = next_norm is not None and next_norm[4] == "stats"
+        res = runtime.attn_out_ffn(o, wo, x, norm.weight, norm.bias, w1, self._packed_w2(), mask, norm_eps=norm.eps,
+                                   want_stats=want, stats_eps=next_norm[2] if want else 1e-5)
+        return (res[0], res[2]) if want else (res[0], None)
+
     def forward_prenorm(self, x: Tensor, norm, *, mask: Optional[Tensor] = None, next_norm: Optional[tuple] = None):
         """y = [mask] * (x + feed_forward(norm(x))) in one kernel (ispk_ffn_bf16_prenorm), x fp32; with `next_norm` =
         (.., eps, .., "stats") also the output rows' (mean, rstd) for the next layer's q/kv GEMM.  Returns (y, stats)."""

@@ -62,6 +62,10 @@ class TransformerLayer(nn.Module, Constructor):
         # batches on (33.0 vs 22.1 + 15.0 us at 32,768 rows); at 6,400 rows the output is split over many workgroups that
         # each repeat the fp32 staging, and the separate 4.9-us LayerNorm is cheaper (18.6 vs 9.4 + 4.9 us)
         self.lnin_self_min_rows = 128 * 128
+        # to_out + residual + mask inside the feed-forward kernel (ispk_attn_out_ffn_bf16): parity-tested, OFF - its plain
+        # projection prologue takes 35 us against the 32-us out-projection GEMM it replaces (150 vs 146 us for the pair,
+        # 2.21-2.34 vs 2.09 ms per step: the longer lock-step kernel overlaps worse with the second batch in flight)
+        self.fuse_out_proj = False
         norm = (lambda: AdaptiveLayerNorm(dim, condition_dim=condition_dim)) if adaptive_norm else (lambda: LayerNorm(dim))
         self.attention_norm = norm()
         self.attention = Attention.init(attention if attention is not None else AttentionConfig(), dim=dim)
@@ -91,17 +95,30 @@ class TransformerLayer(nn.Module, Constructor):
                and attention_mask is None and x.shape[-1] in (256, 384) and self.attention_norm.weight is not None
                and self.attention_norm.bias is not None and os.environ.get("ISPK_LNIN_SELF") != "0"
                and x.numel() // x.shape[-1] >= self.lnin_self_min_rows)
+        # to_out + residual + mask fused into the feed-forward kernel (one launch for the layer's second half)?
+        ffw = self.feed_forward
+        fuse_out = (cdt == torch.bfloat16 and mask is not None and ada is None and context is None
+                    and attention_mask is None and (next_norm is None or next_norm[4] == "stats")
+                    and self.attention.heads * 64 == x.shape[-1] and ffw.net[3].bias is None
+                    and ffw.prenorm_ok(x, self.feed_forward_norm)
+                    and (self.fuse_out_proj or os.environ.get("ISPK_FUSE_OUT_PROJ") == "1"))
         if cdt == torch.bfloat16 and (handed or own):
             # attention_norm inside the q/kv GEMM, applied while it stages x: with the row statistics the previous layer's
             # feed-forward kernel handed over, or (first layer of a stack) computed by the GEMM's own waves
             an = self.attention_norm
-            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x,
+            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x, defer_out=fuse_out,
                                                prenorm=(normed if handed else None, an.weight, an.bias, an.eps))
         else:
             h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
             x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
-                                               attention_mask=attention_mask, key_len=key_len, residual=x)
+                                               attention_mask=attention_mask, key_len=key_len, residual=x,
+                                               defer_out=fuse_out)
         hn = None
+        if fuse_out:   # here `x1` is the heads' output before to_out
+            wo = self.attention._staged(torch.bfloat16)[1]
+            y, hn = ffw.forward_attn_out_prenorm(x1, wo, x, self.feed_forward_norm, mask=mask, next_norm=next_norm)
+            return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
+                                          shared_intermediates=shared, next_normed=hn)
         if (ada is None and (next_norm is None or next_norm[4] == "stats")
                 and self.feed_forward.prenorm_ok(x1, self.feed_forward_norm)):
             # feed_forward_norm inside the fused feed-forward kernel (its waves own whole rows); the `* mask` of :102

@@ -40,6 +40,8 @@ SIGNATURES = {
     "ispk_ffn_bf16_ln": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64,
                          _U32, _P],
     "ispk_ffn_bf16_prenorm": [_P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
+    "ispk_attn_out_ffn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32,
+                               _P, _F32, _P],
     "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _F32, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -387,6 +389,29 @@ def ffn_prenorm(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w
             x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w1.stride(0),
             w2p.data_ptr(), _ptr(bias2), _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())
     return (out, stats) if want_stats else out
+
+
+def attn_out_ffn(o: Tensor, wo: Tensor, x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2p: Tensor,
+                 mask: Tensor, norm_eps: float = 1e-5, want_stats: bool = False, stats_eps: float = 1e-5):
+    """ispk_attn_out_ffn_bf16: x1 = x + mask * (o @ wo^T); out = mask * (x1 + gelu(LN(x1) @ w1^T) @ w2^T) in one launch.
+    o bf16 [..., D] (attention output before to_out), x fp32 [..., D].  Returns (out, x1[, stats])."""
+    _dev(o, wo, x, norm_weight, norm_bias, w1, w2p, mask)
+    assert o.dtype == torch.bfloat16 and wo.dtype == torch.bfloat16 and x.dtype == torch.float32
+    o2, x2 = _rows2d(o), _rows2d(x)
+    R, D = x2.shape
+    Fi = w1.shape[0]
+    assert o2.shape == (R, D) and wo.shape == (D, D) and wo.is_contiguous() and w1.shape == (Fi, D) and w1.stride(1) == 1
+    assert w2p.shape == (Fi // 32, D, 32) and w2p.is_contiguous()
+    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
+    x1 = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
+    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    mask = mask.reshape(-1).contiguous()
+    nb = o2.numel() * 2 + x2.numel() * 4 + x1.numel() * 8 + out.numel() * 4 + (wo.numel() + w1.numel() + w2p.numel()) * 2
+    _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi + 2.0 * R * D * D, float(nb), lib().ispk_attn_out_ffn_bf16,
+            o2.data_ptr(), o2.stride(0), wo.data_ptr(), x2.data_ptr(), x2.stride(0), norm_weight.data_ptr(),
+            norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w1.stride(0), w2p.data_ptr(), mask.data_ptr(), x1.data_ptr(), D,
+            out.data_ptr(), D, R, D, Fi, _ptr(stats), stats_eps, _stream())
+    return (out, x1, stats) if want_stats else (out, x1)
 
 
 def gemm_lnin(x: Tensor, stats: Optional[Tensor], ln_weight: Tensor, ln_bias: Tensor, w: Tensor,

@@ -466,6 +466,34 @@ def test_fused_ffn_with_layernorm_prologue(R, D, Fi, masked):
     assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("R,D,Fi", [(128 * 9 + 17, 384, 1536), (300, 256, 1024)])
+def test_attention_output_projection_fused_into_the_feed_forward(R, D, Fi):
+    """ispk_attn_out_ffn_bf16 == ispk_gemm_bf16 (to_out + residual + mask) followed by ispk_ffn_bf16_prenorm: x1 is the
+    same MFMA reduction in the same order (exact or an ulp apart), the block output differs by bf16 flips of the
+    normalised operand only; the statistics describe the output rows; masked rows: x1 = x, out = 0."""
+    o = _bf(synth._normal(f"t/pj/o{R}", (R, D)))
+    wo = _bf(synth._normal(f"t/pj/wo{D}", (D, D), D ** -0.5))
+    x = synth._normal(f"t/pj/x{R}", (R, D), 1.5, 0.4)
+    w1, w2 = _bf(synth._normal(f"t/pj/w1{D}", (Fi, D), D ** -0.5)), _bf(synth._normal(f"t/pj/w2{D}", (D, Fi), Fi ** -0.5))
+    g, b = synth._normal("t/pj/g", (D,), 0.1, 1.0), synth._normal("t/pj/b", (D,), 0.1)
+    mask = torch.arange(R) % 7 != 3
+    d = lambda t: t.to(DEV)  # noqa: E731
+    w2p = runtime.ffn_pack_w2(d(w2))
+    x1_ref = runtime.gemm(d(o), d(wo), resid=d(x), mask=d(mask), flags=runtime.EP_MASK_ACC, out_dtype=torch.float32)
+    ref = runtime.ffn_prenorm(x1_ref, d(g), d(b), d(w1), w2p, mask=d(mask), flags=runtime.EP_MASK_OUT)
+    out, x1, stats = runtime.attn_out_ffn(d(o), d(wo), d(x), d(g), d(b), d(w1), w2p, d(mask), want_stats=True)
+    out_b, x1_b = runtime.attn_out_ffn(d(o), d(wo), d(x), d(g), d(b), d(w1), w2p, d(mask))
+    assert torch.equal(out, out_b) and torch.equal(x1, x1_b)
+    assert (x1 - x1_ref).abs().max().item() <= 2e-6
+    assert torch.equal(x1.cpu()[~mask], x[~mask]) and out.cpu()[~mask].abs().max().item() == 0.0
+    err = (out - ref).abs()
+    assert err.max().item() <= 2e-2 and err.pow(2).mean().sqrt().item() <= 1e-3
+    o64 = out.double().cpu()
+    assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
+    rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
+    assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
+
+
 def test_attention_bf16_several_query_tiles_per_workgroup(monkeypatch):
     """With the whole key range resident in LDS a workgroup serves several 64-query tiles off one K/V fetch (the launcher
     does this by itself only for large batches; forced here).  Same values as one tile per workgroup, bit for bit."""

@@ -321,6 +321,26 @@ def test_bf16_prenorm_feed_forward_matches_separate_layernorm_at_full_size(gpu_m
     assert (fused.float() * ~mask[..., None]).abs().max() == 0
 
 
+def test_bf16_fused_output_projection_matches_separate_launches_at_full_size(gpu_model, monkeypatch):
+    """Decoder stack at the benchmark shape with to_out + residual + mask inside the feed-forward kernel
+    (ispk_attn_out_ffn_bf16, opt-in) against out-projection GEMM + pre-norm feed-forward kernel (the default)."""
+    x = synth._normal("t/chain/x", (64, 512, 384)).to(DEV)
+    lens = torch.full((64,), 512, device=DEV)
+    lens[2::5] = 211
+    mask = torch.arange(512, device=DEV)[None] < lens[:, None]
+    dec = gpu_model.decoder
+    try:
+        dec.set_compute_dtype(torch.bfloat16)
+        plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+        monkeypatch.setenv("ISPK_FUSE_OUT_PROJ", "1")          # opt-in (measured slower than the two launches)
+        fused = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
+    finally:
+        dec.set_compute_dtype(torch.float32)
+    diff = (fused.float() - plain.float()).abs()
+    assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
+    assert (fused.float() * ~mask[..., None]).abs().max() == 0
+
+
 def test_bf16_encoder_with_layernorms_inside_the_gemms_matches_separate_layernorms(gpu_model, monkeypatch):
     """Encoder-sized stack (two-GEMM feed-forward): attention_norm inside the q/kv GEMM and feed_forward_norm inside the
     first feed-forward GEMM (ispk_gemm_bf16_lnin, statistics by the GEMM's own waves) against separate LayerNorm launches."""

@@ -239,6 +239,12 @@ int32_t ispk_alibi_mqa_attn_f32(const float* q, int64_t ldq, const float* k, con
 int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v, int64_t ldkv,
                                  const float* slopes, const int64_t* key_len, uint16_t* out, int64_t ldo, int32_t B,
                                  int32_t N, int32_t H, ispk_stream_t stream);
+/* Same kernel with the work split chosen by the caller: `q_tiles_per_workgroup` 64-query tiles of one batch item share
+ * one K/V fetch (only while the whole key range fits the LDS ring, N <= 512; else 1).  0 = automatic (what
+ * ispk_alibi_mqa_attn_bf16 uses: as many as still leave >= 256 workgroups).  Results are identical bit for bit. */
+int32_t ispk_alibi_mqa_attn_bf16_tiles(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v, int64_t ldkv,
+                                       const float* slopes, const int64_t* key_len, uint16_t* out, int64_t ldo, int32_t B,
+                                       int32_t N, int32_t H, int32_t q_tiles_per_workgroup, ispk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Aligner front-end (the ConvAttention that produces the MAS input), fp32, channel-last padded layout.

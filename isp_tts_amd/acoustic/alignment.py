@@ -13,35 +13,22 @@ from typing import NamedTuple, Optional
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 from torch import Tensor
 
 from .. import runtime
+from ..staging import StagedWeights
 from ..modules.aligner import mas_device
 from ..modules.constructor import Constructor
-from ..utils import get_mask_from_lengths, max_dtype_value, min_dtype_value
 
 
-def batch_diagonal_prior(text_lengths: Tensor, mel_lengths: Tensor, gamma: float = 0.1, threshold: float = 1e-4,
-                         max_text: Optional[int] = None, max_mel: Optional[int] = None) -> Tensor:
-    """alignment.py:18-37: exp(-(t/T - m/M)^2 / 2 gamma^2), zero outside the lengths, rows normalised (+1e-5), values
-    under 1e-4 zeroed.  [B, M, T] fp32."""
-    dev = text_lengths.device
-    max_text = int(text_lengths.max().item()) if max_text is None else max_text
-    max_mel = int(mel_lengths.max().item()) if max_mel is None else max_mel
-    gt = torch.arange(max_text, dtype=torch.float32, device=dev).view(1, -1) / text_lengths.view(-1, 1)
-    gm = torch.arange(max_mel, dtype=torch.float32, device=dev).view(1, -1) / mel_lengths.view(-1, 1)
-    grid = gt.unsqueeze(1) - gm.unsqueeze(2)
-    prior = torch.exp(-grid ** 2 / (2 * gamma ** 2))
-    prior = prior * get_mask_from_lengths(text_lengths, max_text)[:, None, :]
-    prior = prior * get_mask_from_lengths(mel_lengths, max_mel)[:, :, None]
-    prior = prior / (prior.sum(dim=-1, keepdim=True) + 1e-5)
-    return prior.masked_fill(prior < threshold, 0.0)
+_NOT_A_PATH = ("{} only owns parameters (the reference's state_dict names); its arithmetic runs inside the fused HIP "
+               "kernels that ConvAttention launches (csrc/aligner.hip) - there is no PyTorch/MIOpen path to fall back to")
 
 
 class MaskedInstanceNorm1d(nn.Module):
-    """modules/normalization.py:160-208 (`_masked_norm`, instance): statistics over valid positions only (biased
-    variance, eps 1e-5), every position normalised, affine.  Parameter names weight / bias like nn.InstanceNorm1d."""
+    """modules/normalization.py:160-208 (`_masked_norm`, instance).  Parameter names weight / bias like
+    nn.InstanceNorm1d; the normalisation itself is `ispk_masked_instnorm_f32` (statistics over valid positions only,
+    biased variance, eps 1e-5, every position normalised, affine)."""
 
     def __init__(self, num_features: int, eps: float = 1e-5):
         super().__init__()
@@ -49,18 +36,14 @@ class MaskedInstanceNorm1d(nn.Module):
         self.weight = nn.Parameter(torch.ones(num_features))
         self.bias = nn.Parameter(torch.zeros(num_features))
 
-    def forward(self, x: Tensor, mask: Tensor) -> Tensor:
-        m = mask.to(x.dtype)
-        n = m.sum(dim=2, keepdim=True)
-        mx = m * x
-        mean = mx.sum(dim=2, keepdim=True) / n
-        var = (((mx - mean) * m) ** 2).sum(dim=2, keepdim=True) / n
-        out = (x - mean) / (var + self.eps).sqrt()
-        return out * self.weight.view(1, -1, 1) + self.bias.view(1, -1, 1)
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(_NOT_A_PATH.format("MaskedInstanceNorm1d"))
 
 
 class ConvBlock1D(nn.Module):
-    """alignment.py:40-83: x*mask -> Conv1d (no bias when normalised) -> activation -> masked norm -> dropout(eval: id)."""
+    """alignment.py:40-83: x*mask -> Conv1d (no bias when normalised) -> activation -> masked norm -> dropout(eval: id).
+    Holds `conv.weight` / `norm.{weight,bias}`; ConvAttention runs the block as one MFMA GEMM over overlapping rows of a
+    padded channel-last buffer (GELU in the epilogue) plus one fused masked-instance-norm kernel."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 1, activation: str = "relu",
                  normalization: Optional[str] = "batch", bias: bool = True):
@@ -74,13 +57,8 @@ class ConvBlock1D(nn.Module):
         self.gelu = activation == "gelu"
         self.norm = MaskedInstanceNorm1d(out_channels) if normalization is not None else None
 
-    def forward(self, x: Tensor, input_mask: Tensor, output_mask: Tensor) -> Tensor:
-        y = self.conv(x * input_mask)
-        if self.gelu:
-            y = F.gelu(y)
-        if self.norm is not None:
-            y = self.norm(y, output_mask)
-        return y
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError(_NOT_A_PATH.format("ConvBlock1D"))
 
 
 class ConvAttention(nn.Module, Constructor):
@@ -101,16 +79,17 @@ class ConvAttention(nn.Module, Constructor):
             ConvBlock1D(mel_dim, attention_dim, 1, "linear", None, bias=False)])
         self.attention_prior = attention_prior
         self.compute_dtype = torch.float32
-        self._cache: dict = {}
+        self._cache = StagedWeights()
 
     def _staged(self):
         """Conv weights as GEMM weights [O][k*C] (tap-major, matching the padded channel-last window)."""
         ps = [c.conv.weight for c in list(self.key_proj) + list(self.query_proj)]
-        key = (self.compute_dtype,) + tuple((p.data_ptr(), p._version, p.device) for p in ps)
-        if self._cache.get("key") != key:
-            w2d = [p.detach().permute(0, 2, 1).reshape(p.shape[0], -1).to(self.compute_dtype).contiguous() for p in ps]
-            self._cache = {"key": key, "k": w2d[:2], "q": w2d[2:]}
-        return self._cache["k"], self._cache["q"]
+        dt = self.compute_dtype
+
+        def build():
+            w2d = [p.detach().permute(0, 2, 1).reshape(p.shape[0], -1).to(dt).contiguous() for p in ps]
+            return w2d[:2], w2d[2:]
+        return self._cache.get(dt, ps, build)
 
     def project_queries(self, queries: Tensor, query_len: Tensor) -> Tensor:
         """The mel-side half of alignment.py:159-208 (query_proj: conv-GELU-norm, conv-GELU-norm, 1x1 conv).  It needs

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .. import runtime
+from ..staging import StagedWeights
 from ..modules.constructor import Constructor
 from ..modules.transformer import Transformer
 from ..utils import get_mask_from_lengths
@@ -54,26 +55,35 @@ class AcousticModel(nn.Module, Constructor):
         self.register_buffer("pitch_mean", torch.tensor(float(pitch_mean or 0.)))
         self.register_buffer("pitch_std", torch.tensor(float(pitch_std or 1.)))
         self.compute_dtype = torch.float32
-        self._cache: dict = {}
+        self._cache = StagedWeights()
 
-    def set_compute_dtype(self, dtype: torch.dtype):
-        """fp32 (parity path: exact-fp32 MFMA) or bf16 (throughput path: bf16 operands, fp32 accumulation,
-        fp32 residual stream / LayerNorm / softmax statistics).  Applies to all four transformer stacks."""
-        self.encoder.set_compute_dtype(dtype)
+    def set_compute_dtype(self, dtype: torch.dtype, *, alignment_dtype: Optional[torch.dtype] = None):
+        """fp32 (parity path: exact-fp32 MFMA) or bf16 (throughput path: bf16 operands, fp32 accumulation, fp32 residual
+        stream / LayerNorm / softmax statistics) for the decoder and the temporal adaptor's stacks - where the FLOPs are.
+
+        `alignment_dtype` is the precision of everything UPSTREAM OF MAS: text encoder -> aligner key convolutions, mel ->
+        aligner query convolutions, scores / log-softmax / prior.  MAS turns those logits into DISCRETE outputs (the hard
+        alignment, the durations), and a near-tie between two paths flips on any change of the logits' low bits, so only
+        the same fp32 arithmetic reproduces the fp32 path's alignments:
+          * torch.float32: the alignment chain runs exactly the fp32 path's kernels - MAS paths and durations are
+            bit-identical to the fp32 path's on every utterance, whatever `dtype` is;
+          * None (default) = fp32 for the aligner front-end itself (the reference's `ConvAttention`, alignment.py:159-208,
+            always fp32 here) and `dtype` for the text encoder: with a bf16 encoder the logits carry the encoder's
+            bf16 rounding (about 1e-2) and some alignments move by a frame (counted by the tests and by bench.py)."""
+        enc_dtype = alignment_dtype if alignment_dtype is not None else dtype
+        assert enc_dtype in (torch.float32, torch.bfloat16)
+        self.encoder.set_compute_dtype(enc_dtype)
         self.decoder.set_compute_dtype(dtype)
         self.temporal_adaptor.predictor.transformer.set_compute_dtype(dtype)
         self.temporal_adaptor.embedding.transformer.set_compute_dtype(dtype)
-        self.aligner.attention.compute_dtype = dtype
+        self.aligner.attention.compute_dtype = torch.float32
         self.compute_dtype = dtype
         return self
 
     def _to_mel(self, dec_out: Tensor, dec_mask: Optional[Tensor]) -> Tensor:
         w = self.to_mel.weight
         if dec_out.dtype == torch.bfloat16:
-            key = (w.data_ptr(), w._version, w.device)
-            if self._cache.get("key") != key:
-                self._cache = {"key": key, "w16": w.detach().to(torch.bfloat16).contiguous()}
-            w = self._cache["w16"]
+            w = self._cache.get(torch.bfloat16, (w,), lambda: w.detach().to(torch.bfloat16).contiguous())
         return runtime.to_mel(dec_out, w, self.to_mel.bias, dec_mask)
 
     @torch.no_grad()

@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from torch import Tensor
 
 from .. import runtime
+from ..staging import StagedWeights
 from ..modules.constructor import Constructor
 from ..modules.transformer import Transformer, TimePositionalEmbedding
 from ..utils import get_float_mask_from_lengths, get_mask_3d, masked_mean
@@ -30,14 +31,11 @@ class TransformerTemporalModule(nn.Module, Constructor):
         self.transformer = Transformer.init(transformer, emb_dim=input_dim)
         self.linear_layer = nn.Linear(self.transformer.dim, output_dim, bias=True)
         self.detach_inputs = detach_inputs
-        self._cache: dict = {}
+        self._cache = StagedWeights()
 
     def _weight(self, dtype: torch.dtype) -> Tensor:
         w = self.linear_layer.weight
-        key = (w.data_ptr(), w._version, w.device, dtype)
-        if self._cache.get("key") != key:
-            self._cache = {"key": key, "w": w.detach().to(dtype).contiguous()}
-        return self._cache["w"]
+        return self._cache.get(dtype, (w,), lambda: w.detach().to(dtype).contiguous())
 
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, *, key_len: Optional[Tensor] = None) -> Tensor:
         """`key_len` (= mask.sum(1), when the caller already has the lengths) saves the reduction launch."""
@@ -66,14 +64,11 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
                                             condition_dim=time_embedding_dim)
         self.linear_layer = nn.Linear(self.transformer.dim, output_dim, bias=True)
         self.output_dim, self.sigma, self.detach_inputs = output_dim, sigma, detach_inputs
-        self._cache: dict = {}
+        self._cache = StagedWeights()
 
     def _cond_weight(self, dtype: torch.dtype) -> Tensor:
         w = self.transformer.project_emb.weight
-        key = (w.data_ptr(), w._version, w.device, dtype)
-        if self._cache.get("key") != key:
-            self._cache = {"key": key, "wc": w.detach()[:, self.output_dim:].to(dtype).contiguous()}
-        return self._cache["wc"]
+        return self._cache.get(dtype, (w,), lambda: w.detach()[:, self.output_dim:].to(dtype).contiguous())
 
     def _project(self, x_t: Tensor, cond_proj: Tensor) -> Tensor:
         w = self.transformer.project_emb.weight
@@ -251,15 +246,13 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
         `dec_lens.max()` back to the host."""
         m3 = enc_mask[..., None] if enc_mask is not None else None
         pred = self.predictor.infer(enc_out, mask=m3, steps=steps, noise=noise)
-        if duration_target is None or bool((duration_target < 0).any()):
-            duration_pred = torch.clamp(duration_factor * (torch.exp(pred[..., 0]) - 1), min=0)
-            if duration_target is not None:
-                neg = duration_target < 0
-                duration_target = duration_target.float()
-                duration_target[neg] = duration_pred[neg]
-                duration_pred = duration_target
-        else:
-            duration_pred = duration_target
+        # :351-364.  The reference tests `(duration_target < 0).any()` on the host and only then fills the negative entries
+        # with predictions; selecting per element on the device gives the same values without the round trip, which keeps
+        # the call capturable in a HIP graph.  (Integer targets come back as fp32 - exact for any frame count.)
+        duration_pred = torch.clamp(duration_factor * (torch.exp(pred[..., 0]) - 1), min=0)
+        if duration_target is not None:
+            tgt = duration_target if duration_target.is_floating_point() else duration_target.to(duration_pred.dtype)
+            duration_pred = torch.where(tgt < 0, duration_pred.to(tgt.dtype), tgt)
         pitch = (pred[..., 1:2] if pitch_target is None else pitch_target.unsqueeze(-1)) * pitch_factor + pitch_delta
         energy = (pred[..., 2:3] if energy_target is None else energy_target.unsqueeze(-1)) * energy_factor + energy_delta
         enc_out = enc_out + self.embedding(torch.cat([pitch, energy], dim=-1))

@@ -14,6 +14,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libispk.so")
+# the tools' build (tools/stamp_*.py, tools/sweep_gemm.py): the same sources with -DISPK_EXPERIMENTS, which compiles in the
+# ISPK_* environment knobs, the in-kernel stamps and the ablation hooks.  Never loaded by the product (runtime.LIB_PATH).
+LIB_EXP = os.path.join(HERE, "libispk_exp.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
@@ -28,11 +31,11 @@ def _deps_mtime() -> float:
     return max(os.path.getmtime(h) for h in hdrs)
 
 
-def _compile(src: str, verbose: bool) -> str:
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def _compile(src: str, verbose: bool, experiments: bool = False) -> str:
+    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".exp.o" if experiments else ".o"))
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _deps_mtime()):
         return obj
-    cmd = [HIPCC, *FLAGS, "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *(["-DISPK_EXPERIMENTS"] if experiments else []), "-c", src, "-o", obj]
     if verbose:
         cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -43,18 +46,20 @@ def _compile(src: str, verbose: bool) -> str:
     return obj
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+def build_lib(force: bool = False, verbose: bool = False, experiments: bool = False) -> str:
     os.makedirs(OBJ, exist_ok=True)
+    lib = LIB_EXP if experiments else LIB
     if force:
         for f in os.listdir(OBJ):
-            os.remove(os.path.join(OBJ, f))
+            if f.endswith(".exp.o") == experiments:
+                os.remove(os.path.join(OBJ, f))
     srcs = _sources()
     with ThreadPoolExecutor(max_workers=min(6, len(srcs))) as ex:
-        objs = list(ex.map(lambda s: _compile(s, verbose), srcs))
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(o) for o in objs):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
-    return LIB
+        objs = list(ex.map(lambda s: _compile(s, verbose, experiments), srcs))
+    if force or not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(o) for o in objs):
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    print(build_lib(force="--force" in sys.argv, verbose="-v" in sys.argv, experiments="--experiments" in sys.argv))

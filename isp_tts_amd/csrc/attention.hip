@@ -530,9 +530,10 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
 
 }  // namespace
 
-extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v,
-                                            int64_t ldkv, const float* slopes, const int64_t* key_len, uint16_t* out,
-                                            int64_t ldo, int32_t B, int32_t N, int32_t H, ispk_stream_t stream) {
+extern "C" int32_t ispk_alibi_mqa_attn_bf16_tiles(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v,
+                                                  int64_t ldkv, const float* slopes, const int64_t* key_len,
+                                                  uint16_t* out, int64_t ldo, int32_t B, int32_t N, int32_t H,
+                                                  int32_t q_tiles_per_workgroup, ispk_stream_t stream) {
     ISPK_REQUIRE(q && k && v && slopes && out, ISPK_E_NULL, "attn: null pointer");
     ISPK_REQUIRE(B >= 0 && N >= 1 && H >= 1 && H <= 8, ISPK_E_SHAPE, "attn: bad shape B=%d N=%d H=%d (H <= 8)", B, N, H);
     ISPK_REQUIRE(B <= 65535, ISPK_E_SHAPE, "attn: B=%d exceeds the grid limit 65535", B);
@@ -548,7 +549,9 @@ extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, cons
     int qpw = 1;
     if (N <= kChunkKeys * kSlots)
         while (qpw < 4 && (int64_t)B * ((nqt + 2 * qpw - 1) / (2 * qpw)) >= 256) qpw *= 2;
-    if (const char* e = getenv("ISPK_ATTN_QPW")) qpw = atoi(e) > 0 && N <= kChunkKeys * kSlots ? atoi(e) : 1;   // experiments
+    ISPK_REQUIRE(q_tiles_per_workgroup >= 0 && q_tiles_per_workgroup <= 8, ISPK_E_SHAPE,
+                 "attn: q_tiles_per_workgroup=%d (0 = automatic, else 1..8)", q_tiles_per_workgroup);
+    if (q_tiles_per_workgroup > 0) qpw = N <= kChunkKeys * kSlots ? q_tiles_per_workgroup : 1;   // explicit choice
     dim3 grid((nqt + qpw - 1) / qpw, B), block(2 * H * 64);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
 #define ISPK_ATTN_GO(MAXT_, IPL_)                                                                                  \
@@ -557,7 +560,8 @@ extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, cons
         hipLaunchKernelGGL((attn_bf16_kernel<MAXT_, IPL_>), grid, block, kAttnLds, st, q, ldq, k, v, ldkv, slopes,  \
                            key_len, out, ldo, N, H, qpw, nullptr);                                                 \
     } while (0)
-    if (const char* e = getenv("ISPK_ATTN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[waves][6]
+#ifdef ISPK_EXPERIMENTS
+    if (const char* e = ispk_knob("ISPK_ATTN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[waves][6]
         ISPK_REQUIRE(H >= 4 && H <= 6, ISPK_E_UNSUPPORTED, "attn stamps: H = 4..6 only");
         uint64_t* stamps = reinterpret_cast<uint64_t*>(strtoull(e, nullptr, 16));
         ISPK_RESERVE_LDS((&attn_bf16_kernel<768, 4, true>), kAttnLds, "attn");
@@ -565,10 +569,17 @@ extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, cons
                            out, ldo, N, H, qpw, stamps);
         return ispk_launch_status();
     }
+#endif
     if (H >= 7) ISPK_ATTN_GO(1024, 4);       // 14 / 16 waves, 8 loaders
     else if (H >= 4) ISPK_ATTN_GO(768, 4);   // 8 .. 12 waves, 8 loaders
     else if (H >= 2) ISPK_ATTN_GO(768, 8);   // 4 / 6 waves, 4 loaders
     else ISPK_ATTN_GO(768, 16);              // 2 waves, both load
 #undef ISPK_ATTN_GO
     return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_alibi_mqa_attn_bf16(const uint16_t* q, int64_t ldq, const uint16_t* k, const uint16_t* v,
+                                            int64_t ldkv, const float* slopes, const int64_t* key_len, uint16_t* out,
+                                            int64_t ldo, int32_t B, int32_t N, int32_t H, ispk_stream_t stream) {
+    return ispk_alibi_mqa_attn_bf16_tiles(q, ldq, k, v, ldkv, slopes, key_len, out, ldo, B, N, H, 0, stream);
 }

@@ -53,6 +53,16 @@ static inline int32_t ispk_launch_status() {
     return 0;
 }
 
+// Experiment knobs (tools/stamp_*.py, tools/sweep_gemm.py): compiled in only with -DISPK_EXPERIMENTS
+// (`python -m isp_tts_amd.build --experiments` -> libispk_exp.so).  In the product build every knob reads as "unset" at
+// compile time, the branches that test one are removed, and nothing the library does depends on the process environment.
+#ifdef ISPK_EXPERIMENTS
+#include <stdlib.h>
+static inline const char* ispk_knob(const char* name) { return getenv(name); }
+#else
+#define ispk_knob(name) (static_cast<const char*>(nullptr))
+#endif
+
 static inline bool ispk_aligned(const void* p, size_t a) { return ((uintptr_t)p % a) == 0; }
 
 // bf16 <-> fp32 (round to nearest even; a plain cast keeps NaN a NaN on gfx950)

@@ -1120,7 +1120,7 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
     constexpr size_t lds = (size_t)64 * (64 * KC + 8) * sizeof(uint16_t) + 4 * kStageBytes;
     const int ntiles = (p.N + 63) / 64, mblocks = (p.M + 127) / 128;
     int nsplit = (512 + mblocks - 1) / mblocks;          // aim for >= 512 workgroups (2 per CU)
-    if (const char* e = getenv("ISPK_PANEL_NSPLIT")) nsplit = atoi(e);  // experiments only
+    if (const char* e = ispk_knob("ISPK_PANEL_NSPLIT")) nsplit = atoi(e);  // experiments only
     nsplit = nsplit < 1 ? 1 : (nsplit > ntiles ? ntiles : nsplit);
     const int per = (ntiles + nsplit - 1) / nsplit;
     nsplit = (ntiles + per - 1) / per;
@@ -1136,13 +1136,15 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
     constexpr int kQkv = ISPK_EP_OUT_BF16, kFfn1 = ISPK_EP_OUT_BF16 | ISPK_EP_GELU, kProj = ISPK_EP_MASK_ACC | kEpResid;
     constexpr int kMelT = ISPK_EP_ROWS_T | ISPK_EP_MASK_OUT | kEpBias;   // to_mel (model.py:167-168)
     const int key = p.cpb == -7 ? -2 : ep_key(p);
-    if (const char* e = getenv("ISPK_PANEL_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][6]
+#ifdef ISPK_EXPERIMENTS
+    if (const char* e = ispk_knob("ISPK_PANEL_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][6]
         GemmParams q = p;
         q.ln_out = reinterpret_cast<void*>(strtoull(e, nullptr, 16));
         if (key == kQkv) ISPK_PANEL_GO(kQkv, true, q);
         if (key == kFfn1) ISPK_PANEL_GO(kFfn1, true, q);
         ISPK_PANEL_GO(kEpDyn, true, q);
     }
+#endif
     if (p.ln_flags & 0x100u) {   // fp32 A + LayerNorm in the prologue (ispk_gemm_bf16_lnin)
 #define ISPK_PANEL_GO_LN(EP_, LNP_)                                                                                     \
     do {                                                                                                               \
@@ -1160,7 +1162,7 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
         ISPK_PANEL_GO_LN(kEpDyn, 2);
 #undef ISPK_PANEL_GO_LN
     }
-    if (getenv("ISPK_EP_DYN") == nullptr) {   // (set: experiments, forces the generic epilogue)
+    if (ispk_knob("ISPK_EP_DYN") == nullptr) {   // (set: experiments, forces the generic epilogue)
         if (key == kQkv) ISPK_PANEL_GO(kQkv, false, p);
         if (key == kFfn1) ISPK_PANEL_GO(kFfn1, false, p);
         if (key == kProj) ISPK_PANEL_GO(kProj, false, p);
@@ -1171,17 +1173,17 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
 }
 
 bool panel_ok(const GemmParams& p) {
-    return (p.K == 256 || p.K == 384) && vec_epilogue_ok(p) && rows_epilogue_ok(p) && getenv("ISPK_NO_PANEL") == nullptr;
+    return (p.K == 256 || p.K == 384) && vec_epilogue_ok(p) && rows_epilogue_ok(p) && ispk_knob("ISPK_NO_PANEL") == nullptr;
 }
 
 // The row-block kernel fits (a) the long reductions and (b) skinny outputs (N <= 192: the aligner's convolutions over
 // 33,000 mel frames with 80-160 output channels), where one 64-row workgroup covers every output feature and the
 // activations stream through exactly once; the generic 128x128 tiling wastes half its columns there.
 bool wide_ok(const GemmParams& p) {
-    const bool long_k = (p.K >= 512 || getenv("ISPK_FORCE_WIDE")) && (p.N == 384 || p.N == 256 || p.N % 192 == 0);
-    const bool skinny = p.N <= 192 && getenv("ISPK_NO_SKINNY") == nullptr;
+    const bool long_k = (p.K >= 512 || ispk_knob("ISPK_FORCE_WIDE")) && (p.N == 384 || p.N == 256 || p.N % 192 == 0);
+    const bool skinny = p.N <= 192 && ispk_knob("ISPK_NO_SKINNY") == nullptr;
     return (long_k || skinny) && p.M >= 128 * 16 && vec_epilogue_ok(p) && !(p.flags & ISPK_EP_OUT_BF16) &&
-           getenv("ISPK_NO_WIDE") == nullptr;
+           ispk_knob("ISPK_NO_WIDE") == nullptr;
 }
 
 template <int TM, int TN>
@@ -1220,7 +1222,7 @@ int32_t check_common(const GemmParams& p, int elt) {
 // tile choice: the largest tile that still gives every one of the 256 CUs a workgroup.  Returns TM*10 + TN.
 extern "C" int32_t ispk_gemm_f32_tile(int32_t M, int32_t N, int32_t K) {
     (void)K;
-    if (const char* e = getenv("ISPK_GEMM_TILE")) return atoi(e);  // experiments only (tools/bench_kernels.py)
+    if (const char* e = ispk_knob("ISPK_GEMM_TILE")) return atoi(e);  // experiments only (tools/bench_kernels.py)
     const int64_t wg128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
     const int64_t wg64x128 = (int64_t)((M + 63) / 64) * ((N + 127) / 128);
     if (wg128 >= 256) return 22;
@@ -1256,7 +1258,9 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
                                   int32_t N, int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride,
                                   ispk_stream_t stream) {
     GemmParams p{A, lda, W, ldw, C, ldc, bias, resid, ldr, mask, M, N, K, flags, cols_per_batch, batch_stride};
-    if (getenv("ISPK_PANEL_NOEPI")) p.cpb = -7;  // experiments only
+#ifdef ISPK_EXPERIMENTS
+    if (ispk_knob("ISPK_PANEL_NOEPI")) p.cpb = -7;  // skips the epilogue: timing probes only, WRONG results
+#endif
     if (int32_t rc = check_common(p, 2)) return rc;
     if (M == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -1268,7 +1272,7 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
         g_last_bf16_variant = 1000 + K / 64;
         return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
     }
-    if (panel_ok(p) && !(getenv("ISPK_FORCE_WIDE") && (N == 384 || N == 256) && !(flags & ISPK_EP_OUT_BF16))) {
+    if (panel_ok(p) && !(ispk_knob("ISPK_FORCE_WIDE") && (N == 384 || N == 256) && !(flags & ISPK_EP_OUT_BF16))) {
         g_last_bf16_variant = 1000 + K / 64;
         return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
     }
@@ -1940,7 +1944,7 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
     ISPK_REQUIRE((int64_t)F * ldw1 < (1ll << 30) && (int64_t)D * ldw2 < (1ll << 30), ISPK_E_SHAPE, "ffn: weights too large");
     ISPK_REQUIRE(ldw1 == D, ISPK_E_UNSUPPORTED, "ffn: W1 rows must be contiguous (ldw1 == dim)");
     constexpr int kHot = ISPK_EP_MASK_OUT | kEpResid;   // the transformer layer's call (transformer.py:105-110), no bias2
-    const bool hot = ep_key(p) == kHot && getenv("ISPK_EP_DYN") == nullptr;
+    const bool hot = ep_key(p) == kHot && ispk_knob("ISPK_EP_DYN") == nullptr;
     const bool packed = ldw2 == 0;   // W2 laid out by ispk_ffn_pack_w2_bf16
     if (ln) {
         const bool stats_only = ln->flags & 4u;   // ln_out = float [rows][2] (mean, rstd); gamma / beta unused
@@ -1970,11 +1974,13 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
         p.pj_o = pj->o; p.pj_ldo = pj->ldo; p.pj_w = pj->Wo; p.pj_x = pj->x; p.pj_ldx = pj->ldx;
     }
     void* stamp = nullptr;
-    if (const char* e = getenv("ISPK_FFN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][3]
+#ifdef ISPK_EXPERIMENTS
+    if (const char* e = ispk_knob("ISPK_FFN_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][3]
         stamp = reinterpret_cast<void*>(strtoull(e, nullptr, 16));
         ISPK_REQUIRE(D == 384 && packed && !bias1 && hot && !ln && !lx && !pj, ISPK_E_UNSUPPORTED, "ffn stamps: the hot instance only");
         p.ln_out = stamp;
     }
+#endif
 #define ISPK_FFN_GO(KC_, B1_, PK_, EP_, ST_)                                                                          \
     do {                                                                                                              \
         constexpr size_t lds = (size_t)(2 * 32 * (64 * KC_ + 8) + 2 * 64 * KC_ * 40) * 2 + 4 * kStageBytes;             \
@@ -2006,6 +2012,11 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
                            W2, ldw2, bias1, F);                                                                       \
         return ispk_launch_status();                                                                                  \
     } while (0)
+#ifdef ISPK_EXPERIMENTS
+#define ISPK_FFN_STAMPED() do { if (stamp) ISPK_FFN_GO(6, false, true, kHot, true); } while (0)
+#else
+#define ISPK_FFN_STAMPED() (void)stamp
+#endif
 #define ISPK_FFN_KC(KC_)                                                   \
     do {                                                                   \
         if (pj && ln) ISPK_FFN_GO_PJ(KC_, true);                           \
@@ -2016,7 +2027,7 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
         if (lx) ISPK_FFN_GO_LX(KC_, kEpDyn, false);                        \
         if (ln && hot) ISPK_FFN_GO_LN(KC_, kHot);                          \
         if (ln) ISPK_FFN_GO_LN(KC_, kEpDyn);                               \
-        if (stamp) ISPK_FFN_GO(6, false, true, kHot, true);                \
+        ISPK_FFN_STAMPED();                                                \
         if (!bias1 && packed && hot) ISPK_FFN_GO(KC_, false, true, kHot, false);  \
         if (!bias1 && packed) ISPK_FFN_GO(KC_, false, true, kEpDyn, false);  \
         if (!bias1) ISPK_FFN_GO(KC_, false, false, kEpDyn, false);          \
@@ -2025,6 +2036,7 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
     } while (0)
     if (D == 384) ISPK_FFN_KC(6); else ISPK_FFN_KC(4);
 #undef ISPK_FFN_KC
+#undef ISPK_FFN_STAMPED
 #undef ISPK_FFN_GO_PJ
 #undef ISPK_FFN_GO_LX
 #undef ISPK_FFN_GO_LN

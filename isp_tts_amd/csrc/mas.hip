@@ -83,8 +83,12 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
     const float ninf = -__builtin_huge_valf();
 
     for (int j = tid; j < L_max; j += 256) cnt[j] = 0;
-    const int abl = (int)(stride_m >> 40);   // experiments only: phase ablation code smuggled in the high stride bits
+#ifdef ISPK_EXPERIMENTS
+    const int abl = (int)(stride_m >> 40);   // phase ablation code (tools/bench_mas.py) in the high stride bits
     stride_m &= ((int64_t)1 << 40) - 1;
+#else
+    constexpr int abl = 0;
+#endif
 
     if (wave == 0) {
         // ---------------------------------------------------------------- forward DP
@@ -229,7 +233,9 @@ template <int NC>
 int32_t launch(const float* logits, const int64_t* text_len, const int64_t* mel_len, int16_t* attn_hard, int64_t* dur,
                int16_t* path, int B, int M_max, int L_max, int64_t sb, int64_t sm, size_t lds, hipStream_t stream) {
     ISPK_RESERVE_LDS((&mas_kernel<NC>), lds, "mas");
-    if (const char* e = getenv("ISPK_MAS_ABLATE")) sm |= (int64_t)atoi(e) << 40;  // experiments only
+#ifdef ISPK_EXPERIMENTS
+    if (const char* e = ispk_knob("ISPK_MAS_ABLATE")) sm |= (int64_t)atoi(e) << 40;  // experiments only
+#endif
     hipLaunchKernelGGL(mas_kernel<NC>, dim3(B), dim3(256), lds, stream, logits, text_len, mel_len, attn_hard, dur, path,
                        M_max, L_max, sb, sm);
     return ispk_launch_status();

@@ -159,7 +159,7 @@ int32_t layernorm_dispatch(const float* x, int64_t ldx, const float* gamma, cons
                         ispk_aligned(y, sizeof(OutT) * 4) && (!gamma || ispk_aligned(gamma, 16)) &&
                         (!beta || ispk_aligned(beta, 16)) &&
                         (!ada_scale || (ispk_aligned(ada_scale, 16) && ada_stride % 4 == 0)) &&
-                        (!ada_shift || ispk_aligned(ada_shift, 16)) && getenv("ISPK_LN_SCALAR") == nullptr;
+                        (!ada_shift || ispk_aligned(ada_shift, 16)) && ispk_knob("ISPK_LN_SCALAR") == nullptr;
     if (vec_ok) {
         dim3 grid8((rows + 7) / 8), block8(256);
 #define ISPK_LNV_CASE(NV4)                                                                                               \

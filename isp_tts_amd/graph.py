@@ -13,6 +13,8 @@ from typing import Optional
 import torch
 from torch import Tensor
 
+from . import staging
+
 
 class GraphedForward:
     def __init__(self, model, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor,
@@ -36,6 +38,8 @@ class GraphedForward:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._run()
+        # the graph holds raw pointers to the modules' staged weight images: remember their generation
+        self._staged_at_capture = staging.replacements()
 
     def _run(self):
         s = self.static
@@ -43,6 +47,9 @@ class GraphedForward:
                           flow_noise=s["flow_noise"], flow_time=s["flow_time"])
 
     def replay(self):
+        if staging.replacements() != self._staged_at_capture:
+            raise RuntimeError("a staged weight image was rebuilt after this graph was captured (parameters changed: "
+                               "load() / an optimizer step); the graph points at freed memory - capture a new one")
         self.graph.replay()
         return self.out
 

@@ -17,6 +17,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ... import runtime
+from ...staging import StagedWeights
 from ..constructor import Constructor, ModuleConfig
 from .attend import Attend, AttentionIntermediates
 from .embeddings import LearnedALiBiPositionalBias
@@ -65,21 +66,22 @@ class Attention(nn.Module, Constructor):
         self.attend = Attend(causal=causal, dropout=dropout, scale=self.scale)
         self.to_out = nn.Linear(self.out_dim, dim, bias=False)
         self.compute_dtype = torch.float32
-        self._cache: dict = {}
+        self._cache = StagedWeights()
 
-    # weights staged for the kernels (fused [to_q; to_kv], optional bf16 copies), rebuilt when a parameter changes
+    # weights staged for the kernels (fused [to_q; to_kv], optional bf16 copies): one image per dtype, rebuilt when a
+    # parameter changes (staging.StagedWeights)
     def _staged(self, dtype: torch.dtype):
         ps = (self.to_q.weight, self.to_kv.weight, self.to_out.weight) + \
              ((self.rel_pos.learned_logslopes,) if self.rel_pos is not None else ())
-        key = (dtype,) + tuple((p.data_ptr(), p._version, p.device) for p in ps)
-        if self._cache.get("key") != key:
+
+        def build():
             with torch.no_grad():
                 wqkv = torch.cat([self.to_q.weight, self.to_kv.weight], dim=0).to(dtype).contiguous()
                 wo = self.to_out.weight.detach().to(dtype).contiguous()
                 slopes = (self.rel_pos.head_slopes() if self.rel_pos is not None
                           else torch.zeros(self.heads, device=wo.device)).detach()
-            self._cache = {"key": key, "wqkv": wqkv, "wo": wo, "slopes": slopes}
-        return self._cache["wqkv"], self._cache["wo"], self._cache["slopes"]
+            return wqkv, wo, slopes
+        return self._cache.get(dtype, ps, build)
 
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,

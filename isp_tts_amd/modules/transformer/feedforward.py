@@ -5,7 +5,6 @@ carry the residual add and row mask of transformer.py:105,110.  Dropout is ident
 """
 from __future__ import annotations
 
-import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -14,6 +13,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ... import runtime
+from ...staging import StagedWeights
 from ..constructor import Constructor, ModuleConfig
 
 _ACTS = {"gelu": runtime.EP_GELU, "swish": runtime.EP_SILU, "linear": 0}
@@ -30,6 +30,10 @@ class FeedForwardConfig(ModuleConfig):
 
 
 class FeedForward(nn.Module, Constructor):
+    # path switches: class attributes (override on the class or an instance; nothing reads the environment)
+    prenorm_fused = True   # norm -> feed-forward -> residual as one kernel (ispk_ffn_bf16_prenorm) when a caller offers it
+    lnin_self = True       # two-GEMM path: feed_forward_norm applied by the first GEMM's own waves (ispk_gemm_bf16_lnin)
+
     def __init__(self, dim: int = 384, inner_dim: int = 1536, dropout: float = 0.0, activation: str = "relu",
                  bias: bool = False, glu: bool = False):
         super().__init__()
@@ -46,22 +50,17 @@ class FeedForward(nn.Module, Constructor):
         # the fused kernel gives a workgroup 128 rows: below ~256 workgroups it under-fills the chip and the two-GEMM
         # path (which splits the feature axis as well) is faster
         self.fused_min_rows = 128 * 128
-        self.prenorm_fused = True            # norm -> feed-forward -> residual as one kernel when a caller offers it
-        self._cache: dict = {}
+        self._cache = StagedWeights()
 
     def _staged(self, dtype: torch.dtype):
         ps = (self.net[0].weight, self.net[3].weight)
-        key = (dtype,) + tuple((p.data_ptr(), p._version, p.device) for p in ps)
-        if self._cache.get("key") != key:
-            self._cache = {"key": key, "w1": ps[0].detach().to(dtype).contiguous(),
-                           "w2": ps[1].detach().to(dtype).contiguous()}
-        return self._cache["w1"], self._cache["w2"]
+        return self._cache.get(dtype, ps, lambda: (ps[0].detach().to(dtype).contiguous(),
+                                                   ps[1].detach().to(dtype).contiguous()))
 
     def _packed_w2(self) -> Tensor:
         """W2 in the fused kernel's chunk-contiguous layout, staged once per weight version."""
-        if "w2p" not in self._cache:
-            self._cache["w2p"] = runtime.ffn_pack_w2(self._cache["w2"])
-        return self._cache["w2p"]
+        return self._cache.get("w2p", (self.net[3].weight,),
+                               lambda: runtime.ffn_pack_w2(self._staged(torch.bfloat16)[1]))
 
     def fused_with_norm_ok(self, x: Tensor) -> bool:
         """Can `forward_with_norm` emit the next LayerNorm from the fused kernel's epilogue for this input?"""
@@ -88,7 +87,7 @@ class FeedForward(nn.Module, Constructor):
     def prenorm_ok(self, x: Tensor, norm) -> bool:
         """Can `forward_prenorm` run the block (norm -> feed-forward -> residual) as one kernel for this input?"""
         rows = x.numel() // x.shape[-1]
-        return (self.prenorm_fused and os.environ.get("ISPK_FFN_PRENORM") != "0" and isinstance(norm, nn.LayerNorm)
+        return (self.prenorm_fused and isinstance(norm, nn.LayerNorm)
                 and norm.weight is not None and norm.bias is not None and x.dtype == torch.float32
                 and self.compute_dtype == torch.bfloat16 and self.act_flag == runtime.EP_GELU and x.shape[-1] in (256, 384)
                 and rows >= self.fused_min_rows and self.net[0].bias is None
@@ -98,7 +97,7 @@ class FeedForward(nn.Module, Constructor):
         """Two-GEMM path (e.g. an activation the fused kernel lacks): can the first Linear's GEMM apply `norm` itself?
         Only from decoder-sized batches on - below, the separate LayerNorm launch is cheaper (28.8 vs 19.4 + 4.9 us at
         6,400 rows: every workgroup of the split output repeats the fp32 staging)."""
-        return (os.environ.get("ISPK_LNIN_SELF") != "0" and isinstance(norm, nn.LayerNorm) and norm.weight is not None
+        return (self.lnin_self and isinstance(norm, nn.LayerNorm) and norm.weight is not None
                 and norm.bias is not None and x.dtype == torch.float32 and self.compute_dtype == torch.bfloat16
                 and x.shape[-1] in (256, 384) and x.numel() // x.shape[-1] >= self.fused_min_rows
                 and not (self.training and self.dropout_p > 0))

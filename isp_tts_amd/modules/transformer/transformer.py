@@ -12,8 +12,6 @@ The residual stream (x, x1, y) is always fp32; with compute_dtype = bf16 the GEM
 """
 from __future__ import annotations
 
-import os
-
 from dataclasses import dataclass, field
 from typing import NamedTuple, Optional, Union
 
@@ -22,6 +20,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from ... import runtime
+from ...staging import StagedWeights
 from ..constructor import Constructor, ModuleConfig
 from .attend import AttentionIntermediates
 from .attention import Attention, AttentionConfig, AttentionSharedIntermediates
@@ -51,6 +50,14 @@ class TransformerLayerConfig(ModuleConfig):
 
 
 class TransformerLayer(nn.Module, Constructor):
+    # Path switches are plain class attributes (set them on the class or on an instance; nothing reads the environment).
+    # LayerNorm applied by the consuming GEMM's own waves (ispk_gemm_bf16_lnin with row_stats = NULL), decoder-sized batches:
+    lnin_self = True
+    # to_out + residual + mask inside the feed-forward kernel (ispk_attn_out_ffn_bf16): parity-tested, OFF - its plain
+    # projection prologue takes 35 us against the 32-us out-projection GEMM it replaces (150 vs 146 us for the pair,
+    # 2.21-2.34 vs 2.09 ms per step: the longer lock-step kernel overlaps worse with the second batch in flight)
+    fuse_out_proj = False
+
     def __init__(self, dim: int = 384, attention=None, feed_forward=None, pre_norm: bool = True,
                  adaptive_norm: bool = False, condition_dim: Optional[int] = None):
         super().__init__()
@@ -62,10 +69,6 @@ class TransformerLayer(nn.Module, Constructor):
         # batches on (33.0 vs 22.1 + 15.0 us at 32,768 rows); at 6,400 rows the output is split over many workgroups that
         # each repeat the fp32 staging, and the separate 4.9-us LayerNorm is cheaper (18.6 vs 9.4 + 4.9 us)
         self.lnin_self_min_rows = 128 * 128
-        # to_out + residual + mask inside the feed-forward kernel (ispk_attn_out_ffn_bf16): parity-tested, OFF - its plain
-        # projection prologue takes 35 us against the 32-us out-projection GEMM it replaces (150 vs 146 us for the pair,
-        # 2.21-2.34 vs 2.09 ms per step: the longer lock-step kernel overlaps worse with the second batch in flight)
-        self.fuse_out_proj = False
         norm = (lambda: AdaptiveLayerNorm(dim, condition_dim=condition_dim)) if adaptive_norm else (lambda: LayerNorm(dim))
         self.attention_norm = norm()
         self.attention = Attention.init(attention if attention is not None else AttentionConfig(), dim=dim)
@@ -93,7 +96,7 @@ class TransformerLayer(nn.Module, Constructor):
         handed = normed is not None and normed.dtype == torch.float32 and normed.shape[-1] == 2
         own = (normed is None and ada is None and isinstance(self.attention_norm, nn.LayerNorm) and context is None
                and attention_mask is None and x.shape[-1] in (256, 384) and self.attention_norm.weight is not None
-               and self.attention_norm.bias is not None and os.environ.get("ISPK_LNIN_SELF") != "0"
+               and self.attention_norm.bias is not None and self.lnin_self
                and x.numel() // x.shape[-1] >= self.lnin_self_min_rows)
         # to_out + residual + mask fused into the feed-forward kernel (one launch for the layer's second half)?
         ffw = self.feed_forward
@@ -101,7 +104,7 @@ class TransformerLayer(nn.Module, Constructor):
                     and attention_mask is None and (next_norm is None or next_norm[4] == "stats")
                     and self.attention.heads * 64 == x.shape[-1] and ffw.net[3].bias is None
                     and ffw.prenorm_ok(x, self.feed_forward_norm)
-                    and (self.fuse_out_proj or os.environ.get("ISPK_FUSE_OUT_PROJ") == "1"))
+                    and self.fuse_out_proj)
         if cdt == torch.bfloat16 and (handed or own):
             # attention_norm inside the q/kv GEMM, applied while it stages x: with the row statistics the previous layer's
             # feed-forward kernel handed over, or (first layer of a stack) computed by the GEMM's own waves
@@ -200,21 +203,21 @@ class Transformer(nn.Module, Constructor):
         self.pos_emb = None
         self.project_emb = nn.Linear(emb_dim, dim) if emb_dim != dim else nn.Identity()  # transformer.py:170
         self.norm = nn.LayerNorm(dim)                                                      # transformer.py:172
-        self._ada_cache: dict = {}
+        self._ada_cache = StagedWeights()
 
     def _ada_all(self, condition: Tensor):
         """Projects the condition for every AdaptiveLayerNorm of the stack in ONE launch (2 norms x 2 Linears per layer
         would otherwise be 4*depth tiny launches): concatenated [4*depth*dim, cond] weight, sliced per norm."""
         norms = [n for layer in self.layers for n in (layer.attention_norm, layer.feed_forward_norm)]
         ps = [p for n in norms for p in (n.weight.weight, n.weight.bias, n.bias.weight, n.bias.bias)]
-        key = tuple((p.data_ptr(), p._version, p.device) for p in ps)
-        if self._ada_cache.get("key") != key:
+
+        def build():
             with torch.no_grad():
-                w = torch.cat([torch.cat([n.weight.weight, n.bias.weight]) for n in norms]).contiguous()
-                b = torch.cat([torch.cat([n.weight.bias, n.bias.bias]) for n in norms]).contiguous()
-            self._ada_cache = {"key": key, "w": w, "b": b}
+                return (torch.cat([torch.cat([n.weight.weight, n.bias.weight]) for n in norms]).contiguous(),
+                        torch.cat([torch.cat([n.weight.bias, n.bias.bias]) for n in norms]).contiguous())
+        w_all, b_all = self._ada_cache.get("ada", ps, build)
         cond = condition.reshape(-1, condition.shape[-1]).float().contiguous()
-        proj = runtime.linear_small(cond, self._ada_cache["w"], self._ada_cache["b"])       # [Bc, 2*len(norms)*dim]
+        proj = runtime.linear_small(cond, w_all, b_all)       # [Bc, 2*len(norms)*dim]
         d = self.dim
         parts = [(proj[:, (2 * i) * d:(2 * i + 1) * d], proj[:, (2 * i + 1) * d:(2 * i + 2) * d])
                  for i in range(len(norms))]
@@ -234,7 +237,7 @@ class Transformer(nn.Module, Constructor):
     # Variant of the above that moves only the STATISTICS: the fused feed-forward kernel writes (mean, rstd) per row and the
     # next layer's q/kv GEMM (ispk_gemm_bf16_lnin) normalises while it stages its fp32 input - no normalised copy in HBM.
     # ON: the feed-forward kernel is unchanged in time (106.6 us), q/kv goes 21.8 -> 26.6 us and the 15.0-us LayerNorm
-    # launch disappears: 2.636 -> 2.587 ms per step with one batch in flight, 2.162 -> 2.147 with two (ISPK_STATS_LN=0: off).
+    # launch disappears: 2.636 -> 2.587 ms per step with one batch in flight, 2.162 -> 2.147 with two.
     stats_layernorm = True
 
     def _fusable(self, context, context_mask, attention_mask) -> bool:
@@ -286,11 +289,11 @@ class Transformer(nn.Module, Constructor):
         ada = self._ada_all(adaptive_condition) if (self.adaptive_norm and adaptive_condition is not None) else None
         # bf16, plain LayerNorm: a layer's fused feed-forward kernel also emits the LayerNorm that consumes its output
         # (the next layer's attention_norm, or the final norm) when the batch is large enough for that kernel
-        # (ISPK_CHAIN_LN=1: experiments only - measured neutral with one and with two batches in flight)
-        chain = ((self.chain_layernorm or os.environ.get("ISPK_CHAIN_LN") == "1") and not self.adaptive_norm
+        # (`chain_layernorm`: opt-in - measured neutral with one and with two batches in flight)
+        chain = (self.chain_layernorm and not self.adaptive_norm
                  and self.layers[0].attention.compute_dtype == torch.bfloat16)
         cdt = self.layers[0].attention.compute_dtype
-        stats = (not chain and self.stats_layernorm and os.environ.get("ISPK_STATS_LN") != "0" and not self.adaptive_norm
+        stats = (not chain and self.stats_layernorm and not self.adaptive_norm
                  and cdt == torch.bfloat16 and context is None and attention_mask is None)
         chain = chain or stats
         normed = None

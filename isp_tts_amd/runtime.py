@@ -46,6 +46,7 @@ SIGNATURES = {
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
+    "ispk_alibi_mqa_attn_bf16_tiles": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_cast_f32_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ispk_flow_mix_f32": [_P, _P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
     "ispk_flow_finish_f32": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
@@ -510,7 +511,7 @@ def linear(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, act: int = 0) ->
 
 # ------------------------------------------------------------------------------------------------- attention
 def alibi_mqa_attention_raw(q: Tensor, ldq: int, k: Tensor, v: Tensor, ldkv: int, slopes: Tensor,
-                            key_len: Optional[Tensor], B: int, N: int, heads: int) -> Tensor:
+                            key_len: Optional[Tensor], B: int, N: int, heads: int, q_tiles: int = 0) -> Tensor:
     """ispk_alibi_mqa_attn_*: q is any tensor whose storage holds [B][N][H*64] rows at leading stride ldq starting at
     q.data_ptr(); k / v likewise [B][N][64] at stride ldkv.  Returns the merged heads [B, N, H*64]."""
     _dev(q, k, v, slopes, key_len)
@@ -518,20 +519,26 @@ def alibi_mqa_attention_raw(q: Tensor, ldq: int, k: Tensor, v: Tensor, ldkv: int
     if key_len is not None:
         key_len = key_len.to(torch.int64).contiguous()
     slopes = slopes.to(torch.float32).contiguous()
-    fn = lib().ispk_alibi_mqa_attn_f32 if q.dtype == torch.float32 else lib().ispk_alibi_mqa_attn_bf16
     es = q.element_size()
-    _launch(("attn_f32_kernel" if es == 4 else "attn_bf16_kernel") + ("<768>" if heads <= 6 else "<1024>"), 256.0 * B * N * N * heads,
-            float(B) * N * (2 * heads * 64 + 128) * es, fn, q.data_ptr(), ldq, k.data_ptr(), v.data_ptr(), ldkv,
+    label = ("attn_f32_kernel" if es == 4 else "attn_bf16_kernel") + ("<768>" if heads <= 6 else "<1024>")
+    flops, nbytes = 256.0 * B * N * N * heads, float(B) * N * (2 * heads * 64 + 128) * es
+    if q_tiles:   # explicit query tiles per workgroup (bf16 kernel only; 0 = the launcher's own choice)
+        assert es == 2
+        _launch(label, flops, nbytes, lib().ispk_alibi_mqa_attn_bf16_tiles, q.data_ptr(), ldq, k.data_ptr(), v.data_ptr(),
+                ldkv, slopes.data_ptr(), _ptr(key_len), out.data_ptr(), heads * 64, B, N, heads, q_tiles, _stream())
+        return out
+    fn = lib().ispk_alibi_mqa_attn_f32 if es == 4 else lib().ispk_alibi_mqa_attn_bf16
+    _launch(label, flops, nbytes, fn, q.data_ptr(), ldq, k.data_ptr(), v.data_ptr(), ldkv,
             slopes.data_ptr(), _ptr(key_len), out.data_ptr(), heads * 64, B, N, heads, _stream())
     return out
 
 
-def alibi_mqa_attention(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor]) -> Tensor:
+def alibi_mqa_attention(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor], q_tiles: int = 0) -> Tensor:
     """qkv [B, N, H*64 + 128] = [Q | K | V] (the fused to_q / to_kv projection) -> merged heads [B, N, H*64]."""
     B, N, W = qkv.shape
     assert W == heads * 64 + 128 and qkv.is_contiguous()
     return alibi_mqa_attention_raw(qkv, W, qkv[..., heads * 64:], qkv[..., heads * 64 + 64:], W, slopes, key_len, B, N,
-                                   heads)
+                                   heads, q_tiles)
 
 
 # ------------------------------------------------------------------------------------------------- aligner front-end

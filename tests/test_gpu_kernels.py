@@ -494,18 +494,17 @@ def test_attention_output_projection_fused_into_the_feed_forward(R, D, Fi):
     assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
 
 
-def test_attention_bf16_several_query_tiles_per_workgroup(monkeypatch):
+def test_attention_bf16_several_query_tiles_per_workgroup():
     """With the whole key range resident in LDS a workgroup serves several 64-query tiles off one K/V fetch (the launcher
     does this by itself only for large batches; forced here).  Same values as one tile per workgroup, bit for bit."""
     B, N, H = 3, 450, 6
     qkv = _bf(synth._normal("t/at/qpw", (B, N, H * 64 + 128))).to(DEV)
     slopes = torch.tensor(synth.alibi_default_slopes(H), device=DEV)
     key_len = torch.tensor([450, 123, 300], device=DEV)
-    monkeypatch.setenv("ISPK_ATTN_QPW", "1")
-    one = runtime.alibi_mqa_attention(qkv, H, slopes, key_len).cpu()
-    for qpw in ("2", "4"):
-        monkeypatch.setenv("ISPK_ATTN_QPW", qpw)
-        assert torch.equal(runtime.alibi_mqa_attention(qkv, H, slopes, key_len).cpu().view(torch.int16), one.view(torch.int16))
+    one = runtime.alibi_mqa_attention(qkv, H, slopes, key_len, q_tiles=1).cpu()
+    for qpw in (2, 4, 0):   # 0 = the launcher's own choice
+        got = runtime.alibi_mqa_attention(qkv, H, slopes, key_len, q_tiles=qpw).cpu()
+        assert torch.equal(got.view(torch.int16), one.view(torch.int16))
 
 
 def test_layernorm_bf16_output_and_cast():

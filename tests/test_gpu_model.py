@@ -11,6 +11,7 @@ from conftest import crc, golden
 pytestmark = pytest.mark.gpu
 
 from isp_tts_amd import synth  # noqa: E402
+from isp_tts_amd.modules.transformer import FeedForward, Transformer, TransformerLayer  # noqa: E402
 from oracle import acoustic_oracle as orc  # noqa: E402
 
 DEV = "cuda"
@@ -279,7 +280,7 @@ def test_bf16_layernorm_statistics_handoff_matches_separate_layernorm_at_full_si
     """Decoder stack at the benchmark shape with layers 2..6's attention LayerNorm applied inside the q/kv GEMM from the
     previous feed-forward kernel's row statistics (`Transformer.stats_layernorm`) against separate LayerNorm launches:
     same fp32 statistics up to the reduction tree, so only 1-ulp bf16 roundings of the normalised operand differ."""
-    monkeypatch.setenv("ISPK_FFN_PRENORM", "0")          # isolate the hand-off (ispk_ffn_bf16_ln -> ispk_gemm_bf16_lnin)
+    monkeypatch.setattr(FeedForward, "prenorm_fused", False)   # isolate the hand-off (ispk_ffn_bf16_ln -> ispk_gemm_bf16_lnin)
     x = synth._normal("t/chain/x", (64, 512, 384)).to(DEV)
     lens = torch.full((64,), 512, device=DEV)
     lens[2::5] = 211
@@ -310,9 +311,10 @@ def test_bf16_prenorm_feed_forward_matches_separate_layernorm_at_full_size(gpu_m
     try:
         dec.set_compute_dtype(torch.bfloat16)
         fused = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
-        monkeypatch.setenv("ISPK_FFN_PRENORM", "0")
-        monkeypatch.setenv("ISPK_STATS_LN", "0")
-        monkeypatch.setenv("ISPK_LNIN_SELF", "0")
+        monkeypatch.setattr(FeedForward, "prenorm_fused", False)
+        monkeypatch.setattr(Transformer, "stats_layernorm", False)
+        monkeypatch.setattr(FeedForward, "lnin_self", False)
+        monkeypatch.setattr(TransformerLayer, "lnin_self", False)
         plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
     finally:
         dec.set_compute_dtype(torch.float32)
@@ -332,7 +334,7 @@ def test_bf16_fused_output_projection_matches_separate_launches_at_full_size(gpu
     try:
         dec.set_compute_dtype(torch.bfloat16)
         plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
-        monkeypatch.setenv("ISPK_FUSE_OUT_PROJ", "1")          # opt-in (measured slower than the two launches)
+        monkeypatch.setattr(TransformerLayer, "fuse_out_proj", True)   # opt-in (measured slower than the two launches)
         fused = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
     finally:
         dec.set_compute_dtype(torch.float32)
@@ -357,7 +359,8 @@ def test_bf16_encoder_with_layernorms_inside_the_gemms_matches_separate_layernor
             l.feed_forward.fused_min_rows = 0
             l.feed_forward.prenorm_fused = False
         fused = enc(x, mask=mask, key_len=lens).out
-        monkeypatch.setenv("ISPK_LNIN_SELF", "0")
+        monkeypatch.setattr(FeedForward, "lnin_self", False)
+        monkeypatch.setattr(TransformerLayer, "lnin_self", False)
         plain = enc(x, mask=mask, key_len=lens).out
     finally:
         for l, (a, b) in zip(enc.layers, saved):

@@ -1,73 +1,103 @@
 #!/usr/bin/env python3
 """Headline benchmark: mel-frames/s of the acoustic-model forward path (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            # starts N fresh worker processes itself when N > 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                # or under a launcher (RANK / LOCAL_RANK / WORLD_SIZE set)
 
-A "step" is one pass of the full `AcousticModel.forward` (encoder -> aligner front-end -> MAS -> temporal adaptor with
-one flow-matching evaluation -> decoder -> to_mel) over one batch of synthetic fixed-length utterances that is already
-resident in HBM: BASELINE config 3, B = 64 utterances x 100 phonemes x 512 mel frames PER GPU (weak scaling: each rank
-owns its own utterances — they are independent end to end — and the only exchange is one RCCL all-gather of the mel
-outputs per step, inside the timed region).  Synthetic weights and inputs (isp_tts_amd.synth); no work is skipped.
+A "step" is one pass of the full `AcousticModel.forward` (text encoder -> aligner front-end -> MAS -> temporal adaptor
+with one flow-matching evaluation -> decoder -> to_mel) over one batch of synthetic utterances already resident in HBM.
+Workload = BASELINE config 3: B = 64 utterances x 100 phonemes x 512 mel frames, bf16 - per GPU with `--scaling weak`
+(default: every rank owns its own 64 utterances), or 64 in total with `--scaling strong` (64 / N per rank).  Utterances
+are independent end to end, so the only exchange is ONE RCCL gather of the mel outputs per step, inside the timed
+region.  `value` is measured with ONE batch in flight per GPU; the double-buffered figure is a named extra.
 
-Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     the dominant kernel of the timed region (by summed HIP-event time on the launch stream): achieved
-                  algorithmic FLOP/s (or B/s) per launch vs the gfx950 peak; "kernels" lists every timed kernel;
-  "cpu_baseline": the oracle (CPU restatement of the reference algorithm, oracle/) timed on this host's cores on a
-                  bounded sample of the same workload (N=1 only).
+Rank 0 prints ONE JSON line: the contract fields plus
+  "roofline"      the dominant kernel of the step (HIP events on the launch stream): achieved algorithmic FLOP/s or B/s
+                  against the gfx950 peak, PMC traffic from profiles/, every other kernel under "kernels";
+  "cpu_baseline"  the oracle (CPU restatement of the reference's algorithm, oracle/) on this host's cores, N = 1 only;
+  extras          two_batches_in_flight, strong_scaling (N > 1), config4 (B = 256 variable-length, sharded by cost,
+                  gathered and un-permuted), and at N = 1: infer_steps4, config2_fp32, f32_parity_path,
+                  fp32_alignment_chain.
+No work is skipped in any timed region; synthetic weights and inputs (isp_tts_amd.synth).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from isp_tts_amd import runtime, synth  # noqa: E402
-from isp_tts_amd.acoustic import AcousticModel  # noqa: E402
-from isp_tts_amd.config import AcousticDims  # noqa: E402
-from isp_tts_amd.dist import MelGatherPipeline  # noqa: E402
-from isp_tts_amd.graph import GraphedForward, GraphedForwardLanes  # noqa: E402
-
 # gfx950 peaks from /opt/skills/guides/MI355X_MICROARCH.md ("Chip-level parameters", dense, no sparsity)
 PEAK = {"hbm_GBs": 8000.0, "mfma_f32_TFs": 157.3, "mfma_bf16_TFs": 2500.0}
-FLOP_PER_FRAME = 29.0e6  # full forward, SURVEY 8(d) / BASELINE.md section 4
+FLOP_PER_FRAME = 29.0e6          # full forward, SURVEY 8(d) / BASELINE.md section 4
+FLOP_PER_FRAME_INFER = 30.8e6    # infer(steps=4)
+FLOP_PER_FRAME_C2 = 26.8e6       # encoder + decoder + to_mel
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --batch utterances per GPU; strong: --batch utterances in total (batch / N per GPU)")
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (weak) or in total (strong)")
     ap.add_argument("--text-len", type=int, default=100)
     ap.add_argument("--mel-len", type=int, default=512)
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="bf16 = BASELINE config 3 (throughput path); f32 = the 1e-4 parity path")
-    ap.add_argument("--no-f32-line", action="store_true", help="skip the short fp32 parity-path measurement (N=1 only)")
+    ap.add_argument("--alignment", choices=["auto", "f32"], default="auto",
+                    help="precision of the chain upstream of MAS: auto = fp32 aligner front-end, encoder in --dtype; "
+                         "f32 = text encoder in fp32 too (MAS paths identical to the fp32 path)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="batches in flight per GPU for the headline value (graph instances replayed round-robin on their "
+                         "own streams); the 2-in-flight figure is always reported as an extra")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (+ roofline)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--in-flight", type=int, default=2,
-                    help="batches in flight per GPU: consecutive steps alternate between this many HIP-graph instances on "
-                         "their own streams, so one batch's small text-side launches overlap another's decoder (1 = serial)")
-    ap.add_argument("--cpu-batch", type=int, default=16, help="utterances in the CPU-baseline sample")
+    ap.add_argument("--cpu-batch", type=int, default=64, help="utterances in the CPU-baseline sample")
     ap.add_argument("--cpu-iters", type=int, default=5)
-    return ap.parse_args()
+    ap.add_argument("--c4-batch", type=int, default=256, help="config 4: utterances in total")
+    ap.add_argument("--c4-frames", type=int, default=32768, help="config 4: padded frames per micro-batch (n x M_pad)")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------------ parent: start N ranks
+def launch_workers(args) -> int:
+    """`python bench.py --gpus N` without a launcher: this process touches no GPU API (torch is not even imported) and
+    starts N fresh workers, one per GPU, with the rendezvous in the environment; rank 0's JSON line is relayed."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--worker"]
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ helpers (worker side)
 def host_cores() -> int:
     """Cores this process may actually use: affinity mask, cgroup CPU quota, and the GPU box's per-GPU share (16)."""
-    if os.environ.get("ISPK_CPU_THREADS"):
-        return int(os.environ["ISPK_CPU_THREADS"])
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
@@ -78,38 +108,50 @@ def host_cores() -> int:
     return max(1, min(n, 16))
 
 
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(args, sd):
-    """Oracle forward (reference algorithm restated on PyTorch-CPU + C MAS) on a bounded sample: cpu_batch utterances
-    of the same shape, 1 warm-up + cpu_iters timed passes, median."""
-    from oracle import acoustic_oracle as orc
+    """Oracle forward (the reference's algorithm restated on PyTorch-CPU + C MAS) on a bounded sample of the SAME workload:
+    cpu_batch utterances of the config-3 shape, 2 warm-up + cpu_iters timed passes, median."""
+    import torch
+    from isp_tts_amd import synth
+    from oracle import acoustic_oracle as orc      # the checker, timed as the reported baseline - never the product
     torch.set_num_threads(host_cores())
     os.environ["OMP_NUM_THREADS"] = str(host_cores())
     inp = synth.make_inputs(args.cpu_batch, args.text_len, args.mel_len)
     a = (inp["text"], inp["text_len"], inp["mel"], inp["mel_len"], inp["pitch"], inp["energy"], inp["flow_x0"],
          inp["flow_t"])
-    orc.acoustic_forward(sd, *a)
+    for _ in range(2):
+        orc.acoustic_forward(sd, *a)
     ts = []
     for _ in range(args.cpu_iters):
         t0 = time.perf_counter()
         orc.acoustic_forward(sd, *a)
         ts.append(time.perf_counter() - t0)
     med = sorted(ts)[len(ts) // 2]
-    return {"value": args.cpu_batch * args.mel_len / med, "unit": "mel-frames/s", "cores": torch.get_num_threads(),
-            "kind": "port",
+    return {"value": round(args.cpu_batch * args.mel_len / med, 1), "unit": "mel-frames/s", "cores": torch.get_num_threads(),
+            "kind": "port", "cpu": cpu_model(),
             "sample": f"oracle acoustic_forward fp32, B={args.cpu_batch} x L={args.text_len} x M={args.mel_len}, "
-                      f"1 warm-up + {args.cpu_iters} timed, median {med * 1e3:.0f} ms"}
+                      f"2 warm-up + {args.cpu_iters} timed, median {med * 1e3:.0f} ms"}
 
 
 def roofline(prof_summary: dict, steps: int, event_floor_us: float):
-    """Per kernel label: average launch duration (HIP events on the launch stream), achieved algorithmic
-    FLOP/s and B/s, and the fraction of the roofline that BINDS it: time floor = max(FLOPs / MFMA peak, bytes / HBM peak).
-    The dominant kernel (largest summed time) is the headline object."""
+    """Per kernel label: average launch duration (HIP events on the launch stream), achieved algorithmic FLOP/s and B/s
+    (both always reported), and the fraction of the roofline that BINDS it: time floor = max(FLOPs / MFMA peak,
+    bytes / HBM peak).  The dominant kernel (largest summed time) is the headline object."""
     if not prof_summary:
         return None
     kernels = {}
     for label, d in sorted(prof_summary.items(), key=lambda kv: -kv[1]["total_ms"]):
-        us = d["avg_us"]   # raw event-pair interval (the empty-pair interval is reported beside it, not subtracted:
-        #                    inside a busy stream the real overhead is ~1-2 us and rocprofv3 agrees with the raw value)
+        us = d["avg_us"]   # raw event-pair interval (the empty-pair interval is reported beside it, not subtracted)
         sec = us * 1e-6
         flops, nbytes = d["flops"] / d["launches"], d["bytes"] / d["launches"]
         peak_tf = PEAK["mfma_bf16_TFs"] if "bf16" in label else PEAK["mfma_f32_TFs"]
@@ -117,7 +159,8 @@ def roofline(prof_summary: dict, steps: int, event_floor_us: float):
         bound = "mfma" if t_mfma >= t_hbm else "hbm"
         kernels[label] = {"launches_per_step": round(d["launches"] / steps, 2), "avg_us": round(us, 2),
                           "ms_per_step": round(us * d["launches"] / steps / 1e3, 4),
-                          "TFLOPs": round(flops / sec / 1e12, 2), "GBs": round(nbytes / sec / 1e9, 1), "bound": bound,
+                          "TFLOPs": round(flops / sec / 1e12, 2), "mfma_frac": round(t_mfma / sec, 4),
+                          "GBs": round(nbytes / sec / 1e9, 1), "hbm_frac": round(t_hbm / sec, 4), "bound": bound,
                           "frac": round(max(t_mfma, t_hbm) / sec, 4)}
     top = next(iter(kernels))
     k = kernels[top]
@@ -127,24 +170,401 @@ def roofline(prof_summary: dict, steps: int, event_floor_us: float):
     else:
         rl = {"kernel": top, "bound": "hbm", "achieved": k["GBs"], "peak": PEAK["hbm_GBs"], "unit": "GB/s"}
     rl.update({"frac": k["frac"], "traffic": traffic_from_profiles(top), "avg_us": k["avg_us"],
-               "event_floor_us": round(event_floor_us, 2), "kernels": kernels})
+               "event_floor_us": round(event_floor_us, 2), "kernels": kernels, "other_kernels": other_from_profiles()})
     return rl
+
+
+def _profile_json(name: str):
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
 
 
 def traffic_from_profiles(kernel: str):
     """HBM bytes per launch of `kernel` from the committed PMC pass (profiles/traffic.json, written by
     tools/pmc_traffic.py from separate rocprofv3 --pmc runs; FETCH_SIZE doubled per the gfx950 note of the guide)."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        with open(path) as f:
-            entry = json.load(f).get(kernel)
-            return entry["hbm_bytes_per_launch"] if entry else None
-    except (OSError, ValueError):
-        return None
+    entry = (_profile_json("traffic.json") or {}).get(kernel)
+    return entry["hbm_bytes_per_launch"] if entry else None
 
 
-def event_floor() -> float:
-    """Median interval of an empty HIP-event pair on the launch stream, in us (subtracted from per-launch timings)."""
+def other_from_profiles():
+    """Kernels of the timed region that are NOT libispk launches (ATen element-wise glue, Tensile GEMMs, copies): they
+    carry no HIP-event label here, so their per-step time comes from the committed rocprofv3 kernel trace of this same
+    command (profiles/other_kernels.json, written by tools/collect_profiles.py)."""
+    return _profile_json("other_kernels.json")
+
+
+# ------------------------------------------------------------------------------------------------ worker
+def worker(args) -> int:
+    import torch
+    from isp_tts_amd import runtime, synth
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    from isp_tts_amd.dist import MelGatherPipeline, plan_micro_batches, unshard
+    from isp_tts_amd.graph import GraphedCall, GraphedForward, GraphedForwardLanes
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    # ISPK_BENCH_FORCE_DIST=1: take the distributed path (RCCL init, gather, barriers) even with one rank, so the
+    # multi-GPU code can be rehearsed on a one-GPU box
+    use_dist = world > 1 or os.environ.get("ISPK_BENCH_FORCE_DIST") == "1"
+    dist = None
+    if use_dist:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,     # nccl == RCCL on ROCm
+                                timeout=datetime.timedelta(seconds=300))
+
+    dims = AcousticDims()
+    sd = synth.make_state_dict()
+    model = AcousticModel.init(dims.model_config()).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev)
+    cdt = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    align_dt = torch.float32 if args.alignment == "f32" else None
+    model.set_compute_dtype(cdt, alignment_dtype=align_dt)
+
+    L, M = args.text_len, args.mel_len
+    if args.scaling == "strong":
+        assert args.batch % world == 0, "--scaling strong needs --batch divisible by --gpus"
+    B = args.batch if args.scaling == "weak" else args.batch // world
+    gather_root = None if os.environ.get("ISPK_BENCH_ALLGATHER") == "1" else 0
+
+    def to_dev(inp):
+        return {k: v.to(dev) for k, v in inp.items()}
+
+    def fwd_args(d):
+        return (d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"], d["flow_x0"], d["flow_t"])
+
+    def fence(pipes=()):
+        for p in pipes:
+            p.wait()               # every submitted gather has completed
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(seconds: float) -> float:
+        if not use_dist:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def measure(step_fn, steps, warmup, pipes=()):
+        """warmup untimed steps, then EXACTLY `steps` steps between barrier + synchronize pairs; MAX over ranks."""
+        for _ in range(warmup):
+            step_fn()
+        fence(pipes)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step_fn()
+        fence(pipes)
+        return max_over_ranks(time.perf_counter() - t0)
+
+    def fixed_batch_runner(batch, in_flight, seed_shift=0):
+        """Config-3 style stream of fixed-shape batches: graph instance(s) + the overlapped gather. -> (step_fn, pipes, lanes)"""
+        d = to_dev(synth.make_inputs(batch, L, M, seed=synth.SEED + rank + seed_shift))   # each rank: its own utterances
+        pipe = MelGatherPipeline(batch, dims.mel_dim, M, dev, root=gather_root) if use_dist else None
+        if args.no_graph:
+            def step():
+                out = model(*fwd_args(d)[:6], flow_noise=d["flow_x0"], flow_time=d["flow_t"])
+                if pipe is not None:
+                    pipe.submit(out.mel, out.adaptor_output.dec_lengths)
+                return out
+            return step, ([pipe] if pipe else []), None, d
+        lanes = GraphedForwardLanes(model, *fwd_args(d), lanes=in_flight, calibrate=in_flight > 1)
+
+        def step():
+            g, stream = lanes.next_lane()
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream):
+                out = g.replay()
+                if pipe is not None:   # the one exchange of the path: mel outputs over xGMI (RCCL gather), overlapped
+                    pipe.submit(out.mel, out.adaptor_output.dec_lengths)
+            return out
+        return step, ([pipe] if pipe else []), lanes, d
+
+    # ---------------------------------------------------------------------------------------------- headline (config 3)
+    step, pipes, lanes, d = fixed_batch_runner(B, max(1, args.in_flight))
+    elapsed = measure(step, args.steps, args.warmup, pipes)
+    out = step()
+    fence(pipes)
+    assert torch.isfinite(out.mel).all()
+    frames = world * B * M * args.steps
+    value = frames / elapsed
+    line = None
+    if rank == 0:
+        name, cus = runtime.device_info()
+        line = {
+            "metric": "mel-frames/s (whole node), batch=64 x 512-frame utterances"
+                      + (" per GPU" if args.scaling == "weak" else " in total") + ", full forward incl. MAS",
+            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: AcousticModel.forward (TextEncoder + Aligner/MAS + TemporalAdaptor "
+                                   "1 flow eval + MelDecoder + to_mel), fixed-length synthetic random-phoneme batch, "
+                                   "random-init weights of the recipe architecture (23.2 M params)",
+                       "batch_per_gpu": B, "global_batch": world * B, "text_len": L, "mel_len": M,
+                       "alignment_chain": "fp32 (text encoder + aligner front-end: MAS paths identical to the fp32 path)"
+                       if args.alignment == "f32" or args.dtype == "f32" else
+                       "aligner front-end fp32, text encoder in the compute dtype",
+                       "parallelism": (f"dp{world} (utterances sharded, one RCCL "
+                                       f"{'all-gather' if gather_root is None else 'gather to rank 0'} of mel per step, "
+                                       "overlapped with the next step)") if world > 1 else "single GPU",
+                       "device": name, "compute_units": cus,
+                       "launch": "eager" if lanes is None else "HIP graph replay",
+                       "batches_in_flight": 1 if lanes is None else len(lanes)},
+            "model_TFLOPs": round(value * FLOP_PER_FRAME / 1e12, 2),
+        }
+
+    # ---------------------------------------------------------------------------------------------- roofline (rank 0)
+    if rank == 0 and not args.no_kernel_events:
+        # graph replays cannot carry timing events: time the SAME kernels, launched eagerly, right after the timed region
+        prof = runtime.LaunchProfiler()
+        runtime.set_profiler(prof)
+        prof_steps = min(args.steps, 5)
+        for _ in range(prof_steps):
+            model(*fwd_args(d)[:6], flow_noise=d["flow_x0"], flow_time=d["flow_t"])
+        torch.cuda.synchronize()
+        runtime.set_profiler(None)
+        line["roofline"] = roofline(prof.summary(), prof_steps, event_floor(torch))
+        line["roofline"]["timing"] = (f"HIP events around every launch of {prof_steps} eager passes of the same step "
+                                      "(the timed region replays them as one HIP graph)")
+    if use_dist:
+        dist.barrier()
+
+    def extra(name, fn):
+        """Extras never take the headline down: an exception is reported in place of the figure.  (Every rank runs the
+        same extras in the same order; the ones with collectives use only what the headline already exercised.)"""
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001
+            res = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if line is not None and res is not None:
+            line[name] = res
+
+    if not args.no_extras and not args.no_graph:
+        # ------------------------------------------------------------------------- two batches in flight (all ranks)
+        lanes = pipes = step = None          # release the headline's graph instance before the next capture
+
+        def two_in_flight():
+            st, pp, ln, _ = fixed_batch_runner(B, 2)
+            el = measure(st, args.steps, args.warmup, pp)
+            return {"value": round(world * B * M * args.steps / el, 1), "unit": "mel-frames/s",
+                    "ms_per_step": round(1e3 * el / args.steps, 3), "steps": args.steps,
+                    "lane_overlap_gain": None if ln.overlap is None else round(ln.overlap, 3),
+                    "note": "two HIP-graph instances replayed alternately on two streams: one batch's small text-side "
+                            "launches overlap the other's decoder; every step is still a complete forward of its own batch"}
+        if max(1, args.in_flight) == 1:
+            extra("two_batches_in_flight", two_in_flight)
+
+        # ------------------------------------------------------------------------- strong scaling (N > 1, weak headline)
+        if world > 1 and args.scaling == "weak" and args.batch % world == 0:
+            def strong():
+                bs = args.batch // world
+                st, pp, _, _ = fixed_batch_runner(bs, 1, seed_shift=100)
+                el = measure(st, args.steps, args.warmup, pp)
+                return {"value": round(args.batch * M * args.steps / el, 1), "unit": "mel-frames/s", "scaling": "strong",
+                        "global_batch": args.batch, "batch_per_gpu": bs, "ms_per_step": round(1e3 * el / args.steps, 3),
+                        "steps": args.steps}
+            extra("strong_scaling", strong)
+
+        # ------------------------------------------------------------------------- BASELINE config 4 (all ranks)
+        def config4():
+            Bt, Lm, Mm = args.c4_batch, 200, 1024
+            full = synth.make_inputs(Bt, Lm, Mm, variable=True)
+            shards, plans = plan_micro_batches(full["mel_len"].tolist(), full["text_len"].tolist(), world, args.c4_frames)
+            slot = max(len(s) for s in shards)
+            block = torch.zeros((slot, dims.mel_dim, Mm), dtype=torch.float32, device=dev)
+            lens = torch.full((slot,), -1, dtype=torch.int64, device=dev)
+            graphs, off = [], 0
+            for idx, m_pad, l_pad in plans[rank]:
+                ii = torch.tensor(idx)
+                mb = {"text": full["text"][ii, :l_pad], "text_len": full["text_len"][ii], "mel": full["mel"][ii, :, :m_pad],
+                      "mel_len": full["mel_len"][ii], "pitch": full["pitch"][ii, :m_pad], "energy": full["energy"][ii, :m_pad],
+                      "flow_x0": full["flow_x0"][ii, :l_pad], "flow_t": full["flow_t"][ii]}
+                g = GraphedForward(model, *fwd_args(to_dev(mb)))
+                graphs.append((g, off, len(idx), m_pad))
+                off += len(idx)
+            pipe = MelGatherPipeline(slot, dims.mel_dim, Mm, dev, root=gather_root) if use_dist else None
+            result = {}
+
+            def st():
+                for g, o, n, m_pad in graphs:
+                    out_ = g.replay()
+                    block[o:o + n, :, :m_pad].copy_(out_.mel)
+                    lens[o:o + n].copy_(out_.adaptor_output.dec_lengths)
+                if pipe is not None:
+                    pipe.submit(block, lens)
+
+            def finish():   # root: wait for the exchange, restore the original utterance order
+                if pipe is not None:
+                    got = pipe.wait()
+                    if got is not None:
+                        result["mel"], result["len"] = unshard(got[0], got[1], shards)
+                else:
+                    result["mel"], result["len"] = unshard(block[None], lens[None], shards)
+
+            for _ in range(2):
+                st()
+            finish()
+            fence()
+            steps4 = max(3, args.steps // 4)
+            t0 = time.perf_counter()
+            for _ in range(steps4):
+                st()
+                finish()
+            fence()
+            el = max_over_ranks(time.perf_counter() - t0)
+            valid = int(full["mel_len"].sum())
+            ok = None
+            if "len" in result:
+                ok = bool(torch.equal(result["len"].cpu(), full["mel_len"]))
+            return {"value": round(valid * steps4 / el, 1), "unit": "valid mel-frames/s", "scaling": "strong",
+                    "global_batch": Bt, "mel_len": "U{128..1024}", "text_len": "clamp(round(mel/5.12), 25, 200)",
+                    "valid_frames": valid, "padded_frames_per_rank": [sum(len(i) * m for i, m, _ in p) for p in plans],
+                    "micro_batches_per_rank": [len(p) for p in plans], "ms_per_step": round(1e3 * el / steps4, 3),
+                    "steps": steps4, "gathered_lengths_match": ok,
+                    "workload": "BASELINE config 4: B=256 variable-length forward; cost-balanced contiguous length ranges per "
+                                "rank -> micro-batches padded to their own maximum -> one gather of [slot, 80, 1024] blocks "
+                                "-> original order restored on rank 0"}
+        extra("config4", config4)
+
+    # ---------------------------------------------------------------------------------------------- N = 1 extras
+    if world == 1 and rank == 0 and not args.no_extras and not args.no_graph:
+        def timed_graph(g, n):
+            g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                g.replay()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / n
+
+        def infer_line():
+            d2 = to_dev(synth.make_inputs(B, L, M))
+            dur = torch.full((B, L), M // L, dtype=torch.int64, device=dev)
+            dur[:, : M - (M // L) * L] += 1                                      # every row sums to M frames
+            g = GraphedCall(lambda: model.infer(d2["text"], text_lengths=d2["text_len"], duration_target=dur, steps=4,
+                                                flow_noise=d2["flow_x0"], max_dec_len=M))
+            sec = timed_graph(g, 10)
+            mel, ao = g.out
+            assert mel.shape == (B, dims.mel_dim, M) and bool((ao.dec_lengths == M).all())
+            v = B * M / sec
+            return {"value": round(v, 1), "unit": "mel-frames/s", "ms_per_step": round(sec * 1e3, 3), "steps": 10,
+                    "model_TFLOPs": round(v * FLOP_PER_FRAME_INFER / 1e12, 2),
+                    "workload": f"AcousticModel.infer(steps=4, duration_target sum={M}), B={B}, {args.dtype}: 4 Euler steps of "
+                                "the flow predictor, no aligner / MAS (model.py:177-238)"}
+        extra("infer_steps4", infer_line)
+
+        def alignment_chain_line():
+            if args.dtype != "bf16" or args.alignment == "f32":
+                return None
+            model.set_compute_dtype(torch.bfloat16, alignment_dtype=torch.float32)
+            try:
+                g = GraphedForward(model, *fwd_args(d))
+                sec = timed_graph(g, 10)
+                paths = g.out.aligner_output.attn_hard.clone()
+            finally:
+                model.set_compute_dtype(cdt, alignment_dtype=align_dt)
+            return {"value": round(B * M / sec, 1), "unit": "mel-frames/s", "ms_per_step": round(sec * 1e3, 3), "steps": 10,
+                    "note": "bf16 decoder / adaptor with the text encoder in fp32 as well: everything upstream of MAS is the "
+                            "fp32 path's arithmetic, so alignments and durations are bit-identical to the fp32 path's"}, paths
+
+        def f32_line():
+            model.set_compute_dtype(torch.float32)
+            try:
+                g = GraphedForward(model, *fwd_args(d))
+                sec = timed_graph(g, 5)
+                res = g.out
+                paths, mel32 = res.aligner_output.attn_hard.clone(), res.mel.clone()
+            finally:
+                model.set_compute_dtype(cdt, alignment_dtype=align_dt)
+            return {"value": round(B * M / sec, 1), "unit": "mel-frames/s", "ms_per_step": round(sec * 1e3, 3),
+                    "steps": 5, "note": "exact-fp32 MFMA everywhere: the path that holds mel L-inf < 1e-4 vs the oracle"}, paths, mel32
+
+        if args.dtype == "bf16":
+            state = {}
+
+            def run_f32():
+                res, state["p32"], state["mel32"] = f32_line()
+                return res
+            extra("f32_parity_path", run_f32)
+
+            def run_chain():
+                r = alignment_chain_line()
+                if r is None:
+                    return None
+                res, pc = r
+                if "p32" in state:
+                    same = (pc == state["p32"]).flatten(1).all(1)
+                    res["mas_paths_identical_to_fp32_path"] = f"{int(same.sum())}/{B}"
+                return res
+            extra("fp32_alignment_chain", run_chain)
+
+            def accuracy():
+                """the headline path's outputs against the fp32 path of the same build on the same batch"""
+                if "p32" not in state:
+                    return None
+                g = GraphedForward(model, *fwd_args(d))
+                o = g.replay()
+                torch.cuda.synchronize()
+                same = (o.aligner_output.attn_hard == state["p32"]).flatten(1).all(1)
+                err = (o.mel - state["mel32"]).abs()
+                rel = (err.pow(2).mean().sqrt() / state["mel32"].pow(2).mean().sqrt()).item()
+                return {"mel_linf_vs_fp32": round(err.max().item(), 6), "mel_rel_rms_vs_fp32": round(rel, 6),
+                        "mas_paths_identical_to_fp32_path": f"{int(same.sum())}/{B}",
+                        "dec_lengths_equal": bool(torch.equal(o.adaptor_output.dec_lengths, d["mel_len"]))}
+            extra("accuracy_vs_fp32_path", accuracy)
+
+        def config2_line():
+            """BASELINE config 2: B=32 fixed-length, TextEncoder + MelDecoder + to_mel on given activations, fp32."""
+            b2 = 32
+            tok = synth._normal("bench/c2/tok", (b2, L, dims.text_dim)).to(dev)
+            dec_in = synth._normal("bench/c2/dec", (b2, M, dims.text_dim)).to(dev)
+            model.set_compute_dtype(torch.float32)
+            try:
+                def run():
+                    enc = model.encoder(tok).out
+                    dec = model.decoder(dec_in).out
+                    return enc, model._to_mel(dec, None)
+                g = GraphedCall(run)
+                sec = timed_graph(g, 5)
+            finally:
+                model.set_compute_dtype(cdt, alignment_dtype=align_dt)
+            v = b2 * M / sec
+            return {"value": round(v, 1), "unit": "mel-frames/s", "ms_per_step": round(sec * 1e3, 3), "steps": 5,
+                    "dtype": "f32", "model_TFLOPs": round(v * FLOP_PER_FRAME_C2 / 1e12, 2),
+                    "frac_of_fp32_mfma_peak": round(v * FLOP_PER_FRAME_C2 / 1e12 / PEAK["mfma_f32_TFs"], 4),
+                    "workload": "BASELINE config 2: B=32 x L=100 / M=512, ALiBi-MHA + FFN kernels of TextEncoder + MelDecoder "
+                                "+ to_mel, fp32"}
+        extra("config2_fp32", config2_line)
+
+        if not args.no_cpu_baseline:
+            extra("cpu_baseline", lambda: cpu_baseline(args, sd))
+            if isinstance(line.get("cpu_baseline"), dict) and "value" in line["cpu_baseline"]:
+                line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
+def event_floor(torch) -> float:
+    """Median interval of an empty HIP-event pair on the launch stream, in us (reported beside per-launch timings)."""
     torch.cuda.synchronize()
     ts = []
     for _ in range(50):
@@ -157,160 +577,12 @@ def event_floor() -> float:
     return v[len(v) // 2]
 
 
-def main():
+def main() -> int:
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    # ISPK_BENCH_FORCE_DIST=1: take the distributed path (RCCL init, all-gather, barriers) even with one rank — lets the
-    # multi-GPU code be rehearsed on a one-GPU box
-    use_dist = world > 1 or os.environ.get("ISPK_BENCH_FORCE_DIST") == "1"
-    if use_dist:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
-
-    sd = synth.make_state_dict()
-    model = AcousticModel.init(AcousticDims().model_config()).eval()
-    model.load_state_dict(sd, strict=True)
-    model = model.to(dev)
-    model.set_compute_dtype(torch.float32 if args.dtype == "f32" else torch.bfloat16)
-
-    B, L, M = args.batch, args.text_len, args.mel_len
-    inp = synth.make_inputs(B, L, M, seed=synth.SEED + rank)           # each rank owns different utterances
-    d = {k: v.to(dev) for k, v in inp.items()}
-
-    def eager_step():
-        return model(d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
-                     flow_noise=d["flow_x0"], flow_time=d["flow_t"])
-
-    graphed = None
-    lanes = None
-    if not args.no_graph:   # the whole forward as one HIP graph: ~300 launches per step would otherwise be host-bound
-        # `--in-flight` graph instances (own static buffers, own stream): step k replays instance k % n, so consecutive
-        # batches overlap on the GPU - every step still runs the complete forward on its own batch of B utterances
-        lanes = GraphedForwardLanes(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
-                                    d["flow_x0"], d["flow_t"], lanes=args.in_flight)
-        graphed = lanes.lanes[0][0]
-
-    # the one exchange of the path: every rank's mel outputs gathered on rank 0 (ISPK_BENCH_ALLGATHER=1: on every rank)
-    gather_root = None if os.environ.get("ISPK_BENCH_ALLGATHER") == "1" else 0
-    gather = MelGatherPipeline(B, AcousticDims().mel_dim, M, dev, root=gather_root) if use_dist else None
-
-    def step():
-        if lanes is not None:
-            g, stream = lanes.next_lane()
-            stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(stream):
-                out = g.replay()
-                if use_dist:   # the one exchange of the path: mel outputs over xGMI (RCCL gather), overlapped too
-                    gather.submit(out.mel, out.adaptor_output.dec_lengths)
-            return out
-        out = eager_step()
-        if use_dist:
-            gather.submit(out.mel, out.adaptor_output.dec_lengths)
-        return out
-
-    def fence():
-        if use_dist:
-            gather.wait()          # every submitted gather has completed
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    prof = None
-    if not args.no_kernel_events and rank == 0 and graphed is None:
-        prof = runtime.LaunchProfiler()          # eager mode: events around every launch of the timed region
-        runtime.set_profiler(prof)
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    runtime.set_profiler(None)
-    assert torch.isfinite(out.mel).all()
-    prof_steps = args.steps
-    if not args.no_kernel_events and rank == 0 and graphed is not None:
-        # graph replays cannot carry timing events: time the SAME kernels, launched eagerly, right after the timed region
-        prof = runtime.LaunchProfiler()
-        runtime.set_profiler(prof)
-        prof_steps = min(args.steps, 5)
-        for _ in range(prof_steps):
-            eager_step()
-        torch.cuda.synchronize()
-        runtime.set_profiler(None)
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        frames = world * B * M * args.steps
-        value = frames / elapsed
-        name, cus = runtime.device_info()
-        line = {
-            "metric": "mel-frames/s (whole node), batch=64 x 512-frame utterances per GPU, full forward incl. MAS",
-            "value": round(value, 1), "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "BASELINE config 3: AcousticModel.forward (TextEncoder + Aligner/MAS + TemporalAdaptor "
-                                   "1 flow eval + MelDecoder + to_mel), fixed-length synthetic random-phoneme batch, "
-                                   "random-init weights of the recipe architecture (23.2 M params)",
-                       "batch_per_gpu": B, "global_batch": world * B, "text_len": L, "mel_len": M,
-                       "parallelism": f"dp{world} (utterances sharded, RCCL {'all-gather' if gather_root is None else 'gather to rank 0'} of mel overlapped with the next step)" if world > 1 else "single GPU",
-                       "device": name, "compute_units": cus,
-                       "launch": "eager" if graphed is None else "HIP graph replay",
-                       "batches_in_flight": len(lanes) if lanes is not None else 1,
-                       "lane_overlap_gain": None if lanes is None or lanes.overlap is None else round(lanes.overlap, 3)},
-            "model_TFLOPs": round(value * FLOP_PER_FRAME / 1e12, 2),
-        }
-        if prof is not None:
-            line["roofline"] = roofline(prof.summary(), prof_steps, event_floor())
-            line["roofline"]["timing"] = ("HIP events around every launch of the timed region" if graphed is None else
-                                          f"HIP events around every launch of {prof_steps} eager passes of the same step "
-                                          "(the timed region replays them as one HIP graph)")
-        if world == 1 and lanes is not None and len(lanes) > 1:
-            # for transparency: the same step with ONE batch in flight (lane 0 replayed back to back) - the latency-oriented
-            # figure; `value` above is the throughput with len(lanes) batches in flight
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(10):
-                graphed.replay()
-            torch.cuda.synchronize()
-            ms1 = (time.perf_counter() - ts) / 10 * 1e3
-            line["one_batch_in_flight"] = {"value": round(B * M / ms1 * 1e3, 1), "unit": "mel-frames/s",
-                                           "ms_per_step": round(ms1, 3), "steps": 10}
-        if world == 1 and not args.no_f32_line and args.dtype == "bf16":
-            # the same step on the fp32 parity path (exact-fp32 MFMA; the path that holds mel L-inf < 1e-4), 5 replays
-            model.set_compute_dtype(torch.float32)
-            g32 = GraphedForward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
-                                 d["flow_x0"], d["flow_t"])
-            g32.replay()
-            torch.cuda.synchronize()
-            t32 = time.perf_counter()
-            for _ in range(5):
-                g32.replay()
-            torch.cuda.synchronize()
-            ms32 = (time.perf_counter() - t32) / 5 * 1e3
-            line["f32_parity_path"] = {"value": round(B * M / ms32 * 1e3, 1), "unit": "mel-frames/s",
-                                       "ms_per_step": round(ms32, 3), "steps": 5}
-            model.set_compute_dtype(torch.bfloat16)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args, sd)
-            line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
-        print(json.dumps(line), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.worker:
+        return launch_workers(args)        # no GPU API has been touched in this process
+    return worker(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

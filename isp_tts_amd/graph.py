@@ -16,7 +16,34 @@ from torch import Tensor
 from . import staging
 
 
-class GraphedForward:
+class GraphedCall:
+    """`fn()` (any sequence of launches on the current stream over tensors that stay alive and in place) captured once
+    into a HIP graph; `replay()` runs it again and returns the static outputs."""
+
+    def __init__(self, fn, warmup: int = 2):
+        self._fn = fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # warm-up on a side stream: stages weights, reserves LDS, fills the allocator
+            for _ in range(warmup):
+                self.out = fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = fn()
+        # the graph holds raw pointers to the modules' staged weight images: remember their generation
+        self._staged_at_capture = staging.replacements()
+
+    def replay(self):
+        if staging.replacements() != self._staged_at_capture:
+            raise RuntimeError("a staged weight image was rebuilt after this graph was captured (parameters changed: "
+                               "load() / an optimizer step); the graph points at freed memory - capture a new one")
+        self.graph.replay()
+        return self.out
+
+
+class GraphedForward(GraphedCall):
     def __init__(self, model, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor,
                  energy: Tensor, flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None,
                  warmup: int = 2):
@@ -28,30 +55,12 @@ class GraphedForward:
         self.static["flow_noise"] = (flow_noise.clone() if flow_noise is not None
                                      else torch.randn(b, l, 3, device=dev))
         self.static["flow_time"] = flow_time.clone() if flow_time is not None else torch.rand(b, device=dev)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):      # warm-up on a side stream: stages weights, reserves LDS, fills the allocator
-            for _ in range(warmup):
-                self.out = self._run()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = self._run()
-        # the graph holds raw pointers to the modules' staged weight images: remember their generation
-        self._staged_at_capture = staging.replacements()
+        super().__init__(self._run, warmup)
 
     def _run(self):
         s = self.static
         return self.model(s["text"], s["text_len"], s["mel"], s["mel_len"], s["pitch"], s["energy"],
                           flow_noise=s["flow_noise"], flow_time=s["flow_time"])
-
-    def replay(self):
-        if staging.replacements() != self._staged_at_capture:
-            raise RuntimeError("a staged weight image was rebuilt after this graph was captured (parameters changed: "
-                               "load() / an optimizer step); the graph points at freed memory - capture a new one")
-        self.graph.replay()
-        return self.out
 
     def __call__(self, **inputs: Tensor):
         for k, v in inputs.items():

@@ -157,6 +157,25 @@ def _rank_main(rank, world, port, q):
             ok = ok and all(torch.equal(res[1][r], mel_len[:2] + 2) for r in range(world))
         else:
             ok = ok and res is None
+        # BASELINE config 4 as bench.py runs it: cost-balanced shards cut into micro-batches that are padded to their OWN
+        # maximum, outputs written into one fixed [slot, 80, M_max] block per rank, ONE gather of the blocks, unshard
+        tl4, ml4 = synth.make_lengths(21, 40, 96, variable=True, seed=5)
+        shards4, plans4 = idist.plan_micro_batches(ml4.tolist(), tl4.tolist(), world, frame_budget=4 * 96)
+        slot = max(len(s) for s in shards4)
+        block, blens = torch.zeros(slot, 80, 96), torch.full((slot,), -1, dtype=torch.int64)
+        off = 0
+        for idx, m_pad, l_pad in plans4[rank]:
+            ii = torch.tensor(idx)
+            assert m_pad >= int(ml4[ii].max()) and m_pad % 8 == 0 and l_pad >= int(tl4[ii].max())
+            block[off:off + len(idx), :, :m_pad] = _fake_forward(tl4[ii], ml4[ii], m_pad)
+            blens[off:off + len(idx)] = ml4[ii]
+            off += len(idx)
+        pipe = idist.MelGatherPipeline(slot, 80, 96, "cpu", root=0)
+        pipe.submit(block, blens)
+        res = pipe.wait()
+        if rank == 0:
+            full4, dec4 = idist.unshard(res[0], res[1], shards4)
+            ok = ok and torch.equal(full4, _fake_forward(tl4, ml4, 96)) and torch.equal(dec4, ml4)
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
@@ -175,6 +194,45 @@ def test_shard_gather_unshard_world_size_2_gloo():
         assert p.exitcode == 0
     res = sorted(q.get(timeout=10) for _ in range(2))
     assert res == [(0, True), (1, True)]
+
+
+def test_plan_micro_batches_covers_every_utterance_once_and_balances_padded_cost():
+    text_len, mel_len = synth.make_lengths(256, 200, 1024, variable=True)
+    for world in (1, 2, 4, 8):
+        shards, plans = idist.plan_micro_batches(mel_len.tolist(), text_len.tolist(), world, frame_budget=32768)
+        assert sorted(i for p in plans for idx, _, _ in p for i in idx) == list(range(256))
+        for r, p in enumerate(plans):
+            assert [i for idx, _, _ in p for i in idx] == shards[r]
+            lens = [int(mel_len[i]) for i in shards[r]]
+            assert lens == sorted(lens, reverse=True)
+            for idx, m_pad, l_pad in p:
+                assert len(idx) * m_pad <= 32768 and m_pad <= 1024 and l_pad <= 200
+                assert m_pad - max(int(mel_len[i]) for i in idx) < 8 and l_pad - max(int(text_len[i]) for i in idx) < 4
+        # contiguous length ranges: a rank pads to a maximum close to its own members ...
+        padded = sum(len(idx) * m for p in plans for idx, m, _ in p)
+        assert padded <= 1.2 * int(mel_len.sum())
+        # ... and the ranks' PADDED costs (what they really run) are balanced
+        cost = [sum(len(idx) * m * (1 + m / 512) for idx, m, _ in p) for p in plans]
+        assert max(cost) <= 1.05 * sum(cost) / world
+    # fewer utterances than ranks: one each, the rest idle
+    shards = idist.shard_by_length_range([96, 17, 14, 78, 74], 8)
+    assert [len(s) for s in shards] == [1, 1, 1, 1, 1, 0, 0, 0] and sorted(i for s in shards for i in s) == [0, 1, 2, 3, 4]
+
+
+def test_bench_starts_fresh_worker_processes_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent (which imports no torch and touches no
+    GPU API) starts two workers and relays their exit status.  On this GPU-less box each worker stops at its own
+    "needs a GPU" assertion - two of them prove both ranks were started with a rendezvous in their environment."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HIP_VISIBLE_DEVICES"] = ""          # also holds on a GPU box: the workers must see no device
+    env["CUDA_VISIBLE_DEVICES"] = ""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert r.stderr.count("AssertionError: bench.py needs a GPU") == 2 and r.stdout.strip() == ""
 
 
 def test_from_pretrained_reads_the_reference_checkpoint_layout(tmp_path):

@@ -55,8 +55,8 @@ def parse(argv=None):
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
                     help="bf16 = BASELINE config 3 (throughput path); f32 = the 1e-4 parity path")
     ap.add_argument("--alignment", choices=["auto", "f32"], default="auto",
-                    help="precision of the chain upstream of MAS: auto = fp32 aligner front-end, encoder in --dtype; "
-                         "f32 = text encoder in fp32 too (MAS paths identical to the fp32 path)")
+                    help="precision of the chain upstream of MAS (text encoder + aligner front-end): auto = --dtype; "
+                         "f32 = fp32 whatever --dtype is (MAS paths identical to the fp32 path)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="batches in flight per GPU for the headline value (graph instances replayed round-robin on their "
                          "own streams); the 2-in-flight figure is always reported as an extra")
@@ -317,7 +317,7 @@ def worker(args) -> int:
                        "batch_per_gpu": B, "global_batch": world * B, "text_len": L, "mel_len": M,
                        "alignment_chain": "fp32 (text encoder + aligner front-end: MAS paths identical to the fp32 path)"
                        if args.alignment == "f32" or args.dtype == "f32" else
-                       "aligner front-end fp32, text encoder in the compute dtype",
+                       "text encoder + aligner front-end in the compute dtype (see accuracy_vs_fp32_path / fp32_alignment_chain)",
                        "parallelism": (f"dp{world} (utterances sharded, one RCCL "
                                        f"{'all-gather' if gather_root is None else 'gather to rank 0'} of mel per step, "
                                        "overlapped with the next step)") if world > 1 else "single GPU",

@@ -46,7 +46,8 @@ int32_t ispk_device_info(char* name, int32_t cap);
  *   text_len  [B] int64 (reference `in_lens`),  1 <= text_len[b] <= L_max <= 512
  *   mel_len   [B] int64 (reference `out_lens`), 1 <= mel_len[b]  <= M_max <= 4096
  *   attn_hard [B][M_max][L_max] int16, contiguous: one-hot rows, zero outside (mel_len, text_len)  (fully written)
- *   dur       [B][L_max] int64 or NULL: column sums of attn_hard (alignment.py:275 `attn_hard.sum(dim=1)`)
+ *   dur       [B][L_max] int64 or NULL: column sums of attn_hard (alignment.py:275 `attn_hard.sum(dim=1)`) with the
+ *             reference's fix-up applied (alignment.py:278-282: mel_len[b] - sum goes to column 0; zero for valid lengths)
  *   path      [B][M_max] int16 or NULL: chosen text index per mel row, -1 for rows >= mel_len
  * One wavefront runs the DP of one utterance; ties go to the diagonal predecessor exactly as mas.py:17.
  */
@@ -292,11 +293,42 @@ int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const 
  * ispk_flow_finish_f32  pf = pred_raw * mask ;  pred = (x0 + pf) * mask (:145) ;  duration = max(exp(pred[..., 0]) - 1, 0)
  *                       (the adaptor's duration estimate, :221 of this repo's mirror / temporal_adaptor.py:276) ;
  *                       loss_ratio[b] = sum over valid (l, c) of (pf - flow)^2 / max(C * valid_l, 1e-5): masked_mean of the
- *                       MSE (:146, utils/functions.py:44-58) before its final mean over the batch.  mask uint8 [B][L]. */
+ *                       MSE (:146, utils/functions.py:44-58) before its final mean over the batch; loss_mean[0] (or NULL)
+ *                       = that mean, the flow loss itself.  mask uint8 [B][L]. */
 int32_t ispk_flow_mix_f32(const float* x0, const float* x1, const float* t, float sigma, float* x_t, float* flow, int32_t B,
                           int32_t L, int32_t C, ispk_stream_t stream);
 int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow, const float* x0, const uint8_t* mask, float* pred,
-                             float* duration, float* loss_ratio, int32_t B, int32_t L, int32_t C, ispk_stream_t stream);
+                             float* duration, float* loss_ratio, float* loss_mean, int32_t B, int32_t L, int32_t C,
+                             ispk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The steps between the transformer stacks, one launch each instead of ATen glue / a library bmm.
+ *
+ * ispk_embed_tokens_f32     models/acoustic/model.py:131-134: emb[b][l][:] = table[text[b][l]][:] (nn.Embedding lookup, row
+ *                           0 = padding row) and mask[b][l] = l < text_len[b] (utils/functions.py:61-65; mask / text_len may
+ *                           be NULL).  Ids outside [0, vocab) read row 0 (the host-side F.embedding would raise).
+ * ispk_time_embedding_f32   modules/transformer/embeddings.py:131-157 with `with_steps` (temporal_adaptor.py:87-89):
+ *                           f = [t, sin(t * freq_scale * inv_freq), cos(..)] (1 + 2*half_dim values),
+ *                           out[n][:] = W1 silu(W0 f + b0) + b1; w0 [emb_dim][1 + 2*half_dim], w1 [emb_dim][emb_dim];
+ *                           freq_scale is the module's 1-element buffer (device pointer: no host read).
+ * ispk_length_regulate_f32  models/acoustic/modules/temporal_adaptor.py:411-436 (LengthRegulator, soft branch):
+ *                           out[b][y][:] = sum_t A[b][y][t] * x[b][t][:], dec_len[b] = (sum_t dur[b][t] + 0.5).long()
+ *                           clamped to max_len when max_len >= 0, dec_mask[b][y] = y < dec_len[b] (or NULL).
+ *                           A = `alignment` fp32 [B][M][L] (forward: the aligner's attn_soft) or, with alignment NULL, the
+ *                           soft path of :468-478 generated on the fly from the fp32 durations (infer, :388-397):
+ *                           P[t][y] = clamp(cum[t] - y, 0, 1) - clamp(cum[t-1] - y, 0, 1), cum = cumsum(dur) in index order,
+ *                           masked by t < enc_len[b] (NULL: L) and y < dec_len[b].  Exactly one of dur_f32 / dur_i64
+ *                           [B][L] is given (int64: the MAS durations).  x fp32 [B][L][D] rows at stride ldx, D 256 / 384;
+ *                           exact fp32 products (v_mfma_f32_32x32x2_f32). */
+int32_t ispk_embed_tokens_f32(const int64_t* text, const float* table, int64_t ld_table, int32_t vocab,
+                              const int64_t* text_len, float* emb, uint8_t* mask, int32_t B, int32_t L, int32_t D,
+                              ispk_stream_t stream);
+int32_t ispk_time_embedding_f32(const float* t, int32_t n, const float* inv_freq, const float* freq_scale, int32_t half_dim,
+                                const float* w0, const float* b0, const float* w1, const float* b1, int32_t emb_dim,
+                                float* out, ispk_stream_t stream);
+int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, const int64_t* dur_i64, const int64_t* enc_len,
+                                 const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
+                                 int32_t M, int32_t L, int32_t D, int32_t max_len, ispk_stream_t stream);
 
 /* fp32 -> bf16 conversion (round-to-nearest-even) of a [rows][cols] matrix; used to stage weights/activations. */
 int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int32_t rows, int32_t cols,

@@ -142,12 +142,11 @@ class Aligner(nn.Module, Constructor):
 
     def forward(self, mel: Tensor, enc_text: Tensor, mel_len: Tensor, text_len: Tensor,
                 q_proj: Optional[Tensor] = None) -> AlignerOutput:
-        """alignment.py:259-289.  The duration fix-up of :278-282 (sum of durations != mel_len, possible only when
-        text_len > mel_len) is applied unconditionally on the device: adding `mel_len - sum` (zero otherwise) to column
-        0 gives the same result without the host round-trip of the reference's `torch.all(...)` check."""
+        """alignment.py:259-289.  The duration fix-up of :278-282 (an item whose durations do not sum to mel_len gets the
+        difference added to column 0) happens inside the MAS kernel, on the device and unconditionally - the reference
+        tests `torch.all(...)` on the host first; adding a zero difference gives the same result without the round trip."""
         attn_soft, attn_logits = self.attention(mel, enc_text, mel_len, text_len, q_proj=q_proj)
         attn_hard, dur = self.binarize_attention_parallel(attn_logits, text_len, mel_len, return_duration=True)
-        dur[:, 0] += mel_len - dur.sum(dim=1)
         return AlignerOutput(attn_soft=attn_soft, attn_logits=attn_logits, attn_hard=attn_hard, attn_hard_duration=dur)
 
     @torch.no_grad()

@@ -64,19 +64,22 @@ class AcousticModel(nn.Module, Constructor):
         `alignment_dtype` is the precision of everything UPSTREAM OF MAS: text encoder -> aligner key convolutions, mel ->
         aligner query convolutions, scores / log-softmax / prior.  MAS turns those logits into DISCRETE outputs (the hard
         alignment, the durations), and a near-tie between two paths flips on any change of the logits' low bits, so only
-        the same fp32 arithmetic reproduces the fp32 path's alignments:
-          * torch.float32: the alignment chain runs exactly the fp32 path's kernels - MAS paths and durations are
-            bit-identical to the fp32 path's on every utterance, whatever `dtype` is;
-          * None (default) = fp32 for the aligner front-end itself (the reference's `ConvAttention`, alignment.py:159-208,
-            always fp32 here) and `dtype` for the text encoder: with a bf16 encoder the logits carry the encoder's
-            bf16 rounding (about 1e-2) and some alignments move by a frame (counted by the tests and by bench.py)."""
-        enc_dtype = alignment_dtype if alignment_dtype is not None else dtype
-        assert enc_dtype in (torch.float32, torch.bfloat16)
-        self.encoder.set_compute_dtype(enc_dtype)
+        the same fp32 arithmetic reproduces the fp32 path's alignments.  Measured at B = 64 x 100 x 512 (MI355X, round 2):
+          * None (default: the chain follows `dtype`): all-bf16, 38/64 alignments identical to the fp32 path's;
+          * aligner front-end alone in fp32 (bf16 text encoder): 44/64 - the logits still carry the encoder's bf16
+            rounding - for +0.45 ms per step; not offered as a mode;
+          * torch.float32: text encoder AND aligner front-end run exactly the fp32 path's kernels - logits, MAS paths
+            and durations are bit-identical to the fp32 path's on all 64 utterances (and equal the oracle's on all 64),
+            at 4.9 instead of 2.5 ms per step (the 6,400-row fp32 encoder costs 16 x the bf16 MFMA time).
+        mel does not depend on the hard alignment (the decoder input is built from attn_soft and the dense targets,
+        temporal_adaptor.py:284-300); the durations and the flow-matching duration target do."""
+        chain = alignment_dtype if alignment_dtype is not None else dtype
+        assert chain in (torch.float32, torch.bfloat16)
+        self.encoder.set_compute_dtype(chain)
         self.decoder.set_compute_dtype(dtype)
         self.temporal_adaptor.predictor.transformer.set_compute_dtype(dtype)
         self.temporal_adaptor.embedding.transformer.set_compute_dtype(dtype)
-        self.aligner.attention.compute_dtype = torch.float32
+        self.aligner.attention.compute_dtype = chain
         self.compute_dtype = dtype
         return self
 
@@ -102,8 +105,7 @@ class AcousticModel(nn.Module, Constructor):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 q_proj = self.aligner.attention.project_queries(mel, mel_len)
-        token_emb = self.text_embedding(text)
-        enc_mask = get_mask_from_lengths(text_len, text.shape[1])
+        token_emb, enc_mask = runtime.embed_tokens(text, self.text_embedding.weight, text_len)   # model.py:131-134
         enc_out = self.encoder(token_emb, mask=enc_mask, key_len=text_len).out
         if q_proj is not None:
             main.wait_stream(side)
@@ -116,7 +118,7 @@ class AcousticModel(nn.Module, Constructor):
             pitch_target_dense=pitch, energy_target_dense=energy, noise=flow_noise, time_steps=flow_time,
             enc_len=text_len, predictor_stream=side if q_proj is not None else None)
         dec_len = adaptor_output.dec_lengths
-        dec_mask = get_mask_from_lengths(dec_len, adaptor_output.enc_out.shape[1])
+        dec_mask = adaptor_output.dec_mask              # arange(frames) < dec_len, from the length-regulation kernel
         dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, key_len=dec_len, out_dtype=self.compute_dtype).out
         mel_out = self._to_mel(dec_out, dec_mask)
         if q_proj is not None:
@@ -137,13 +139,8 @@ class AcousticModel(nn.Module, Constructor):
               max_dec_len: Optional[int] = None):
         """model.py:177-238: masks only for batch > 1 (:191-201, :228)."""
         batch_infer = input_sequence.shape[0] > 1
-        token_emb = self.text_embedding(input_sequence)
-        enc_mask = None
-        if batch_infer:
-            if text_lengths is None:
-                text_lengths = torch.full((input_sequence.shape[0],), input_sequence.shape[1], dtype=torch.int64,
-                                          device=input_sequence.device)
-            enc_mask = get_mask_from_lengths(text_lengths, input_sequence.shape[1])
+        token_emb, enc_mask = runtime.embed_tokens(input_sequence, self.text_embedding.weight,
+                                                   text_lengths if batch_infer else None, want_mask=batch_infer)
         enc_out = self.encoder(token_emb, mask=enc_mask).out
         if pitch_normalize:
             if pitch_target is not None:
@@ -153,9 +150,7 @@ class AcousticModel(nn.Module, Constructor):
             enc_out=enc_out, enc_mask=enc_mask, duration_target=duration_target, pitch_target=pitch_target,
             energy_target=energy_target, duration_factor=duration_factor, pitch_factor=pitch_factor,
             pitch_delta=pitch_delta, steps=steps, noise=flow_noise, max_dec_len=max_dec_len)
-        dec_mask = None
-        if batch_infer:
-            dec_mask = get_mask_from_lengths(adaptor_output.dec_lengths, adaptor_output.enc_out.shape[1])
+        dec_mask = adaptor_output.dec_mask if batch_infer else None
         dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, out_dtype=self.compute_dtype).out
         return self._to_mel(dec_out, dec_mask), adaptor_output
 

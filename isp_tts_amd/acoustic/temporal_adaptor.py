@@ -37,13 +37,16 @@ class TransformerTemporalModule(nn.Module, Constructor):
         w = self.linear_layer.weight
         return self._cache.get(dtype, (w,), lambda: w.detach().to(dtype).contiguous())
 
-    def forward(self, x: Tensor, mask: Optional[Tensor] = None, *, key_len: Optional[Tensor] = None) -> Tensor:
-        """`key_len` (= mask.sum(1), when the caller already has the lengths) saves the reduction launch."""
+    def forward(self, x: Tensor, mask: Optional[Tensor] = None, *, key_len: Optional[Tensor] = None,
+                residual: Optional[Tensor] = None) -> Tensor:
+        """`key_len` (= mask.sum(1), when the caller already has the lengths) saves the reduction launch; `residual`
+        (fp32 [B, L, output_dim]) is added AFTER the mask in the output GEMM's epilogue - the caller's
+        `enc_out + embedding(...)` (temporal_adaptor.py:297) without a separate add."""
         m2 = mask[..., 0] if mask is not None else None
         cdt = self.transformer.layers[0].attention.compute_dtype   # bf16 path: the output Linear is an MFMA GEMM too
         out = self.transformer(x, mask=m2, out_dtype=cdt, key_len=key_len if m2 is not None else None).out
-        flags = runtime.EP_MASK_OUT if m2 is not None else 0
-        return runtime.gemm(out, self._weight(cdt), bias=self.linear_layer.bias, mask=m2, flags=flags,
+        flags = runtime.EP_MASK_ACC if m2 is not None else 0       # (acc + bias) * mask, then + residual
+        return runtime.gemm(out, self._weight(cdt), bias=self.linear_layer.bias, mask=m2, flags=flags, resid=residual,
                             out_dtype=torch.float32)
 
     def infer(self, x: Tensor, mask: Optional[Tensor] = None, steps: int = 4) -> Tensor:
@@ -100,8 +103,8 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         raw = runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias)
         # pred_flow = raw * m3 ; loss = masked_mean(mse(pred_flow, flow), m3) ; pred = (x0 + pred_flow) * m3 ;
         # duration estimate = clamp(exp(pred[..., 0]) - 1, 0): one launch + the mean over the batch
-        pred, self._duration_estimate, ratio = runtime.flow_finish(raw, flow, x0, mask)
-        return pred, {"flow_loss": ratio.mean()}
+        pred, self._duration_estimate, _, loss = runtime.flow_finish(raw, flow, x0, mask)
+        return pred, {"flow_loss": loss}
 
     def euler_grid(self, steps: int, step_factor: float, device) -> Tensor:
         """temporal_adaptor.py:150-156 (steps=4, factor .75 -> [0, .3657, .6400, .8457, 1])."""
@@ -142,20 +145,26 @@ class TemporalAdaptorOutput(NamedTuple):
     pitch_target: Optional[Tensor]
     energy_target: Optional[Tensor]
     losses: Optional[dict] = None
+    dec_mask: Optional[Tensor] = None   # arange(frames) < dec_lengths (not in the reference's tuple; saves the caller a launch)
 
 
 class LengthRegulator(nn.Module):
     """temporal_adaptor.py:411-436, soft branch (the recipes' soft_duration): out = alignment @ x,
-    dec_lens = (sum(dur) + .5).long(), both cut to max_len."""
+    dec_lens = (sum(dur) + .5).long(), both cut to max_len.  One kernel (`ispk_length_regulate_f32`: exact-fp32 MFMA
+    products, decoder lengths and the decoder mask from the same launch; the mask of the last call is kept in
+    `self.dec_mask` for the caller that needs it next).  `alignment=None` with fp32 durations: the soft path of
+    `generate_soft_path` is generated inside the kernel (`infer`)."""
 
-    def forward(self, x: Tensor, durations: Tensor, max_len: Optional[int] = None, alignment: Optional[Tensor] = None):
-        if alignment is None:
+    def forward(self, x: Tensor, durations: Tensor, max_len: Optional[int] = None, alignment: Optional[Tensor] = None, *,
+                enc_len: Optional[Tensor] = None, frames: Optional[int] = None):
+        if alignment is None and (frames is None or durations.dtype == torch.int64):
             raise NotImplementedError("hard (repeat) length regulation is unused by the recipes (soft_duration: true)")
-        dec_lens = (durations.sum(dim=1) + 0.5).long()
-        out = torch.bmm(alignment, x)
-        if max_len is not None:
-            out = out[:, :max_len]
-            dec_lens = torch.clamp_max(dec_lens, max_len)
+        rows = alignment.shape[1] if alignment is not None else frames
+        if max_len is not None and alignment is not None:
+            rows = min(rows, max_len)
+            alignment = alignment[:, :rows]
+        out, dec_lens, self.dec_mask = runtime.length_regulate(x.float(), durations, alignment, rows,
+                                                               max_len=-1 if max_len is None else max_len, enc_len=enc_len)
         return out, dec_lens
 
 
@@ -228,13 +237,13 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
         else:
             pred, losses, duration_pred = predict()
         log_duration_pred = pred[..., 0]
-        features = torch.cat([pitch_target, energy_target], dim=-1)
-        enc_out = enc_out + self.embedding(features, mask=m3, key_len=enc_len)
+        features = targets[..., 1:3]                 # = cat([pitch_target, energy_target], -1): a view, no copy
+        enc_out = self.embedding(features, mask=m3, key_len=enc_len, residual=enc_out)   # enc_out + embedding(...)
         enc_out, dec_lens = self.length_regulator(enc_out, duration_target, max_len=max_dec_len, alignment=alignment)
         return TemporalAdaptorOutput(enc_out=enc_out, log_duration=log_duration_pred, duration=duration_pred,
                                      dec_lengths=dec_lens, pitch=pred[..., 1], energy=pred[..., 2],
                                      pitch_target=pitch_target.squeeze(-1), energy_target=energy_target.squeeze(-1),
-                                     losses=losses)
+                                     losses=losses, dec_mask=self.length_regulator.dec_mask)
 
     def infer(self, enc_out: Tensor, enc_mask: Optional[Tensor] = None, duration_target: Optional[Tensor] = None,
               duration_factor: float = 1.0, pitch_target: Optional[Tensor] = None, pitch_factor: float = 1.0,
@@ -255,14 +264,13 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
             duration_pred = torch.where(tgt < 0, duration_pred.to(tgt.dtype), tgt)
         pitch = (pred[..., 1:2] if pitch_target is None else pitch_target.unsqueeze(-1)) * pitch_factor + pitch_delta
         energy = (pred[..., 2:3] if energy_target is None else energy_target.unsqueeze(-1)) * energy_factor + energy_delta
-        enc_out = enc_out + self.embedding(torch.cat([pitch, energy], dim=-1))
-        b, l = enc_out.shape[:2]
-        enc_lens = torch.full((b,), l, device=enc_out.device) if enc_mask is None else enc_mask.sum(dim=1)
-        dec_lens = (duration_pred.sum(dim=1) + 0.5).long()
-        max_h = int(dec_lens.max().item()) if max_dec_len is None else max_dec_len
-        mask = get_mask_3d(enc_lens, dec_lens, l, max_h).float()
-        alignment = generate_soft_path(duration_pred, mask).transpose(1, 2)
-        enc_out, dec_lens = self.length_regulator(enc_out, duration_pred, alignment=alignment)
+        enc_out = self.embedding(torch.cat([pitch, energy], dim=-1), residual=enc_out)      # no mask, even batched (:384)
+        enc_lens = None if enc_mask is None else enc_mask.sum(dim=1)
+        if max_dec_len is None:   # the output shape is data: like the reference, read the longest decoder length back
+            max_dec_len = int((duration_pred.sum(dim=1) + 0.5).long().max().item())
+        # :388-397: soft path (generate_soft_path) and length regulation in one kernel
+        enc_out, dec_lens = self.length_regulator(enc_out, duration_pred, alignment=None, enc_len=enc_lens,
+                                                  frames=max_dec_len)
         return TemporalAdaptorOutput(enc_out=enc_out, log_duration=None, duration=duration_pred, dec_lengths=dec_lens,
                                      pitch=pitch.squeeze(-1), energy=energy.squeeze(-1), pitch_target=pitch_target,
-                                     energy_target=energy_target)
+                                     energy_target=energy_target, dec_mask=self.length_regulator.dec_mask)

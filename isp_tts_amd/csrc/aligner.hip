@@ -407,39 +407,45 @@ __global__ __launch_bounds__(256) void flow_mix_kernel(const float* __restrict__
     flow[i] = b - sa;
 }
 
-// flow_finish (one workgroup per utterance):  pf = raw * m ;  pred = (x0 + pf) * m ;  dur = max(exp(pred[..., 0]) - 1, 0) ;
-//            ratio[b] = sum_{valid l, c} (pf - flow)^2 / max(C * #valid, 1e-5)     (utils.masked_mean before its .mean())
-__global__ __launch_bounds__(256) void flow_finish_kernel(const float* __restrict__ raw, const float* __restrict__ flow,
-                                                          const float* __restrict__ x0, const uint8_t* __restrict__ mask,
-                                                          float* __restrict__ pred, float* __restrict__ dur,
-                                                          float* __restrict__ ratio, int L, int C) {
-    __shared__ float red[2][4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float num = 0.f, den = 0.f;
-    for (int e = tid; e < L * C; e += 256) {
-        const int l = e / C, c = e - l * C;
-        const int64_t i = (int64_t)b * L * C + e;
-        const bool m = mask[(int64_t)b * L + l] != 0;
-        const float pf = m ? raw[i] : 0.f;
-        const float pr = m ? x0[i] + pf : 0.f;
-        pred[i] = pr;
-        if (c == 0) dur[(int64_t)b * L + l] = fmaxf(expf(pr) - 1.0f, 0.f);
-        if (m) {
-            const float d = pf - flow[i];
-            num += d * d;
-            den += 1.0f;
+// flow_finish (ONE workgroup for the whole batch: B * L * C is a few thousand values, and the loss needs the mean over the
+//            batch):  pf = raw * m ;  pred = (x0 + pf) * m ;  dur = max(exp(pred[..., 0]) - 1, 0) ;
+//            ratio[b] = sum_{valid l, c} (pf - flow)^2 / max(C * #valid, 1e-5)   (utils.masked_mean before its .mean()) ;
+//            loss = mean_b ratio[b]                                               (its .mean(), summed in index order)
+// wave w of the 16 handles utterances w, w + 16, ...
+__global__ __launch_bounds__(1024) void flow_finish_kernel(const float* __restrict__ raw, const float* __restrict__ flow,
+                                                           const float* __restrict__ x0, const uint8_t* __restrict__ mask,
+                                                           float* __restrict__ pred, float* __restrict__ dur,
+                                                           float* __restrict__ ratio, float* __restrict__ loss, int B, int L,
+                                                           int C) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int b = wave; b < B; b += 16) {
+        float num = 0.f, den = 0.f;
+        for (int e = lane; e < L * C; e += 64) {
+            const int l = e / C, c = e - l * C;
+            const int64_t i = (int64_t)b * L * C + e;
+            const bool m = mask[(int64_t)b * L + l] != 0;
+            const float pf = m ? raw[i] : 0.f;
+            const float pr = m ? x0[i] + pf : 0.f;
+            pred[i] = pr;
+            if (c == 0) dur[(int64_t)b * L + l] = fmaxf(expf(pr) - 1.0f, 0.f);
+            if (m) {
+                const float d = pf - flow[i];
+                num += d * d;
+                den += 1.0f;
+            }
         }
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        num += __shfl_xor(num, off, 64);
-        den += __shfl_xor(den, off, 64);
+        for (int off = 32; off > 0; off >>= 1) {
+            num += __shfl_xor(num, off, 64);
+            den += __shfl_xor(den, off, 64);
+        }
+        if (lane == 0) ratio[b] = num / fmaxf(den, 1e-5f);
     }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = num; red[1][tid >> 6] = den; }
-    __syncthreads();
-    if (tid == 0) {
-        const float n = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), d = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-        ratio[b] = n / fmaxf(d, 1e-5f);
+    __syncthreads();          // (global writes of this workgroup are visible to it after the barrier)
+    if (loss && tid == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += ratio[b];
+        loss[0] = s / (float)B;
     }
 }
 
@@ -550,12 +556,12 @@ extern "C" int32_t ispk_flow_mix_f32(const float* x0, const float* x1, const flo
 }
 
 extern "C" int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow, const float* x0, const uint8_t* mask,
-                                        float* pred, float* duration, float* loss_ratio, int32_t B, int32_t L, int32_t C,
-                                        ispk_stream_t stream) {
+                                        float* pred, float* duration, float* loss_ratio, float* loss_mean, int32_t B,
+                                        int32_t L, int32_t C, ispk_stream_t stream) {
     ISPK_REQUIRE(pred_raw && flow && x0 && mask && pred && duration && loss_ratio, ISPK_E_NULL, "flow_finish: null pointer");
     ISPK_REQUIRE(B >= 0 && L >= 1 && C >= 1 && B <= 65535, ISPK_E_SHAPE, "flow_finish: bad shape B=%d L=%d C=%d", B, L, C);
     if (B == 0) return 0;
-    hipLaunchKernelGGL(flow_finish_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred_raw, flow, x0,
-                       mask, pred, duration, loss_ratio, L, C);
+    hipLaunchKernelGGL(flow_finish_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pred_raw, flow, x0,
+                       mask, pred, duration, loss_ratio, loss_mean, B, L, C);
     return ispk_launch_status();
 }

@@ -225,7 +225,11 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
     __syncthreads();
     if (dur) {
         int64_t* d = dur + (int64_t)b * L_max;
-        for (int jx = tid; jx < L_max; jx += 256) d[jx] = cnt[jx];
+        // column sums of the one-hot rows; they add up to n.  The reference's fix-up (alignment.py:278-282: when an item's
+        // durations do not sum to mel_len, the difference goes to column 0) is applied here too - it is non-zero only for a
+        // mel_len outside [1, M_max], which the kernel clamped above
+        const int64_t fix = mel_len[b] - (int64_t)n;
+        for (int jx = tid; jx < L_max; jx += 256) d[jx] = cnt[jx] + (jx == 0 ? fix : 0);
     }
 }
 

@@ -86,8 +86,7 @@ class SinusoidalEmbedding(nn.Module):
 
 
 class TimePositionalEmbedding(nn.Module):
-    """embeddings.py:131-157: sinusoid -> Linear -> SiLU -> Linear.  The sinusoid of B (or 1) scalars is host-side
-    plumbing in torch; both Linears run through ispk_linear_small_f32 (SiLU fused into the first)."""
+    """embeddings.py:131-157: sinusoid -> Linear -> SiLU -> Linear, as one kernel."""
 
     def __init__(self, freq_dim: int = 256, emb_dim: int = 512, theta: float = 1000., freq_scale: float = 1000.,
                  with_steps: bool = False):
@@ -97,6 +96,9 @@ class TimePositionalEmbedding(nn.Module):
                                  nn.Linear(emb_dim, emb_dim, bias=True))
 
     def forward(self, x: Tensor) -> Tensor:
-        f = self.freq_emb(x).float().contiguous()
-        h = runtime.linear_small(f, self.mlp[0].weight, self.mlp[0].bias, act=runtime.EP_SILU)
-        return runtime.linear_small(h, self.mlp[2].weight, self.mlp[2].bias)
+        """x [...] time values -> [..., emb_dim]; one kernel (sinusoid, Linear + SiLU, Linear: `ispk_time_embedding_f32`)."""
+        fe = self.freq_emb
+        if not fe.with_positions:
+            raise NotImplementedError("built for the flow predictor's embedding (with_steps=True, temporal_adaptor.py:87-89)")
+        return runtime.time_embedding(x, fe.inv_freq, fe.freq_scale, self.mlp[0].weight, self.mlp[0].bias,
+                                      self.mlp[2].weight, self.mlp[2].bias)

@@ -267,7 +267,7 @@ class Transformer(nn.Module, Constructor):
         elif isinstance(self.project_emb, nn.Identity):
             out = x.float()
         else:
-            out = runtime.linear(x.float().contiguous(), self.project_emb.weight, self.project_emb.bias)
+            out = runtime.linear(x.float(), self.project_emb.weight, self.project_emb.bias)   # (strided rows are fine)
         if mask is not None and key_len is None:
             key_len = mask.sum(dim=1)
         intermediates = []

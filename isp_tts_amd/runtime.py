@@ -49,7 +49,10 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_bf16_tiles": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_cast_f32_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ispk_flow_mix_f32": [_P, _P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
-    "ispk_flow_finish_f32": [_P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_flow_finish_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_embed_tokens_f32": [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_time_embedding_f32": [_P, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P],
+    "ispk_length_regulate_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F32, _P],
     "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
@@ -630,7 +633,7 @@ def flow_mix(x0: Tensor, x1: Tensor, t: Tensor, sigma: float):
 
 
 def flow_finish(pred_raw: Tensor, flow: Tensor, x0: Tensor, mask: Tensor):
-    """ispk_flow_finish_f32 -> (pred [B,L,C], duration [B,L], loss_ratio [B])."""
+    """ispk_flow_finish_f32 -> (pred [B,L,C], duration [B,L], loss_ratio [B], loss = mean(loss_ratio) 0-d)."""
     _dev(pred_raw, flow, x0, mask)
     B, L, C = pred_raw.shape
     assert mask.dtype == torch.bool and mask.shape == (B, L)
@@ -638,9 +641,71 @@ def flow_finish(pred_raw: Tensor, flow: Tensor, x0: Tensor, mask: Tensor):
     pred = torch.empty_like(pr)
     dur = torch.empty((B, L), dtype=torch.float32, device=pr.device)
     ratio = torch.empty((B,), dtype=torch.float32, device=pr.device)
+    loss = torch.empty((), dtype=torch.float32, device=pr.device)
     _launch("flow_finish_kernel", 0.0, 20.0 * B * L * C, lib().ispk_flow_finish_f32, pr.data_ptr(), fl.data_ptr(),
-            x0c.data_ptr(), mk.data_ptr(), pred.data_ptr(), dur.data_ptr(), ratio.data_ptr(), B, L, C, _stream())
-    return pred, dur, ratio
+            x0c.data_ptr(), mk.data_ptr(), pred.data_ptr(), dur.data_ptr(), ratio.data_ptr(), loss.data_ptr(), B, L, C,
+            _stream())
+    return pred, dur, ratio, loss
+
+
+# ------------------------------------------------------------------------------------------------- between the stacks
+def embed_tokens(text: Tensor, table: Tensor, text_len: Optional[Tensor] = None, want_mask: bool = True):
+    """ispk_embed_tokens_f32: (emb fp32 [B,L,D], mask bool [B,L] | None) - nn.Embedding lookup + the key mask."""
+    _dev(text, table, text_len)
+    assert text.dtype == torch.int64 and text.ndim == 2 and table.dtype == torch.float32 and table.stride(1) == 1
+    B, L = text.shape
+    V, D = table.shape
+    text = text.contiguous()
+    emb = torch.empty((B, L, D), dtype=torch.float32, device=text.device)
+    mask = torch.empty((B, L), dtype=torch.bool, device=text.device) if want_mask else None
+    if text_len is not None:
+        text_len = text_len.to(torch.int64).contiguous()
+    _launch("embed_tokens_kernel", 0.0, 8.0 * B * L * D, lib().ispk_embed_tokens_f32, text.data_ptr(), table.data_ptr(),
+            table.stride(0), V, _ptr(text_len), emb.data_ptr(), _ptr(mask), B, L, D, _stream())
+    return emb, mask
+
+
+def time_embedding(t: Tensor, inv_freq: Tensor, freq_scale: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
+    """ispk_time_embedding_f32: t [...] -> [..., emb_dim] (sinusoid with the raw position, Linear, SiLU, Linear)."""
+    _dev(t, inv_freq, freq_scale, w0, b0, w1, b1)
+    tf = t.to(torch.float32).contiguous()
+    E, H = w1.shape[0], inv_freq.numel()
+    assert w0.shape == (E, 1 + 2 * H) and w1.shape == (E, E) and w0.is_contiguous() and w1.is_contiguous()
+    out = torch.empty((*t.shape, E), dtype=torch.float32, device=t.device)
+    _launch("time_embedding_kernel", 0.0, 0.0, lib().ispk_time_embedding_f32, tf.data_ptr(), tf.numel(), inv_freq.data_ptr(),
+            freq_scale.data_ptr(), H, w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr(), E, out.data_ptr(),
+            _stream())
+    return out
+
+
+def length_regulate(x: Tensor, durations: Tensor, alignment: Optional[Tensor], frames: int, max_len: int = -1,
+                    enc_len: Optional[Tensor] = None, want_mask: bool = True):
+    """ispk_length_regulate_f32 -> (out fp32 [B, frames, D], dec_len int64 [B], dec_mask bool [B, frames] | None).
+    alignment fp32 [B, frames, L] (forward), or None: the soft path generated from the fp32 `durations` (infer)."""
+    _dev(x, durations, alignment, enc_len)
+    assert x.dtype == torch.float32 and x.ndim == 3
+    if x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
+        x = x.contiguous()
+    B, L, D = x.shape
+    if alignment is not None:
+        assert alignment.dtype == torch.float32 and alignment.shape == (B, frames, L)
+        alignment = alignment.contiguous()
+    dur_f = dur_i = None
+    if durations.dtype == torch.int64:
+        assert alignment is not None, "the soft path is generated from fp32 durations"
+        dur_i = durations.contiguous()
+    else:
+        dur_f = durations.to(torch.float32).contiguous()
+    if enc_len is not None:
+        enc_len = enc_len.to(torch.int64).contiguous()
+    out = torch.empty((B, frames, D), dtype=torch.float32, device=x.device)
+    dec_len = torch.empty((B,), dtype=torch.int64, device=x.device)
+    mask = torch.empty((B, frames), dtype=torch.bool, device=x.device) if want_mask else None
+    nb = 4.0 * B * (frames * D + L * D + (frames * L if alignment is not None else 0))
+    _launch("length_regulate_kernel", 2.0 * B * frames * L * D, nb, lib().ispk_length_regulate_f32, _ptr(alignment),
+            _ptr(dur_f), _ptr(dur_i), _ptr(enc_len), x.data_ptr(), x.stride(1), out.data_ptr(), dec_len.data_ptr(),
+            _ptr(mask), B, frames, L, D, max_len, _stream())
+    return out, dec_len, mask
 
 
 def cast_bf16(x: Tensor) -> Tensor:

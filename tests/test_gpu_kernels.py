@@ -536,10 +536,102 @@ def test_flow_matching_algebra_kernels():
     pf = raw * m3
     pred_ref = (x0 + pf) * m3
     loss_ref = masked_mean(F.mse_loss(pf, flow_ref, reduction="none"), m3)
-    pred, dur, ratio = runtime.flow_finish(raw.to(DEV), flow, x0.to(DEV), mask.to(DEV))
+    pred, dur, ratio, loss = runtime.flow_finish(raw.to(DEV), flow, x0.to(DEV), mask.to(DEV))
     assert torch.equal(pred.cpu(), pred_ref)
     assert (dur.cpu() - torch.clamp(torch.exp(pred_ref[..., 0]) - 1, min=0)).abs().max() < 1e-5
     assert abs(float(ratio.mean()) - float(loss_ref)) < 1e-5 * max(1.0, float(loss_ref))
+    assert loss.shape == () and abs(float(loss) - float(loss_ref)) < 1e-5 * max(1.0, float(loss_ref))
+    # a batch larger than the kernel's 16 waves (every wave takes several utterances)
+    B2 = 70
+    x0b, rawb = synth._normal("t/flow/x0b", (B2, L, C)), synth._normal("t/flow/rawb", (B2, L, C))
+    flb = synth._normal("t/flow/flb", (B2, L, C))
+    mb = torch.arange(L)[None] < (torch.arange(B2) % L + 1)[:, None]
+    m3b = mb[..., None].expand(-1, -1, C)
+    ref2 = masked_mean(F.mse_loss(rawb * m3b, flb, reduction="none"), m3b)
+    _, _, ratio2, loss2 = runtime.flow_finish(rawb.to(DEV), flb.to(DEV), x0b.to(DEV), mb.to(DEV))
+    assert abs(float(loss2) - float(ref2)) < 1e-5 * max(1.0, float(ref2)) and ratio2.shape == (B2,)
+
+
+# ------------------------------------------------------------------------------------------------ between the stacks
+def test_embed_tokens_is_the_embedding_lookup_plus_mask():
+    """ispk_embed_tokens_f32 == F.embedding (a row copy: bit-exact) and arange(L) < text_len."""
+    V, D, B, L = 149, 384, 5, 77
+    table = synth._normal("t/emb/table", (V, D))
+    table[0].zero_()
+    g = synth._rng("t/emb/ids")
+    text = torch.from_numpy(g.integers(0, V, size=(B, L)).astype(np.int64))
+    lens = torch.tensor([77, 1, 40, 76, 13])
+    emb, mask = runtime.embed_tokens(text.to(DEV), table.to(DEV), lens.to(DEV))
+    assert torch.equal(emb.cpu(), F.embedding(text, table, padding_idx=0))
+    assert mask.dtype == torch.bool and torch.equal(mask.cpu(), torch.arange(L)[None] < lens[:, None])
+    emb2, none = runtime.embed_tokens(text.to(DEV), table.to(DEV), None, want_mask=False)
+    assert none is None and torch.equal(emb2, emb)
+
+
+def test_time_embedding_against_the_oracle(state_dict):
+    """ispk_time_embedding_f32 (sinusoid with the raw step, Linear + SiLU, Linear) vs oracle.time_embedding."""
+    p = "temporal_adaptor.predictor.time_embedding"
+    t = torch.cat([synth._normal("t/temb/t", (64,)).abs().clamp(max=1.0), torch.tensor([0.0, 1.0, 0.36572])])
+    ref = orc.time_embedding(state_dict, t)
+    inv_freq = 1000.0 ** -(torch.arange(32).float() / 32)
+    d = lambda k: state_dict[f"{p}.{k}"].to(DEV)          # noqa: E731
+    out = runtime.time_embedding(t.to(DEV), inv_freq.to(DEV), d("freq_emb.freq_scale"), d("mlp.0.weight"), d("mlp.0.bias"),
+                                 d("mlp.2.weight"), d("mlp.2.bias"))
+    assert out.shape == (67, 32)
+    # sin / cos of arguments up to 1000 rad: fp32 argument reduction differs by an ulp or two between libms
+    assert (out.cpu() - ref).abs().max().item() < 2e-5
+    out11 = runtime.time_embedding(t[:1].view(1, 1).to(DEV), inv_freq.to(DEV), d("freq_emb.freq_scale"), d("mlp.0.weight"),
+                                   d("mlp.0.bias"), d("mlp.2.weight"), d("mlp.2.bias"))
+    assert out11.shape == (1, 1, 32) and torch.equal(out11.view(-1), out[0])
+
+
+@pytest.mark.parametrize("B,M,L,D", [(3, 512, 100, 384), (2, 390, 73, 384), (4, 65, 17, 256), (1, 1024, 200, 384)])
+def test_length_regulate_with_an_alignment(B, M, L, D):
+    """ispk_length_regulate_f32 (forward mode): alignment @ x with exact-fp32 MFMA products vs float64, the decoder
+    lengths (sum of the int64 MAS durations, clamped) and the decoder mask (temporal_adaptor.py:419-434)."""
+    x = synth._normal(f"t/lr/x{M}", (B, L, D))
+    a = torch.softmax(synth._normal(f"t/lr/a{M}", (B, M, L), 3.0), dim=-1)
+    g = synth._rng(f"t/lr/d{M}")
+    dur = torch.from_numpy(g.integers(0, 2 * M // L + 2, size=(B, L)).astype(np.int64))
+    out, dec, mask = runtime.length_regulate(x.to(DEV), dur.to(DEV), a.to(DEV), M, max_len=M)
+    ref = torch.bmm(a.double(), x.double())
+    assert out.shape == (B, M, D) and (out.cpu().double() - ref).abs().max().item() < 2e-5
+    want = torch.clamp((dur.sum(1) + 0.5).long(), max=M)
+    assert torch.equal(dec.cpu(), want) and torch.equal(mask.cpu(), torch.arange(M)[None] < want[:, None])
+    # no clamp when max_len is not given
+    _, dec2, _ = runtime.length_regulate(x.to(DEV), dur.to(DEV), a.to(DEV), M)
+    assert torch.equal(dec2.cpu(), (dur.sum(1) + 0.5).long())
+
+
+@pytest.mark.parametrize("B,L,M,D", [(3, 100, 512, 384), (2, 37, 300, 384), (1, 50, 130, 256)])
+def test_length_regulate_from_a_soft_path(B, L, M, D):
+    """ispk_length_regulate_f32 (infer mode): the soft path generated inside the kernel from fractional durations vs
+    the oracle's generate_soft_path + matmul (temporal_adaptor.py:388-397, :468-478), masked by token and frame lengths."""
+    x = synth._normal(f"t/sp/x{M}", (B, L, D))
+    dur = synth._normal(f"t/sp/d{M}", (B, L)).abs() * (1.8 * M / L)
+    enc_len = torch.tensor([L, max(1, L // 2), L - 3][:B])
+    dur = dur * (torch.arange(L)[None] < enc_len[:, None])
+    dec_ref = (dur.sum(1) + 0.5).long()
+    m3 = ((torch.arange(L)[None] < enc_len[:, None]).unsqueeze(2) & (torch.arange(M)[None] < dec_ref[:, None]).unsqueeze(1))
+    path = orc.generate_soft_path(dur, m3.float()).transpose(1, 2)                  # [B, M, L]
+    ref = torch.bmm(path.double(), x.double())
+    # The path weights are DIFFERENCES of clamped (cumsum - frame) ramps: an ulp of the fp32 cumulative sums (6e-5 at 700
+    # frames) moves a weight by as much, so implementations that add in a different order agree only to ~1e-4 * |x| - the
+    # reference's own arithmetic is that ill-conditioned.  Pin the kernel tightly against the SAME formula with the
+    # cumulative sums taken sequentially in fp32 (numpy's cumsum; the kernel's order) ...
+    cum = torch.from_numpy(np.cumsum(dur.numpy(), axis=1, dtype=np.float32))
+    ramp = (cum.unsqueeze(2) - torch.arange(M, dtype=torch.float32)).clamp(0., 1.)            # [B, L, M]
+    seq = ((ramp - F.pad(ramp, [0, 0, 1, 0])[:, :-1]) * m3.float()).transpose(1, 2)
+    ref_seq = torch.bmm(seq.double(), x.double())
+    out, dec, mask = runtime.length_regulate(x.to(DEV), dur.to(DEV), None, M, enc_len=enc_len.to(DEV))
+    assert torch.equal(dec.cpu(), dec_ref)
+    assert (out.cpu().double() - ref_seq).abs().max().item() < 2e-5
+    # ... and against the oracle's (torch.cumsum's summation order) at the conditioning of the formula
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-3
+    assert torch.equal(mask.cpu(), torch.arange(M)[None] < dec_ref[:, None])
+    # B = 1 without masks (infer of a single utterance, model.py:191-201): enc_len None = every token
+    out1, dec1, _ = runtime.length_regulate(x[:1].to(DEV), dur[:1].to(DEV), None, M)
+    assert torch.equal(dec1.cpu(), dec_ref[:1]) and (out1.cpu().double() - ref_seq[:1]).abs().max().item() < 2e-5
 
 
 @pytest.mark.parametrize("B,T,C", [(3, 203, 80), (2, 512, 384), (4, 33, 5)])

@@ -174,6 +174,20 @@ int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const float* norm_gam
                               const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner,
                               uint32_t flags, float* row_stats, float stats_eps, ispk_stream_t stream);
 
+/* Second-generation kernel for the same block (dim 384 only; what the module mirror calls by default):
+ *   out[i][:] = [mask[i]] * ( x[i][:] + gelu_erf( LN(x[i][:])·W1ᵀ )·W2ᵀ )          transformer.py:101-110 as above
+ * 128 rows per workgroup on EIGHT waves, two per SIMD: the two waves that share a SIMD own the same 32 rows and split both
+ * products (K-halves of the first, output-feature halves of the second), so one wave's GELU runs beside the other's
+ * MFMAs (csrc/ffn2.hip).  GELU by Abramowitz-Stegun 7.1.27 (|gelu error| <= 2.5e-4 |x|, below the bf16 rounding of the
+ * value it feeds).  W1 bf16 [inner][384] contiguous; W2_chunks = ispk_ffn_chunk_w2_bf16(W2): [inner/32][384][32], hidden
+ * units in natural order; no biases.  flags / mask / row_stats as ispk_ffn_bf16_prenorm. */
+int32_t ispk_ffn_chunk_w2_bf16(const uint16_t* W2, int64_t ldw2, int32_t dim, int32_t inner, uint16_t* out,
+                               ispk_stream_t stream);
+int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                               const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask, float* out, int64_t ldo,
+                               int32_t rows, int32_t dim, int32_t inner, uint32_t flags, float* row_stats, float stats_eps,
+                               ispk_stream_t stream);
+
 /* The second half of a pre-norm transformer layer in one kernel - attention output projection, residual, mask,
  * feed_forward_norm, feed-forward, residual, mask:
  *   x1[i][:]  = x[i][:] + mask[i] * ( attn_out[i][:]·Woᵀ )                                  attention.py:168-172, transformer.py:91

@@ -19,6 +19,9 @@ LIB = os.path.join(HERE, "libispk.so")
 LIB_EXP = os.path.join(HERE, "libispk_exp.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# per-file extras.  ffn2.hip: keep the GELU's fp32 arithmetic scalar - the SLP vectoriser would pack adjacent values into
+# v_pk_*_f32, which issue slowly beside MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
+EXTRA_FLAGS = {"ffn2.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources() -> list[str]:
@@ -35,7 +38,8 @@ def _compile(src: str, verbose: bool, experiments: bool = False) -> str:
     obj = os.path.join(OBJ, os.path.basename(src)[:-4] + (".exp.o" if experiments else ".o"))
     if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), _deps_mtime()):
         return obj
-    cmd = [HIPCC, *FLAGS, *(["-DISPK_EXPERIMENTS"] if experiments else []), "-c", src, "-o", obj]
+    cmd = [HIPCC, *FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), []), *(["-DISPK_EXPERIMENTS"] if experiments else []),
+           "-c", src, "-o", obj]
     if verbose:
         cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -1,0 +1,652 @@
+// Pre-norm feed-forward block of a transformer layer, decoder-sized batches, bf16 operands (second generation):
+//     out = [mask] * ( x + gelu( LN(x) · W1ᵀ ) · W2ᵀ )        transformer.py:101-110, normalization.py:20-27, feedforward.py:33-40
+// ONE kernel; the [rows, inner] hidden activations never leave the CU.
+//
+// Why a second kernel (gemm.hip's ffn_bf16_kernel is the first): that one gives a wave 32 rows x ALL 384 output features,
+// 192 accumulator + 96 operand registers = one wave per SIMD, and a wave's own VALU work (the GELU) does not overlap its
+// own MFMAs: the matrix pipe was busy 35 % of the time.  Here a workgroup of 128 rows runs EIGHT waves, two per SIMD, so
+// one wave's GELU / LDS traffic / waits run beside the other's MFMAs - and every weight fragment read from LDS still
+// feeds a 32-row MFMA (v_mfma_f32_32x32x16_bf16: 1 KB of LDS per 32 matrix cycles per SIMD = half the LDS bandwidth;
+// 16-row waves would need all of it).  The two waves of a SIMD share the same 32 rows ("row group" rg = wave & 3) and
+// split the work of both products between them (half = wave >> 2):
+//   product 1  S = W1[chunk] · LN(x)ᵀ  (32 hidden x 32 rows): each half sums over ITS HALF OF K (192 features, 12 MFMAs;
+//              only that half of the normalised rows stays in registers: 48) and hands the partner the 8 partial sums per
+//              lane that the partner will finish (fp32, through LDS: 32 B per lane);
+//   finish     own 8 partial sums + the partner's, GELU, round to bf16, into the row group's P tile in LDS;
+//   product 2  Yᵀ[192 features of this half] += W2[those features][chunk] · Pᵀ   (12 MFMAs, 96 accumulator registers).
+// The three stages of a 32-hidden chunk run in consecutive iterations (software pipeline of depth 3), so ONE workgroup
+// barrier per iteration covers every hand-off, and the two halves run the stages in a different order - while one is in
+// its VALU stage the other is in a matrix stage (two waves of a SIMD that run the same program in lock-step would do
+// their VALU work at the same time and leave the matrix pipe idle).
+// Weights stream through LDS by LDS-DMA (global_load_lds_dwordx4, no staging registers): per iteration one 48-KB group
+// {W1 chunk it+1, W2 chunk it-1} into the buffer the previous iteration released, 6 DMA instructions per wave, a whole
+// iteration to land.  Both images are lane-linear as the DMA writes them; bank conflicts are removed by XOR-swizzling the
+// LDS images are what the DMA's per-lane SOURCE addresses make them (the destination is lane-linear): the W1 chunk gets
+// rows of 768 + 16 bytes (the pad slots re-fetch a neighbouring piece) - conflict-free fragment reads AND one address
+// register for all twelve of them (base + immediate; an XOR swizzle would need an address per k-step); W2 and P rows
+// (64 B) are XOR-swizzled, 16-byte chunk ^ ((row >> 2) & 3): two addresses.  tools/lds_conflicts.py checks every
+// fragment read: 4 LDS cycles, conflict-free.
+// Prologue: the LayerNorm (two-pass fp32 statistics, 16 rows per wave) writes bf16 rows into an LDS tile from which every
+// wave takes its fragments.  Epilogue: 64 rows at a time through an fp32 LDS tile, so that whole rows come back out:
+// residual add (the fp32 rows are re-read: the file has no room to keep them), mask, the (mean, rstd) of the finished
+// rows for the next layer's q/kv GEMM, 16-byte coalesced stores.
+#include "common.h"
+
+namespace {
+
+constexpr int kD = 384, kHC = 32;
+constexpr int kW1Row = kD * 2 + 16;              // W1 chunk rows in LDS: 768 B + one 16-byte pad (see the header comment)
+constexpr int kW1Dma = 25;                       // DMA instructions (1 KB each) that cover the padded W1 image (25,088 B)
+constexpr int kW1Bytes = kW1Dma * 1024;          // 25,600
+constexpr int kW1Src = kHC * kD * 2;             // 24,576: W1 chunk [32 hidden][384] bf16 in memory
+constexpr int kW2Bytes = kD * kHC * 2;           // 24,576: W2 chunk [384 features][32 hidden] bf16 (24 DMA instructions)
+constexpr int kWbuf = kW1Bytes + kW2Bytes;       // 50,176 per buffer, two buffers
+constexpr int kDmaPerWave = 7;                   // 49 instructions per group over 8 waves: wave w issues q = w, w + 8, ...
+constexpr int kPOff = 2 * kWbuf;                 // P tiles  [2][4 row groups][32 rows][64 B]
+constexpr int kXcOff = kPOff + 2 * 4 * 2048;     // exchange [2][8 waves][64 lanes][32 B]
+constexpr int kLds = kXcOff + 2 * 8 * 2048;      // 149,504 B
+constexpr int kXtOff = kWbuf;                    // prologue: LN(x) tile [128 rows][768 B] over buffer 1 + P + exchange
+constexpr int kLdT = 388;                        // epilogue: fp32 tile [64 rows][388] at 0 (99,328 B)
+static_assert(kXtOff + 128 * kD * 2 <= kLds && 64 * kLdT * 4 <= kLds, "LDS carve-up");
+
+struct Ffn2Params {
+    const float* x;
+    int64_t ldx;
+    const float* gamma;
+    const float* beta;
+    float eps;
+    const uint16_t* W1;    // [inner][384]
+    const uint16_t* W2c;   // [inner / 32][384][32]  (ispk_ffn_chunk_w2_bf16)
+    const uint8_t* mask;
+    float* out;
+    int64_t ldo;
+    int rows, inner;
+    uint32_t flags;
+    float* stats;
+    float stats_eps;
+    unsigned long long* stamps = nullptr;   // experiments build, ABL == 3: per-wave phase cycle sums [grid * 8][8]
+};
+
+// GELU(erf) for values that are rounded to bf16 right away.  erf by Abramowitz-Stegun 7.1.27:
+// erf(z) = 1 - (1 + a1 z + a2 z^2 + a3 z^3 + a4 z^4)^-4, z >= 0, |error| <= 5e-4, so |gelu error| <= 2.5e-4 |x| - an eighth of
+// the bf16 rounding step or less over the whole range.  11 plain fp32 instructions per value (scalar on purpose: packed
+// fp32 instructions are slow beside MFMAs).  Eight values at a time, LEVEL BY LEVEL: written value by value hipcc
+// interleaves only two of the dependent chains, and every instruction then waits for its predecessor's result (measured:
+// 8 cycles per instruction instead of 4).  The coefficients sit in SGPRs (`opaque`): as 32-bit literals every FMA is a
+// two-dword instruction.
+__device__ __forceinline__ float opaque(float c) {
+    asm volatile("" : "+s"(c));
+    return c;
+}
+__device__ __forceinline__ void gelu8_bf16_grade(float (&v)[8]) {
+    const float kRs2 = opaque(0.70710678118654752440f), a4 = opaque(0.078108f), a3 = opaque(0.000972f),
+                a2 = opaque(0.230389f), a1 = opaque(0.278393f);
+    float z[8], q[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = fabsf(v[i]) * kRs2;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = fmaf(z[i], a4, a3);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = fmaf(q[i], z[i], a2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = fmaf(q[i], z[i], a1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = fmaf(q[i], z[i], 1.0f);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = q[i] * q[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = q[i] * q[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = __builtin_amdgcn_rcpf(q[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = 0.5f * fabsf(v[i]);        // hx
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) q[i] = fmaf(-z[i], q[i], z[i]);    // hx - hx r
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaf(0.5f, v[i], q[i]);
+}
+
+// Variant: the tanh form, gelu(x) ~ x / (1 + exp(-2 u)), u = sqrt(2/pi) (x + 0.044715 x^3): 7 instructions per value, two
+// of them transcendental; max |error| vs the erf form about 5e-4 (at |x| ~ 2).
+__device__ __forceinline__ void gelu8_tanh_form(float (&v)[8]) {
+    const float c1 = opaque(-2.0f * 0.7978845608028654f * 1.4426950408889634f), c3 = opaque(-2.0f * 0.7978845608028654f * 0.044715f * 1.4426950408889634f);
+    float t[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = v[i] * v[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = fmaf(t[i], c3, c1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = t[i] * v[i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_exp2f(t[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = t[i] + 1.0f;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t[i] = __builtin_amdgcn_rcpf(t[i]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = v[i] * t[i];
+}
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ABL (experiments build only, tools/bench_ffn.py): 1 = weight DMA only for the first two groups (the products then run on
+// stale buffers: WRONG results, compute-bound timing); 2 = DMA and barriers only, no products / finish (streaming-bound
+// timing); 3 = s_memtime stamps: per wave, cycles in [prologue, barrier waits, DMA issue, finish, product 1, product 2,
+// epilogue, total]
+template <int ABL>
+__global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // experiment switches (ABL 6 .. 9): MFMA stages at raised priority; tanh-form GELU; the DMA group issued by half 0 only
+    constexpr bool kPrio = ABL == 6 || ABL == 9, kTanh = ABL == 7 || ABL == 9, kDmaHalf0 = ABL == 8 || ABL == 9;
+    [[maybe_unused]] unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    [[maybe_unused]] unsigned long long t_prev = 0, t_first = 0;
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (ABL == 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t = __builtin_readcyclecounter();
+            __builtin_amdgcn_sched_barrier(0);
+            if (slot >= 0) ts[slot] += t - t_prev; else t_first = t;
+            t_prev = t;
+        }
+    };
+    stamp(-1);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave & 3, half = wave >> 2;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 128;
+    const int nchunks = p.inner / kHC;
+    const char* W1b = reinterpret_cast<const char*>(p.W1);
+    const char* W2b = reinterpret_cast<const char*>(p.W2c);
+
+    // ---- this lane's part of the wave's DMA instructions (q = wave + 8 j of the group's 49): byte offset inside the chunk
+    // in memory.  q < 25: the padded W1 image - 16-byte slot t = 64 q + lane is (row t / 49, piece t % 49), piece 48 and rows
+    // past 31 are padding; q >= 25: the W2 image, slot -> (row, piece ^ ((row >> 2) & 3)).
+    uint32_t soff[kDmaPerWave];
+#pragma unroll
+    for (int j = 0; j < kDmaPerWave; ++j) {
+        const uint32_t q = wave + 8 * j;
+        if (q < (uint32_t)kW1Dma) {
+            const uint32_t t = 64u * q + lane;
+            uint32_t r = t / 49u, c = t - r * 49u;
+            r = r < 32u ? r : 31u;
+            c = c < 48u ? c : 47u;
+            soff[j] = r * 768u + 16u * c;
+        } else {
+            const uint32_t t = 64u * (q - kW1Dma) + lane;
+            const uint32_t r = t >> 2, c = t & 3u;
+            soff[j] = r * 64u + 16u * (c ^ ((r >> 2) & 3u));
+        }
+    }
+    // Every instruction's source base / chunk stride is wave-uniform and fixed (W1 or W2 image): no branch per instruction.
+    // The caller clamps the chunk indices, so a group is always issued whole - at the ends of the pipeline a few pieces
+    // are fetched again into a buffer nobody reads (cheaper than a dozen scalar branches per iteration).
+    // One DMA instruction occupies the CU's address path for 16 cycles; eight waves issuing their six or seven right
+    // behind the barrier queue up for 49 x 16 cycles (stamped: 440 - 700 cycles per wave and iteration).  Issuing them one
+    // at a time from inside the matrix stages (dma_one<J>, experiment ABL 5) moved that wait into the stages and changed
+    // nothing in total, so the group goes out at the barrier.
+    int64_t dma_o1 = 0, dma_o2 = 0;     // byte offsets of the chunks being fetched this iteration
+    char* dma_base = smem;
+    auto dma_begin = [&](int c1, int c2, int buf) __attribute__((always_inline)) {
+        dma_o1 = (int64_t)c1 * kW1Src;
+        dma_o2 = (int64_t)c2 * kW2Bytes;
+        dma_base = smem + buf * kWbuf + wave * 1024;
+    };
+    auto dma_one = [&](auto jc) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const int q = wave + 8 * j;               // wave-uniform
+        if (j == kDmaPerWave - 1 && q >= kW1Dma + 24) return;            // only wave 0 has a seventh instruction
+        const char* src = (q < kW1Dma ? W1b + dma_o1 : W2b + dma_o2) + soff[j];
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dma_base + j * 8192), 16, 0, 0);
+    };
+    auto issue = [&](int c1, int c2, int buf) __attribute__((always_inline)) {     // a whole group at once
+        dma_begin(c1, c2, buf);
+        static_for<0, kDmaPerWave>([&](auto jc) { dma_one(jc); });
+    };
+    issue(0, 0, 0);   // W1 chunk 0 -> buffer 0 (and a W2 chunk nobody reads), on its way during the LayerNorm (the tile below
+                      // does not touch buffer 0)
+
+    // ---- prologue: LayerNorm of 16 rows per wave (two rows at a time: 32 lanes x 3 float4 cover a row), bf16 into the tile
+    {
+        const int rbase = rg * 32 + half * 16;
+        f32x4 g4[3], b4[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            g4[j] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * (l31 + 32 * j));
+            b4[j] = *reinterpret_cast<const f32x4*>(p.beta + 4 * (l31 + 32 * j));
+        }
+        f32x4 v[8][3];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int r = row0 + rbase + 2 * i + h;
+            r = r < p.rows ? r : p.rows - 1;            // rows past the end: a valid row, never stored
+#pragma unroll
+            for (int j = 0; j < 3; ++j) v[i][j] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)r * p.ldx + 4 * (l31 + 32 * j));
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) s += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+            const float mean = s * (1.0f / kD);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = v[i][j][e] - mean;
+                    q = fmaf(d, d, q);
+                }
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+            const float rstd = 1.0f / sqrtf(q * (1.0f / kD) + p.eps);
+            const int rl = rbase + 2 * i + h;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fmaf((v[i][j][e] - mean) * rstd, g4[j][e], b4[j][e]);
+                uint2 pk;
+                pk.x = pack_bf16(y[0], y[1]);
+                pk.y = pack_bf16(y[2], y[3]);
+                const int c16 = (l31 + 32 * j) >> 1;     // 16-byte chunk of the row; this lane owns its half (l31 & 1)
+                *reinterpret_cast<uint2*>(smem + kXtOff + rl * 768 + 16 * (c16 ^ (rl & 15)) + 8 * (l31 & 1)) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    bf16x8 xf[12];   // B operands of product 1: LN(x)[row rg*32 + l31][this half's 192 features], k-step ks = 16 features
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks)
+        xf[ks] = *reinterpret_cast<const bf16x8*>(smem + kXtOff + (rg * 32 + l31) * 768 + 16 * ((24 * half + 2 * ks + h) ^ (l31 & 15)));
+    __syncthreads();   // the tile is dead: buffer 1, the P tiles and the exchange area may be written from here on
+
+    stamp(0);
+    f32x16 acc2[6];
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
+    float keep[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) keep[i] = 0.f;
+
+    // Operand fragments come through small register rings of hand-counted asm reads (common.h: lds_read_b128_asm /
+    // lds_wait): hipcc sinks every plain ds_read next to its MFMA and waits for it there - at most two in flight, an LDS
+    // round trip exposed per pair of MFMAs.  A stage's first fragments are requested BEFORE the stage in front of it (both
+    // weight images and the P tile are complete at the iteration's barrier), so each matrix stage starts on landed data.
+    const int psw = (l31 >> 2) & 3;   // swizzle of a 64-byte row (P tile row l31; W2 row 192*half + 32*nt + l31)
+    const uint32_t lds0 = lds_addr(smem);
+    const uint32_t w1a = lds0 + l31 * kW1Row + 16 * (24 * half + h);                        // + buffer, + 32 ks
+    const uint32_t w2a0 = lds0 + kW1Bytes + (192 * half + l31) * 64 + 16 * ((0 + h) ^ psw);  // + buffer, + 2048 nt  (k-step 0)
+    const uint32_t w2a1 = lds0 + kW1Bytes + (192 * half + l31) * 64 + 16 * ((2 + h) ^ psw);  //                        (k-step 1)
+    const uint32_t pa0 = lds0 + kPOff + rg * 2048 + l31 * 64 + 16 * ((0 + h) ^ psw);         // + 8192 parity
+    const uint32_t pa1 = lds0 + kPOff + rg * 2048 + l31 * 64 + 16 * ((2 + h) ^ psw);
+    bf16x8 r1[4];          // product 1 ring: W1 fragments
+    bf16x8 r2[4], pb[2];   // product 2 ring: W2 fragments; the two P fragments
+
+    auto prefetch1 = [&](int it) __attribute__((always_inline)) {     // first 4 W1 fragments of chunk `it`
+        const uint32_t a = w1a + (it & 1) * kWbuf;
+        static_for<0, 4>([&](auto kc) { lds_read_b128_asm<32 * decltype(kc)::value>(r1[decltype(kc)::value], a); });
+    };
+    auto product1 = [&](int it, bool dma) __attribute__((always_inline)) {   // S = W1[chunk it][:, this half of K] · xfᵀ ; send 8, keep 8
+        const uint32_t a = w1a + (it & 1) * kWbuf;
+        f32x16 S;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[r] = 0.f;
+        if constexpr (kPrio) __builtin_amdgcn_s_setprio(1);
+        static_for<0, 12>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            lds_wait<(11 - ks) < 3 ? (11 - ks) : 3>();            // fragment ks is in; up to 3 younger reads may be in flight
+            __builtin_amdgcn_sched_barrier(0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1[ks & 3], xf[ks], S, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ks + 4 < 12) lds_read_b128_asm<32 * (ks + 4)>(r1[ks & 3], a);
+            if constexpr ((ks & 3) == 1) {
+                if (dma) dma_one(std::integral_constant<int, ks / 4>{});           // DMA instructions 0, 1, 2
+            }
+        });
+        if constexpr (kPrio) __builtin_amdgcn_s_setprio(0);
+        // S[r] = partial H[hidden (r & 3) + 8 (r >> 2) + 4 h][row l31]; half 0 finishes r < 8, half 1 finishes r >= 8
+        f32x4* xc = reinterpret_cast<f32x4*>(smem + kXcOff + ((it & 1) * 8 + wave) * 2048 + lane * 32);
+        f32x4 s0, s1v;
+        if (half == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0[i] = S[8 + i]; s1v[i] = S[12 + i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) keep[i] = S[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { s0[i] = S[i]; s1v[i] = S[4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) keep[i] = S[8 + i];
+        }
+        xc[0] = s0;
+        xc[1] = s1v;
+    };
+    auto finish = [&](int c) __attribute__((always_inline)) {         // chunk c: own + partner's partial sums -> GELU -> bf16 -> P tile
+        const f32x4* pc = reinterpret_cast<const f32x4*>(smem + kXcOff + ((c & 1) * 8 + (wave ^ 4)) * 2048 + lane * 32);
+        const f32x4 a0 = pc[0], a1 = pc[1];
+        float g[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            g[i] = keep[i] + a0[i];
+            g[4 + i] = keep[4 + i] + a1[i];
+        }
+        if constexpr (kTanh) gelu8_tanh_form(g); else gelu8_bf16_grade(g);
+        char* pt = smem + kPOff + ((c & 1) * 4 + rg) * 2048 + l31 * 64 + 8 * h;
+#pragma unroll
+        for (int gq = 0; gq < 2; ++gq) {
+            uint2 pk;
+            pk.x = pack_bf16(g[4 * gq], g[4 * gq + 1]);
+            pk.y = pack_bf16(g[4 * gq + 2], g[4 * gq + 3]);
+            *reinterpret_cast<uint2*>(pt + 16 * ((2 * half + gq) ^ psw)) = pk;
+        }
+    };
+    // product 2 reads, in order: P k-step 0, P k-step 1, then W2 fragment j = 2 nt + ks for j = 0 .. 11
+    auto w2read = [&](auto jc, uint32_t b0, uint32_t b1) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        if constexpr (j & 1) lds_read_b128_asm<2048 * (j >> 1)>(r2[j & 3], b1);
+        else lds_read_b128_asm<2048 * (j >> 1)>(r2[j & 3], b0);
+    };
+    auto prefetch2 = [&](int it) __attribute__((always_inline)) {     // the P fragments and the first 4 W2 fragments
+        const uint32_t b0 = w2a0 + (it & 1) * kWbuf, b1 = w2a1 + (it & 1) * kWbuf;
+        lds_read_b128_asm<0>(pb[0], pa0 + (it & 1) * 8192);
+        lds_read_b128_asm<0>(pb[1], pa1 + (it & 1) * 8192);
+        static_for<0, 4>([&](auto jc) { w2read(jc, b0, b1); });
+    };
+    auto product2 = [&](int it, bool dma) __attribute__((always_inline)) {   // acc2 += W2[this half's 192 features][chunk it - 2] · Pᵀ
+        const uint32_t b0 = w2a0 + (it & 1) * kWbuf, b1 = w2a1 + (it & 1) * kWbuf;
+        if constexpr (kPrio) __builtin_amdgcn_s_setprio(1);
+        static_for<0, 12>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            lds_wait<(11 - j) < 3 ? (11 - j) : 3>();
+            __builtin_amdgcn_sched_barrier(0);
+            acc2[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2[j & 3], pb[j & 1], acc2[j >> 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j + 4 < 12) w2read(std::integral_constant<int, j + 4>{}, b0, b1);
+            if constexpr ((j & 3) == 1) {
+                if (dma) dma_one(std::integral_constant<int, 3 + j / 4>{});        // DMA instructions 3, 4, 5
+            }
+            if constexpr (j == 10) {
+                if (dma) dma_one(std::integral_constant<int, 6>{});                // (wave 0 only)
+            }
+        });
+        if constexpr (kPrio) __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- main loop.  Iteration `it`: product 1 of chunk it, finish of chunk it-1, product 2 of chunk it-2.
+    // Stage order: finish, product 1, product 2 for half 0; product 2, finish, product 1 for half 1 (finish always
+    // precedes product 1, which overwrites the partial sums it consumes): whenever one wave of a SIMD is in its VALU stage
+    // the other is in a matrix stage.  The whole loop exists twice, once per order, selected ONCE: a per-iteration choice
+    // (a branch or a rotation loop around the stages) turns the 96 accumulators into loop-carried phi copies - twice the
+    // registers, spills, and 96 moves per iteration.
+    auto main_loop = [&](auto order) __attribute__((always_inline)) {
+        constexpr int kOrder = decltype(order)::value;
+#pragma unroll 1
+        for (int it = 0; it <= nchunks + 1; ++it) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA instructions of the previous iteration
+            __syncthreads();   // group `it` has landed; every wave is done with iteration it-1
+            stamp(1);
+            // group it+1 = {W1 chunk it+1, W2 chunk it-1} (indices clamped at the pipeline's ends) into the buffer iteration
+            // it-1 released; nothing in the last iteration (the epilogue reuses the buffers right after the loop)
+            bool dma = it <= nchunks && (ABL != 1 || it < 2);
+            dma_begin(it + 1 < nchunks ? it + 1 : nchunks - 1, it < 1 ? 0 : (it <= nchunks ? it - 1 : nchunks - 1), (it + 1) & 1);
+            const bool p1 = ABL != 2 && it < nchunks, fi = ABL != 2 && it >= 1 && it <= nchunks, p2 = ABL != 2 && it >= 2;
+            // a stage that does not run this iteration (pipeline fill / drain) cannot carry its share of the DMA group
+            if constexpr (kDmaHalf0) {   // experiment: half 0 (which waits at the barrier anyway) issues the whole group
+                if (dma && half == 0) {
+                    static_for<0, 13>([&](auto jc) {
+                        constexpr int j = decltype(jc)::value;
+                        const int q = wave + 4 * j;
+                        if (q < kW1Dma + 24) {
+                            const uint32_t t = 64u * (q < kW1Dma ? q : q - kW1Dma) + lane;
+                            uint32_t so;
+                            if (q < kW1Dma) {
+                                uint32_t r = t / 49u, c = t - r * 49u;
+                                r = r < 32u ? r : 31u;
+                                c = c < 48u ? c : 47u;
+                                so = r * 768u + 16u * c;
+                            } else {
+                                const uint32_t r = t >> 2, c = t & 3u;
+                                so = r * 64u + 16u * (c ^ ((r >> 2) & 3u));
+                            }
+                            const char* src = (q < kW1Dma ? W1b + dma_o1 : W2b + dma_o2) + so;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                             (__attribute__((address_space(3))) void*)(smem + ((it + 1) & 1) * kWbuf + q * 1024), 16, 0, 0);
+                        }
+                    });
+                }
+                dma = false;
+            }
+            if (ABL != 5) {        // the whole group right behind the barrier (ABL == 5, experiment: one instruction at a time
+                                   // from inside the matrix stages - measured no faster, and hipcc then drops the vmcnt(0)
+                                   // in front of the barrier: racy without the explicit wait below)
+                if (dma) static_for<0, kDmaPerWave>([&](auto jc) { dma_one(jc); });
+                dma = false;
+            }
+            if (dma && !p1) static_for<0, 3>([&](auto jc) { dma_one(jc); });
+            if (dma && !p2) static_for<3, kDmaPerWave>([&](auto jc) { dma_one(jc); });
+            stamp(2);
+            if constexpr (kOrder == 0) {
+                if (p1) prefetch1(it);
+                if (fi) finish(it - 1);
+                stamp(3);
+                if (p1) product1(it, dma);
+                stamp(4);
+                if (p2) {
+                    prefetch2(it);
+                    product2(it, dma);
+                }
+                stamp(5);
+            } else {
+                if (p2) {
+                    prefetch2(it);
+                    product2(it, dma);
+                }
+                stamp(5);
+                if (p1) prefetch1(it);
+                if (fi) finish(it - 1);
+                stamp(3);
+                if (p1) product1(it, dma);
+                stamp(4);
+            }
+        }
+    };
+    if (half == 0) main_loop(std::integral_constant<int, 0>{});
+    else main_loop(std::integral_constant<int, 1>{});
+
+    // ---- epilogue: 64 rows per pass through the fp32 tile; then whole rows: + x, mask, statistics, coalesced stores
+    const bool mask_acc = p.flags & ISPK_EP_MASK_ACC, mask_out = p.flags & ISPK_EP_MASK_OUT;
+    float* T = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+        if ((rg >> 1) == pass) {
+            float* trow = T + ((rg & 1) * 32 + l31) * kLdT + 192 * half + 4 * h;
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = acc2[nt][4 * gq + e];
+                    *reinterpret_cast<f32x4*>(trow + 32 * nt + 8 * gq) = o;
+                }
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int rl = wave * 8 + 2 * i + h;                 // row of the tile
+            const int r = row0 + pass * 64 + rl;
+            const bool live = r < p.rows;
+            const int rc = live ? r : p.rows - 1;
+            const float mk = (p.mask && (mask_acc || mask_out)) ? (p.mask[rc] ? 1.0f : 0.0f) : 1.0f;
+            f32x4 y[3];
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int c = 4 * (l31 + 32 * j);
+                f32x4 a = *reinterpret_cast<const f32x4*>(T + rl * kLdT + c);
+                const f32x4 xr = *reinterpret_cast<const f32x4*>(p.x + (int64_t)rc * p.ldx + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = mask_acc ? a[e] * mk : a[e];
+                    t += xr[e];
+                    a[e] = mask_out ? t * mk : t;
+                }
+                y[j] = a;
+                s += (a[0] + a[1]) + (a[2] + a[3]);
+            }
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(p.out + (int64_t)r * p.ldo + 4 * (l31 + 32 * j)) = y[j];
+            }
+            if (p.stats) {
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                const float mean = s * (1.0f / kD);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = y[j][e] - mean;
+                        q = fmaf(d, d, q);
+                    }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+                if (live && l31 == 0) {
+                    p.stats[2 * (int64_t)r] = mean;
+                    p.stats[2 * (int64_t)r + 1] = 1.0f / sqrtf(q * (1.0f / kD) + p.stats_eps);
+                }
+            }
+        }
+    }
+    if constexpr (ABL == 3) {
+        stamp(6);
+        ts[7] = t_prev - t_first;
+        if (lane == 0 && p.stamps) {
+            unsigned long long* o = p.stamps + ((int64_t)blockIdx.x * 8 + wave) * 8;
+            for (int i = 0; i < 8; ++i) o[i] = ts[i];
+        }
+    }
+}
+
+// W2 [dim][inner] (nn.Linear layout) -> chunk-contiguous [inner / 32][dim][32]: chunk c is one 24-KB block
+__global__ __launch_bounds__(256) void ffn_chunk_w2_kernel(const uint16_t* __restrict__ W2, int64_t ldw2,
+                                                           uint16_t* __restrict__ out, int dim, int inner) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one 16-byte piece (8 hidden units) per thread
+    const int64_t total = (int64_t)dim * inner / 8;
+    if (i >= total) return;
+    const int piece = (int)(i & 3);
+    const int64_t rest = i >> 2;
+    const int d = (int)(rest % dim), c = (int)(rest / dim);
+    *reinterpret_cast<u32x4*>(out + (((int64_t)c * dim + d) * 32 + piece * 8)) =
+        *reinterpret_cast<const u32x4*>(W2 + (int64_t)d * ldw2 + c * 32 + piece * 8);
+}
+
+}  // namespace
+
+extern "C" int32_t ispk_ffn_chunk_w2_bf16(const uint16_t* W2, int64_t ldw2, int32_t dim, int32_t inner, uint16_t* out,
+                                          ispk_stream_t stream) {
+    ISPK_REQUIRE(W2 && out, ISPK_E_NULL, "ffn_chunk_w2: null pointer");
+    ISPK_REQUIRE(dim >= 1 && inner >= 32 && inner % 32 == 0 && ldw2 >= inner, ISPK_E_SHAPE, "ffn_chunk_w2: bad shape %d x %d",
+                 dim, inner);
+    ISPK_REQUIRE(ldw2 % 8 == 0 && ispk_aligned(W2, 16) && ispk_aligned(out, 16), ISPK_E_ALIGN,
+                 "ffn_chunk_w2: 16-byte alignment required");
+    const int64_t total = (int64_t)dim * inner / 8;
+    hipLaunchKernelGGL(ffn_chunk_w2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), W2, ldw2, out, dim, inner);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta,
+                                          float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask,
+                                          float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
+                                          float* row_stats, float stats_eps, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && norm_gamma && norm_beta && W1 && W2_chunks && out, ISPK_E_NULL, "ffn_prenorm2: null pointer");
+    ISPK_REQUIRE(dim == kD, ISPK_E_UNSUPPORTED, "ffn_prenorm2: dim %d (built for 384)", dim);
+    ISPK_REQUIRE(rows >= 0 && inner >= 32 && inner % 32 == 0, ISPK_E_SHAPE, "ffn_prenorm2: bad shape rows=%d inner=%d", rows,
+                 inner);
+    ISPK_REQUIRE((flags & ~(ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) == 0, ISPK_E_UNSUPPORTED, "ffn_prenorm2: unsupported flags");
+    ISPK_REQUIRE(!((flags & (ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) && !mask), ISPK_E_NULL, "ffn_prenorm2: mask flag without mask");
+    ISPK_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ldx >= dim && ldo >= dim && ispk_aligned(x, 16) && ispk_aligned(out, 16) &&
+                     ispk_aligned(W1, 16) && ispk_aligned(W2_chunks, 16) && ispk_aligned(norm_gamma, 16) &&
+                     ispk_aligned(norm_beta, 16) && (!row_stats || ispk_aligned(row_stats, 8)),
+                 ISPK_E_ALIGN, "ffn_prenorm2: 16-byte alignment / strides that are multiples of 4 required");
+    if (rows == 0) return 0;
+    Ffn2Params p{x, ldx, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, mask, out, ldo, rows, inner, flags, row_stats, stats_eps};
+    const dim3 grid((rows + 127) / 128);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+#ifdef ISPK_EXPERIMENTS
+    if (const char* e = ispk_knob("ISPK_FFN2_ABLATE")) {
+        if (atoi(e) == 1) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<1>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<1>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 2) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<2>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<2>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 6) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<6>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<6>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 7) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<7>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<7>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 8) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<8>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<8>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 9) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<9>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<9>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 5) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<5>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<5>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 3) {
+            const char* sp = ispk_knob("ISPK_FFN2_STAMP");
+            p.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 16)) : nullptr;
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<3>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<3>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+    }
+#endif
+    ISPK_RESERVE_LDS((&ffn2_bf16_kernel<0>), kLds, "ffn_prenorm2");
+    hipLaunchKernelGGL(ffn2_bf16_kernel<0>, grid, dim3(512), kLds, s, p);
+    return ispk_launch_status();
+}

@@ -33,6 +33,7 @@ class FeedForward(nn.Module, Constructor):
     # path switches: class attributes (override on the class or an instance; nothing reads the environment)
     prenorm_fused = True   # norm -> feed-forward -> residual as one kernel (ispk_ffn_bf16_prenorm) when a caller offers it
     lnin_self = True       # two-GEMM path: feed_forward_norm applied by the first GEMM's own waves (ispk_gemm_bf16_lnin)
+    pair_kernel = True     # dim 384: the eight-wave kernel (ispk_ffn_bf16_prenorm2, csrc/ffn2.hip) instead of the four-wave one
 
     def __init__(self, dim: int = 384, inner_dim: int = 1536, dropout: float = 0.0, activation: str = "relu",
                  bias: bool = False, glu: bool = False):
@@ -61,6 +62,11 @@ class FeedForward(nn.Module, Constructor):
         """W2 in the fused kernel's chunk-contiguous layout, staged once per weight version."""
         return self._cache.get("w2p", (self.net[3].weight,),
                                lambda: runtime.ffn_pack_w2(self._staged(torch.bfloat16)[1]))
+
+    def _chunked_w2(self) -> Tensor:
+        """W2 as chunk-contiguous [inner/32][D][32] blocks (ispk_ffn_bf16_prenorm2), staged once per weight version."""
+        return self._cache.get("w2c", (self.net[3].weight,),
+                               lambda: runtime.ffn_chunk_w2(self._staged(torch.bfloat16)[1]))
 
     def fused_with_norm_ok(self, x: Tensor) -> bool:
         """Can `forward_with_norm` emit the next LayerNorm from the fused kernel's epilogue for this input?"""
@@ -126,6 +132,11 @@ class FeedForward(nn.Module, Constructor):
         (.., eps, .., "stats") also the output rows' (mean, rstd) for the next layer's q/kv GEMM.  Returns (y, stats)."""
         w1, _ = self._staged(torch.bfloat16)
         want = next_norm is not None and next_norm[4] == "stats"
+        if self.pair_kernel and x.shape[-1] == 384 and self.net[3].bias is None and w1.shape[0] % 32 == 0:
+            res = runtime.ffn_prenorm2(x, norm.weight, norm.bias, w1, self._chunked_w2(), mask=mask,
+                                       flags=runtime.EP_MASK_OUT if mask is not None else 0, norm_eps=norm.eps,
+                                       want_stats=want, stats_eps=next_norm[2] if want else 1e-5)
+            return res if want else (res, None)
         res = runtime.ffn_prenorm(x, norm.weight, norm.bias, w1, self._packed_w2(), mask=mask, bias2=self.net[3].bias,
                                   flags=runtime.EP_MASK_OUT if mask is not None else 0, norm_eps=norm.eps,
                                   want_stats=want, stats_eps=next_norm[2] if want else 1e-5)

@@ -40,6 +40,8 @@ SIGNATURES = {
     "ispk_ffn_bf16_ln": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64,
                          _U32, _P],
     "ispk_ffn_bf16_prenorm": [_P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
+    "ispk_ffn_chunk_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
+    "ispk_ffn_bf16_prenorm2": [_P, _I64, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
     "ispk_attn_out_ffn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32,
                                _P, _F32, _P],
     "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _F32, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
@@ -392,6 +394,38 @@ def ffn_prenorm(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w
     _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_prenorm, x2.data_ptr(),
             x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w1.stride(0),
             w2p.data_ptr(), _ptr(bias2), _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())
+    return (out, stats) if want_stats else out
+
+
+def ffn_chunk_w2(w2: Tensor) -> Tensor:
+    """ispk_ffn_chunk_w2_bf16: W2 bf16 [D, inner] -> chunk-contiguous [inner/32, D, 32] (weight staging for ffn_prenorm2)."""
+    _dev(w2)
+    assert w2.dtype == torch.bfloat16 and w2.dim() == 2 and w2.stride(1) == 1
+    D, Fi = w2.shape
+    out = torch.empty((Fi // 32, D, 32), dtype=torch.bfloat16, device=w2.device)
+    _launch("ffn_chunk_w2_kernel", 0.0, 4.0 * D * Fi, lib().ispk_ffn_chunk_w2_bf16, w2.data_ptr(), w2.stride(0), D, Fi,
+            out.data_ptr(), _stream())
+    return out
+
+
+def ffn_prenorm2(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2c: Tensor, mask: Optional[Tensor] = None,
+                 flags: int = 0, norm_eps: float = 1e-5, want_stats: bool = False, stats_eps: float = 1e-5):
+    """ispk_ffn_bf16_prenorm2 (dim 384, eight-wave kernel): out fp32 [..., D] = [mask] * (x + gelu(LN(x) @ w1^T) @ w2^T) from the
+    fp32 rows x; with `want_stats` also the (mean, rstd) of the output rows, fp32 [rows, 2].  w2c = `ffn_chunk_w2(w2)`."""
+    _dev(x, norm_weight, norm_bias, w1, w2c, mask)
+    assert x.dtype == torch.float32 and w1.dtype == torch.bfloat16 and w2c.dtype == torch.bfloat16
+    x2 = _rows2d(x)
+    R, D = x2.shape
+    Fi = w1.shape[0]
+    assert w1.shape == (Fi, D) and w1.is_contiguous() and w2c.shape == (Fi // 32, D, 32) and w2c.is_contiguous()
+    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
+    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+    nb = x2.numel() * 8 + (w1.numel() + w2c.numel()) * 2 + out.numel() * 4 + (R * 8 if want_stats else 0)
+    _launch(f"ffn2_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_prenorm2, x2.data_ptr(),
+            x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w2c.data_ptr(), _ptr(mask),
+            out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())
     return (out, stats) if want_stats else out
 
 

@@ -430,6 +430,44 @@ def test_fused_ffn_row_statistics_feed_the_next_linear():
     assert err.max().item() <= 2 ** -5 and err.pow(2).mean().sqrt().item() <= 2e-3
 
 
+@pytest.mark.parametrize("R,Fi,masked", [(128 * 9 + 17, 1536, True), (128 * 3, 1536, False), (70, 64, True), (128 * 40, 1536, True)])
+def test_eight_wave_ffn_kernel(R, Fi, masked):
+    """ispk_ffn_bf16_prenorm2 (csrc/ffn2.hip: two waves per SIMD, K-split first product, partial sums and P handed over
+    through LDS, three-stage pipeline) against float64 on the un-rounded LayerNorm, and against the four-wave kernel -
+    same math, another summation order and a coarser (still sub-bf16-ulp) GELU; ragged row counts, masked rows exactly
+    zero, the output rows' statistics, run-to-run determinism."""
+    D = 384
+    x = synth._normal(f"t/ffn2/x{R}", (R, D), 1.5, 0.4)
+    w1, w2 = _bf(synth._normal(f"t/ffn2/w1{Fi}", (Fi, D), D ** -0.5)), _bf(synth._normal(f"t/ffn2/w2{Fi}", (D, Fi), Fi ** -0.5))
+    g, b = synth._normal("t/ffn2/g", (D,), 0.1, 1.0), synth._normal("t/ffn2/b", (D,), 0.1)
+    mask = (torch.arange(R) % 7 != 3) if masked else None
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    w2c = runtime.ffn_chunk_w2(d(w2))
+    assert torch.equal(w2c.cpu(), w2.view(D, Fi // 32, 32).permute(1, 0, 2).contiguous())
+    fl = runtime.EP_MASK_OUT if masked else 0
+    out, stats = runtime.ffn_prenorm2(d(x), d(g), d(b), d(w1), w2c, mask=d(mask), flags=fl, want_stats=True)
+    again = runtime.ffn_prenorm2(d(x), d(g), d(b), d(w1), w2c, mask=d(mask), flags=fl)
+    assert torch.equal(out, again)
+    out = out.cpu()
+    x64 = x.double()
+    hn = (x64 - x64.mean(1, keepdim=True)) / torch.sqrt(x64.var(1, unbiased=False, keepdim=True) + 1e-5) * g.double() + b.double()
+    ref64 = x64 + F.gelu(hn @ w1.double().t()) @ w2.double().t()
+    if masked:
+        ref64 = ref64 * mask[:, None]
+        assert out[~mask].abs().max().item() == 0.0
+    err = (out.double() - ref64).abs()
+    print(f"ffn2 R={R} Fi={Fi}: max err vs float64 = {err.max().item():.3e}, rms = {err.pow(2).mean().sqrt().item():.3e}")
+    assert err.max().item() <= 0.06 and err.pow(2).mean().sqrt().item() <= 6e-3
+    if Fi % 32 == 0 and Fi >= 64:
+        old = runtime.ffn_prenorm(d(x), d(g), d(b), d(w1), runtime.ffn_pack_w2(d(w2)), mask=d(mask), flags=fl).cpu()
+        e2 = (out - old).abs()
+        assert e2.max().item() <= 3e-2 and e2.pow(2).mean().sqrt().item() <= 2e-3
+    o64 = out.double()
+    assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
+    rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
+    assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
+
+
 @pytest.mark.parametrize("R,D,Fi,masked", [(128 * 9 + 17, 384, 1536, True), (300, 256, 1024, True), (128 * 3, 384, 1536, False)])
 def test_fused_ffn_with_layernorm_prologue(R, D, Fi, masked):
     """ispk_ffn_bf16_prenorm == LayerNorm kernel (bf16 out, row mask) -> ispk_ffn_bf16 with the fp32 rows as residual:

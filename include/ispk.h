@@ -287,7 +287,8 @@ int32_t ispk_alibi_mqa_attn_bf16_tiles(const uint16_t* q, int64_t ldq, const uin
  * ispk_soft_average_f32    TemporalAverager soft branch for pitch and energy plus log1p(duration)
  *                          (models/acoustic/modules/temporal_adaptor.py:257-269, :446-449):
  *                          feats[b][l] = { log1p(dur[b][l]), mask*sum_m pitch[b][m] A[b][m][l] / (sum_m A + 1e-5), same for
- *                          energy }, feats [B][L][3].
+ *                          energy }, feats [B][L][3].  duration may be NULL (column 0 is then written as 0): the pitch /
+ *                          energy targets need only attn_soft, so they can be had before MAS has finished.
  */
 int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_c, const int64_t* len,
                           void* out, int32_t out_bf16, int32_t B, int32_t T, int32_t C, ispk_stream_t stream);
@@ -332,7 +333,10 @@ int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow, const flo
  *                           soft path of :468-478 generated on the fly from the fp32 durations (infer, :388-397):
  *                           P[t][y] = clamp(cum[t] - y, 0, 1) - clamp(cum[t-1] - y, 0, 1), cum = cumsum(dur) in index order,
  *                           masked by t < enc_len[b] (NULL: L) and y < dec_len[b].  Exactly one of dur_f32 / dur_i64
- *                           [B][L] is given (int64: the MAS durations).  x fp32 [B][L][D] rows at stride ldx, D 256 / 384;
+ *                           is given: fp32 [B][L], or int64 [B][dur_cols] (the MAS durations, dur_cols = L; they are only
+ *                           summed, so any [B][dur_cols] array with the same row sums serves - the teacher-forced forward
+ *                           passes mel_len as [B][1], which equals the sum of the MAS durations by construction, and so
+ *                           does not wait for MAS).  x fp32 [B][L][D] rows at stride ldx, D 256 / 384;
  *                           exact fp32 products (v_mfma_f32_32x32x2_f32). */
 int32_t ispk_embed_tokens_f32(const int64_t* text, const float* table, int64_t ld_table, int32_t vocab,
                               const int64_t* text_len, float* emb, uint8_t* mask, int32_t B, int32_t L, int32_t D,
@@ -342,7 +346,7 @@ int32_t ispk_time_embedding_f32(const float* t, int32_t n, const float* inv_freq
                                 float* out, ispk_stream_t stream);
 int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, const int64_t* dur_i64, const int64_t* enc_len,
                                  const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
-                                 int32_t M, int32_t L, int32_t D, int32_t max_len, ispk_stream_t stream);
+                                 int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream);
 
 /* fp32 -> bf16 conversion (round-to-nearest-even) of a [rows][cols] matrix; used to stage weights/activations. */
 int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int32_t rows, int32_t cols,

@@ -141,12 +141,20 @@ class Aligner(nn.Module, Constructor):
                                        attention_prior=attention_prior)
 
     def forward(self, mel: Tensor, enc_text: Tensor, mel_len: Tensor, text_len: Tensor,
-                q_proj: Optional[Tensor] = None) -> AlignerOutput:
+                q_proj: Optional[Tensor] = None, mas_stream=None) -> AlignerOutput:
         """alignment.py:259-289.  The duration fix-up of :278-282 (an item whose durations do not sum to mel_len gets the
         difference added to column 0) happens inside the MAS kernel, on the device and unconditionally - the reference
         tests `torch.all(...)` on the host first; adding a zero difference gives the same result without the round trip."""
         attn_soft, attn_logits = self.attention(mel, enc_text, mel_len, text_len, q_proj=q_proj)
-        attn_hard, dur = self.binarize_attention_parallel(attn_logits, text_len, mel_len, return_duration=True)
+        if mas_stream is not None and attn_logits.is_cuda:
+            # `mas_stream`: MAS (one wavefront per utterance: 64 waves on a 1024-SIMD chip for 80 us) runs on that stream
+            # beside whatever the caller launches next; the caller joins the stream before it reads attn_hard / durations
+            mas_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(mas_stream):
+                attn_hard, dur = self.binarize_attention_parallel(attn_logits, text_len, mel_len, return_duration=True)
+            attn_logits.record_stream(mas_stream)
+        else:
+            attn_hard, dur = self.binarize_attention_parallel(attn_logits, text_len, mel_len, return_duration=True)
         return AlignerOutput(attn_soft=attn_soft, attn_logits=attn_logits, attn_hard=attn_hard, attn_hard_duration=dur)
 
     @torch.no_grad()

@@ -101,7 +101,12 @@ class AcousticModel(nn.Module, Constructor):
         q_proj = None
         if mel.is_cuda and self.overlap_streams:
             main = torch.cuda.current_stream()
-            side = self._side_streams.setdefault(mel.device, torch.cuda.Stream(device=mel.device))
+            # HIGH priority: the side branches are chains of small launches (aligner mel-side convolutions; MAS and the flow
+            # predictor) beside chip-filling ones on the main stream - at equal priority they only get the CUs the big
+            # kernels leave over, and the predictor's chain then ends 100 us after the decoder instead of inside it
+            if mel.device not in self._side_streams:
+                self._side_streams[mel.device] = torch.cuda.Stream(device=mel.device, priority=-1)
+            side = self._side_streams[mel.device]
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 q_proj = self.aligner.attention.project_queries(mel, mel_len)
@@ -110,22 +115,26 @@ class AcousticModel(nn.Module, Constructor):
         if q_proj is not None:
             main.wait_stream(side)
             q_proj.record_stream(main)
+        # MAS and the flow predictor (which wants the MAS durations as a target) leave the main stream here: the decoder
+        # path needs neither - it is built from attn_soft and the dense targets, and its lengths are sum(durations) =
+        # mel_len.  They run on the side stream beside the embedding stack, the length regulator and the decoder.
+        branch = side if q_proj is not None else None
         aligner_output = self.aligner(mel=mel, enc_text=enc_out.transpose(1, 2).detach(), mel_len=mel_len,
-                                      text_len=text_len, q_proj=q_proj)
+                                      text_len=text_len, q_proj=q_proj, mas_stream=branch)
         adaptor_output = self.temporal_adaptor(
             enc_out=enc_out, enc_mask=enc_mask, max_dec_len=mel.size(2),
             duration_target=aligner_output.attn_hard_duration, alignment=aligner_output.attn_soft,
             pitch_target_dense=pitch, energy_target_dense=energy, noise=flow_noise, time_steps=flow_time,
-            enc_len=text_len, predictor_stream=side if q_proj is not None else None)
+            enc_len=text_len, predictor_stream=branch, duration_sum=mel_len if branch is not None else None)
         dec_len = adaptor_output.dec_lengths
         dec_mask = adaptor_output.dec_mask              # arange(frames) < dec_len, from the length-regulation kernel
         dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, key_len=dec_len, out_dtype=self.compute_dtype).out
         mel_out = self._to_mel(dec_out, dec_mask)
         if q_proj is not None:
-            # join the flow-predictor branch (it ran beside the embedding stack and the decoder) before handing out its tensors
+            # join the MAS / flow-predictor branch (it ran beside the embedding stack and the decoder) before handing out its tensors
             main.wait_stream(side)
             for t in (adaptor_output.log_duration, adaptor_output.duration, adaptor_output.pitch, adaptor_output.energy,
-                      *(adaptor_output.losses or {}).values()):
+                      aligner_output.attn_hard, aligner_output.attn_hard_duration, *(adaptor_output.losses or {}).values()):
                 if isinstance(t, Tensor):
                     t.record_stream(main)
         return AcousticModelOutput(mel=mel_out, adaptor_output=adaptor_output, aligner_output=aligner_output)

@@ -210,36 +210,60 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
                 alignment: Optional[Tensor] = None, pitch_target_dense: Optional[Tensor] = None,
                 energy_target_dense: Optional[Tensor] = None, *, noise: Optional[Tensor] = None,
                 time_steps: Optional[Tensor] = None, enc_len: Optional[Tensor] = None,
-                predictor_stream=None) -> TemporalAdaptorOutput:
+                predictor_stream=None, duration_sum: Optional[Tensor] = None) -> TemporalAdaptorOutput:
         """temporal_adaptor.py:238-312 (teacher-forced: the decoder input uses the TARGET pitch/energy, :284,:292).
-        The three flow targets (log1p duration, soft-averaged pitch and energy, :257-269) come from ONE kernel.
 
-        `predictor_stream`: in the teacher-forced forward the flow predictor's outputs (predicted duration / pitch /
-        energy, flow loss) feed nothing downstream - the decoder input is built from the TARGETS - so that whole branch
-        (a 2-layer AdaLN stack on 6,400 rows: small, latency-bound launches) can run on this second stream beside the
-        embedding stack, the length regulator and the decoder.  The CALLER joins the stream before using those outputs
-        (`AcousticModel.forward` does, just before returning)."""
+        What the DECODER waits for is short: pitch / energy targets (soft averages over attn_soft), the embedding stack,
+        the length regulator.  Two things it does not wait for:
+          * the flow predictor - its outputs (predicted duration / pitch / energy, flow loss) feed nothing downstream in
+            the teacher-forced forward; with `predictor_stream` its ~40 small launches go to that stream, issued AFTER the
+            decoder-critical ones (in a captured graph launch order follows creation order);
+          * the hard alignment - `duration_target` enters the decoder path only as dec_lens = sum of durations, and
+            `duration_sum` (int64 [B]) says what that sum is (AcousticModel.forward passes mel_len: the MAS durations add
+            up to it by construction, alignment.py:278-282).  `duration_target` itself may then still be in flight on
+            `predictor_stream` (MAS runs there); it is only read on that stream (log1p duration target of the predictor).
+        The CALLER joins `predictor_stream` before using the predictor's outputs (`AcousticModel.forward` does)."""
         assert alignment is not None and duration_target is not None
         assert pitch_target_dense is not None and energy_target_dense is not None
         m3 = enc_mask[..., None]
         if enc_len is None:
             enc_len = enc_mask.sum(dim=1)
-        targets = runtime.soft_average(alignment, pitch_target_dense, energy_target_dense, duration_target, enc_len)
-        pitch_target, energy_target = targets[..., 1:2], targets[..., 2:3]
+        side = predictor_stream if (predictor_stream is not None and enc_out.is_cuda) else None
+        cond = enc_out
+        if side is None or duration_sum is None:
+            # one stream, or no shortcut for the lengths: the three flow targets (log1p duration, soft-averaged pitch and
+            # energy, :257-269) from ONE kernel, read by both branches
+            targets = runtime.soft_average(alignment, pitch_target_dense, energy_target_dense, duration_target, enc_len)
+            feats = targets
+            len_src = duration_target
+        else:
+            feats = runtime.soft_average(alignment, pitch_target_dense, energy_target_dense, None, enc_len)   # no durations
+            targets = None
+            len_src = duration_sum.view(-1, 1)
+        if side is not None:   # the predictor's inputs are complete here; its launches are issued further down
+            ready = torch.cuda.Event()
+            ready.record()
+        pitch_target, energy_target = feats[..., 1:2], feats[..., 2:3]
+        features = feats[..., 1:3]                   # = cat([pitch_target, energy_target], -1): a view, no copy
+        enc_out = self.embedding(features, mask=m3, key_len=enc_len, residual=enc_out)   # enc_out + embedding(...)
+        enc_out, dec_lens = self.length_regulator(enc_out, len_src, max_len=max_dec_len, alignment=alignment)
+
         def predict():
-            pred_, losses_ = self.predictor(enc_out, targets, m3, noise=noise, time_steps=time_steps, key_len=enc_len)
+            tg = targets
+            if tg is None:     # on the predictor's stream, behind MAS: the targets again, with the log1p durations this time
+                tg = runtime.soft_average(alignment, pitch_target_dense, energy_target_dense, duration_target, enc_len)
+            pred_, losses_ = self.predictor(cond, tg, m3, noise=noise, time_steps=time_steps, key_len=enc_len)
             return pred_, losses_, self.predictor._duration_estimate   # = clamp(exp(pred[..., 0]) - 1, min=0)
 
-        if predictor_stream is not None and enc_out.is_cuda:
-            predictor_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(predictor_stream):
+        if side is not None:
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
                 pred, losses, duration_pred = predict()
+            for t in (cond, feats, alignment, pitch_target_dense, energy_target_dense):
+                t.record_stream(side)
         else:
             pred, losses, duration_pred = predict()
         log_duration_pred = pred[..., 0]
-        features = targets[..., 1:3]                 # = cat([pitch_target, energy_target], -1): a view, no copy
-        enc_out = self.embedding(features, mask=m3, key_len=enc_len, residual=enc_out)   # enc_out + embedding(...)
-        enc_out, dec_lens = self.length_regulator(enc_out, duration_target, max_len=max_dec_len, alignment=alignment)
         return TemporalAdaptorOutput(enc_out=enc_out, log_duration=log_duration_pred, duration=duration_pred,
                                      dec_lengths=dec_lens, pitch=pred[..., 1], energy=pred[..., 2],
                                      pitch_target=pitch_target.squeeze(-1), energy_target=energy_target.squeeze(-1),

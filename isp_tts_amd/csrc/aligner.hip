@@ -382,7 +382,7 @@ __global__ __launch_bounds__(64 * kSaLanes) void soft_average_kernel(const float
         }
         const float mk = l < (int)text_len[b] ? 1.0f : 0.0f;
         float* f = feats + ((int64_t)b * L + l) * 3;
-        f[0] = log1pf((float)dur[(int64_t)b * L + l]);
+        f[0] = dur ? log1pf((float)dur[(int64_t)b * L + l]) : 0.0f;
         f[1] = pp / (a + 1e-5f) * mk;
         f[2] = ee / (a + 1e-5f) * mk;
     }
@@ -535,7 +535,7 @@ extern "C" int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_
 extern "C" int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const float* energy,
                                          const int64_t* duration, const int64_t* text_len, float* feats, int32_t B,
                                          int32_t M, int32_t L, ispk_stream_t stream) {
-    ISPK_REQUIRE(attn_soft && pitch && energy && duration && text_len && feats, ISPK_E_NULL, "soft_average: null pointer");
+    ISPK_REQUIRE(attn_soft && pitch && energy && text_len && feats, ISPK_E_NULL, "soft_average: null pointer");
     ISPK_REQUIRE(B >= 0 && M >= 1 && L >= 1 && B <= 65535, ISPK_E_SHAPE, "soft_average: bad shape B=%d M=%d L=%d", B, M, L);
     if (B == 0) return 0;
     hipLaunchKernelGGL(soft_average_kernel, dim3((L + 63) / 64, B), dim3(64 * kSaLanes), 0, reinterpret_cast<hipStream_t>(stream),

@@ -43,7 +43,7 @@ constexpr int kW2Bytes = kD * kHC * 2;           // 24,576: W2 chunk [384 featur
 constexpr int kWbuf = kW1Bytes + kW2Bytes;       // 50,176 per buffer, two buffers
 constexpr int kDmaPerWave = 7;                   // 49 instructions per group over 8 waves: wave w issues q = w, w + 8, ...
 constexpr int kPOff = 2 * kWbuf;                 // P tiles  [2][4 row groups][32 rows][64 B]
-constexpr int kXcOff = kPOff + 2 * 4 * 2048;     // exchange [2][8 waves][64 lanes][32 B]
+constexpr int kXcOff = kPOff + 2 * 4 * 2048;     // exchange [2][8 waves][2 planes][64 lanes][16 B]
 constexpr int kLds = kXcOff + 2 * 8 * 2048;      // 149,504 B
 constexpr int kXtOff = kWbuf;                    // prologue: LN(x) tile [128 rows][768 B] over buffer 1 + P + exchange
 constexpr int kLdT = 388;                        // epilogue: fp32 tile [64 rows][388] at 0 (99,328 B)
@@ -308,7 +308,8 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
 
     auto prefetch1 = [&](int it) __attribute__((always_inline)) {     // first 4 W1 fragments of chunk `it`
         const uint32_t a = w1a + (it & 1) * kWbuf;
-        static_for<0, 4>([&](auto kc) { lds_read_b128_asm<32 * decltype(kc)::value>(r1[decltype(kc)::value], a); });
+        if constexpr (ABL != 11)
+            static_for<0, 4>([&](auto kc) { lds_read_b128_asm<32 * decltype(kc)::value>(r1[decltype(kc)::value], a); });
     };
     auto product1 = [&](int it, bool dma) __attribute__((always_inline)) {   // S = W1[chunk it][:, this half of K] · xfᵀ ; send 8, keep 8
         const uint32_t a = w1a + (it & 1) * kWbuf;
@@ -318,18 +319,18 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
         if constexpr (kPrio) __builtin_amdgcn_s_setprio(1);
         static_for<0, 12>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
-            lds_wait<(11 - ks) < 3 ? (11 - ks) : 3>();            // fragment ks is in; up to 3 younger reads may be in flight
+            if constexpr (ABL != 11) lds_wait<(11 - ks) < 3 ? (11 - ks) : 3>();   // fragment ks is in; up to 3 younger reads may be in flight
             __builtin_amdgcn_sched_barrier(0);
             S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1[ks & 3], xf[ks], S, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ks + 4 < 12) lds_read_b128_asm<32 * (ks + 4)>(r1[ks & 3], a);
+            if constexpr (ks + 4 < 12 && ABL != 11) lds_read_b128_asm<32 * (ks + 4)>(r1[ks & 3], a);
             if constexpr ((ks & 3) == 1) {
                 if (dma) dma_one(std::integral_constant<int, ks / 4>{});           // DMA instructions 0, 1, 2
             }
         });
         if constexpr (kPrio) __builtin_amdgcn_s_setprio(0);
         // S[r] = partial H[hidden (r & 3) + 8 (r >> 2) + 4 h][row l31]; half 0 finishes r < 8, half 1 finishes r >= 8
-        f32x4* xc = reinterpret_cast<f32x4*>(smem + kXcOff + ((it & 1) * 8 + wave) * 2048 + lane * 32);
+        f32x4* xc = reinterpret_cast<f32x4*>(smem + kXcOff + ((it & 1) * 8 + wave) * 2048 + lane * 16);   // two 1-KB planes
         f32x4 s0, s1v;
         if (half == 0) {
 #pragma unroll
@@ -343,11 +344,11 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             for (int i = 0; i < 8; ++i) keep[i] = S[8 + i];
         }
         xc[0] = s0;
-        xc[1] = s1v;
+        xc[64] = s1v;
     };
     auto finish = [&](int c) __attribute__((always_inline)) {         // chunk c: own + partner's partial sums -> GELU -> bf16 -> P tile
-        const f32x4* pc = reinterpret_cast<const f32x4*>(smem + kXcOff + ((c & 1) * 8 + (wave ^ 4)) * 2048 + lane * 32);
-        const f32x4 a0 = pc[0], a1 = pc[1];
+        const f32x4* pc = reinterpret_cast<const f32x4*>(smem + kXcOff + ((c & 1) * 8 + (wave ^ 4)) * 2048 + lane * 16);
+        const f32x4 a0 = pc[0], a1 = pc[64];
         float g[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -372,20 +373,22 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     };
     auto prefetch2 = [&](int it) __attribute__((always_inline)) {     // the P fragments and the first 4 W2 fragments
         const uint32_t b0 = w2a0 + (it & 1) * kWbuf, b1 = w2a1 + (it & 1) * kWbuf;
-        lds_read_b128_asm<0>(pb[0], pa0 + (it & 1) * 8192);
-        lds_read_b128_asm<0>(pb[1], pa1 + (it & 1) * 8192);
-        static_for<0, 4>([&](auto jc) { w2read(jc, b0, b1); });
+        if constexpr (ABL != 11) {
+            lds_read_b128_asm<0>(pb[0], pa0 + (it & 1) * 8192);
+            lds_read_b128_asm<0>(pb[1], pa1 + (it & 1) * 8192);
+            static_for<0, 4>([&](auto jc) { w2read(jc, b0, b1); });
+        }
     };
     auto product2 = [&](int it, bool dma) __attribute__((always_inline)) {   // acc2 += W2[this half's 192 features][chunk it - 2] · Pᵀ
         const uint32_t b0 = w2a0 + (it & 1) * kWbuf, b1 = w2a1 + (it & 1) * kWbuf;
         if constexpr (kPrio) __builtin_amdgcn_s_setprio(1);
         static_for<0, 12>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            lds_wait<(11 - j) < 3 ? (11 - j) : 3>();
+            if constexpr (ABL != 11) lds_wait<(11 - j) < 3 ? (11 - j) : 3>();
             __builtin_amdgcn_sched_barrier(0);
             acc2[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2[j & 3], pb[j & 1], acc2[j >> 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j + 4 < 12) w2read(std::integral_constant<int, j + 4>{}, b0, b1);
+            if constexpr (j + 4 < 12 && ABL != 11) w2read(std::integral_constant<int, j + 4>{}, b0, b1);
             if constexpr ((j & 3) == 1) {
                 if (dma) dma_one(std::integral_constant<int, 3 + j / 4>{});        // DMA instructions 3, 4, 5
             }
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             // it-1 released; nothing in the last iteration (the epilogue reuses the buffers right after the loop)
             bool dma = it <= nchunks && (ABL != 1 || it < 2);
             dma_begin(it + 1 < nchunks ? it + 1 : nchunks - 1, it < 1 ? 0 : (it <= nchunks ? it - 1 : nchunks - 1), (it + 1) & 1);
-            const bool p1 = ABL != 2 && it < nchunks, fi = ABL != 2 && it >= 1 && it <= nchunks, p2 = ABL != 2 && it >= 2;
+            const bool p1 = ABL != 2 && it < nchunks, fi = ABL != 2 && ABL != 10 && it >= 1 && it <= nchunks, p2 = ABL != 2 && it >= 2;
             // a stage that does not run this iteration (pipeline fill / drain) cannot carry its share of the DMA group
             if constexpr (kDmaHalf0) {   // experiment: half 0 (which waits at the barrier anyway) issues the whole group
                 if (dma && half == 0) {
@@ -630,6 +633,16 @@ extern "C" int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const flo
         if (atoi(e) == 9) {
             ISPK_RESERVE_LDS((&ffn2_bf16_kernel<9>), kLds, "ffn_prenorm2");
             hipLaunchKernelGGL(ffn2_bf16_kernel<9>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 10) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<10>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<10>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 11) {
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<11>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<11>, grid, dim3(512), kLds, s, p);
             return ispk_launch_status();
         }
         if (atoi(e) == 5) {

@@ -81,7 +81,8 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
                                                               const int64_t* __restrict__ enc_len,
                                                               const float* __restrict__ x, int64_t ldx,
                                                               float* __restrict__ out, int64_t* __restrict__ dec_len,
-                                                              uint8_t* __restrict__ dec_mask, int M, int L, int max_len) {
+                                                              uint8_t* __restrict__ dec_mask, int M, int L, int max_len,
+                                                              int dur_cols) {
     constexpr int D = 128 * NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     int64_t& s_dec = *reinterpret_cast<int64_t*>(smem);                      // (all LDS in the dynamic region: a static
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
         int64_t dl;
         if (dur_i) {
             int64_t s = 0;
-            for (int t = lane; t < L; t += 64) s += dur_i[(int64_t)b * L + t];
+            for (int t = lane; t < dur_cols; t += 64) s += dur_i[(int64_t)b * dur_cols + t];
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
             dl = (int64_t)((float)s + 0.5f);
@@ -236,11 +237,13 @@ extern "C" int32_t ispk_time_embedding_f32(const float* t, int32_t n, const floa
 extern "C" int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, const int64_t* dur_i64,
                                             const int64_t* enc_len, const float* x, int64_t ldx, float* out,
                                             int64_t* dec_len, uint8_t* dec_mask, int32_t B, int32_t M, int32_t L, int32_t D,
-                                            int32_t max_len, ispk_stream_t stream) {
+                                            int32_t max_len, int32_t dur_cols, ispk_stream_t stream) {
     ISPK_REQUIRE(x && out && dec_len, ISPK_E_NULL, "length_regulate: null pointer");
     ISPK_REQUIRE((dur_f32 != nullptr) != (dur_i64 != nullptr), ISPK_E_NULL,
                  "length_regulate: exactly one of dur_f32 / dur_i64 must be given");
     ISPK_REQUIRE(alignment || dur_f32, ISPK_E_NULL, "length_regulate: the soft path (alignment NULL) needs fp32 durations");
+    ISPK_REQUIRE(dur_cols == L || (dur_i64 && dur_cols >= 1), ISPK_E_SHAPE,
+                 "length_regulate: dur_cols=%d (L, or any width >= 1 for int64 durations that are only summed)", dur_cols);
     ISPK_REQUIRE(B >= 0 && M >= 1 && L >= 1 && L <= 4096 && B <= 65535, ISPK_E_SHAPE,
                  "length_regulate: bad shape B=%d M=%d L=%d", B, M, L);
     ISPK_REQUIRE(D == 256 || D == 384, ISPK_E_UNSUPPORTED, "length_regulate: dim %d (built for 256 / 384)", D);
@@ -253,11 +256,11 @@ extern "C" int32_t ispk_length_regulate_f32(const float* alignment, const float*
     if (D == 384) {
         ISPK_RESERVE_LDS((&length_regulate_kernel<3>), lds, "length_regulate");
         hipLaunchKernelGGL(length_regulate_kernel<3>, grid, dim3(256), lds, s, alignment, dur_f32, dur_i64, enc_len, x, ldx,
-                           out, dec_len, dec_mask, M, L, max_len);
+                           out, dec_len, dec_mask, M, L, max_len, dur_cols);
     } else {
         ISPK_RESERVE_LDS((&length_regulate_kernel<2>), lds, "length_regulate");
         hipLaunchKernelGGL(length_regulate_kernel<2>, grid, dim3(256), lds, s, alignment, dur_f32, dur_i64, enc_len, x, ldx,
-                           out, dec_len, dec_mask, M, L, max_len);
+                           out, dec_len, dec_mask, M, L, max_len, dur_cols);
     }
     return ispk_launch_status();
 }

@@ -54,7 +54,7 @@ SIGNATURES = {
     "ispk_flow_finish_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_embed_tokens_f32": [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_time_embedding_f32": [_P, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P],
-    "ispk_length_regulate_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "ispk_length_regulate_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F32, _P],
     "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
@@ -644,13 +644,14 @@ def aligner_scores(q_enc: Tensor, k_enc: Tensor, text_len: Tensor, mel_len: Tens
     return soft, logits
 
 
-def soft_average(attn_soft: Tensor, pitch: Tensor, energy: Tensor, duration: Tensor, text_len: Tensor) -> Tensor:
-    """ispk_soft_average_f32 -> feats [B, L, 3] = (log1p(duration), pitch target, energy target)."""
+def soft_average(attn_soft: Tensor, pitch: Tensor, energy: Tensor, duration: Optional[Tensor], text_len: Tensor) -> Tensor:
+    """ispk_soft_average_f32 -> feats [B, L, 3] = (log1p(duration) - or 0 without durations -, pitch target, energy target)."""
     _dev(attn_soft, pitch, energy, duration, text_len)
     B, M, L = attn_soft.shape
     feats = torch.empty((B, L, 3), dtype=torch.float32, device=attn_soft.device)
+    dur = None if duration is None else duration.to(torch.int64).contiguous()
     _launch("soft_average_kernel", 0.0, 4.0 * B * M * L, lib().ispk_soft_average_f32, attn_soft.contiguous().data_ptr(),
-            pitch.contiguous().data_ptr(), energy.contiguous().data_ptr(), duration.to(torch.int64).contiguous().data_ptr(),
+            pitch.contiguous().data_ptr(), energy.contiguous().data_ptr(), _ptr(dur),
             text_len.to(torch.int64).contiguous().data_ptr(), feats.data_ptr(), B, M, L, _stream())
     return feats
 
@@ -725,11 +726,14 @@ def length_regulate(x: Tensor, durations: Tensor, alignment: Optional[Tensor], f
         assert alignment.dtype == torch.float32 and alignment.shape == (B, frames, L)
         alignment = alignment.contiguous()
     dur_f = dur_i = None
-    if durations.dtype == torch.int64:
+    dur_cols = L
+    if durations.dtype == torch.int64:   # only summed: any [B, cols] with the right row sums (e.g. mel_len as [B, 1])
         assert alignment is not None, "the soft path is generated from fp32 durations"
-        dur_i = durations.contiguous()
+        dur_i = durations.reshape(B, -1).contiguous()
+        dur_cols = dur_i.shape[1]
     else:
         dur_f = durations.to(torch.float32).contiguous()
+        assert dur_f.shape == (B, L)
     if enc_len is not None:
         enc_len = enc_len.to(torch.int64).contiguous()
     out = torch.empty((B, frames, D), dtype=torch.float32, device=x.device)
@@ -738,7 +742,7 @@ def length_regulate(x: Tensor, durations: Tensor, alignment: Optional[Tensor], f
     nb = 4.0 * B * (frames * D + L * D + (frames * L if alignment is not None else 0))
     _launch("length_regulate_kernel", 2.0 * B * frames * L * D, nb, lib().ispk_length_regulate_f32, _ptr(alignment),
             _ptr(dur_f), _ptr(dur_i), _ptr(enc_len), x.data_ptr(), x.stride(1), out.data_ptr(), dec_len.data_ptr(),
-            _ptr(mask), B, frames, L, D, max_len, _stream())
+            _ptr(mask), B, frames, L, D, max_len, dur_cols, _stream())
     return out, dec_len, mask
 
 

@@ -639,6 +639,10 @@ def test_length_regulate_with_an_alignment(B, M, L, D):
     # no clamp when max_len is not given
     _, dec2, _ = runtime.length_regulate(x.to(DEV), dur.to(DEV), a.to(DEV), M)
     assert torch.equal(dec2.cpu(), (dur.sum(1) + 0.5).long())
+    # the durations are only summed: a [B, 1] array with the same row sums gives the same lengths (what the teacher-forced
+    # forward passes - mel_len - so that the decoder path does not wait for MAS)
+    out3, dec3, mask3 = runtime.length_regulate(x.to(DEV), dur.sum(1, keepdim=True).to(DEV), a.to(DEV), M, max_len=M)
+    assert torch.equal(dec3, dec) and torch.equal(out3, out) and torch.equal(mask3, mask)
 
 
 @pytest.mark.parametrize("B,L,M,D", [(3, 100, 512, 384), (2, 37, 300, 384), (1, 50, 130, 256)])

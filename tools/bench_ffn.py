@@ -35,6 +35,8 @@ if runtime.LIB_PATH == build.LIB_EXP:
     variants["eight-wave + tanh-form GELU"] = ablated("7")
     variants["eight-wave + DMA issued by half 0 only"] = ablated("8")
     variants["eight-wave + all three"] = ablated("9")
+    variants["eight-wave without the finish stage (no GELU / exchange)"] = ablated("10")
+    variants["eight-wave, matrix stages without operand reads"] = ablated("11")
 for f in variants.values():
     for _ in range(3):
         f()

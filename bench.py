@@ -24,6 +24,7 @@ No work is skipped in any timed region; synthetic weights and inputs (isp_tts_am
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import socket
@@ -209,6 +210,12 @@ def worker(args) -> int:
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # stdout carries exactly ONE line, rank 0's JSON.  Libraries write there too (RCCL prints a five-line version banner
+    # when its first communicator comes up, on every rank): from here on descriptor 1 IS stderr, and the JSON line goes to
+    # a private duplicate of the original stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback of the product path)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -352,10 +359,16 @@ def worker(args) -> int:
             res = {"error": f"{type(e).__name__}: {e}"[:300]}
         if line is not None and res is not None:
             line[name] = res
+        # an extra's graph instances die HERE, with the device idle - not whenever the cyclic collector next runs (inside
+        # a later capture or replay, where destroying a graph aborts / crashes the HIP runtime)
+        torch.cuda.synchronize()
+        gc.collect()
 
     if not args.no_extras and not args.no_graph:
         # ------------------------------------------------------------------------- two batches in flight (all ranks)
         lanes = pipes = step = None          # release the headline's graph instance before the next capture
+        torch.cuda.synchronize()
+        gc.collect()
 
         def two_in_flight():
             st, pp, ln, _ = fixed_batch_runner(B, 2)
@@ -556,7 +569,8 @@ def worker(args) -> int:
                 line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
 
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+    os.close(json_fd)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

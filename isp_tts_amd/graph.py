@@ -8,6 +8,7 @@ Inputs are static buffers: `GraphedForward.__call__` copies new inputs in, repla
 """
 from __future__ import annotations
 
+import gc
 from typing import Optional
 
 import torch
@@ -30,8 +31,18 @@ class GraphedCall:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = fn()
+        # No cyclic garbage collection while the stream is capturing: collecting an unreachable OLD graph there runs
+        # hipGraphDestroy inside the capture ("operation not permitted when stream is capturing": abort, or a segfault in a
+        # later replay).  Collect first, at a point where the device is idle, then hold the collector off.
+        gc.collect()
+        gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = fn()
+        finally:
+            if gc_was_on:
+                gc.enable()
         # the graph holds raw pointers to the modules' staged weight images: remember their generation
         self._staged_at_capture = staging.replacements()
 

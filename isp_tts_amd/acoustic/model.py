@@ -101,12 +101,9 @@ class AcousticModel(nn.Module, Constructor):
         q_proj = None
         if mel.is_cuda and self.overlap_streams:
             main = torch.cuda.current_stream()
-            # HIGH priority: the side branches are chains of small launches (aligner mel-side convolutions; MAS and the flow
-            # predictor) beside chip-filling ones on the main stream - at equal priority they only get the CUs the big
-            # kernels leave over, and the predictor's chain then ends 100 us after the decoder instead of inside it
-            if mel.device not in self._side_streams:
-                self._side_streams[mel.device] = torch.cuda.Stream(device=mel.device, priority=-1)
-            side = self._side_streams[mel.device]
+            # (a high-priority side stream changes nothing for one graph - HIP graph replay does not seem to honour stream
+            # priorities - and it stops two graph instances in flight from overlapping at all: measured 4.99 vs 2.37 ms)
+            side = self._side_streams.setdefault(mel.device, torch.cuda.Stream(device=mel.device))
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 q_proj = self.aligner.attention.project_queries(mel, mel_len)

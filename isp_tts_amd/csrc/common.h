@@ -106,6 +106,25 @@ __device__ __forceinline__ float gelu_fast(float x) {
     v.y = x;
     return gelu_fast2(v).x;
 }
+// The same erf (Abramowitz-Stegun 7.1.28, |error| <= 3e-7) in plain scalar fp32, for fp32 outputs: |gelu error| <= 1.5e-7 |x|,
+// two orders below the fp32 path's 1e-4 mel bar, at 16 instructions instead of libm erff's ~40 with branches.
+__device__ __forceinline__ float gelu_as28(float x) {
+    const float ax = fabsf(x);
+    const float z = ax * 0.70710678118654752440f;
+    float q = fmaf(z, 0.0000430638f, 0.0002765672f);
+    q = fmaf(q, z, 0.0001520143f);
+    q = fmaf(q, z, 0.0092705272f);
+    q = fmaf(q, z, 0.0422820123f);
+    q = fmaf(q, z, 0.0705230784f);
+    q = fmaf(q, z, 1.0f);
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    q = q * q;
+    const float r = 1.0f / q;           // (IEEE division: q^16 overflows to +inf for |x| > ~25, 1/inf = 0 as it should be)
+    const float hx = 0.5f * ax;
+    return fmaf(0.5f, x, fmaf(-hx, r, hx));
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 constexpr int kWave = 64;

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     float v = acc[mi][ni][r] + bj;
-                    if (gelu) v = gelu_erf(v);
+                    if (gelu) v = gelu_as28(v);
                     if (silu_f) v = silu(v);
                     if (mask_acc) v *= mk[r];
                     v += rv[r];

@@ -82,12 +82,18 @@ def test_forward_against_reference_golden(gpu_model):
     print(f"forward mel L-inf vs reference = {d:.3e}")
     assert d < MEL_TOL
     assert np.array_equal(out.adaptor_output.dec_lengths.cpu().numpy(), g["dec_lengths"])
-    assert _maxdiff(out.aligner_output.attn_logits, g["attn_logits"]) < 1e-3      # PyTorch-ROCm conv front-end
-    assert _maxdiff(out.aligner_output.attn_soft[:, ::8], g["attn_soft_rows"]) < 1e-4
-    assert _maxdiff(out.adaptor_output.log_duration, g["log_duration"]) < 1e-3
-    assert _maxdiff(out.adaptor_output.pitch, g["pitch"]) < 1e-3
-    assert _maxdiff(out.adaptor_output.pitch_target, g["pitch_target"]) < 1e-4
-    assert abs(float(out.adaptor_output.losses["flow_loss"]) - float(g["flow_loss"])) < 1e-3
+    diffs = {"attn_logits": _maxdiff(out.aligner_output.attn_logits, g["attn_logits"]),
+             "attn_soft": _maxdiff(out.aligner_output.attn_soft[:, ::8], g["attn_soft_rows"]),
+             "log_duration": _maxdiff(out.adaptor_output.log_duration, g["log_duration"]),
+             "pitch": _maxdiff(out.adaptor_output.pitch, g["pitch"]),
+             "pitch_target": _maxdiff(out.adaptor_output.pitch_target, g["pitch_target"]),
+             "flow_loss": abs(float(out.adaptor_output.losses["flow_loss"]) - float(g["flow_loss"]))}
+    print("forward vs reference: " + ", ".join(f"{k} {v:.2e}" for k, v in diffs.items()))
+    assert diffs["attn_logits"] < 2e-4        # HIP front-end (fp32 MFMA convolutions); logits reach down to -35
+    assert diffs["attn_soft"] < 2e-5
+    assert diffs["log_duration"] < 1e-4 and diffs["pitch"] < 1e-4
+    assert diffs["pitch_target"] < 2e-5
+    assert diffs["flow_loss"] < 1e-5
     # MAS on the reference's own pre-MAS logits is bit-exact (the end-to-end path may differ at near-ties because the
     # front-end logits differ in the last bits, SURVEY 7 "MAS bit-exactness")
     hard = gpu_model.aligner.binarize_attention_parallel(torch.from_numpy(g["attn_logits"]).to(DEV),

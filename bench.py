@@ -572,6 +572,46 @@ def worker(args) -> int:
                                 "+ to_mel, fp32"}
         extra("config2_fp32", config2_line)
 
+        def ingest_line():
+            """PCIe-inclusive rate: collated HOST batches (the reference collator's dict, pageable memory) through
+            `ingest.BatchIngest` (pinned ring + copy stream) into the graphed forward; never the headline `value`."""
+            from isp_tts_amd import ingest
+            hb = []
+            for k in range(3):
+                i_ = synth.make_inputs(B, L, M, seed=synth.SEED + 50 + k)
+                hb.append({"text_vector": i_["text"], "text_vector_len": i_["text_len"], "mel": i_["mel"],
+                           "mel_len": i_["mel_len"], "pitch": i_["pitch"], "energy": i_["energy"]})
+            nbytes = sum(t.numel() * t.element_size() for t in hb[0].values())
+            g = GraphedForward(model, *fwd_args(d))
+            n = max(10, args.steps)
+
+            def overlapped():
+                ing = ingest.BatchIngest(dev, B, L, M, dims.mel_dim, slots=2)
+                ing.submit(hb[0])
+                for k in range(n):
+                    if k + 1 < n:
+                        ing.submit(hb[(k + 1) % 3])
+                    g(**ingest.model_inputs(ing.get()))
+                    ing.done()
+                torch.cuda.synchronize()
+
+            def synchronous():          # what accelerate's device placement does: pageable .to(device) on the compute stream
+                for k in range(n):
+                    g(**ingest.model_inputs({k_: v.to(dev) for k_, v in hb[k % 3].items()}))
+                torch.cuda.synchronize()
+            res = {}
+            for name, fn in (("overlapped", overlapped), ("synchronous_pageable", synchronous)):
+                fn()
+                t0 = time.perf_counter()
+                fn()
+                res[name] = (time.perf_counter() - t0) / n
+            return {"value": round(B * M / res["overlapped"], 1), "unit": "mel-frames/s",
+                    "ms_per_step": round(res["overlapped"] * 1e3, 3), "steps": n, "host_bytes_per_batch": nbytes,
+                    "synchronous_pageable_copy_ms_per_step": round(res["synchronous_pageable"] * 1e3, 3),
+                    "note": "host batches in pageable memory -> pinned slot (host memcpy on this thread) -> copy stream -> "
+                            "graph's input buffers; the copy of batch k+1 runs under the forward of batch k"}
+        extra("host_batches_over_pcie", ingest_line)
+
         if not args.no_cpu_baseline:
             extra("cpu_baseline", lambda: cpu_baseline(args, sd))
             if isinstance(line.get("cpu_baseline"), dict) and "value" in line["cpu_baseline"]:

@@ -571,3 +571,28 @@ def test_rccl_all_gather_of_mel_single_rank():
             assert torch.equal(g3[0], mel + 2) and torch.equal(l3[0], lens + 2)
     finally:
         dist.destroy_process_group()
+
+
+def test_batch_ingest_feeds_the_forward(gpu_model):
+    """Row f4 on the GPU: collator-layout host batches through pinned staging + a copy stream (`ingest.BatchIngest`), the
+    next batch's copy queued before the current one is consumed; the forward on the ingested tensors equals the forward on
+    directly uploaded ones, for every batch and after slots were reused."""
+    from isp_tts_amd import ingest
+    ing = ingest.BatchIngest(DEV, max_batch=6, max_text=60, max_mel=200, slots=2)
+    host, ref = [], []
+    for k, (b, l, m) in enumerate([(6, 60, 200), (4, 37, 150), (5, 60, 96), (6, 44, 200)]):
+        inp = synth.make_inputs(b, l, m, variable=True, seed=40 + k)
+        host.append((inp, {"text_vector": inp["text"], "text_vector_len": inp["text_len"], "mel": inp["mel"],
+                           "mel_len": inp["mel_len"], "pitch": inp["pitch"], "energy": inp["energy"]}))
+        d = {k_: v.to(DEV) for k_, v in inp.items()}
+        ref.append(gpu_model(d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
+                             flow_noise=d["flow_x0"], flow_time=d["flow_t"]).mel.clone())
+    ing.submit(host[0][1])
+    for k in range(4):
+        if k + 1 < 4:
+            ing.submit(host[k + 1][1])             # the next batch's copy is in flight while this one computes
+        got = ingest.model_inputs(ing.get())
+        assert got["mel"].is_cuda and got["mel"].shape == host[k][0]["mel"].shape
+        out = gpu_model(**got, flow_noise=host[k][0]["flow_x0"].to(DEV), flow_time=host[k][0]["flow_t"].to(DEV))
+        ing.done()
+        assert torch.equal(out.mel, ref[k]), f"batch {k}"

@@ -275,3 +275,36 @@ def test_load_filters_keys_like_the_reference_and_freeze_sets_requires_grad():
     trainable = {n for n, p in model.named_parameters() if p.requires_grad}
     assert trainable and all(n.startswith(("decoder.layers.5", "to_mel")) for n in trainable)
     assert any(n.startswith("to_mel") for n in trainable)
+
+
+def test_bucket_by_length_and_batch_ingest_on_cpu():
+    """Row f4 host logic: length buckets cover every sample once with little padding; BatchIngest hands back exactly what
+    the collator-layout batch held, slot after slot (CPU tensors: pinned memory / streams need the GPU box)."""
+    from isp_tts_amd import ingest
+    text_len, mel_len = synth.make_lengths(300, 200, 1024, variable=True, seed=9)
+    buckets = ingest.bucket_by_length(mel_len.tolist(), frame_budget=64 * 512)
+    assert sorted(i for b in buckets for i in b) == list(range(300))
+    padded = sum(len(b) * int(mel_len[b[0]]) for b in buckets)
+    assert all(len(b) * int(mel_len[b[0]]) <= 64 * 512 for b in buckets) and padded <= 1.15 * int(mel_len.sum())
+    assert all(int(mel_len[b[0]]) == max(int(mel_len[i]) for i in b) for b in buckets)
+    assert max(len(b) for b in ingest.bucket_by_length(mel_len.tolist(), 64 * 512, max_batch=40)) <= 40
+
+    ing = ingest.BatchIngest("cpu", max_batch=8, max_text=40, max_mel=96, slots=2)
+    batches = []
+    for k, (b, l, m) in enumerate([(8, 40, 96), (3, 17, 50), (5, 40, 33)]):
+        inp = synth.make_inputs(b, l, m, variable=True, seed=k)
+        batches.append({"text_vector": inp["text"], "text_vector_len": inp["text_len"], "mel": inp["mel"],
+                        "mel_len": inp["mel_len"], "pitch": inp["pitch"], "energy": inp["energy"]})
+    ing.submit(batches[0])
+    ing.submit(batches[1])
+    with pytest.raises(AssertionError):
+        ing.submit(batches[2])                       # both slots still hold batches nobody has taken
+    for k in range(3):
+        got = ing.get()
+        for name, t in batches[k].items():
+            assert got[name].shape == t.shape and torch.equal(got[name], t), name
+        kw = ingest.model_inputs(got)
+        assert set(kw) == {"text", "text_len", "mel", "mel_len", "pitch", "energy"} and kw["text"] is got["text_vector"]
+        ing.done()
+        if k == 0:
+            ing.submit(batches[2])

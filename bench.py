@@ -585,8 +585,9 @@ def worker(args) -> int:
             g = GraphedForward(model, *fwd_args(d))
             n = max(10, args.steps)
 
+            ing = ingest.BatchIngest(dev, B, L, M, dims.mel_dim, slots=2)     # pinned allocation: once, outside the loop
+
             def overlapped():
-                ing = ingest.BatchIngest(dev, B, L, M, dims.mel_dim, slots=2)
                 ing.submit(hb[0])
                 for k in range(n):
                     if k + 1 < n:

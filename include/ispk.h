@@ -348,6 +348,64 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
                                  const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
                                  int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Training step (BASELINE config 5) - first cut: fp32, dropout 0.  The reference has no backward code of its
+ * own (autograd of the modules above); what these replace is cited per entry.
+ *
+ * ispk_transpose_f32           y[c][r] = x[r][c]: weights for dX = dY . W through the NT GEMM (ispk_gemm_f32 wants W^T rows).
+ * ispk_gemm_tn_f32             C[N1][N2] (+)= sum_m mask[m] A[m][N1-slice] B[m][N2-slice]: dW = dY^T . X of every nn.Linear
+ *                              (autograd of F.linear).  Rows are split into ranges whose partial products go to `workspace`
+ *                              (>= N1*N2 floats; more = more ranges, up to 256) and are added in range order: deterministic.
+ *                              row_mask uint8 [M] or NULL; accumulate != 0 adds to C.
+ * ispk_layernorm_bwd_f32       backward of modules/transformer/normalization.py:20-31 followed by `* mask` (transformer.py:102):
+ *                              dx (=) or (+=, add_to_dx) rstd (g - mean(g) - xhat mean(g xhat)), g = dy mask gamma;
+ *                              dgamma = sum_rows dy mask xhat, dbeta = sum_rows dy mask (either may be NULL; both NULL needs no
+ *                              workspace, else ceil(rows / 64) * 2 * dim floats).  dim 256 or 384; statistics are recomputed
+ *                              from x (two-pass, as the forward kernel).
+ * ispk_gelu_f32                a = gelu(u), exact erf (modules/layers.py:29), as a pass of its own: the training forward keeps
+ *                              the pre-activation u for the backward (the inference GEMMs apply GELU in their epilogue).
+ * ispk_gelu_bwd_f32            du = da * (Phi(u) + u phi(u)): exact-erf GELU (modules/layers.py:29), n % 4 == 0.
+ * ispk_alibi_mqa_attn_bwd_f32  backward of ispk_alibi_mqa_attn_f32 (attend.py:49-122, embeddings.py:51-82, attention.py:128-152):
+ *                              qkv / dqkv fp32 [B][N][H*64 + 128] = [Q heads | K | V] at row stride ld_qkv, o / d_o fp32
+ *                              [B][N][H*64] at ld_o, slopes [H] = exp(learned_logslopes), key_len int64 [B] or NULL.
+ *                              dQ per head; dK, dV summed over the H heads that share them; dlogslopes[h] = slope_h *
+ *                              sum_ij dS_ij (-|i - j|) (or NULL).  The softmax statistics are recomputed (no state is
+ *                              kept from the forward).  workspace >= 2*B*H*N + H*B*ceil(N/32) floats.
+ * ispk_mel_loss_f32            models/acoustic/loss.py:22-35 (MelLoss, weight folded into grad_out by the caller):
+ *                              ratio[b] = sum over (c, t < mel_len[b]) of (out - target)^2 / max(C * len_b, 1e-5)
+ *                              (utils/functions.py:44-58), loss[0] = mean_b ratio[b]; grad (or NULL) = d loss / d mel_out *
+ *                              grad_out, zero on padded frames.  mel fp32 [B][C][T].
+ * ispk_grad_sqnorm_f32         out[0] = sum g[i]^2 over a flat gradient arena (what clip_grad_norm_ needs,
+ *                              experiments/optimizers.py:236-237); partial = 1024 floats of scratch; fixed summation order.
+ * ispk_adamw_f32               one torch.optim.AdamW step (optimizers.py:72-74; amsgrad off) over flat arenas p, g, m, v of n
+ *                              floats.  Elements [0, n_decay) are the weight-decay group of optimizers.py:15-20 (tensors
+ *                              with >= 2 non-unit dimensions): they get `weight_decay` and, when grad_sqnorm (device, the
+ *                              sum of squares of that group's UNSCALED gradients) is given, the clip coefficient
+ *                              min(1, max_norm / (grad_scale * sqrt(sqnorm) + 1e-6)) - the reference clips group 0 only.
+ *                              Every gradient is first multiplied by grad_scale (1 / world size after a summing
+ *                              reduce-scatter).  step >= 1 is the 1-based step count of the bias corrections. */
+int32_t ispk_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t rows, int32_t cols,
+                           ispk_stream_t stream);
+int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
+                         int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
+                         int64_t workspace_floats, ispk_stream_t stream);
+int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
+                               const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
+                               float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,
+                               float eps, ispk_stream_t stream);
+int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, ispk_stream_t stream);
+int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, ispk_stream_t stream);
+int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
+                                    const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
+                                    float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
+                                    ispk_stream_t stream);
+int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
+                          float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
+int32_t ispk_grad_sqnorm_f32(const float* g, int64_t n, float* partial, float* out, ispk_stream_t stream);
+int32_t ispk_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, int32_t step, const float* grad_sqnorm, float max_norm,
+                       float grad_scale, ispk_stream_t stream);
+
 /* fp32 -> bf16 conversion (round-to-nearest-even) of a [rows][cols] matrix; used to stage weights/activations. */
 int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int32_t rows, int32_t cols,
                            ispk_stream_t stream);

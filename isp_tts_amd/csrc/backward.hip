@@ -1,0 +1,559 @@
+// Backward kernels of the transformer stacks ("backward for attention / FFN / LN kernels"), fp32, gfx950.
+// First correct cut: exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere, operands fetched straight from global memory (L2
+// resident at these sizes) in MFMA-fragment order, no LDS staging yet.  Every reduction has a fixed order (two-stage
+// partial sums, no floating-point atomics), so gradients are reproducible run to run.
+//
+//   ispk_transpose_f32          weights for dX = dY . W  (the NT GEMM of gemm.hip wants W^T rows)
+//   ispk_gemm_tn_f32            dW = dY^T . X            (reduction over the rows; split over row ranges, then summed)
+//   ispk_layernorm_bwd_f32      normalization.py:20-31 backward (dx, d gamma, d beta), optional row mask
+//   ispk_gelu_bwd_f32           d/du of the exact-erf GELU (layers.py:29)
+//   ispk_alibi_mqa_attn_bwd_f32 attend.py:49-122 + embeddings.py:51-82 backward: dQ per head, dK / dV summed over the heads
+//                               that share them, d log-slope
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+
+// Row of the 32x32 fp32 accumulator tile that register r of lane l holds (the column is l % 32); also the order in which
+// a lane half walks the reduction index when an accumulator is fed back as an MFMA operand (step t <-> register t).
+__device__ __forceinline__ int acc_row(int r, int hf) { return 8 * (r >> 2) + 4 * hf + (r & 3); }
+
+// ------------------------------------------------------------------------------------------------ transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+                                                        int rows, int cols) {
+    __shared__ float t[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8)
+        if (r0 + k < rows && c0 + tx < cols) t[k][tx] = x[(int64_t)(r0 + k) * ldx + c0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < cols && r0 + tx < rows) y[(int64_t)(c0 + k) * ldy + r0 + tx] = t[tx][k];
+}
+
+// ------------------------------------------------------------------------------------------------ C = A^T . B  (over rows)
+// A [M][N1], B [M][N2] row-major, C [N1][N2].  With the rows as the MFMA reduction index both operands are read in their
+// natural layout: lane (c = l % 32, hf = l / 32) supplies A[m0 + 2t + hf][n1 + c] and B[m0 + 2t + hf][n2 + c] - two
+// coalesced 128-byte row segments per load instruction, no transposition anywhere.  A workgroup (2 x 2 waves) owns a
+// 128 x 128 tile of C for one range of rows; the ranges' partial tiles go to a workspace and a second kernel adds them in
+// range order (deterministic; optional accumulation into C).  `mask` (uint8 per row, or NULL) zeroes rows of A.
+template <bool kMask>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                      int64_t ldb, float* __restrict__ part, int M, int N1, int N2,
+                                                      int rows_per_split, const uint8_t* __restrict__ mask) {
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, hf = l >> 5;
+    const int n1 = blockIdx.x * 128 + (wave >> 1) * 64, n2 = blockIdx.y * 128 + (wave & 1) * 64;
+    const int split = blockIdx.z;
+    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const bool a0 = n1 + c < N1, a1 = n1 + 32 + c < N1, b0 = n2 + c < N2, b1 = n2 + 32 + c < N2;
+    const float* pa = A + n1 + c;
+    const float* pb = B + n2 + c;
+    for (int m0 = m_begin; m0 < m_end; m0 += 16) {   // 8 MFMA k-steps (16 rows) per trip: 32 loads in flight per wave
+        float va0[8], va1[8], vb0[8], vb1[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int m = m0 + 2 * t + hf;
+            const bool ok = m < m_end;
+            const int64_t ra = (int64_t)(ok ? m : m_begin) * lda, rb = (int64_t)(ok ? m : m_begin) * ldb;
+            float s = ok ? 1.f : 0.f;
+            if (kMask) s = (ok && mask[m]) ? 1.f : 0.f;
+            va0[t] = a0 ? pa[ra] * s : 0.f;
+            va1[t] = a1 ? pa[ra + 32] * s : 0.f;
+            vb0[t] = (b0 && ok) ? pb[rb] : 0.f;
+            vb1[t] = (b1 && ok) ? pb[rb + 32] : 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            acc[0][0] = mfma2(va0[t], vb0[t], acc[0][0]);
+            acc[0][1] = mfma2(va0[t], vb1[t], acc[0][1]);
+            acc[1][0] = mfma2(va1[t], vb0[t], acc[1][0]);
+            acc[1][1] = mfma2(va1[t], vb1[t], acc[1][1]);
+        }
+    }
+    float* out = part + (int64_t)split * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n2 + 32 * j + c;
+            if (col >= N2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n1 + 32 * i + acc_row(r, hf);
+                if (row < N1) out[(int64_t)row * N2 + col] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int splits, int64_t n, int cols,
+                                                           float* __restrict__ C, int64_t ldc, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(int64_t)k * n + i];
+    float* dst = C + (i / cols) * ldc + (i % cols);
+    *dst = accumulate ? *dst + s : s;
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// y = (x - mean) * rstd * gamma + beta (eps inside the root), optionally y *= mask[row] afterwards.
+//   g = dy * mask * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  d gamma = sum_rows dy * mask * xhat;
+//   d beta = sum_rows dy * mask.
+// One wave per row at a time, NV float4s per lane (D = 128 * NV... D = 256 -> 1 float4 per lane, 384 -> 1.5: handled as
+// D / 64 scalars per lane in column-interleaved order so that loads stay coalesced).  A workgroup of 4 waves walks 64 rows
+// and leaves one partial (d gamma, d beta) pair; stage 2 adds the partials in order.
+template <int NPL>   // floats per lane = D / 64
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                            int64_t lddy, const float* __restrict__ gamma,
+                                                            const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                                            int64_t lddx, int add_to_dx, float* __restrict__ part, int rows,
+                                                            float eps) {
+    constexpr int D = NPL * 64;
+    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float gm[NPL], dg[NPL], db[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        gm[k] = gamma ? gamma[l + 64 * k] : 1.f;
+        dg[k] = 0.f;
+        db[k] = 0.f;
+    }
+    const int row0 = blockIdx.x * 64;
+    for (int rr = wave; rr < 64; rr += 4) {
+        const int row = row0 + rr;
+        if (row >= rows) break;
+        const float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
+        float xv[NPL], gv[NPL];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            xv[k] = x[(int64_t)row * ldx + l + 64 * k];
+            gv[k] = dy[(int64_t)row * lddy + l + 64 * k] * mk;
+            s += xv[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            xv[k] -= mean;
+            q += xv[k] * xv[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float rstd = 1.f / sqrtf(q * (1.f / D) + eps);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            xv[k] *= rstd;                 // xhat
+            dg[k] += gv[k] * xv[k];
+            db[k] += gv[k];
+            gv[k] *= gm[k];                // g
+            c1 += gv[k];
+            c2 += gv[k] * xv[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            c1 += __shfl_xor(c1, off, 64);
+            c2 += __shfl_xor(c2, off, 64);
+        }
+        c1 *= (1.f / D);
+        c2 *= (1.f / D);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const float v = rstd * (gv[k] - c1 - xv[k] * c2);
+            float* d = dx + (int64_t)row * lddx + l + 64 * k;
+            *d = add_to_dx ? *d + v : v;
+        }
+    }
+    if (!part) return;
+    __shared__ float red[4][2][D];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        red[wave][0][l + 64 * k] = dg[k];
+        red[wave][1][l + 64 * k] = db[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int w = i / D, col = i % D;
+        part[(int64_t)blockIdx.x * 2 * D + i] = (red[0][w][col] + red[1][w][col]) + (red[2][w][col] + red[3][w][col]);
+    }
+}
+
+// d gamma / d beta: thread i of [2 * D] adds its column of the `nparts` partial rows, 8 interleaved running sums.
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part, int nparts, int twoD,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= twoD) return;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int p = 0;
+    for (; p + 8 <= nparts; p += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s[k] += part[(int64_t)(p + k) * twoD + i];
+    for (int k = 0; p < nparts; ++p, ++k) s[k] += part[(int64_t)p * twoD + i];
+    const float v = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    const int D = twoD / 2;
+    if (i < D) {
+        if (dgamma) dgamma[i] = v;
+    } else if (dbeta) {
+        dbeta[i - D] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GELU backward
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ u,
+                                                       float* __restrict__ du, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 a = reinterpret_cast<const f32x4*>(da)[i], x = reinterpret_cast<const f32x4*>(u)[i];
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float cdf = 0.5f * (1.f + erff(x[k] * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * expf(-0.5f * x[k] * x[k]);
+        o[k] = a[k] * (cdf + x[k] * pdf);
+    }
+    reinterpret_cast<f32x4*>(du)[i] = o;
+}
+
+// the training forward keeps the pre-activation u (for the line above), so its GELU is a pass of its own: a = gelu(u)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ a, int64_t n4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 x = reinterpret_cast<const f32x4*>(u)[i];
+    reinterpret_cast<f32x4*>(a)[i] = f32x4{gelu_erf(x.x), gelu_erf(x.y), gelu_erf(x.z), gelu_erf(x.w)};
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+// Forward (attend.py:49-122, embeddings.py:51-82): S = Q K^T / 8 - slope_h |i - j|, keys j >= key_len masked, P = softmax
+// over keys, O = P V; one K / V head shared by all H query heads.  Backward with dO:
+//   delta_i = sum_d dO_id O_id;  dP = dO V^T;  dS = P (dP - delta);  dQ = dS K / 8;  dK = sum_h dS^T Q / 8;
+//   dV = sum_h P^T dO;  d slope_h = sum_ij dS_ij (-|i - j|).
+// A 32 x 64 operand tile is held as 32 registers per lane: lane (c = l % 32, hf = l / 32) keeps row c, columns
+// 8a + 4hf + {0..3} (eight 16-byte loads).  Register t of that fragment is MFMA step t's operand - the reduction index
+// then runs in the order acc_row(t, hf), the SAME order in which a lane holds the rows of an accumulator tile, so an
+// accumulator (P, dS) feeds the next product as its B operand without moving (the trick the forward kernels use for P).
+struct Frag { float v[32]; };
+
+__device__ __forceinline__ Frag load_frag(const float* __restrict__ base, int64_t ld, int row, int nrows, int hf) {
+    Frag f;
+    const bool ok = row < nrows;
+    const f32x4* p = reinterpret_cast<const f32x4*>(base + (int64_t)(ok ? row : 0) * ld + 4 * hf);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) {
+        const f32x4 q = ok ? p[2 * a] : f32x4{0.f, 0.f, 0.f, 0.f};
+        f.v[4 * a + 0] = q.x;
+        f.v[4 * a + 1] = q.y;
+        f.v[4 * a + 2] = q.z;
+        f.v[4 * a + 3] = q.w;
+    }
+    return f;
+}
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+__device__ __forceinline__ f32x16 dot_frags(const Frag& a, const Frag& b) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int t = 0; t < 32; ++t) acc = mfma2(a.v[t], b.v[t], acc);
+    return acc;
+}
+
+// dQ kernel: one wave per (query tile of 32, head, batch item), transposed orientation S^T[key][query] (query on the lane).
+// Pass 1: row maxima / sums -> LSE (kept, and written for the dK/dV kernel together with delta).  Pass 2: P, dP, dS,
+// dQ^T += K^T dS^T, slope partial.
+__global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ o,
+                                                         const float* __restrict__ dout, int64_t ldo,
+                                                         const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
+                                                         float* __restrict__ dqkv, float* __restrict__ lse,
+                                                         float* __restrict__ delta, float* __restrict__ slope_part, int N,
+                                                         int H, float scale) {
+    const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, l = threadIdx.x, c = l & 31, hf = l >> 5;
+    const int ntiles = gridDim.x;
+    const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
+    const int i = tile * 32 + c;
+    const float* qb = qkv + (int64_t)b * N * ld;
+    const float* kb = qb + H * 64;
+    const float* vb = kb + 64;
+    const float* ob = o + (int64_t)b * N * ldo + h * 64;
+    const float* dob = dout + (int64_t)b * N * ldo + h * 64;
+    const float slope = slopes[h];
+    const Frag qf = load_frag(qb + h * 64, ld, i, N, hf);
+    const Frag dof = load_frag(dob, ldo, i, N, hf);
+    float dl = 0.f;
+    {
+        const Frag of = load_frag(ob, ldo, i, N, hf);
+#pragma unroll
+        for (int t = 0; t < 32; ++t) dl += of.v[t] * dof.v[t];
+        dl += __shfl_xor(dl, 32, 64);
+    }
+    const int kt_end = (klen + 31) / 32;
+    // pass 1
+    float mx = -INFINITY, sum = 0.f;
+    for (int kt = 0; kt < kt_end; ++kt) {
+        const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
+        const f32x16 s = dot_frags(kf, qf);
+        float sv[16], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = kt * 32 + acc_row(r, hf);
+            sv[r] = j < klen ? s[r] * scale - slope * fabsf((float)(i - j)) : -INFINITY;
+            tmax = fmaxf(tmax, sv[r]);
+        }
+        const float nm = fmaxf(mx, tmax);
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : expf(sv[r] - nm);
+        sum = (mx == -INFINITY ? 0.f : sum * expf(mx - nm)) + part;
+        mx = nm;
+    }
+    {   // merge the two lane halves of a query
+        const float om = __shfl_xor(mx, 32, 64), os = __shfl_xor(sum, 32, 64);
+        const float nm = fmaxf(mx, om);
+        const float a = mx == -INFINITY ? 0.f : sum * expf(mx - nm), bb = om == -INFINITY ? 0.f : os * expf(om - nm);
+        // add in half order (half 0 first) so that both lanes of a query hold identical bits
+        sum = hf == 0 ? a + bb : bb + a;
+        mx = nm;
+    }
+    const float L = sum > 0.f ? mx + logf(sum) : INFINITY;   // no valid key: P = exp(s - inf) = 0
+    if (hf == 0 && i < N) {
+        lse[((int64_t)b * H + h) * N + i] = L;
+        delta[((int64_t)b * H + h) * N + i] = dl;
+    }
+    // pass 2
+    f32x16 dq[2] = {zero16(), zero16()};
+    float gs = 0.f;
+    for (int kt = 0; kt < kt_end; ++kt) {
+        const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
+        const f32x16 s = dot_frags(kf, qf);
+        const Frag vf = load_frag(vb, ld, kt * 32 + c, N, hf);
+        const f32x16 dp = dot_frags(vf, dof);
+        float ds[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = kt * 32 + acc_row(r, hf);
+            const float dist = fabsf((float)(i - j));
+            const float p = (j < klen && i < N) ? expf(s[r] * scale - slope * dist - L) : 0.f;
+            ds[r] = p * (dp[r] - dl);
+            gs -= ds[r] * dist;
+        }
+        // dQ^T[d][i] += sum_j K[j][d] dS^T[j][i]: A = K^T, its reduction index j walked in accumulator-row order
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = kt * 32 + acc_row(t, hf);
+            const float* kr = kb + (int64_t)(j < N ? j : 0) * ld;
+            const float k0 = j < N ? kr[c] : 0.f, k1 = j < N ? kr[32 + c] : 0.f;
+            dq[0] = mfma2(k0, ds[t], dq[0]);
+            dq[1] = mfma2(k1, ds[t], dq[1]);
+        }
+    }
+    if (i < N) {
+        float* dst = dqkv + ((int64_t)b * N + i) * ld + h * 64;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 w = {dq[mt][4 * a] * scale, dq[mt][4 * a + 1] * scale, dq[mt][4 * a + 2] * scale, dq[mt][4 * a + 3] * scale};
+                *reinterpret_cast<f32x4*>(dst + 32 * mt + 8 * a + 4 * hf) = w;
+            }
+    }
+    for (int off = 32; off > 0; off >>= 1) gs += __shfl_xor(gs, off, 64);
+    if (l == 0) slope_part[((int64_t)h * gridDim.z + b) * ntiles + tile] = gs;
+}
+
+// dK / dV kernel: one wave per (key tile of 32, batch item); loops over the heads and the query tiles (S[query][key], key on
+// the lane), so the sums over heads and queries stay in registers: no atomics, one write per element.
+__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ dout,
+                                                          int64_t ldo, const float* __restrict__ slopes,
+                                                          const int64_t* __restrict__ key_len, const float* __restrict__ lse,
+                                                          const float* __restrict__ delta, float* __restrict__ dqkv, int N,
+                                                          int H, float scale) {
+    const int kt = blockIdx.x, b = blockIdx.y, l = threadIdx.x, c = l & 31, hf = l >> 5;
+    const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
+    const int j = kt * 32 + c;
+    const float* qb = qkv + (int64_t)b * N * ld;
+    const float* kb = qb + H * 64;
+    const float* vb = kb + 64;
+    f32x16 dk[2] = {zero16(), zero16()}, dv[2] = {zero16(), zero16()};
+    if (kt * 32 < klen) {
+        const Frag kf = load_frag(kb, ld, j, N, hf);
+        const Frag vf = load_frag(vb, ld, j, N, hf);
+        const int qt_end = (N + 31) / 32;
+        for (int h = 0; h < H; ++h) {
+            const float slope = slopes[h];
+            const float* qh = qb + h * 64;
+            const float* doh = dout + (int64_t)b * N * ldo + h * 64;
+            const float* lh = lse + ((int64_t)b * H + h) * N;
+            const float* dh = delta + ((int64_t)b * H + h) * N;
+            for (int qt = 0; qt < qt_end; ++qt) {
+                const Frag qf = load_frag(qh, ld, qt * 32 + c, N, hf);
+                const f32x16 s = dot_frags(qf, kf);
+                const Frag dof = load_frag(doh, ldo, qt * 32 + c, N, hf);
+                const f32x16 dp = dot_frags(dof, vf);
+                float p[16], ds[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int i = qt * 32 + acc_row(r, hf);
+                    const bool ok = i < N && j < klen;
+                    const float L = i < N ? lh[i] : 0.f, dl = i < N ? dh[i] : 0.f;
+                    p[r] = ok ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
+                    ds[r] = p[r] * (dp[r] - dl);
+                }
+#pragma unroll
+                for (int t = 0; t < 16; ++t) {
+                    const int i = qt * 32 + acc_row(t, hf);
+                    const bool ok = i < N;
+                    const float* dor = doh + (int64_t)(ok ? i : 0) * ldo;
+                    const float* qr = qh + (int64_t)(ok ? i : 0) * ld;
+                    const float d0 = ok ? dor[c] : 0.f, d1 = ok ? dor[32 + c] : 0.f;
+                    const float q0 = ok ? qr[c] : 0.f, q1 = ok ? qr[32 + c] : 0.f;
+                    dv[0] = mfma2(d0, p[t], dv[0]);
+                    dv[1] = mfma2(d1, p[t], dv[1]);
+                    dk[0] = mfma2(q0, ds[t], dk[0]);
+                    dk[1] = mfma2(q1, ds[t], dk[1]);
+                }
+            }
+        }
+    }
+    if (j < N) {
+        float* dst = dqkv + ((int64_t)b * N + j) * ld + H * 64;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                f32x4 wk = {dk[mt][4 * a] * scale, dk[mt][4 * a + 1] * scale, dk[mt][4 * a + 2] * scale, dk[mt][4 * a + 3] * scale};
+                f32x4 wv = {dv[mt][4 * a], dv[mt][4 * a + 1], dv[mt][4 * a + 2], dv[mt][4 * a + 3]};
+                *reinterpret_cast<f32x4*>(dst + 32 * mt + 8 * a + 4 * hf) = wk;
+                *reinterpret_cast<f32x4*>(dst + 64 + 32 * mt + 8 * a + 4 * hf) = wv;
+            }
+    }
+}
+
+// d log-slope_h = slope_h * sum of the (batch, tile) partials, in index order (the parameter is log-slope:
+// slope = exp(learned_logslopes), embeddings.py:59-82)
+__global__ __launch_bounds__(64) void slope_reduce_kernel(const float* __restrict__ part, int per_head, const float* __restrict__ slopes,
+                                                          float* __restrict__ dlogslopes, int H) {
+    const int h = threadIdx.x;
+    if (h >= H) return;
+    float s = 0.f;
+    for (int k = 0; k < per_head; ++k) s += part[(int64_t)h * per_head + k];
+    dlogslopes[h] = s * slopes[h];
+}
+
+}  // namespace
+
+extern "C" int32_t ispk_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t rows, int32_t cols,
+                                      ispk_stream_t stream) {
+    ISPK_REQUIRE(x && y, -1, "ispk_transpose_f32: null pointer");
+    ISPK_REQUIRE(rows >= 1 && cols >= 1 && ldx >= cols && ldy >= rows, -2, "ispk_transpose_f32: bad shape %d x %d", rows, cols);
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x, ldx, y, ldy, rows, cols);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
+                                    int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
+                                    int64_t workspace_floats, ispk_stream_t stream) {
+    ISPK_REQUIRE(A && B && C && workspace, -1, "ispk_gemm_tn_f32: null pointer");
+    ISPK_REQUIRE(M >= 1 && N1 >= 1 && N2 >= 1 && lda >= N1 && ldb >= N2 && ldc >= N2, -2,
+                 "ispk_gemm_tn_f32: bad shape M=%d N1=%d N2=%d", M, N1, N2);
+    const int64_t tile = (int64_t)N1 * N2;
+    ISPK_REQUIRE(workspace_floats >= tile, -3, "ispk_gemm_tn_f32: workspace holds %lld floats, one partial needs %lld",
+                 (long long)workspace_floats, (long long)tile);
+    // row ranges: enough workgroups to fill the chip (>= 1024), at least 64 rows each, bounded by the workspace
+    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    int64_t splits = (1024 + tiles - 1) / tiles;
+    splits = splits < (M + 63) / 64 ? splits : (M + 63) / 64;
+    splits = splits < workspace_floats / tile ? splits : workspace_floats / tile;
+    splits = splits < 1 ? 1 : (splits > 256 ? 256 : splits);
+    int rows_per = (int)((M + splits - 1) / splits);
+    rows_per = (rows_per + 15) / 16 * 16;
+    splits = (M + rows_per - 1) / rows_per;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((N1 + 127) / 128, (N2 + 127) / 128, (unsigned)splits);
+    if (row_mask)
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per, row_mask);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per, row_mask);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((tile + 255) / 256)), dim3(256), 0, s, workspace, (int)splits, tile,
+                       N2, C, ldc, accumulate);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
+                                          const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
+                                          float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,
+                                          float eps, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && dy && dx, -1, "ispk_layernorm_bwd_f32: null pointer");
+    ISPK_REQUIRE(rows >= 1 && (dim == 256 || dim == 384) && ldx >= dim && lddy >= dim && lddx >= dim, -2,
+                 "ispk_layernorm_bwd_f32: rows=%lld dim=%d (dim must be 256 or 384)", (long long)rows, dim);
+    const int blocks = (int)((rows + 63) / 64);
+    const bool want = dgamma || dbeta;
+    ISPK_REQUIRE(!want || (workspace && workspace_floats >= (int64_t)blocks * 2 * dim), -3,
+                 "ispk_layernorm_bwd_f32: workspace needs %lld floats", (long long)blocks * 2 * dim);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* part = want ? workspace : nullptr;
+    if (dim == 384)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<6>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
+                           add_to_dx, part, (int)rows, eps);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
+                           add_to_dx, part, (int)rows, eps);
+    if (want)
+        hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * dim + 255) / 256), dim3(256), 0, s, part, blocks, 2 * dim, dgamma,
+                           dbeta);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, ispk_stream_t stream) {
+    ISPK_REQUIRE(da && u && du, -1, "ispk_gelu_bwd_f32: null pointer");
+    ISPK_REQUIRE(n >= 0 && n % 4 == 0 && ispk_aligned(da, 16) && ispk_aligned(u, 16) && ispk_aligned(du, 16), -2,
+                 "ispk_gelu_bwd_f32: n must be a multiple of 4 and the arrays 16-byte aligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       da, u, du, n / 4);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, ispk_stream_t stream) {
+    ISPK_REQUIRE(u && a, -1, "ispk_gelu_f32: null pointer");
+    ISPK_REQUIRE(n >= 0 && n % 4 == 0 && ispk_aligned(u, 16) && ispk_aligned(a, 16), -2,
+                 "ispk_gelu_f32: n must be a multiple of 4 and the arrays 16-byte aligned");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       u, a, n / 4);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
+                                               const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
+                                               float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
+                                               ispk_stream_t stream) {
+    ISPK_REQUIRE(qkv && o && d_o && slopes && dqkv && workspace, -1, "ispk_alibi_mqa_attn_bwd_f32: null pointer");
+    ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 64 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
+                     ld_o % 4 == 0, -2, "ispk_alibi_mqa_attn_bwd_f32: bad shape B=%d N=%d H=%d", B, N, H);
+    ISPK_REQUIRE(ispk_aligned(qkv, 16) && ispk_aligned(o, 16) && ispk_aligned(d_o, 16) && ispk_aligned(dqkv, 16), -3,
+                 "ispk_alibi_mqa_attn_bwd_f32: arrays must be 16-byte aligned");
+    const int tiles = (N + 31) / 32;
+    const int64_t stat = (int64_t)B * H * N, need = 2 * stat + (int64_t)H * B * tiles;
+    ISPK_REQUIRE(workspace_floats >= need, -4, "ispk_alibi_mqa_attn_bwd_f32: workspace needs %lld floats", (long long)need);
+    float *lse = workspace, *delta = workspace + stat, *spart = workspace + 2 * stat;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const float scale = 0.125f;
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse,
+                       delta, spart, N, H, scale);
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(tiles, B), dim3(64), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len, lse, delta,
+                       dqkv, N, H, scale);
+    if (dlogslopes)
+        hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64), 0, s, spart, B * tiles, slopes, dlogslopes, H);
+    return ispk_launch_status();
+}

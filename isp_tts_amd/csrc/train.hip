@@ -1,0 +1,199 @@
+// The optimizer side of the training step, as gfx950 kernels over FLAT parameter / gradient / moment
+// arenas: the squared gradient norm of the weight-decay group (what experiments/optimizers.py:236-237 clips), AdamW with
+// the clip folded in (torch.optim.AdamW as built at optimizers.py:72-74 with the parameter grouping of :15-20, :34-40),
+// and the mel loss with its gradient (models/acoustic/loss.py:22-35).
+//
+// All of it is HBM-bound streaming: AdamW reads p, g, m, v and writes p, m, v once - 28 B per parameter, 648 MB for the
+// 23.1 M parameters of the recipe model, ~0.1 ms at 8 TB/s - where the reference's unfused torch.optim.AdamW makes ~12
+// element-wise passes per tensor over ~290 tensors (~3,500 launches).
+#include <math.h>
+
+#include "common.h"
+
+namespace {
+
+constexpr int kNormBlocks = 1024;   // partial sums of stage 1 (fixed: the summation order never depends on the device)
+
+// ------------------------------------------------------------------------------------------------ sum of squares
+// Stage 1: block b sums elements b*256*4 + k*stride ... in a fixed order (per-thread running sum over its float4s, then a
+// wave tree by DPP-free shuffles, then 4 wave partials in index order).  Stage 2: one block adds the 1024 partials in a
+// fixed tree.  Deterministic run to run and independent of the CU count.
+__global__ __launch_bounds__(256) void sqnorm_stage1_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+    const int64_t n4 = n >> 2;
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)kNormBlocks * 256) {
+        const f32x4 v = x4[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {          // tail (n not a multiple of 4)
+        const float t = x[(n4 << 2) + threadIdx.x];
+        acc += t * t;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+__global__ __launch_bounds__(1024) void sqnorm_stage2_kernel(const float* __restrict__ partial, float* __restrict__ out) {
+    __shared__ float s[kNormBlocks];
+    s[threadIdx.x] = partial[threadIdx.x];
+    __syncthreads();
+    for (int half = kNormBlocks / 2; half > 0; half >>= 1) {
+        if ((int)threadIdx.x < half) s[threadIdx.x] += s[threadIdx.x + half];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// ------------------------------------------------------------------------------------------------ AdamW
+// One element per lane-slot, float4 at a time.  The update is torch's _single_tensor_adamw in its order:
+//   p *= 1 - lr*wd;  m += (g - m)*(1 - b1);  v = v*b2 + (1 - b2)*g*g;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
+// Elements [0, n_decay) are the weight-decay group (tensors with >= 2 non-unit dimensions): they get the decay and the
+// gradient-norm clip (clip_grad_norm_ on param_groups[0] only, optimizers.py:236-237); the rest get neither.
+struct AdamArgs {
+    float decay_mul;      // 1 - lr * weight_decay
+    float one_m_b1, b2, one_m_b2;
+    float step_size;      // lr / (1 - b1^t)
+    float inv_bc2_sqrt;   // 1 / sqrt(1 - b2^t)   (torch divides; one rounding apart)
+    float bc2_sqrt;
+    float eps, max_norm, grad_scale;
+};
+
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a, float gmul, bool decay) {
+#pragma clang fp contract(off)
+    g *= gmul;
+    if (decay) p *= a.decay_mul;
+    m = m + a.one_m_b1 * (g - m);
+    v = v * a.b2 + (a.one_m_b2 * g) * g;
+    const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+    p = p - a.step_size * (m / denom);
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, int64_t n, int64_t n_decay,
+                                                    const float* __restrict__ sqnorm, AdamArgs a) {
+    // clip coefficient of the decay group: min(1, max_norm / (norm + 1e-6)) on the SCALED gradients (torch
+    // clip_grad_norm_); non-finite norm -> the coefficient is NaN-free only if the gradients are; as in torch, nothing is
+    // skipped (the reference runs bf16/fp32 without a loss scaler on this path)
+    float clip = 1.f;
+    if (sqnorm) {
+        const float norm = sqrtf(sqnorm[0]) * a.grad_scale;
+        clip = fminf(a.max_norm / (norm + 1e-6f), 1.f);
+    }
+    const float g_decay = a.grad_scale * clip, g_rest = a.grad_scale;
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 p4 = reinterpret_cast<f32x4*>(p)[i], m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+        const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
+        float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+        const int64_t e = i << 2;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const bool d = e + k < n_decay;
+            adam_one(pp[k], gg[k], mm[k], vv[k], a, d ? g_decay : g_rest, d);
+        }
+        reinterpret_cast<f32x4*>(p)[i] = f32x4{pp[0], pp[1], pp[2], pp[3]};
+        reinterpret_cast<f32x4*>(m)[i] = f32x4{mm[0], mm[1], mm[2], mm[3]};
+        reinterpret_cast<f32x4*>(v)[i] = f32x4{vv[0], vv[1], vv[2], vv[3]};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t e = (n4 << 2) + threadIdx.x;
+        const bool d = e < n_decay;
+        adam_one(p[e], g[e], m[e], v[e], a, d ? g_decay : g_rest, d);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ mel loss
+// loss.py:22-35 + utils/functions.py:44-58: MSE(mel_out, mel_target) per element, masked to t < mel_len[b], summed per
+// utterance over (80, T), divided by max(80 * len_b, 1e-5), mean over the batch.  One workgroup per utterance computes the
+// ratio (fixed-order reduction) and, when grad is asked for, writes d loss / d mel_out = 2 (out - tgt) / (den_b * B) * go
+// (0 on padded frames); a second tiny launch averages the B ratios in index order.
+__global__ __launch_bounds__(256) void mel_loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+                                                       const int64_t* __restrict__ mel_len, float* __restrict__ ratio,
+                                                       float* __restrict__ grad, float grad_out, int B, int C, int T) {
+    const int b = blockIdx.x;
+    const int len = (int)min((int64_t)T, max((int64_t)0, mel_len[b]));
+    const float den = fmaxf((float)((int64_t)C * len), 1e-5f);
+    const float gmul = 2.f * grad_out / (den * (float)B);
+    const float* o = out + (int64_t)b * C * T;
+    const float* t = tgt + (int64_t)b * C * T;
+    float* gr = grad ? grad + (int64_t)b * C * T : nullptr;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < C * T; i += 256) {
+        const int f = i % T;
+        const float d = o[i] - t[i];
+        const bool valid = f < len;
+        acc += valid ? d * d : 0.f;
+        if (gr) gr[i] = valid ? d * gmul : 0.f;
+    }
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    __shared__ float wsum[4];
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) ratio[b] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / den;
+}
+
+__global__ __launch_bounds__(64) void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s += x[i];
+        out[0] = s / (float)n;
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t ispk_grad_sqnorm_f32(const float* g, int64_t n, float* partial, float* out, ispk_stream_t stream) {
+    ISPK_REQUIRE(g && partial && out, -1, "ispk_grad_sqnorm_f32: null pointer");
+    ISPK_REQUIRE(n >= 0 && ispk_aligned(g, 16), -2, "ispk_grad_sqnorm_f32: n < 0 or g not 16-byte aligned");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sqnorm_stage1_kernel, dim3(kNormBlocks), dim3(256), 0, s, g, n, partial);
+    hipLaunchKernelGGL(sqnorm_stage2_kernel, dim3(1), dim3(kNormBlocks), 0, s, partial, out);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr,
+                                  float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                                  const float* grad_sqnorm, float max_norm, float grad_scale, ispk_stream_t stream) {
+    ISPK_REQUIRE(p && g && m && v, -1, "ispk_adamw_f32: null pointer");
+    ISPK_REQUIRE(n >= 0 && n_decay >= 0 && n_decay <= n && step >= 1, -2,
+                 "ispk_adamw_f32: need 0 <= n_decay <= n and step >= 1 (got n=%lld n_decay=%lld step=%d)", (long long)n,
+                 (long long)n_decay, step);
+    ISPK_REQUIRE(ispk_aligned(p, 16) && ispk_aligned(g, 16) && ispk_aligned(m, 16) && ispk_aligned(v, 16), -3,
+                 "ispk_adamw_f32: arenas must be 16-byte aligned");
+    ISPK_REQUIRE(!grad_sqnorm || max_norm > 0.f, -4, "ispk_adamw_f32: max_norm must be positive when clipping");
+    if (n == 0) return 0;
+    // scalar factors in double, as torch's python-side arithmetic computes them, then rounded once
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamArgs a;
+    a.decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
+    a.one_m_b1 = (float)(1.0 - (double)beta1);
+    a.b2 = beta2;
+    a.one_m_b2 = (float)(1.0 - (double)beta2);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    a.eps = eps;
+    a.max_norm = max_norm;
+    a.grad_scale = grad_scale;
+    const int64_t n4 = (n + 3) >> 2;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, n_decay,
+                       grad_sqnorm, a);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio,
+                                     float* loss, float* grad, float grad_out, int32_t B, int32_t C, int32_t T,
+                                     ispk_stream_t stream) {
+    ISPK_REQUIRE(mel_out && mel_target && mel_len && ratio && loss, -1, "ispk_mel_loss_f32: null pointer");
+    ISPK_REQUIRE(B >= 1 && C >= 1 && T >= 1, -2, "ispk_mel_loss_f32: empty batch (B=%d C=%d T=%d)", B, C, T);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(mel_loss_kernel, dim3(B), dim3(256), 0, s, mel_out, mel_target, mel_len, ratio, grad, grad_out, B, C, T);
+    hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, s, ratio, B, loss);
+    return ispk_launch_status();
+}

@@ -59,6 +59,15 @@ SIGNATURES = {
     "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F32, _P],
     "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_soft_average_f32": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_transpose_f32": [_P, _I64, _P, _I64, _I32, _I32, _P],
+    "ispk_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
+    "ispk_layernorm_bwd_f32": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _I64, _I32, _F32, _P],
+    "ispk_gelu_f32": [_P, _P, _I64, _P],
+    "ispk_gelu_bwd_f32": [_P, _P, _P, _I64, _P],
+    "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
+    "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
+    "ispk_grad_sqnorm_f32": [_P, _I64, _P, _P, _P],
+    "ispk_adamw_f32": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _P, _F32, _F32, _P],
 }
 
 _lib = None
@@ -753,3 +762,157 @@ def cast_bf16(x: Tensor) -> Tensor:
     _launch("cast_bf16_kernel", 0.0, 6.0 * x2.numel(), lib().ispk_cast_f32_bf16, x2.data_ptr(), x2.stride(0),
             y.data_ptr(), x2.shape[1], x2.shape[0], x2.shape[1], _stream())
     return y
+
+
+# ------------------------------------------------------------------------------------------------- training step (row f2)
+def transpose(x: Tensor) -> Tensor:
+    """ispk_transpose_f32: y[c, r] = x[r, c] (fp32 matrix; weights for dX = dY . W through the NT GEMM)."""
+    _dev(x)
+    assert x.dtype == torch.float32 and x.ndim == 2 and x.stride(1) == 1
+    y = torch.empty((x.shape[1], x.shape[0]), dtype=torch.float32, device=x.device)
+    _launch("transpose_kernel", 0.0, 8.0 * x.numel(), lib().ispk_transpose_f32, x.data_ptr(), x.stride(0), y.data_ptr(),
+            y.stride(0), x.shape[0], x.shape[1], _stream())
+    return y
+
+
+_TN_WORKSPACE_FLOATS = 48 << 20     # 192 MB: up to 64+ row ranges of the largest weight (1536 x 384)
+_workspaces: dict = {}
+
+
+def workspace(device, floats: int) -> Tensor:
+    """Per-device scratch for the backward kernels' partial sums (grown on demand, reused; stream-ordered use only)."""
+    key = (torch.device(device).index or 0)
+    w = _workspaces.get(key)
+    if w is None or w.numel() < floats:
+        w = _workspaces[key] = torch.empty((max(floats, _TN_WORKSPACE_FLOATS),), dtype=torch.float32, device=device)
+    return w
+
+
+def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Optional[Tensor] = None,
+            accumulate: bool = False) -> Tensor:
+    """ispk_gemm_tn_f32: C[N1, N2] (+)= sum_m mask[m] a[m, N1] b[m, N2] - the weight gradient dY^T . X of a Linear."""
+    _dev(a, b, row_mask, out)
+    a2, b2 = _rows2d(a), _rows2d(b)
+    assert a2.dtype == torch.float32 and b2.dtype == torch.float32 and a2.shape[0] == b2.shape[0]
+    M, N1 = a2.shape
+    N2 = b2.shape[1]
+    if out is None:
+        assert not accumulate
+        out = torch.empty((N1, N2), dtype=torch.float32, device=a.device)
+    assert out.shape == (N1, N2) and out.stride(1) == 1 and out.dtype == torch.float32
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).contiguous()
+        assert row_mask.dtype == torch.bool and row_mask.numel() == M
+    ws = workspace(a.device, N1 * N2)
+    _launch(f"gemm_tn_kernel<{N1}x{N2}>", 2.0 * M * N1 * N2, 4.0 * (a2.numel() + b2.numel() + out.numel()),
+            lib().ispk_gemm_tn_f32, a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), out.data_ptr(), out.stride(0), M,
+            N1, N2, _ptr(row_mask), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], row_mask: Optional[Tensor] = None,
+                  dx: Optional[Tensor] = None, add_to_dx: bool = False, want_param_grads: bool = True, eps: float = 1e-5):
+    """ispk_layernorm_bwd_f32 -> (dx, dgamma | None, dbeta | None).  `dx` given + add_to_dx: accumulated in place (the
+    residual branch's gradient is already there)."""
+    _dev(x, dy, gamma, row_mask, dx)
+    x2, dy2 = _rows2d(x), _rows2d(dy)
+    rows, D = x2.shape
+    assert x2.dtype == torch.float32 and dy2.dtype == torch.float32 and dy2.shape == x2.shape
+    if dx is None:
+        assert not add_to_dx
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dx2 = _rows2d(dx)
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).contiguous()
+        assert row_mask.dtype == torch.bool and row_mask.numel() == rows
+    dg = db = None
+    ws = None
+    if want_param_grads:
+        dg = torch.empty((D,), dtype=torch.float32, device=x.device)
+        db = torch.empty((D,), dtype=torch.float32, device=x.device)
+        ws = workspace(x.device, ((rows + 63) // 64) * 2 * D)
+    _launch(f"layernorm_bwd_kernel<{D // 64}>", 0.0, 4.0 * rows * D * (3 + int(add_to_dx)), lib().ispk_layernorm_bwd_f32,
+            x2.data_ptr(), x2.stride(0), dy2.data_ptr(), dy2.stride(0), _ptr(gamma), _ptr(row_mask), dx2.data_ptr(),
+            dx2.stride(0), int(add_to_dx), _ptr(dg), _ptr(db), _ptr(ws), ws.numel() if ws is not None else 0, rows, D, eps,
+            _stream())
+    return dx, dg, db
+
+
+def gelu(u: Tensor) -> Tensor:
+    """ispk_gelu_f32: exact-erf GELU as its own pass (the training forward keeps u)."""
+    _dev(u)
+    assert u.dtype == torch.float32 and u.is_contiguous()
+    a = torch.empty_like(u)
+    _launch("gelu_fwd_kernel", 0.0, 8.0 * u.numel(), lib().ispk_gelu_f32, u.data_ptr(), a.data_ptr(), u.numel(), _stream())
+    return a
+
+
+def gelu_bwd(da: Tensor, u: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """ispk_gelu_bwd_f32: du = da * gelu'(u) (exact erf); `out` may alias `da`."""
+    _dev(da, u, out)
+    assert da.dtype == torch.float32 and u.dtype == torch.float32 and da.is_contiguous() and u.is_contiguous()
+    assert da.shape == u.shape
+    if out is None:
+        out = torch.empty_like(da)
+    _launch("gelu_bwd_kernel", 0.0, 12.0 * da.numel(), lib().ispk_gelu_bwd_f32, da.data_ptr(), u.data_ptr(), out.data_ptr(),
+            da.numel(), _stream())
+    return out
+
+
+def alibi_mqa_attention_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor]):
+    """ispk_alibi_mqa_attn_bwd_f32 -> (dqkv fp32 like qkv, dlogslopes fp32 [heads])."""
+    _dev(qkv, o, d_o, slopes, key_len)
+    B, N, W = qkv.shape
+    assert W == heads * 64 + 128 and qkv.dtype == torch.float32 and qkv.is_contiguous()
+    assert o.shape == (B, N, heads * 64) and d_o.shape == o.shape and o.dtype == torch.float32 and d_o.dtype == torch.float32
+    o, d_o = o.contiguous(), d_o.contiguous()
+    slopes = slopes.to(torch.float32).contiguous()
+    if key_len is not None:
+        key_len = key_len.to(torch.int64).contiguous()
+    dqkv = torch.empty_like(qkv)
+    dls = torch.empty((heads,), dtype=torch.float32, device=qkv.device)
+    tiles = (N + 31) // 32
+    ws = workspace(qkv.device, 2 * B * heads * N + heads * B * tiles)
+    _launch("attn_bwd_kernels", 10.0 * B * heads * N * N * 64, 4.0 * (2 * qkv.numel() + 2 * o.numel()),
+            lib().ispk_alibi_mqa_attn_bwd_f32, qkv.data_ptr(), W, o.data_ptr(), d_o.data_ptr(), heads * 64, slopes.data_ptr(),
+            _ptr(key_len), dqkv.data_ptr(), dls.data_ptr(), ws.data_ptr(), ws.numel(), B, N, heads, _stream())
+    return dqkv, dls
+
+
+def mel_loss(mel_out: Tensor, mel_target: Tensor, mel_len: Tensor, want_grad: bool = False, grad_out: float = 1.0):
+    """ispk_mel_loss_f32 -> (loss fp32 [1], grad fp32 like mel_out | None)."""
+    _dev(mel_out, mel_target, mel_len)
+    assert mel_out.dtype == torch.float32 and mel_target.dtype == torch.float32 and mel_out.shape == mel_target.shape
+    mel_out, mel_target = mel_out.contiguous(), mel_target.contiguous()
+    B, C, T = mel_out.shape
+    mel_len = mel_len.to(torch.int64).contiguous()
+    ratio = torch.empty((B,), dtype=torch.float32, device=mel_out.device)
+    loss = torch.empty((1,), dtype=torch.float32, device=mel_out.device)
+    grad = torch.empty_like(mel_out) if want_grad else None
+    _launch("mel_loss_kernel", 0.0, 4.0 * mel_out.numel() * (2 + int(want_grad)), lib().ispk_mel_loss_f32, mel_out.data_ptr(),
+            mel_target.data_ptr(), mel_len.data_ptr(), ratio.data_ptr(), loss.data_ptr(), _ptr(grad), grad_out, B, C, T,
+            _stream())
+    return loss, grad
+
+
+def grad_sqnorm(g: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """ispk_grad_sqnorm_f32: sum of squares of a flat fp32 arena -> fp32 [1] (device)."""
+    _dev(g, out)
+    assert g.dtype == torch.float32 and g.ndim == 1 and g.is_contiguous()
+    if out is None:
+        out = torch.empty((1,), dtype=torch.float32, device=g.device)
+    part = workspace(g.device, 1024)
+    _launch("sqnorm_kernels", 0.0, 4.0 * g.numel(), lib().ispk_grad_sqnorm_f32, g.data_ptr(), g.numel(), part.data_ptr(),
+            out.data_ptr(), _stream())
+    return out
+
+
+def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, n_decay: int, lr: float, betas: tuple, eps: float, weight_decay: float,
+          step: int, grad_sqnorm: Optional[Tensor] = None, max_norm: float = 1.0, grad_scale: float = 1.0) -> None:
+    """ispk_adamw_f32 over flat fp32 arenas (in place)."""
+    _dev(p, g, m, v, grad_sqnorm)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.ndim == 1 and t.is_contiguous() and t.numel() == p.numel()
+    _launch("adamw_kernel", 0.0, 28.0 * p.numel(), lib().ispk_adamw_f32, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+            p.numel(), n_decay, lr, betas[0], betas[1], eps, weight_decay, step, _ptr(grad_sqnorm), max_norm, grad_scale,
+            _stream())

@@ -1,0 +1,35 @@
+"""`MelLoss` (models/acoustic/loss.py:22-35) with forward value and gradient from one kernel."""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .. import runtime
+
+
+class _MelLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mel_out: Tensor, mel_target: Tensor, mel_len: Tensor):
+        # value and d loss / d mel_out in the same pass (the gradient is scaled by the incoming grad in backward)
+        loss, grad = runtime.mel_loss(mel_out, mel_target, mel_len, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_loss: Tensor):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_loss, None, None
+
+
+class MelLoss(torch.nn.Module):
+    """loss.py:22-35: masked mean-squared error per utterance (utils/functions.py:44-58), mean over the batch, times
+    `weight`; `skip_steps` as modules/loss.py:27-31."""
+
+    def __init__(self, weight: float = 1.0, skip_steps: int = 0):
+        super().__init__()
+        self.weight, self.skip_steps = weight, skip_steps
+
+    def forward(self, mels_out: Tensor, mels_target: Tensor, mel_lengths: Tensor, step=None):
+        if step is not None and step < self.skip_steps:
+            return 0.
+        return self.weight * _MelLossFunction.apply(mels_out, mels_target, mel_lengths)

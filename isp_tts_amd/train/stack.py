@@ -1,0 +1,118 @@
+"""A `Transformer` stack as ONE autograd node: the forward keeps what the backward needs, the backward is
+the kernels of csrc/backward.hip plus the forward's own NT GEMM on transposed weights.
+
+Scope of this first cut: plain LayerNorm stacks (TextEncoder, MelDecoder: transformer.py:174-211 with emb_dim == dim),
+fp32, dropout 0 (the recipes train with attention / feed-forward dropout 0.1 - in-kernel Philox masks are not built, so a
+stack with dropout > 0 in training mode raises), ALiBi multi-query attention, exact-erf GELU, no Linear biases.
+
+Forward per layer (transformer.py:62-118 as the inference path launches it, csrc/gemm.hip epilogues), m = row mask:
+    h   = LN1(x)                 qkv = h Wqkv^T            o = ALiBi-MQA(qkv)          x1 = x + m (o Wo^T)
+    h2  = m LN2(x1)              u   = h2 W1^T             a = gelu(u)                 y  = m (x1 + a W2^T)
+and out = m LN_f(y_last).  Backward, given dy (rows of padded positions are exactly zero: the final LayerNorm's backward
+masks them, and every step below keeps zero rows zero):
+    da = (m dy) W2        dW2 = (m dy)^T a        du = da gelu'(u)       dW1 = du^T h2       dh2 = du W1
+    dx1 = dy + LN2'(x1, m dh2)                    dWo = (m dx1)^T o      do  = (m dx1) Wo
+    dqkv, dlogslopes = attention'(qkv, o, do)     dWqkv = dqkv^T h       dh  = dqkv Wqkv
+    dx  = dx1 + LN1'(x, dh)
+Saved per layer: x, h, qkv, o, x1, h2, u, a (fp32): 0.72 GB per decoder layer at 64 x 512 frames - 4.3 GB per stack, small
+beside 288 GB of HBM, so nothing is recomputed except the LayerNorm / softmax statistics.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import Tensor
+
+from .. import runtime
+from ..modules.transformer.transformer import Transformer
+
+
+def _check(tr: Transformer) -> None:
+    if tr.adaptive_norm or not isinstance(tr.project_emb, torch.nn.Identity):
+        raise NotImplementedError("training backward: adaptive-norm / projected stacks (the temporal adaptor) are not built")
+    for layer in tr.layers:
+        att, ff = layer.attention, layer.feed_forward
+        if layer.training and (att.attend.dropout > 0 or ff.dropout_p > 0):
+            raise NotImplementedError("training backward: dropout > 0 is not built (set the stack's dropout to 0)")
+        if ff.net[0].bias is not None or ff.net[3].bias is not None or ff.act_flag != runtime.EP_GELU:
+            raise NotImplementedError("training backward: feed-forward with biases / non-GELU activation is not built")
+
+
+def stack_parameters(tr: Transformer) -> list:
+    """The parameters the node differentiates, in the order `TransformerStackFunction` takes and returns them."""
+    ps = []
+    for layer in tr.layers:
+        att, ff = layer.attention, layer.feed_forward
+        ps += [layer.attention_norm.weight, layer.attention_norm.bias, att.to_q.weight, att.to_kv.weight,
+               att.rel_pos.learned_logslopes, att.to_out.weight, layer.feed_forward_norm.weight, layer.feed_forward_norm.bias,
+               ff.net[0].weight, ff.net[3].weight]
+    return ps + [tr.norm.weight, tr.norm.bias]
+
+
+class TransformerStackFunction(torch.autograd.Function):
+    """out = Transformer(x, mask).out with every parameter of the stack as a differentiable input."""
+
+    @staticmethod
+    def forward(ctx, tr: Transformer, x: Tensor, mask: Optional[Tensor], *params: Tensor):
+        _check(tr)
+        x = x.float().contiguous()
+        key_len = mask.sum(dim=1) if mask is not None else None
+        tape, out = [], x
+        for layer in tr.layers:
+            att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
+            wqkv, wo, slopes = att._staged(torch.float32)
+            w1, w2 = ff._staged(torch.float32)
+            h = runtime.layernorm(out, an.weight, an.bias, eps=an.eps)
+            qkv = runtime.gemm(h, wqkv)
+            o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
+            x1 = runtime.gemm(o, wo, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
+            h2 = runtime.layernorm(x1, fn.weight, fn.bias, row_mask=mask, eps=fn.eps)
+            u = runtime.gemm(h2, w1)
+            a = runtime.gelu(u)
+            y = runtime.gemm(a, w2, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
+            tape.append((out, h, qkv, o, x1, h2, u, a))
+            out = y
+        final = runtime.layernorm(out, tr.norm.weight, tr.norm.bias, row_mask=mask, eps=tr.norm.eps)
+        ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last = tr, mask, key_len, tape, out
+        return final
+
+    @staticmethod
+    def backward(ctx, dfinal: Tensor):
+        tr, mask, key_len = ctx.tr, ctx.mask, ctx.key_len
+        mflag = runtime.EP_MASK_OUT if mask is not None else 0
+        grads: list = []
+        dy, dgf, dbf = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask,
+                                             eps=tr.norm.eps)
+        for layer, (xin, h, qkv, o, x1, h2, u, a) in zip(reversed(tr.layers), reversed(ctx.tape)):
+            att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
+            wqkv, wo, slopes = att._staged(torch.float32)
+            w1, w2 = ff._staged(torch.float32)
+            wqkv_t, wo_t = att._cache.get("t32", (att.to_q.weight, att.to_kv.weight, att.to_out.weight),
+                                          lambda: (runtime.transpose(wqkv), runtime.transpose(wo)))
+            w1_t, w2_t = ff._cache.get("t32", (ff.net[0].weight, ff.net[3].weight),
+                                       lambda: (runtime.transpose(w1), runtime.transpose(w2)))
+            # feed-forward block
+            dw2 = runtime.gemm_tn(dy, a, row_mask=mask)                         # [dim, inner]
+            da = runtime.gemm(dy, w2_t, mask=mask, flags=mflag)                  # (m dy) W2
+            du = runtime.gelu_bwd(da, u, out=da)
+            dw1 = runtime.gemm_tn(du, h2)                                        # [inner, dim]
+            dh2 = runtime.gemm(du, w1_t)
+            dx1, dg2, db2 = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps)
+            # attention block
+            dwo = runtime.gemm_tn(dx1, o, row_mask=mask)                         # [dim, heads*64]
+            d_o = runtime.gemm(dx1, wo_t, mask=mask, flags=mflag)
+            dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len)
+            dwqkv = runtime.gemm_tn(dqkv, h)                                     # [heads*64 + 128, dim]
+            dh = runtime.gemm(dqkv, wqkv_t)
+            dy, dg1, db1 = runtime.layernorm_bwd(xin, dh, an.weight, dx=dx1, add_to_dx=True, eps=an.eps)
+            hq = att.heads * 64
+            ls = att.rel_pos.learned_logslopes
+            grads = [dg1, db1, dwqkv[:hq], dwqkv[hq:], dls[:ls.numel()].view_as(ls), dwo, dg2, db2, dw1, dw2] + grads
+        ctx.tape = None
+        return (None, dy, None, *grads, dgf, dbf)
+
+
+def transformer_train_forward(tr: Transformer, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
+    """`tr(x, mask).out` as a differentiable node (gradients reach x and every parameter of the stack)."""
+    return TransformerStackFunction.apply(tr, x, mask, *stack_parameters(tr))

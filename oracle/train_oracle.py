@@ -1,0 +1,79 @@
+"""ORACLE (test infrastructure, not product): the reference's training-step pieces, restated on CPU with plain PyTorch.
+
+  * `reference_optimizer` / `reference_step`: experiments/optimizers.py:15-20, :34-40 (weight-decay grouping), :72-74
+    (torch.optim.AdamW), :230-244 (clip_grad_norm_ on param_groups[0] only, step, zero_grad).
+  * `mel_loss`: models/acoustic/loss.py:22-35 with utils/functions.py:44-58 (`masked_mean`).
+  * `adamw_flat` / `sqnorm_flat`: the same AdamW arithmetic on flat arenas - the stand-in the CPU (gloo) test plugs into
+    `FlatAdamW` so that the gradient exchange runs without a GPU.
+Gradients of the transformer stacks come from autograd over `acoustic_oracle.transformer` (no separate restatement).
+Parity is pinned through torch.optim.AdamW / torch autograd themselves (the reference calls exactly these); the
+reference holds no fixtures for its training step.
+
+Only tests/ may import this module.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+def group_weight_decayable_params(params):
+    """optimizers.py:15-20."""
+    wd, no_wd = [], []
+    for p in params:
+        (no_wd if p.squeeze().ndim < 2 else wd).append(p)
+    return wd, no_wd
+
+
+def reference_optimizer(params, lr=2e-4, weight_decay=1e-2, betas=(0.9, 0.999), eps=1e-8, group_wd_params=True):
+    """optimizers.py:29-43 + :72-74: two param_groups when weight_decay > 0 (decay group first), else one."""
+    params = list(params)
+    if weight_decay > 0. and group_wd_params:
+        wd, no_wd = group_weight_decayable_params(params)
+        groups = [{"params": wd}, {"params": no_wd, "weight_decay": 0.}]
+    else:
+        groups = params
+    return torch.optim.AdamW(groups, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+
+def reference_step(opt: torch.optim.Optimizer, grad_clip=1.0):
+    """optimizers.py:233-244 after backward: clip group 0, step, zero_grad -> grad norm (None if not finite)."""
+    norm = None
+    if grad_clip is not None:
+        norm = torch.nn.utils.clip_grad_norm_(opt.param_groups[0]["params"], grad_clip)
+        if torch.isnan(norm) or torch.isinf(norm):
+            norm = None
+    opt.step()
+    opt.zero_grad()
+    return norm
+
+
+def mel_loss(mel_out: Tensor, mel_target: Tensor, mel_len: Tensor) -> Tensor:
+    """loss.py:28-35: MSE (reduction none), mask frames >= mel_len, per-utterance sum / count, mean over the batch."""
+    loss = F.mse_loss(mel_out, mel_target, reduction="none")
+    mask = (torch.arange(mel_out.shape[-1])[None, :] < mel_len[:, None])[:, None].expand_as(mel_out)
+    loss = loss.masked_fill(~mask, 0.)
+    num = loss.sum(dim=-1).sum(dim=-1)
+    den = mask.sum(dim=-1).sum(dim=-1)
+    return (num / den.clamp(min=1e-5)).mean()
+
+
+def sqnorm_flat(g: Tensor, out: Tensor) -> Tensor:
+    out.copy_((g.double() ** 2).sum().float().reshape(1))
+    return out
+
+
+def adamw_flat(p, g, m, v, n_decay, lr, betas, eps, weight_decay, step, grad_sqnorm=None, max_norm=1.0, grad_scale=1.0):
+    """torch.optim.AdamW's single-tensor update (torch/optim/adamw.py) on flat arenas, decay + clip on [0, n_decay)."""
+    b1, b2 = betas
+    g = g * grad_scale
+    if grad_sqnorm is not None:
+        coef = min(max_norm / (float(grad_sqnorm.sqrt()) * grad_scale + 1e-6), 1.0)
+        g = torch.cat([g[:n_decay] * coef, g[n_decay:]])
+    p[:n_decay].mul_(1 - lr * weight_decay)
+    m.lerp_(g, 1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / (bc2 ** 0.5)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)

@@ -1,0 +1,241 @@
+"""Training-step kernels (first cut) against the oracle: torch autograd over the oracle's functions for the
+gradients, torch.optim.AdamW + clip_grad_norm_ in the reference's grouping for the optimizer.  Tolerances are written per
+test (floating point: fp32 kernels against an fp32 / fp64 CPU computation)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from isp_tts_amd import runtime, synth, train
+from isp_tts_amd.modules.transformer import Transformer
+from oracle import acoustic_oracle as orc
+from oracle import train_oracle as torc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g) * scale
+
+
+def _close(got, want, tol, what=""):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    err = (got - want).abs().max().item()
+    ref = max(want.abs().max().item(), 1e-30)
+    assert err <= tol * ref, f"{what}: max |diff| {err:.3e} vs scale {ref:.3e} (tol {tol:g} relative)"
+
+
+@pytest.mark.parametrize("M,N1,N2,masked", [(1000, 80, 384, False), (4099, 384, 1536, True), (64, 512, 384, True),
+                                             (6400, 1536, 384, False)])
+def test_gemm_tn_matches_float64(M, N1, N2, masked):
+    """dW = dY^T X: odd row counts (tails of the 16-row steps and of the row ranges), N not a multiple of the 128-wide
+    tile, row mask, accumulation; fixed summation order -> two runs give identical bits."""
+    a, b = _rand((M, N1), 1), _rand((M, N2), 2)
+    mask = (torch.arange(M) % 7 != 3) if masked else None
+    want = ((a * mask[:, None]) if masked else a).double().T @ b.double()
+    ad, bd, md = a.to(DEV), b.to(DEV), (mask.to(DEV) if masked else None)
+    got = runtime.gemm_tn(ad, bd, row_mask=md)
+    _close(got, want, 2e-6, "gemm_tn")
+    assert torch.equal(got, runtime.gemm_tn(ad, bd, row_mask=md))
+    acc = got.clone()
+    runtime.gemm_tn(ad, bd, row_mask=md, out=acc, accumulate=True)
+    _close(acc, 2 * want, 2e-6, "gemm_tn accumulate")
+    # strided operands (column slices of wider matrices)
+    wide = torch.cat([a, a], dim=1).to(DEV)
+    _close(runtime.gemm_tn(wide[:, N1:], bd, row_mask=md), want, 2e-6, "gemm_tn strided")
+
+
+def test_transpose():
+    x = _rand((384, 1536), 3).to(DEV)
+    assert torch.equal(runtime.transpose(x), x.T.contiguous())
+    y = _rand((77, 130), 4).to(DEV)
+    assert torch.equal(runtime.transpose(y), y.T.contiguous())
+
+
+@pytest.mark.parametrize("dim,rows,masked", [(384, 1000, True), (256, 333, False), (384, 64 * 37 + 5, True)])
+def test_layernorm_backward(dim, rows, masked):
+    x = _rand((rows, dim), 5, 2.0).requires_grad_()
+    gamma, beta = (1 + 0.1 * _rand((dim,), 6)).requires_grad_(), _rand((dim,), 7, 0.1).requires_grad_()
+    dy = _rand((rows, dim), 8)
+    mask = (torch.arange(rows) % 5 != 0) if masked else None
+    y = F.layer_norm(x.double(), (dim,), gamma.double(), beta.double(), 1e-5)
+    if masked:
+        y = y * mask[:, None]
+    y.backward(dy.double())
+    dx, dg, db = runtime.layernorm_bwd(x.detach().to(DEV), dy.to(DEV), gamma.detach().to(DEV),
+                                       row_mask=mask.to(DEV) if masked else None)
+    _close(dx, x.grad, 2e-5, "dx")
+    _close(dg, gamma.grad, 2e-5, "dgamma")
+    _close(db, beta.grad, 2e-5, "dbeta")
+    # accumulate into an existing gradient (the residual branch), no parameter gradients
+    base = _rand((rows, dim), 9).to(DEV)
+    dx2, dg2, _ = runtime.layernorm_bwd(x.detach().to(DEV), dy.to(DEV), gamma.detach().to(DEV),
+                                        row_mask=mask.to(DEV) if masked else None, dx=base.clone(), add_to_dx=True,
+                                        want_param_grads=False)
+    assert dg2 is None
+    _close(dx2, x.grad + base.cpu().double(), 2e-5, "dx accumulated")
+
+
+def test_gelu_forward_backward():
+    u = _rand((4096, 16), 10, 3.0).requires_grad_()
+    da = _rand((4096, 16), 11)
+    a = F.gelu(u.double())
+    a.backward(da.double())
+    _close(runtime.gelu(u.detach().to(DEV)), a, 1e-6, "gelu")
+    _close(runtime.gelu_bwd(da.to(DEV), u.detach().to(DEV)), u.grad, 2e-6, "gelu'")
+
+
+@pytest.mark.parametrize("B,N,H,lens", [(3, 100, 6, (100, 73, 33)), (2, 512, 6, (512, 390)), (2, 45, 4, None),
+                                         (1, 1000, 6, (777,))])
+def test_attention_backward_matches_autograd(B, N, H, lens):
+    """dQ / dK / dV / d log-slope of ALiBi-MQA against float64 autograd over the reference's formulation (materialised
+    bias, masked fill, softmax): ragged key lengths, N not a multiple of the 32-row tiles, 4 and 6 heads."""
+    W = H * 64 + 128
+    qkv = _rand((B, N, W), 12, 0.7)
+    d_o = _rand((B, N, H * 64), 13)
+    logs = torch.log(torch.tensor([2.0 ** (-(i + 1) * 8.0 / H) for i in range(H)])) + 0.1 * _rand((H,), 14)
+    key_len = torch.tensor(lens) if lens is not None else None
+    q64 = qkv.double().requires_grad_()
+    l64 = logs.double().requires_grad_()
+    q = q64[..., :H * 64].view(B, N, H, 64).transpose(1, 2)
+    k, v = q64[..., H * 64:H * 64 + 64], q64[..., H * 64 + 64:]
+    idx = torch.arange(N)
+    bias = -(idx[None, :] - idx[:, None]).abs().double()[None] * l64.exp()[:, None, None]          # [H, N, N]
+    s = torch.einsum("bhid,bjd->bhij", q, k) / 8.0 + bias[None]
+    if key_len is not None:
+        s = s.masked_fill(~(idx[None, :] < key_len[:, None])[:, None, None, :], float("-inf"))
+    o = torch.einsum("bhij,bjd->bhid", s.softmax(-1), v).transpose(1, 2).reshape(B, N, H * 64)
+    o.backward(d_o.double())
+    qd, sd = qkv.to(DEV), logs.exp().to(DEV)
+    kd = key_len.to(DEV) if key_len is not None else None
+    o_gpu = runtime.alibi_mqa_attention(qd, H, sd, kd)
+    _close(o_gpu, o, 5e-6, "forward o")
+    dqkv, dls = runtime.alibi_mqa_attention_bwd(qd, o_gpu, d_o.to(DEV), H, sd, kd)
+    if key_len is not None:   # query rows beyond an utterance's length: the forward leaves them undefined, training masks d_o
+        valid = (idx[None, :] < key_len[:, None])
+        d_o = d_o * valid[..., None]
+        q64.grad = None
+        l64.grad = None
+        o2 = torch.einsum("bhij,bjd->bhid", s.softmax(-1), v).transpose(1, 2).reshape(B, N, H * 64)
+        (o2 * d_o.double()).sum().backward()
+        dqkv, dls = runtime.alibi_mqa_attention_bwd(qd, o_gpu, d_o.to(DEV), H, sd, kd)
+    _close(dqkv[..., :H * 64], q64.grad[..., :H * 64], 2e-5, "dQ")
+    _close(dqkv[..., H * 64:H * 64 + 64], q64.grad[..., H * 64:H * 64 + 64], 2e-5, "dK")
+    _close(dqkv[..., H * 64 + 64:], q64.grad[..., H * 64 + 64:], 2e-5, "dV")
+    _close(dls, l64.grad, 5e-5, "dlogslopes")
+    dqkv2, dls2 = runtime.alibi_mqa_attention_bwd(qd, o_gpu, d_o.to(DEV), H, sd, kd)
+    assert torch.equal(dqkv, dqkv2) and torch.equal(dls, dls2), "attention backward is not reproducible"
+
+
+def _decoder_stack(state_dict, depth):
+    """The first `depth` layers + final norm of the MelDecoder stack (recipe configuration, this repo's synthetic weights),
+    dropout set to 0 (the backward's current scope)."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    tr = model.decoder
+    tr.layers = torch.nn.ModuleList(list(tr.layers)[:depth])
+    for layer in tr.layers:
+        layer.attention.attend.dropout = 0.
+        layer.feed_forward.dropout_p = 0.
+    return tr.to(DEV).train()
+
+
+def _oracle_stack_sd(state_dict, depth):
+    keep = {}
+    for k, v in state_dict.items():
+        parts = k.split(".")
+        if parts[0] == "decoder" and (parts[1] != "layers" or int(parts[2]) < depth):
+            keep[k] = v.clone().double().requires_grad_()
+    return keep
+
+
+def test_transformer_stack_gradients_match_autograd(state_dict):
+    """TransformerStackFunction (2 decoder layers + final norm, ragged mask) against torch autograd over the oracle's
+    `transformer`: output, d input and the gradient of every parameter."""
+    tr = _decoder_stack(state_dict, 2)
+    B, N, D = 3, 70, 384
+    x = _rand((B, N, D), 20)
+    lens = torch.tensor([70, 41, 64])
+    mask = torch.arange(N)[None, :] < lens[:, None]
+    dout = _rand((B, N, D), 21)
+    sd = _oracle_stack_sd(state_dict, 2)
+    xo = x.double().requires_grad_()
+    out_ref = orc.transformer(sd, "decoder", xo, mask)
+    out_ref.backward(dout.double())
+    xg = x.to(DEV).requires_grad_()
+    out = train.transformer_train_forward(tr, xg, mask.to(DEV))
+    _close(out, out_ref, 2e-5, "stack output")
+    out.backward(dout.to(DEV))
+    _close(xg.grad, xo.grad, 1e-4, "d input")
+    for name, p in tr.named_parameters():
+        _close(p.grad, sd[f"decoder.{name}"].grad, 2e-4, f"d {name}")
+
+
+def test_mel_loss_value_and_gradient():
+    B, C, T = 5, 80, 300
+    out, tgt = _rand((B, C, T), 30).requires_grad_(), _rand((B, C, T), 31)
+    lens = torch.tensor([300, 17, 255, 1, 128])
+    ref = 0.7 * torc.mel_loss(out.double(), tgt.double(), lens)
+    ref.backward()
+    og = out.detach().to(DEV).requires_grad_()
+    loss = train.MelLoss(weight=0.7)(og, tgt.to(DEV), lens.to(DEV))
+    _close(loss, ref, 2e-6, "mel loss")
+    loss.backward()
+    _close(og.grad, out.grad, 2e-6, "d mel")
+    assert float(og.grad[1, :, 17:].abs().max()) == 0.0
+
+
+def test_flat_adamw_matches_torch_adamw():
+    """FlatAdamW (sqnorm + fused clip + AdamW over the arena) against torch.optim.AdamW with the reference's grouping and
+    clip_grad_norm_ on group 0 only (optimizers.py:15-20, :34-40, :236-237): 6 steps with gradients large enough that the
+    clip is active on some steps and idle on others; then the checkpoint layout round trip."""
+    shapes = [(384, 384), (7,), (1536, 384), (384,), (1, 80, 1), (6, 1, 1), (130, 3)]
+    ref_p = [torch.nn.Parameter(_rand(s, 40 + i, 0.3)) for i, s in enumerate(shapes)]
+    gpu_p = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref_p]
+    ref = torc.reference_optimizer(ref_p, lr=2e-3, weight_decay=1e-2)
+    opt = train.FlatAdamW(gpu_p, lr=2e-3, weight_decay=1e-2, grad_clip=1.0)
+    wd_ref, _ = torc.group_weight_decayable_params(ref_p)
+    assert opt.flat.n_decay_tensors == len(wd_ref) == 3
+    for step in range(6):
+        scale = 1e-3 if step % 2 else 3e-2          # norm of group 0 ~ 0.9 / 27: idle / active clip
+        for i, (a, b) in enumerate(zip(ref_p, gpu_p)):
+            g = _rand(a.shape, 100 * step + i, scale)
+            a.grad = g.clone()
+            b.grad.copy_(g)
+        n_ref = torc.reference_step(ref, 1.0)
+        n_gpu = opt.step()
+        _close(n_gpu, n_ref, 1e-5, f"grad norm, step {step}")
+        for i, (a, b) in enumerate(zip(ref_p, gpu_p)):
+            _close(b, a, 2e-6, f"parameter {i} after step {step}")
+            assert float(b.grad.abs().max()) == 0.0
+    sd = opt.state_dict()
+    ref_sd = ref.state_dict()
+    assert [g["params"] for g in sd["optimizer"]["param_groups"]] == [g["params"] for g in ref_sd["param_groups"]]
+    for i in range(len(shapes)):
+        _close(sd["optimizer"]["state"][i]["exp_avg"], ref_sd["state"][i]["exp_avg"], 2e-6, f"exp_avg {i}")
+        _close(sd["optimizer"]["state"][i]["exp_avg_sq"], ref_sd["state"][i]["exp_avg_sq"], 2e-6, f"exp_avg_sq {i}")
+        assert float(ref_sd["state"][i]["step"]) == float(sd["optimizer"]["state"][i]["step"]) == 6.0
+    opt2 = train.FlatAdamW([torch.nn.Parameter(p.detach().clone()) for p in gpu_p], lr=2e-3, weight_decay=1e-2)
+    opt2.load_state_dict(sd)
+    assert opt2.step_count == 6 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+
+
+def test_stack_training_steps_reduce_the_loss(state_dict):
+    """End to end on the GPU: decoder stack (2 layers) forward -> loss -> backward kernels -> FlatAdamW, 8 steps on one
+    batch; the loss falls and the staged weight images follow the arena (a stale image would freeze the loss)."""
+    tr = _decoder_stack(state_dict, 2)
+    opt = train.FlatAdamW(tr, lr=1e-3, weight_decay=1e-2, grad_clip=1.0)
+    B, N = 4, 96
+    x = _rand((B, N, 384), 50).to(DEV)
+    target = _rand((B, N, 384), 51, 0.5).to(DEV)
+    mask = (torch.arange(N)[None, :] < torch.tensor([96, 80, 50, 96])[:, None]).to(DEV)
+    losses = []
+    for _ in range(8):
+        out = train.transformer_train_forward(tr, x, mask)
+        loss = (((out - target) * mask[..., None]) ** 2).mean()
+        losses.append(float(loss))
+        opt.step(loss)
+    assert losses[-1] < 0.9 * losses[0] and all(b < a for a, b in zip(losses, losses[1:])), losses

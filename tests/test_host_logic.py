@@ -308,3 +308,97 @@ def test_bucket_by_length_and_batch_ingest_on_cpu():
         ing.done()
         if k == 0:
             ing.submit(batches[2])
+
+
+# ------------------------------------------------------------------------------------------------ training step (row f2)
+def _train_params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    shapes = [(48, 32), (5,), (64, 48), (32,), (1, 8, 1), (6, 1, 1), (13, 3)]
+    return [torch.nn.Parameter(torch.randn(s, generator=g) * 0.3) for s in shapes]
+
+
+def _train_grads(step, rank, params):
+    g = torch.Generator().manual_seed(1000 * step + rank)
+    return [torch.randn(p.shape, generator=g) * (0.3 if step % 2 else 0.01) for p in params]
+
+
+def test_flat_parameters_layout_and_flat_adamw_flow_on_cpu():
+    """Host logic of the optimizer (no kernel: the oracle's flat AdamW is plugged into the hooks): the arena orders the
+    weight-decay group first exactly as torch's param_groups do (optimizers.py:15-20, :34-40), parameters / gradients are
+    views of it, and `step` = clip group 0 + AdamW + zero_grad reproduces torch.optim.AdamW step for step."""
+    from isp_tts_amd import train
+    from oracle import train_oracle as torc
+    ref_p, my_p = _train_params(), _train_params()
+    flat = train.FlatParameters(_train_params())
+    wd, no_wd = torc.group_weight_decayable_params(ref_p)
+    assert [tuple(p.shape) for p in flat.params] == [tuple(p.shape) for p in wd + no_wd]
+    assert flat.n_decay_tensors == 3 and flat.n_decay % 64 == 0 and all(o % 64 == 0 for o in flat.offsets)
+    assert flat.n_decay == sum((p.numel() + 63) // 64 * 64 for p in wd) and flat.total % 64 == 0
+    for p, o in zip(flat.params, flat.offsets):
+        assert p.data_ptr() == flat.data.data_ptr() + 4 * o and p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o
+    with pytest.raises(runtime.IspkError):          # the product's update is the HIP kernel: CPU arenas fail loudly
+        train.FlatAdamW(_train_params(), lr=1e-3).step()
+
+    ref = torc.reference_optimizer(ref_p, lr=2e-3, weight_decay=1e-2)
+    opt = train.FlatAdamW(my_p, lr=2e-3, weight_decay=1e-2, grad_clip=1.0, update=torc.adamw_flat, sqnorm=torc.sqnorm_flat)
+    for step in range(5):
+        for a, b, g in zip(ref_p, my_p, _train_grads(step, 0, ref_p)):
+            a.grad = g.clone()
+            b.grad.copy_(g)
+        versions = [p._version for p in my_p]
+        n_ref, n_my = torc.reference_step(ref, 1.0), opt.step()
+        assert abs(float(n_ref) - float(n_my)) < 1e-5 * float(n_ref)
+        assert all(p._version > v for p, v in zip(my_p, versions)), "staged weight images key on the version counter"
+        for a, b in zip(ref_p, my_p):
+            assert (a - b).abs().max() < 1e-6 and float(b.grad.abs().max()) == 0.0
+    # weight_decay == 0: ONE group (optimizers.py:34), so the clip covers every parameter
+    one = train.FlatAdamW(_train_params(), lr=1e-3, weight_decay=0., update=torc.adamw_flat, sqnorm=torc.sqnorm_flat)
+    assert one.flat.n_decay_tensors == 7 and len(one.get_last_lr()) == 1
+    opt.anneal_on_epoch_end()
+    assert abs(opt.lr - 2e-3 * 0.995) < 1e-12 and opt.state_dict()["lr_scheduler"]["last_epoch"] == 1
+
+
+def _train_rank_main(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from isp_tts_amd import train
+    from oracle import train_oracle as torc
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        my_p, ref_p = _train_params(), _train_params()
+        opt = train.FlatAdamW(my_p, lr=2e-3, weight_decay=1e-2, grad_clip=1.0, update=torc.adamw_flat, sqnorm=torc.sqnorm_flat)
+        ref = torc.reference_optimizer(ref_p, lr=2e-3, weight_decay=1e-2)
+        assert opt.world == world and opt.shard * world == opt.flat.total and opt.exp_avg.numel() == opt.shard
+        ok = True
+        for step in range(4):
+            mine = _train_grads(step, rank, my_p)
+            for p, g in zip(my_p, mine):
+                p.grad.copy_(g)
+            every = [_train_grads(step, r, ref_p) for r in range(world)]
+            for i, p in enumerate(ref_p):                      # what DDP hands the reference: the mean over ranks
+                p.grad = sum(e[i] for e in every) / world
+            n_ref, n_my = torc.reference_step(ref, 1.0), opt.step()
+            ok &= abs(float(n_ref) - float(n_my)) < 1e-5 * float(n_ref)
+            ok &= all(float((a - b).abs().max()) < 1e-6 for a, b in zip(ref_p, my_p))
+        sd = opt.state_dict()["optimizer"]["state"]               # sharded moments gathered into torch's layout
+        rsd = ref.state_dict()["state"]
+        ok &= all(float((sd[i]["exp_avg"] - rsd[i]["exp_avg"]).abs().max()) < 1e-6 for i in range(len(my_p)))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_adamw_world_size_2_gloo_matches_ddp_plus_adamw():
+    """N > 1 path of the training step: gradient arena summed across ranks, each rank updates its slice with its slice of
+    the moments, parameters all-gathered - equal to averaged gradients + a replicated torch AdamW on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_train_rank_main, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, True), (1, True)]

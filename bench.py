@@ -206,6 +206,9 @@ def worker(args) -> int:
     from isp_tts_amd.dist import MelGatherPipeline, plan_micro_batches, unshard
     from isp_tts_amd.graph import GraphedCall, GraphedForward, GraphedForwardLanes
 
+    # host threads = this process's CPU share (torch defaults to every hardware thread of the box: 128 OpenMP threads on a
+    # 16-core quota turn each host-side tensor copy into tens of milliseconds of throttled spinning)
+    torch.set_num_threads(host_cores())
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -617,6 +620,69 @@ def worker(args) -> int:
             extra("cpu_baseline", lambda: cpu_baseline(args, sd))
             if isinstance(line.get("cpu_baseline"), dict) and "value" in line["cpu_baseline"]:
                 line["gpu_over_cpu"] = round(value / line["cpu_baseline"]["value"], 1)
+
+    # ---------------------------------------------------------------------------------------------- training step (all ranks)
+    if not args.no_extras:
+        def train_line():
+            """SURVEY row f2, first cut: MelDecoder stack (6 x 384, dropout 0, fp32) forward + backward kernels + sharded
+            flat AdamW; B utterances x M frames per GPU, the upstream gradient is synthetic (to_mel / loss not in this line)."""
+            from isp_tts_amd import train
+            tr = model.decoder.train()
+            for layer in tr.layers:
+                layer.attention.attend.dropout = 0.
+                layer.feed_forward.dropout_p = 0.
+            for p in model.parameters():
+                p.requires_grad_(False)
+            for p in tr.parameters():
+                p.requires_grad_(True)
+            model.set_compute_dtype(torch.float32)
+            opt = train.FlatAdamW(tr, lr=2e-4, weight_decay=1e-2, grad_clip=1.0)
+            opt.check_finite = False
+            x = synth._normal(f"bench/train/x{rank}", (B, M, dims.text_dim)).to(dev)
+            dout = (synth._normal(f"bench/train/d{rank}", (B, M, dims.text_dim)) * 1e-3).to(dev)
+            mlen = synth.make_lengths(B, L, M, variable=True, seed=synth.SEED + rank)[1].to(dev)
+            mask = torch.arange(M, device=dev)[None, :] < mlen[:, None]
+            prof = runtime.LaunchProfiler() if rank == 0 else None
+
+            def st():
+                xg = x.clone().requires_grad_()
+                out = train.transformer_train_forward(tr, xg, mask)
+                out.backward(dout)
+                opt.step()
+            try:
+                n = max(3, args.steps // 4)
+                for _ in range(2):
+                    st()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    st()
+                fence()
+                el = max_over_ranks(time.perf_counter() - t0)
+                kern = None
+                if prof is not None:
+                    runtime.set_profiler(prof)
+                    st()
+                    torch.cuda.synchronize()
+                    runtime.set_profiler(None)
+                    summ = prof.summary()
+                    kern = {k: {"ms": round(v["total_ms"], 3), "launches": v["launches"]} for k, v in
+                            sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:8]}
+            finally:
+                model.set_compute_dtype(cdt, alignment_dtype=align_dt)
+                tr.eval()
+                for p in model.parameters():
+                    p.requires_grad_(True)
+            frames = world * B * M
+            # forward 2 N K per Linear + attention 4 N^2 64 H; backward = 2 x the Linears' + 2.5 x the attention's
+            res = {"value": round(frames * n / el, 1), "unit": "mel-frames/s", "ms_per_step": round(1e3 * el / n, 3), "steps": n,
+                   "dtype": "f32", "global_batch": world * B, "parameters": opt.flat.total,
+                   "optimizer": f"flat AdamW, clip 1.0, {'reduce-scatter + all-gather over RCCL, moments sharded' if world > 1 else 'single rank'}",
+                   "workload": "BASELINE config 5 restricted to the MelDecoder stack (forward + backward + AdamW), eager launches"}
+            if kern:
+                res["ms_by_kernel_one_step"] = kern
+            return res
+        extra("train_step_decoder_stack", train_line)
 
     if rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())

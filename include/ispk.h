@@ -376,7 +376,8 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              (utils/functions.py:44-58), loss[0] = mean_b ratio[b]; grad (or NULL) = d loss / d mel_out *
  *                              grad_out, zero on padded frames.  mel fp32 [B][C][T].
  * ispk_grad_sqnorm_f32         out[0] = sum g[i]^2 over a flat gradient arena (what clip_grad_norm_ needs,
- *                              experiments/optimizers.py:236-237); partial = 1024 floats of scratch; fixed summation order.
+ *                              experiments/optimizers.py:236-237); partial = 2048 floats (8 KB, 8-byte aligned) of scratch;
+ *                              fp64 accumulation in a fixed order.
  * ispk_adamw_f32               one torch.optim.AdamW step (optimizers.py:72-74; amsgrad off) over flat arenas p, g, m, v of n
  *                              floats.  Elements [0, n_decay) are the weight-decay group of optimizers.py:15-20 (tensors
  *                              with >= 2 non-unit dimensions): they get `weight_decay` and, when grad_sqnorm (device, the

@@ -18,34 +18,34 @@ constexpr int kNormBlocks = 1024;   // partial sums of stage 1 (fixed: the summa
 // Stage 1: block b sums elements b*256*4 + k*stride ... in a fixed order (per-thread running sum over its float4s, then a
 // wave tree by DPP-free shuffles, then 4 wave partials in index order).  Stage 2: one block adds the 1024 partials in a
 // fixed tree.  Deterministic run to run and independent of the CU count.
-__global__ __launch_bounds__(256) void sqnorm_stage1_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void sqnorm_stage1_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ partial) {
     const int64_t n4 = n >> 2;
     const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
-    float acc = 0.f;
+    double acc = 0.0;      // fp64 running sums: the pass is HBM-bound, and the clip coefficient then carries no summation error
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)kNormBlocks * 256) {
         const f32x4 v = x4[i];
-        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        acc += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {          // tail (n not a multiple of 4)
-        const float t = x[(n4 << 2) + threadIdx.x];
+        const double t = x[(n4 << 2) + threadIdx.x];
         acc += t * t;
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    __shared__ float wsum[4];
+    __shared__ double wsum[4];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
 }
 
-__global__ __launch_bounds__(1024) void sqnorm_stage2_kernel(const float* __restrict__ partial, float* __restrict__ out) {
-    __shared__ float s[kNormBlocks];
+__global__ __launch_bounds__(1024) void sqnorm_stage2_kernel(const double* __restrict__ partial, float* __restrict__ out) {
+    __shared__ double s[kNormBlocks];
     s[threadIdx.x] = partial[threadIdx.x];
     __syncthreads();
     for (int half = kNormBlocks / 2; half > 0; half >>= 1) {
         if ((int)threadIdx.x < half) s[threadIdx.x] += s[threadIdx.x + half];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[0] = s[0];
+    if (threadIdx.x == 0) out[0] = (float)s[0];
 }
 
 // ------------------------------------------------------------------------------------------------ AdamW
@@ -149,10 +149,12 @@ __global__ __launch_bounds__(64) void mean_kernel(const float* __restrict__ x, i
 
 extern "C" int32_t ispk_grad_sqnorm_f32(const float* g, int64_t n, float* partial, float* out, ispk_stream_t stream) {
     ISPK_REQUIRE(g && partial && out, -1, "ispk_grad_sqnorm_f32: null pointer");
-    ISPK_REQUIRE(n >= 0 && ispk_aligned(g, 16), -2, "ispk_grad_sqnorm_f32: n < 0 or g not 16-byte aligned");
+    ISPK_REQUIRE(n >= 0 && ispk_aligned(g, 16) && ispk_aligned(partial, 8), -2,
+                 "ispk_grad_sqnorm_f32: n < 0, g not 16-byte aligned or partial not 8-byte aligned");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(sqnorm_stage1_kernel, dim3(kNormBlocks), dim3(256), 0, s, g, n, partial);
-    hipLaunchKernelGGL(sqnorm_stage2_kernel, dim3(1), dim3(kNormBlocks), 0, s, partial, out);
+    double* part = reinterpret_cast<double*>(partial);
+    hipLaunchKernelGGL(sqnorm_stage1_kernel, dim3(kNormBlocks), dim3(256), 0, s, g, n, part);
+    hipLaunchKernelGGL(sqnorm_stage2_kernel, dim3(1), dim3(kNormBlocks), 0, s, part, out);
     return ispk_launch_status();
 }
 

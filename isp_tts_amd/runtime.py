@@ -901,7 +901,7 @@ def grad_sqnorm(g: Tensor, out: Optional[Tensor] = None) -> Tensor:
     assert g.dtype == torch.float32 and g.ndim == 1 and g.is_contiguous()
     if out is None:
         out = torch.empty((1,), dtype=torch.float32, device=g.device)
-    part = workspace(g.device, 1024)
+    part = workspace(g.device, 2048)
     _launch("sqnorm_kernels", 0.0, 4.0 * g.numel(), lib().ispk_grad_sqnorm_f32, g.data_ptr(), g.numel(), part.data_ptr(),
             out.data_ptr(), _stream())
     return out

@@ -111,6 +111,7 @@ class FlatAdamW:
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._update = update or runtime.adamw          # (hooks: the CPU gloo test drives the exchange with the oracle's math)
         self._sqnorm = sqnorm or runtime.grad_sqnorm
+        self.check_finite = True      # `step` returns None for a non-finite norm like the reference (:238-239): one host sync
         self._reduce_scatter = self.world > 1 and dist.get_backend(process_group) != "gloo"   # gloo has none
 
     # ------------------------------------------------------------------------------------------------------------ step
@@ -149,7 +150,7 @@ class FlatAdamW:
         if not clip:
             return None
         norm = self.sq.sqrt() / self.world          # norm of the averaged gradients
-        return norm if bool(torch.isfinite(norm)) else None
+        return norm if not self.check_finite or bool(torch.isfinite(norm)) else None
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         self.flat.zero_grad()

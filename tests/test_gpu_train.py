@@ -213,9 +213,10 @@ def test_flat_adamw_matches_torch_adamw():
     ref_sd = ref.state_dict()
     assert [g["params"] for g in sd["optimizer"]["param_groups"]] == [g["params"] for g in ref_sd["param_groups"]]
     for i in range(len(shapes)):
-        # (the clip coefficient comes from a norm summed in another order than torch's: a few ulps of g per step)
+        # (the clip coefficient comes from a norm summed in another order than torch's fp32 one: a few ulps of g per step,
+        # squared and accumulated in exp_avg_sq)
         _close(sd["optimizer"]["state"][i]["exp_avg"], ref_sd["state"][i]["exp_avg"], 1e-5, f"exp_avg {i}")
-        _close(sd["optimizer"]["state"][i]["exp_avg_sq"], ref_sd["state"][i]["exp_avg_sq"], 1e-5, f"exp_avg_sq {i}")
+        _close(sd["optimizer"]["state"][i]["exp_avg_sq"], ref_sd["state"][i]["exp_avg_sq"], 5e-5, f"exp_avg_sq {i}")
         assert float(ref_sd["state"][i]["step"]) == float(sd["optimizer"]["state"][i]["step"]) == 6.0
     opt2 = train.FlatAdamW([torch.nn.Parameter(p.detach().clone()) for p in gpu_p], lr=2e-3, weight_decay=1e-2)
     opt2.load_state_dict(sd)

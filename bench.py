@@ -62,6 +62,7 @@ def parse(argv=None):
                     help="batches in flight per GPU for the headline value (graph instances replayed round-robin on their "
                          "own streams); the 2-in-flight figure is always reported as an extra")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (+ roofline)")
+    ap.add_argument("--extras", default="", help="comma-separated names: run only these extra lines (default: all)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -364,6 +365,8 @@ def worker(args) -> int:
     def extra(name, fn):
         """Extras never take the headline down: an exception is reported in place of the figure.  (Every rank runs the
         same extras in the same order; the ones with collectives use only what the headline already exercised.)"""
+        if args.extras and name not in args.extras.split(","):
+            return
         try:
             res = fn()
         except Exception as e:  # noqa: BLE001

@@ -356,7 +356,8 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  * ispk_gemm_tn_f32             C[N1][N2] (+)= sum_m mask[m] A[m][N1-slice] B[m][N2-slice]: dW = dY^T . X of every nn.Linear
  *                              (autograd of F.linear).  Rows are split into ranges whose partial products go to `workspace`
  *                              (>= N1*N2 floats; more = more ranges, up to 256) and are added in range order: deterministic.
- *                              row_mask uint8 [M] or NULL; accumulate != 0 adds to C.
+ *                              row_mask uint8 [M] or NULL; accumulate != 0 adds to C.  N1, N2, lda, ldb multiples of 4,
+ *                              A and B 16-byte aligned.
  * ispk_layernorm_bwd_f32       backward of modules/transformer/normalization.py:20-31 followed by `* mask` (transformer.py:102):
  *                              dx (=) or (+=, add_to_dx) rstd (g - mean(g) - xhat mean(g xhat)), g = dy mask gamma;
  *                              dgamma = sum_rows dy mask xhat, dbeta = sum_rows dy mask (either may be NULL; both NULL needs no

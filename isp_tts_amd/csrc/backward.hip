@@ -32,19 +32,29 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------ C = A^T . B  (over rows)
-// A [M][N1], B [M][N2] row-major, C [N1][N2].  With the rows as the MFMA reduction index both operands are read in their
-// natural layout: lane (c = l % 32, hf = l / 32) supplies A[m0 + 2t + hf][n1 + c] and B[m0 + 2t + hf][n2 + c] - two
-// coalesced 128-byte row segments per load instruction, no transposition anywhere.  A workgroup (2 x 2 waves) owns a
-// 128 x 128 tile of C for one range of rows; the ranges' partial tiles go to a workspace and a second kernel adds them in
-// range order (deterministic; optional accumulation into C).  `mask` (uint8 per row, or NULL) zeroes rows of A.
+// A [M][N1], B [M][N2] row-major, C [N1][N2].  With the rows as the MFMA reduction index both operands are used in their
+// natural layout: lane (c = l % 32, hf = l / 32) supplies A[m0 + 2t + hf][n1 + c] and B[m0 + 2t + hf][n2 + c] - no
+// transposition anywhere.  A workgroup (2 x 2 waves) owns a 128 x 128 tile of C for one range of rows and stages 32-row
+// chunks of both operands through LDS (16-byte global loads one chunk ahead, conflict-free 4-byte LDS reads); the ranges'
+// partial tiles go to a workspace and a second kernel adds them in range order (deterministic; optional accumulation into
+// C).  `mask` (uint8 per row, or NULL) zeroes rows of A.
+constexpr int kTnRows = 32;          // rows (reduction steps) per LDS stage
+constexpr int kTnLd = 160;           // floats per staged row: 128 + 32, so the two lane halves (rows 2t, 2t + 1) hit disjoint banks
+constexpr int kTnStage = 2 * kTnRows * kTnLd;   // floats per stage: A chunk + B chunk
+
 template <bool kMask>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                       int64_t ldb, float* __restrict__ part, int M, int N1, int N2,
                                                       int rows_per_split, const uint8_t* __restrict__ mask) {
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, hf = l >> 5;
-    const int n1 = blockIdx.x * 128 + (wave >> 1) * 64, n2 = blockIdx.y * 128 + (wave & 1) * 64;
+    // Staging: thread (r = tid / 32, q = tid % 32) fetches float4 q of rows r, r + 8, r + 16, r + 24 of the A chunk and of the
+    // B chunk (512 contiguous bytes per row and wave half), one chunk ahead of the MFMAs, double-buffered in LDS.
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, c = l & 31, hf = l >> 5;
+    const int n1 = blockIdx.x * 128, n2 = blockIdx.y * 128, wa = (wave >> 1) * 64, wb = (wave & 1) * 64;
     const int split = blockIdx.z;
     const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    const int sr = tid >> 5, sq = (tid & 31) * 4;
+    const bool a_ok = n1 + sq < N1, b_ok = n2 + sq < N2;     // (N1, N2 are multiples of 4: a float4 is in or out as a whole)
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -52,41 +62,61 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const bool a0 = n1 + c < N1, a1 = n1 + 32 + c < N1, b0 = n2 + c < N2, b1 = n2 + 32 + c < N2;
-    const float* pa = A + n1 + c;
-    const float* pb = B + n2 + c;
-    for (int m0 = m_begin; m0 < m_end; m0 += 16) {   // 8 MFMA k-steps (16 rows) per trip: 32 loads in flight per wave
-        float va0[8], va1[8], vb0[8], vb1[8];
+    f32x4 ra[4], rb[4];
+    auto fetch = [&](int m0) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const int m = m0 + 2 * t + hf;
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + sr + 8 * j;
             const bool ok = m < m_end;
-            const int64_t ra = (int64_t)(ok ? m : m_begin) * lda, rb = (int64_t)(ok ? m : m_begin) * ldb;
-            float s = ok ? 1.f : 0.f;
+            float s = 1.f;
             if (kMask) s = (ok && mask[m]) ? 1.f : 0.f;
-            va0[t] = a0 ? pa[ra] * s : 0.f;
-            va1[t] = a1 ? pa[ra + 32] * s : 0.f;
-            vb0[t] = (b0 && ok) ? pb[rb] : 0.f;
-            vb1[t] = (b1 && ok) ? pb[rb + 32] : 0.f;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[j] = (ok && a_ok) ? *reinterpret_cast<const f32x4*>(A + (int64_t)m * lda + n1 + sq) : z;
+            rb[j] = (ok && b_ok) ? *reinterpret_cast<const f32x4*>(B + (int64_t)m * ldb + n2 + sq) : z;
+            if (kMask) ra[j] *= s;
         }
+    };
+    auto stash = [&](int buf) {
+        float* sa = lds + buf * kTnStage;
+        float* sb = sa + kTnRows * kTnLd;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            acc[0][0] = mfma2(va0[t], vb0[t], acc[0][0]);
-            acc[0][1] = mfma2(va0[t], vb1[t], acc[0][1]);
-            acc[1][0] = mfma2(va1[t], vb0[t], acc[1][0]);
-            acc[1][1] = mfma2(va1[t], vb1[t], acc[1][1]);
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<f32x4*>(sa + (sr + 8 * j) * kTnLd + sq) = ra[j];
+            *reinterpret_cast<f32x4*>(sb + (sr + 8 * j) * kTnLd + sq) = rb[j];
         }
+    };
+    fetch(m_begin);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += kTnRows) {
+        const bool more = m0 + kTnRows < m_end;
+        if (more) fetch(m0 + kTnRows);
+        const float* sa = lds + buf * kTnStage + wa + c;
+        const float* sb = lds + buf * kTnStage + kTnRows * kTnLd + wb + c;
+#pragma unroll
+        for (int t = 0; t < kTnRows / 2; ++t) {
+            const int row = (2 * t + hf) * kTnLd;
+            const float a0 = sa[row], a1 = sa[row + 32], b0 = sb[row], b1 = sb[row + 32];
+            acc[0][0] = mfma2(a0, b0, acc[0][0]);
+            acc[0][1] = mfma2(a0, b1, acc[0][1]);
+            acc[1][0] = mfma2(a1, b0, acc[1][0]);
+            acc[1][1] = mfma2(a1, b1, acc[1][1]);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
     }
     float* out = part + (int64_t)split * N1 * N2;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int col = n2 + 32 * j + c;
+            const int col = n2 + wb + 32 * j + c;
             if (col >= N2) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = n1 + 32 * i + acc_row(r, hf);
+                const int row = n1 + wa + 32 * i + acc_row(r, hf);
                 if (row < N1) out[(int64_t)row * N2 + col] = acc[i][j][r];
             }
         }
@@ -370,14 +400,16 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
     if (l == 0) slope_part[((int64_t)h * gridDim.z + b) * ntiles + tile] = gs;
 }
 
-// dK / dV kernel: one wave per (key tile of 32, batch item); loops over the heads and the query tiles (S[query][key], key on
-// the lane), so the sums over heads and queries stay in registers: no atomics, one write per element.
-__global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ dout,
-                                                          int64_t ldo, const float* __restrict__ slopes,
-                                                          const int64_t* __restrict__ key_len, const float* __restrict__ lse,
-                                                          const float* __restrict__ delta, float* __restrict__ dqkv, int N,
-                                                          int H, float scale) {
-    const int kt = blockIdx.x, b = blockIdx.y, l = threadIdx.x, c = l & 31, hf = l >> 5;
+// dK / dV kernel: one workgroup per (key tile of 32, batch item), one wave per head; a wave loops over the query tiles
+// (S[query][key], key on the lane) with its head's sums in registers, then the H waves add their tiles into one LDS tile in
+// head order (barrier between heads): no atomics, a fixed summation order, one write per element.
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ dout,
+                                                            int64_t ldo, const float* __restrict__ slopes,
+                                                            const int64_t* __restrict__ key_len, const float* __restrict__ lse,
+                                                            const float* __restrict__ delta, float* __restrict__ dqkv, int N,
+                                                            int H, float scale) {
+    __shared__ float red[2][2][16][64];     // [dk | dv][M tile][register][lane]
+    const int kt = blockIdx.x, b = blockIdx.y, h = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, hf = l >> 5;
     const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
     const int j = kt * 32 + c;
     const float* qb = qkv + (int64_t)b * N * ld;
@@ -388,50 +420,61 @@ __global__ __launch_bounds__(64) void attn_bwd_dkv_kernel(const float* __restric
         const Frag kf = load_frag(kb, ld, j, N, hf);
         const Frag vf = load_frag(vb, ld, j, N, hf);
         const int qt_end = (N + 31) / 32;
-        for (int h = 0; h < H; ++h) {
-            const float slope = slopes[h];
-            const float* qh = qb + h * 64;
-            const float* doh = dout + (int64_t)b * N * ldo + h * 64;
-            const float* lh = lse + ((int64_t)b * H + h) * N;
-            const float* dh = delta + ((int64_t)b * H + h) * N;
-            for (int qt = 0; qt < qt_end; ++qt) {
-                const Frag qf = load_frag(qh, ld, qt * 32 + c, N, hf);
-                const f32x16 s = dot_frags(qf, kf);
-                const Frag dof = load_frag(doh, ldo, qt * 32 + c, N, hf);
-                const f32x16 dp = dot_frags(dof, vf);
-                float p[16], ds[16];
+        const float slope = slopes[h];
+        const float* qh = qb + h * 64;
+        const float* doh = dout + (int64_t)b * N * ldo + h * 64;
+        const float* lh = lse + ((int64_t)b * H + h) * N;
+        const float* dh = delta + ((int64_t)b * H + h) * N;
+        for (int qt = 0; qt < qt_end; ++qt) {
+            const Frag qf = load_frag(qh, ld, qt * 32 + c, N, hf);
+            const f32x16 s = dot_frags(qf, kf);
+            const Frag dof = load_frag(doh, ldo, qt * 32 + c, N, hf);
+            const f32x16 dp = dot_frags(dof, vf);
+            float p[16], ds[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int i = qt * 32 + acc_row(r, hf);
-                    const bool ok = i < N && j < klen;
-                    const float L = i < N ? lh[i] : 0.f, dl = i < N ? dh[i] : 0.f;
-                    p[r] = ok ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
-                    ds[r] = p[r] * (dp[r] - dl);
-                }
+            for (int r = 0; r < 16; ++r) {
+                const int i = qt * 32 + acc_row(r, hf);
+                const bool ok = i < N && j < klen;
+                const float L = i < N ? lh[i] : 0.f, dl = i < N ? dh[i] : 0.f;
+                p[r] = ok ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
+                ds[r] = p[r] * (dp[r] - dl);
+            }
 #pragma unroll
-                for (int t = 0; t < 16; ++t) {
-                    const int i = qt * 32 + acc_row(t, hf);
-                    const bool ok = i < N;
-                    const float* dor = doh + (int64_t)(ok ? i : 0) * ldo;
-                    const float* qr = qh + (int64_t)(ok ? i : 0) * ld;
-                    const float d0 = ok ? dor[c] : 0.f, d1 = ok ? dor[32 + c] : 0.f;
-                    const float q0 = ok ? qr[c] : 0.f, q1 = ok ? qr[32 + c] : 0.f;
-                    dv[0] = mfma2(d0, p[t], dv[0]);
-                    dv[1] = mfma2(d1, p[t], dv[1]);
-                    dk[0] = mfma2(q0, ds[t], dk[0]);
-                    dk[1] = mfma2(q1, ds[t], dk[1]);
-                }
+            for (int t = 0; t < 16; ++t) {
+                const int i = qt * 32 + acc_row(t, hf);
+                const bool ok = i < N;
+                const float* dor = doh + (int64_t)(ok ? i : 0) * ldo;
+                const float* qr = qh + (int64_t)(ok ? i : 0) * ld;
+                const float d0 = ok ? dor[c] : 0.f, d1 = ok ? dor[32 + c] : 0.f;
+                const float q0 = ok ? qr[c] : 0.f, q1 = ok ? qr[32 + c] : 0.f;
+                dv[0] = mfma2(d0, p[t], dv[0]);
+                dv[1] = mfma2(d1, p[t], dv[1]);
+                dk[0] = mfma2(q0, ds[t], dk[0]);
+                dk[1] = mfma2(q1, ds[t], dk[1]);
             }
         }
     }
-    if (j < N) {
+    for (int hh = 0; hh < H; ++hh) {          // heads add in index order
+        if (h == hh) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    red[0][mt][r][l] = hh == 0 ? dk[mt][r] : red[0][mt][r][l] + dk[mt][r];
+                    red[1][mt][r][l] = hh == 0 ? dv[mt][r] : red[1][mt][r][l] + dv[mt][r];
+                }
+        }
+        __syncthreads();
+    }
+    if (h == 0 && j < N) {
         float* dst = dqkv + ((int64_t)b * N + j) * ld + H * 64;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
-                f32x4 wk = {dk[mt][4 * a] * scale, dk[mt][4 * a + 1] * scale, dk[mt][4 * a + 2] * scale, dk[mt][4 * a + 3] * scale};
-                f32x4 wv = {dv[mt][4 * a], dv[mt][4 * a + 1], dv[mt][4 * a + 2], dv[mt][4 * a + 3]};
+                f32x4 wk = {red[0][mt][4 * a][l] * scale, red[0][mt][4 * a + 1][l] * scale, red[0][mt][4 * a + 2][l] * scale,
+                            red[0][mt][4 * a + 3][l] * scale};
+                f32x4 wv = {red[1][mt][4 * a][l], red[1][mt][4 * a + 1][l], red[1][mt][4 * a + 2][l], red[1][mt][4 * a + 3][l]};
                 *reinterpret_cast<f32x4*>(dst + 32 * mt + 8 * a + 4 * hf) = wk;
                 *reinterpret_cast<f32x4*>(dst + 64 + 32 * mt + 8 * a + 4 * hf) = wv;
             }
@@ -464,8 +507,10 @@ extern "C" int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B,
                                     int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
                                     int64_t workspace_floats, ispk_stream_t stream) {
     ISPK_REQUIRE(A && B && C && workspace, -1, "ispk_gemm_tn_f32: null pointer");
-    ISPK_REQUIRE(M >= 1 && N1 >= 1 && N2 >= 1 && lda >= N1 && ldb >= N2 && ldc >= N2, -2,
-                 "ispk_gemm_tn_f32: bad shape M=%d N1=%d N2=%d", M, N1, N2);
+    ISPK_REQUIRE(M >= 1 && N1 >= 4 && N2 >= 4 && N1 % 4 == 0 && N2 % 4 == 0 && lda >= N1 && ldb >= N2 && ldc >= N2 &&
+                     lda % 4 == 0 && ldb % 4 == 0 && ispk_aligned(A, 16) && ispk_aligned(B, 16), -2,
+                 "ispk_gemm_tn_f32: bad shape M=%d N1=%d N2=%d (N1, N2, lda, ldb multiples of 4, 16-byte aligned operands)", M,
+                 N1, N2);
     const int64_t tile = (int64_t)N1 * N2;
     ISPK_REQUIRE(workspace_floats >= tile, -3, "ispk_gemm_tn_f32: workspace holds %lld floats, one partial needs %lld",
                  (long long)workspace_floats, (long long)tile);
@@ -476,14 +521,20 @@ extern "C" int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B,
     splits = splits < workspace_floats / tile ? splits : workspace_floats / tile;
     splits = splits < 1 ? 1 : (splits > 256 ? 256 : splits);
     int rows_per = (int)((M + splits - 1) / splits);
-    rows_per = (rows_per + 15) / 16 * 16;
+    rows_per = (rows_per + kTnRows - 1) / kTnRows * kTnRows;
     splits = (M + rows_per - 1) / rows_per;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((N1 + 127) / 128, (N2 + 127) / 128, (unsigned)splits);
-    if (row_mask)
-        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), 0, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per, row_mask);
-    else
-        hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), 0, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per, row_mask);
+    constexpr size_t lds_bytes = 2 * kTnStage * sizeof(float);   // 80 KB: two workgroups per CU
+    if (row_mask) {
+        ISPK_RESERVE_LDS(gemm_tn_kernel<true>, lds_bytes, "ispk_gemm_tn_f32");
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), lds_bytes, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
+                           row_mask);
+    } else {
+        ISPK_RESERVE_LDS(gemm_tn_kernel<false>, lds_bytes, "ispk_gemm_tn_f32");
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), lds_bytes, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
+                           row_mask);
+    }
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((tile + 255) / 256)), dim3(256), 0, s, workspace, (int)splits, tile,
                        N2, C, ldc, accumulate);
     return ispk_launch_status();
@@ -539,7 +590,7 @@ extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv,
                                                float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
                                                ispk_stream_t stream) {
     ISPK_REQUIRE(qkv && o && d_o && slopes && dqkv && workspace, -1, "ispk_alibi_mqa_attn_bwd_f32: null pointer");
-    ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 64 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
+    ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 8 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
                      ld_o % 4 == 0, -2, "ispk_alibi_mqa_attn_bwd_f32: bad shape B=%d N=%d H=%d", B, N, H);
     ISPK_REQUIRE(ispk_aligned(qkv, 16) && ispk_aligned(o, 16) && ispk_aligned(d_o, 16) && ispk_aligned(dqkv, 16), -3,
                  "ispk_alibi_mqa_attn_bwd_f32: arrays must be 16-byte aligned");
@@ -551,7 +602,7 @@ extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv,
     const float scale = 0.125f;
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse,
                        delta, spart, N, H, scale);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(tiles, B), dim3(64), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len, lse, delta,
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len, lse, delta,
                        dqkv, N, H, scale);
     if (dlogslopes)
         hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64), 0, s, spart, B * tiles, slopes, dlogslopes, H);

@@ -1,7 +1,8 @@
 """Times the phases of ingest.BatchIngest on the GPU box (pageable -> pinned memcpy, H2D on the copy stream)."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from isp_tts_amd import ingest, synth
 dev = "cuda"
 B, L, M = 64, 100, 512

@@ -483,13 +483,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 
 // d log-slope_h = slope_h * sum of the (batch, tile) partials, in index order (the parameter is log-slope:
 // slope = exp(learned_logslopes), embeddings.py:59-82)
-__global__ __launch_bounds__(64) void slope_reduce_kernel(const float* __restrict__ part, int per_head, const float* __restrict__ slopes,
-                                                          float* __restrict__ dlogslopes, int H) {
-    const int h = threadIdx.x;
+__global__ __launch_bounds__(512) void slope_reduce_kernel(const float* __restrict__ part, int per_head, const float* __restrict__ slopes,
+                                                           float* __restrict__ dlogslopes, int H) {
+    const int h = threadIdx.x >> 6, l = threadIdx.x & 63;      // one wave per head; lane l adds partials l, l + 64, ... in order
     if (h >= H) return;
     float s = 0.f;
-    for (int k = 0; k < per_head; ++k) s += part[(int64_t)h * per_head + k];
-    dlogslopes[h] = s * slopes[h];
+    for (int k = l; k < per_head; k += 64) s += part[(int64_t)h * per_head + k];
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if (l == 0) dlogslopes[h] = s * slopes[h];
 }
 
 }  // namespace
@@ -605,6 +606,6 @@ extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv,
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len, lse, delta,
                        dqkv, N, H, scale);
     if (dlogslopes)
-        hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64), 0, s, spart, B * tiles, slopes, dlogslopes, H);
+        hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64 * H), 0, s, spart, B * tiles, slopes, dlogslopes, H);
     return ispk_launch_status();
 }

@@ -432,7 +432,7 @@ def ffn_prenorm2(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, 
     if mask is not None:
         mask = mask.reshape(-1).contiguous()
     nb = x2.numel() * 8 + (w1.numel() + w2c.numel()) * 2 + out.numel() * 4 + (R * 8 if want_stats else 0)
-    _launch(f"ffn2_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_prenorm2, x2.data_ptr(),
+    _launch("ffn2_bf16_kernel<0>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_prenorm2, x2.data_ptr(),
             x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w2c.data_ptr(), _ptr(mask),
             out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())
     return (out, stats) if want_stats else out

@@ -627,8 +627,8 @@ def worker(args) -> int:
     # ---------------------------------------------------------------------------------------------- training step (all ranks)
     if not args.no_extras:
         def train_line():
-            """SURVEY row f2, first cut: MelDecoder stack (6 x 384, dropout 0, fp32) forward + backward kernels + sharded
-            flat AdamW; B utterances x M frames per GPU, the upstream gradient is synthetic (to_mel / loss not in this line)."""
+            """SURVEY row f2, first cut: MelDecoder stack (6 x 384, dropout 0, fp32) + to_mel + mel loss: forward, backward
+            kernels, sharded flat AdamW; B utterances x M frames per GPU, decoder inputs and mel targets synthetic."""
             from isp_tts_amd import train
             tr = model.decoder.train()
             for layer in tr.layers:
@@ -636,22 +636,22 @@ def worker(args) -> int:
                 layer.feed_forward.dropout_p = 0.
             for p in model.parameters():
                 p.requires_grad_(False)
-            for p in tr.parameters():
+            trained = list(tr.parameters()) + list(model.to_mel.parameters())
+            for p in trained:
                 p.requires_grad_(True)
             model.set_compute_dtype(torch.float32)
-            opt = train.FlatAdamW(tr, lr=2e-4, weight_decay=1e-2, grad_clip=1.0)
+            opt = train.FlatAdamW(trained, lr=2e-4, weight_decay=1e-2, grad_clip=1.0)
             opt.check_finite = False
             x = synth._normal(f"bench/train/x{rank}", (B, M, dims.text_dim)).to(dev)
-            dout = (synth._normal(f"bench/train/d{rank}", (B, M, dims.text_dim)) * 1e-3).to(dev)
+            target = synth._normal(f"bench/train/t{rank}", (B, dims.mel_dim, M)).to(dev)
             mlen = synth.make_lengths(B, L, M, variable=True, seed=synth.SEED + rank)[1].to(dev)
+            crit = train.MelLoss()
             mask = torch.arange(M, device=dev)[None, :] < mlen[:, None]
             prof = runtime.LaunchProfiler() if rank == 0 else None
 
             def st():
-                xg = x.clone().requires_grad_()
-                out = train.transformer_train_forward(tr, xg, mask)
-                out.backward(dout)
-                opt.step()
+                mel = train.mel_decoder_train_forward(model, x, mask)
+                opt.step(crit(mel, target, mlen))
             try:
                 n = max(3, args.steps // 4)
                 for _ in range(2):
@@ -681,7 +681,8 @@ def worker(args) -> int:
             res = {"value": round(frames * n / el, 1), "unit": "mel-frames/s", "ms_per_step": round(1e3 * el / n, 3), "steps": n,
                    "dtype": "f32", "global_batch": world * B, "parameters": opt.flat.total,
                    "optimizer": f"flat AdamW, clip 1.0, {'reduce-scatter + all-gather over RCCL, moments sharded' if world > 1 else 'single rank'}",
-                   "workload": "BASELINE config 5 restricted to the MelDecoder stack (forward + backward + AdamW), eager launches"}
+                   "workload": "BASELINE config 5 restricted to MelDecoder + to_mel under the mel loss (forward + backward + clip + "
+                               "AdamW), eager launches"}
             if kern:
                 res["ms_by_kernel_one_step"] = kern
             return res

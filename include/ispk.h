@@ -376,6 +376,10 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              ratio[b] = sum over (c, t < mel_len[b]) of (out - target)^2 / max(C * len_b, 1e-5)
  *                              (utils/functions.py:44-58), loss[0] = mean_b ratio[b]; grad (or NULL) = d loss / d mel_out *
  *                              grad_out, zero on padded frames.  mel fp32 [B][C][T].
+ * ispk_mel_grad_rows_f32       first step of the backward of `to_mel` (Linear + transpose + mask, model.py:167-168):
+ *                              g[(b, t)][c] = mask[b][t] * dmel[b][c][t], frames as rows for the two GEMMs that follow
+ *                              (d dec = g W through ispk_gemm_f32 on W^T, dW = g^T dec through ispk_gemm_tn_f32).
+ * ispk_colsum_f32              out[c] = sum_r x[r][c] (bias gradients), fixed summation order; workspace >= 256 * cols floats.
  * ispk_grad_sqnorm_f32         out[0] = sum g[i]^2 over a flat gradient arena (what clip_grad_norm_ needs,
  *                              experiments/optimizers.py:236-237); partial = 2048 floats (8 KB, 8-byte aligned) of scratch;
  *                              fp64 accumulation in a fixed order.
@@ -403,6 +407,10 @@ int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const floa
                                     ispk_stream_t stream);
 int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
                           float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
+int32_t ispk_mel_grad_rows_f32(const float* dmel, const uint8_t* mask, float* g, int32_t B, int32_t C, int32_t T,
+                               ispk_stream_t stream);
+int32_t ispk_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t cols, float* workspace, int64_t workspace_floats,
+                        float* out, ispk_stream_t stream);
 int32_t ispk_grad_sqnorm_f32(const float* g, int64_t n, float* partial, float* out, ispk_stream_t stream);
 int32_t ispk_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int32_t step, const float* grad_sqnorm, float max_norm,

@@ -145,7 +145,66 @@ __global__ __launch_bounds__(64) void mean_kernel(const float* __restrict__ x, i
     }
 }
 
+// ------------------------------------------------------------------------------------------------ to_mel backward, step 1
+// mel = mask * (dec W^T + b) stored [B][C][T] (model.py:167-168).  The GEMMs of the backward want frames as rows:
+// g[(b, t)][c] = mask[b][t] * dmel[b][c][t].  32 x 32 tiles through LDS: reads run along t, writes along c.
+__global__ __launch_bounds__(256) void mel_grad_rows_kernel(const float* __restrict__ dmel, const uint8_t* __restrict__ mask,
+                                                            float* __restrict__ g, int C, int T) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, t0 = blockIdx.x * 32, c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8)
+        if (c0 + k < C && t0 + tx < T) tile[k][tx] = dmel[((int64_t)b * C + c0 + k) * T + t0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int t = t0 + k, c = c0 + tx;
+        if (t < T && c < C) {
+            const float m = mask ? (mask[(int64_t)b * T + t] ? 1.f : 0.f) : 1.f;
+            g[((int64_t)b * T + t) * C + c] = tile[tx][k] * m;
+        }
+    }
+}
+
+// column sums of a [rows][cols] matrix (bias gradients), two stages with a fixed order: block k adds rows k, k + P, ...
+constexpr int kColParts = 256;
+__global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int cols,
+                                                            float* __restrict__ part) {
+    for (int c = threadIdx.x; c < cols; c += 256) {
+        float s = 0.f;
+        for (int64_t r = blockIdx.x; r < rows; r += kColParts) s += x[r * ld + c];
+        part[(int64_t)blockIdx.x * cols + c] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int cols, float* __restrict__ out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int k = 0; k < kColParts; ++k) s += part[(int64_t)k * cols + c];
+    out[c] = s;
+}
+
 }  // namespace
+
+extern "C" int32_t ispk_mel_grad_rows_f32(const float* dmel, const uint8_t* mask, float* g, int32_t B, int32_t C, int32_t T,
+                                          ispk_stream_t stream) {
+    ISPK_REQUIRE(dmel && g, -1, "ispk_mel_grad_rows_f32: null pointer");
+    ISPK_REQUIRE(B >= 1 && C >= 1 && T >= 1 && B <= 65535, -2, "ispk_mel_grad_rows_f32: bad shape B=%d C=%d T=%d", B, C, T);
+    hipLaunchKernelGGL(mel_grad_rows_kernel, dim3((T + 31) / 32, (C + 31) / 32, B), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), dmel, mask, g, C, T);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t cols, float* workspace,
+                                   int64_t workspace_floats, float* out, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && workspace && out, -1, "ispk_colsum_f32: null pointer");
+    ISPK_REQUIRE(rows >= 1 && cols >= 1 && ldx >= cols && workspace_floats >= (int64_t)kColParts * cols, -2,
+                 "ispk_colsum_f32: rows=%lld cols=%d, workspace needs %lld floats", (long long)rows, cols,
+                 (long long)kColParts * cols);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(kColParts), dim3(256), 0, s, x, ldx, rows, cols, workspace);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, workspace, cols, out);
+    return ispk_launch_status();
+}
 
 extern "C" int32_t ispk_grad_sqnorm_f32(const float* g, int64_t n, float* partial, float* out, ispk_stream_t stream) {
     ISPK_REQUIRE(g && partial && out, -1, "ispk_grad_sqnorm_f32: null pointer");

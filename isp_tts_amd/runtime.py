@@ -66,6 +66,8 @@ SIGNATURES = {
     "ispk_gelu_bwd_f32": [_P, _P, _P, _I64, _P],
     "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
+    "ispk_mel_grad_rows_f32": [_P, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_colsum_f32": [_P, _I64, _I64, _I32, _P, _I64, _P, _P],
     "ispk_grad_sqnorm_f32": [_P, _I64, _P, _P, _P],
     "ispk_adamw_f32": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _P, _F32, _F32, _P],
 }
@@ -893,6 +895,34 @@ def mel_loss(mel_out: Tensor, mel_target: Tensor, mel_len: Tensor, want_grad: bo
             mel_target.data_ptr(), mel_len.data_ptr(), ratio.data_ptr(), loss.data_ptr(), _ptr(grad), grad_out, B, C, T,
             _stream())
     return loss, grad
+
+
+def mel_grad_rows(dmel: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """ispk_mel_grad_rows_f32: [B, C, T] gradient of the mel output -> masked rows [B, T, C] for to_mel's backward."""
+    _dev(dmel, mask)
+    assert dmel.dtype == torch.float32 and dmel.ndim == 3
+    dmel = dmel.contiguous()
+    B, C, T = dmel.shape
+    if mask is not None:
+        mask = mask.contiguous()
+        assert mask.dtype == torch.bool and mask.shape == (B, T)
+    g = torch.empty((B, T, C), dtype=torch.float32, device=dmel.device)
+    _launch("mel_grad_rows_kernel", 0.0, 8.0 * dmel.numel(), lib().ispk_mel_grad_rows_f32, dmel.data_ptr(), _ptr(mask),
+            g.data_ptr(), B, C, T, _stream())
+    return g
+
+
+def colsum(x: Tensor) -> Tensor:
+    """ispk_colsum_f32: column sums of a [rows, cols] fp32 matrix (bias gradients), fixed order."""
+    _dev(x)
+    x2 = _rows2d(x)
+    assert x2.dtype == torch.float32
+    rows, cols = x2.shape
+    out = torch.empty((cols,), dtype=torch.float32, device=x.device)
+    ws = workspace(x.device, 256 * cols)
+    _launch("colsum_kernels", 0.0, 4.0 * x2.numel(), lib().ispk_colsum_f32, x2.data_ptr(), x2.stride(0), rows, cols,
+            ws.data_ptr(), ws.numel(), out.data_ptr(), _stream())
+    return out
 
 
 def grad_sqnorm(g: Tensor, out: Optional[Tensor] = None) -> Tensor:

@@ -6,6 +6,7 @@
              the rank's own slice and an all-gather of the parameters (RCCL over xGMI; optimizer state sharded).
   stack.py   TransformerStackFunction: a `Transformer` stack (plain LayerNorm, dropout 0, fp32) as ONE autograd node whose
              backward is the kernels of csrc/backward.hip.
+  stack.py   also ToMelFunction (to_mel's Linear + transpose + mask, model.py:167-168) and `mel_decoder_train_forward`.
   loss.py    MelLoss with its gradient as one kernel (models/acoustic/loss.py:22-35).
 
 Not built yet: backward of the aligner front-end, the adaptor (AdaLN stacks, flow matching, length
@@ -13,7 +14,7 @@ regulation), dropout, the CTC / binarisation attention losses, bf16 autocast.
 """
 from .loss import MelLoss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params
-from .stack import TransformerStackFunction, transformer_train_forward
+from .stack import ToMelFunction, TransformerStackFunction, mel_decoder_train_forward, transformer_train_forward
 
-__all__ = ["FlatAdamW", "FlatParameters", "MelLoss", "TransformerStackFunction", "group_weight_decayable_params",
-           "transformer_train_forward"]
+__all__ = ["FlatAdamW", "FlatParameters", "MelLoss", "ToMelFunction", "TransformerStackFunction",
+           "group_weight_decayable_params", "mel_decoder_train_forward", "transformer_train_forward"]

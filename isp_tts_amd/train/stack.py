@@ -116,3 +116,29 @@ class TransformerStackFunction(torch.autograd.Function):
 def transformer_train_forward(tr: Transformer, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
     """`tr(x, mask).out` as a differentiable node (gradients reach x and every parameter of the stack)."""
     return TransformerStackFunction.apply(tr, x, mask, *stack_parameters(tr))
+
+
+class ToMelFunction(torch.autograd.Function):
+    """mel = mask * (dec W^T + b), stored [B, 80, T] (model.py:167-168; forward = the inference path's `runtime.to_mel`).
+    Backward: masked gradient rows, then d dec = g W (NT GEMM on W^T), dW = g^T dec, db = column sums of g."""
+
+    @staticmethod
+    def forward(ctx, dec: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor]):
+        dec = dec.float().contiguous()
+        ctx.save_for_backward(dec, weight)
+        ctx.mask = mask
+        return runtime.to_mel(dec, weight.detach(), bias.detach(), mask)
+
+    @staticmethod
+    def backward(ctx, dmel: Tensor):
+        dec, weight = ctx.saved_tensors
+        g = runtime.mel_grad_rows(dmel.float(), ctx.mask)                 # [B, T, 80]
+        d_dec = runtime.gemm(g, runtime.transpose(weight.detach()))        # [B, T, dim]
+        dw = runtime.gemm_tn(g, dec)                                       # [80, dim]
+        return d_dec, dw, runtime.colsum(g), None
+
+
+def mel_decoder_train_forward(model, dec_in: Tensor, dec_mask: Optional[Tensor]) -> Tensor:
+    """MelDecoder + to_mel of `AcousticModel` (model.py:165-168) as differentiable nodes: dec_in [B, T, dim] -> mel [B, 80, T]."""
+    dec = transformer_train_forward(model.decoder, dec_in, dec_mask)
+    return ToMelFunction.apply(dec, model.to_mel.weight, model.to_mel.bias, dec_mask)

@@ -236,6 +236,74 @@ def test_stack_training_steps_reduce_the_loss(state_dict):
     for _ in range(8):
         out = train.transformer_train_forward(tr, x, mask)
         loss = (((out - target) * mask[..., None]) ** 2).mean()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
         opt.step(loss)
     assert losses[-1] < 0.9 * losses[0] and all(b < a for a, b in zip(losses, losses[1:])), losses
+
+
+def test_to_mel_backward_and_colsum(state_dict):
+    """ToMelFunction (Linear + transpose + mask, model.py:167-168) against float64 autograd: d dec, dW, db; ragged mask."""
+    B, T, D, C = 3, 77, 384, 80
+    dec = _rand((B, T, D), 60).requires_grad_()
+    w = state_dict["to_mel.weight"].clone().requires_grad_()
+    bias = state_dict["to_mel.bias"].clone().requires_grad_()
+    mask = torch.arange(T)[None, :] < torch.tensor([77, 40, 64])[:, None]
+    dmel = _rand((B, C, T), 61)
+    ref = (F.linear(dec.double(), w.double(), bias.double()).transpose(1, 2) * mask[:, None, :])
+    ref.backward(dmel.double())
+    dg, wg, bg = dec.detach().to(DEV).requires_grad_(), w.detach().to(DEV).requires_grad_(), bias.detach().to(DEV).requires_grad_()
+    mel = train.ToMelFunction.apply(dg, wg, bg, mask.to(DEV))
+    _close(mel, ref, 5e-6, "mel")
+    mel.backward(dmel.to(DEV))
+    _close(dg.grad, dec.grad, 2e-5, "d dec")
+    _close(wg.grad, w.grad, 2e-5, "d to_mel.weight")
+    _close(bg.grad, bias.grad, 2e-5, "d to_mel.bias")
+    x = _rand((1000, 80), 62)
+    _close(runtime.colsum(x.to(DEV)), x.double().sum(0), 2e-6, "colsum")
+
+
+def test_decoder_to_mel_loss_training_step_matches_reference_step(state_dict):
+    """One whole optimizer step of MelDecoder (2 layers) + to_mel under the mel loss: HIP forward / backward / FlatAdamW
+    against the oracle's forward + torch autograd + torch.optim.AdamW in the reference's grouping with clip 1.0
+    (optimizers.py:230-244).  The loss agrees to 1e-5, the clipped gradient norm to 1e-4, the parameters after the step to a
+    small fraction of the learning rate (gradients themselves are compared tightly in the tests above)."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    depth = 2
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model.decoder.layers = torch.nn.ModuleList(list(model.decoder.layers)[:depth])
+    for layer in model.decoder.layers:
+        layer.attention.attend.dropout = 0.
+        layer.feed_forward.dropout_p = 0.
+    model = model.to(DEV).train()
+    B, T = 3, 90
+    dec_in, target = _rand((B, T, 384), 70), _rand((B, 80, T), 71)
+    lens = torch.tensor([90, 55, 72])
+    mask = torch.arange(T)[None, :] < lens[:, None]
+    # reference step on CPU (fp32, as the GPU path)
+    sd = {k: v.clone().requires_grad_() for k, v in state_dict.items()
+          if k.startswith("to_mel.") or (k.startswith("decoder.") and (k.split(".")[1] != "layers" or int(k.split(".")[2]) < depth))}
+    names = list(sd)
+    ref_opt = torc.reference_optimizer([sd[k] for k in names], lr=1e-3, weight_decay=1e-2)
+    dec = orc.transformer({k: v for k, v in sd.items() if k.startswith("decoder.")}, "decoder", dec_in, mask)
+    mel_ref = F.linear(dec, sd["to_mel.weight"], sd["to_mel.bias"]).transpose(1, 2) * mask[:, None, :]
+    loss_ref = torc.mel_loss(mel_ref, target, lens)
+    loss_ref.backward()
+    norm_ref = torc.reference_step(ref_opt, 1.0)
+    # the same step on the GPU
+    params = list(model.decoder.parameters()) + list(model.to_mel.parameters())
+    opt = train.FlatAdamW(params, lr=1e-3, weight_decay=1e-2, grad_clip=1.0)
+    mel = train.mel_decoder_train_forward(model, dec_in.to(DEV), mask.to(DEV))
+    loss = train.MelLoss()(mel, target.to(DEV), lens.to(DEV))
+    _close(loss, loss_ref, 1e-5, "loss")
+    norm = opt.step(loss)
+    _close(norm, norm_ref, 1e-4, "gradient norm of the clipped group")
+    got = {f"decoder.{n}": p for n, p in model.decoder.named_parameters()}
+    got.update({f"to_mel.{n}": p for n, p in model.to_mel.named_parameters()})
+    # Adam's first step moves every element by ~lr * g / (|g| + eps): where |g| is within rounding noise of 0 the quotient
+    # amplifies that noise, so the bound on single elements is a fraction of lr; the mean difference stays far below it
+    lr = 1e-3
+    for k in names:
+        d = (got[k].detach().cpu() - sd[k].detach()).abs()
+        assert float(d.max()) <= 0.1 * lr and float(d.mean()) <= 2e-3 * lr, (k, float(d.max()), float(d.mean()))

@@ -62,6 +62,10 @@ def parse(argv=None):
                     help="batches in flight per GPU for the headline value (graph instances replayed round-robin on their "
                          "own streams); the 2-in-flight figure is always reported as an extra")
     ap.add_argument("--no-extras", action="store_true", help="only the headline measurement (+ roofline)")
+    ap.add_argument("--three-graphs", action="store_true",
+                    help="headline step as three HIP graphs on two streams (graph.SegmentedForward) instead of one")
+    ap.add_argument("--linear-graph", action="store_true",
+                    help="headline graph without the forward's side-stream branches (experiments: graph turnaround)")
     ap.add_argument("--extras", default="", help="comma-separated names: run only these extra lines (default: all)")
     ap.add_argument("--no-kernel-events", action="store_true", help="skip per-launch HIP events (no roofline object)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured HIP graph")
@@ -205,7 +209,7 @@ def worker(args) -> int:
     from isp_tts_amd.acoustic import AcousticModel
     from isp_tts_amd.config import AcousticDims
     from isp_tts_amd.dist import MelGatherPipeline, plan_micro_batches, unshard
-    from isp_tts_amd.graph import GraphedCall, GraphedForward, GraphedForwardLanes
+    from isp_tts_amd.graph import GraphedCall, GraphedForward, GraphedForwardLanes, SegmentedForward
 
     # host threads = this process's CPU share (torch defaults to every hardware thread of the box: 128 OpenMP threads on a
     # 16-core quota turn each host-side tensor copy into tens of milliseconds of throttled spinning)
@@ -293,11 +297,20 @@ def worker(args) -> int:
                     pipe.submit(out.mel, out.adaptor_output.dec_lengths)
                 return out
             return step, ([pipe] if pipe else []), None, d
+        if args.three_graphs and in_flight == 1:
+            seg = SegmentedForward(model, *fwd_args(d))
+
+            def step():
+                out = seg.replay()
+                if pipe is not None:
+                    pipe.submit(out.mel, out.adaptor_output.dec_lengths)
+                return out
+            return step, ([pipe] if pipe else []), "three", d
         # several graph instances in flight: LINEAR graphs (no side-stream branches inside a forward).  Two branchy graphs
         # do not overlap under HIP graph replay (measured gain 1.03); two linear ones on their own streams do - the other
         # batch's launches then play the part of the side branches.
         branches = model.overlap_streams
-        model.overlap_streams = in_flight == 1
+        model.overlap_streams = in_flight == 1 and not args.linear_graph
         try:
             lanes = GraphedForwardLanes(model, *fwd_args(d), lanes=in_flight, calibrate=in_flight > 1)
         finally:
@@ -341,8 +354,9 @@ def worker(args) -> int:
                                        f"{'all-gather' if gather_root is None else 'gather to rank 0'} of mel per step, "
                                        "overlapped with the next step)") if world > 1 else "single GPU",
                        "device": name, "compute_units": cus,
-                       "launch": "eager" if lanes is None else "HIP graph replay",
-                       "batches_in_flight": 1 if lanes is None else len(lanes)},
+                       "launch": ("eager" if lanes is None else "three HIP graphs per step on two streams" if lanes == "three"
+                                  else "HIP graph replay"),
+                       "batches_in_flight": 1 if lanes is None or lanes == "three" else len(lanes)},
             "model_TFLOPs": round(value * FLOP_PER_FRAME / 1e12, 2),
         }
 

@@ -136,6 +136,62 @@ class AcousticModel(nn.Module, Constructor):
                     t.record_stream(main)
         return AcousticModelOutput(mel=mel_out, adaptor_output=adaptor_output, aligner_output=aligner_output)
 
+    # ------------------------------------------------------------------------------------------------------------------
+    # The same forward in three pieces for `graph.SegmentedForward` (one HIP graph each).  Inside ONE captured graph the
+    # side branch (MAS + flow predictor) is replayed late - its last kernels run alone after to_mel and lengthen the step
+    # by ~0.12 ms; launched as its own graph on its own stream right after the front piece it runs under the decoder.
+    @torch.no_grad()
+    def forward_front(self, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor, energy: Tensor):
+        """Token embedding, text encoder, aligner front-end (model.py:131-141 up to the soft attention) and the dense
+        targets' soft averages -> state for the other two pieces."""
+        main = torch.cuda.current_stream()
+        side = self._side_streams.setdefault(mel.device, torch.cuda.Stream(device=mel.device))
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            q_proj = self.aligner.attention.project_queries(mel, mel_len)
+        token_emb, enc_mask = runtime.embed_tokens(text, self.text_embedding.weight, text_len)
+        enc_out = self.encoder(token_emb, mask=enc_mask, key_len=text_len).out
+        main.wait_stream(side)
+        q_proj.record_stream(main)
+        attn_soft, attn_logits = self.aligner.attention(mel, enc_out.transpose(1, 2).detach(), mel_len, text_len,
+                                                        q_proj=q_proj)
+        feats = runtime.soft_average(attn_soft, pitch, energy, None, text_len)      # pitch / energy targets (no durations)
+        return {"enc_out": enc_out, "enc_mask": enc_mask, "attn_soft": attn_soft, "attn_logits": attn_logits, "feats": feats}
+
+    @torch.no_grad()
+    def forward_side(self, st: dict, text_len: Tensor, mel_len: Tensor, pitch: Tensor, energy: Tensor,
+                     flow_noise: Optional[Tensor], flow_time: Optional[Tensor]):
+        """MAS and the flow predictor (model.py:142, temporal_adaptor.py:257-282): nothing the decoder needs."""
+        attn_hard, dur = self.aligner.binarize_attention_parallel(st["attn_logits"], text_len, mel_len, return_duration=True)
+        ad = self.temporal_adaptor
+        targets = runtime.soft_average(st["attn_soft"], pitch, energy, dur, text_len)
+        pred, losses = ad.predictor(st["enc_out"], targets, st["enc_mask"][..., None], noise=flow_noise, time_steps=flow_time,
+                                    key_len=text_len)
+        return {"attn_hard": attn_hard, "dur": dur, "pred": pred, "losses": losses,
+                "duration_pred": ad.predictor._duration_estimate}
+
+    @torch.no_grad()
+    def forward_back(self, st: dict, text_len: Tensor, mel_len: Tensor, max_dec_len: int):
+        """Embedding stack, length regulator, decoder, to_mel (temporal_adaptor.py:284-300, model.py:160-168)."""
+        ad = self.temporal_adaptor
+        feats = st["feats"]
+        x = ad.embedding(feats[..., 1:3], mask=st["enc_mask"][..., None], key_len=text_len, residual=st["enc_out"])
+        dec_in, dec_len = ad.length_regulator(x, mel_len.view(-1, 1), max_len=max_dec_len, alignment=st["attn_soft"])
+        dec_mask = ad.length_regulator.dec_mask
+        dec_out = self.decoder(dec_in, mask=dec_mask, key_len=dec_len, out_dtype=self.compute_dtype).out
+        return {"mel": self._to_mel(dec_out, dec_mask), "dec_in": dec_in, "dec_len": dec_len, "dec_mask": dec_mask}
+
+    @staticmethod
+    def assemble_output(front: dict, side: dict, back: dict) -> AcousticModelOutput:
+        feats, pred = front["feats"], side["pred"]
+        adaptor = TemporalAdaptorOutput(enc_out=back["dec_in"], log_duration=pred[..., 0], duration=side["duration_pred"],
+                                        dec_lengths=back["dec_len"], pitch=pred[..., 1], energy=pred[..., 2],
+                                        pitch_target=feats[..., 1], energy_target=feats[..., 2], losses=side["losses"],
+                                        dec_mask=back["dec_mask"])
+        aligner = AlignerOutput(attn_soft=front["attn_soft"], attn_logits=front["attn_logits"], attn_hard=side["attn_hard"],
+                                attn_hard_duration=side["dur"])
+        return AcousticModelOutput(mel=back["mel"], adaptor_output=adaptor, aligner_output=aligner)
+
     @torch.no_grad()
     def infer(self, input_sequence: Tensor, text_lengths: Optional[Tensor] = None,
               duration_target: Optional[Tensor] = None, duration_factor: float = 1.0,

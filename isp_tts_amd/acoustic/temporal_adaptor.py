@@ -245,6 +245,7 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
             ready.record()
         pitch_target, energy_target = feats[..., 1:2], feats[..., 2:3]
         features = feats[..., 1:3]                   # = cat([pitch_target, energy_target], -1): a view, no copy
+
         enc_out = self.embedding(features, mask=m3, key_len=enc_len, residual=enc_out)   # enc_out + embedding(...)
         enc_out, dec_lens = self.length_regulator(enc_out, len_src, max_len=max_dec_len, alignment=alignment)
 

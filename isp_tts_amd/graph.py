@@ -79,6 +79,58 @@ class GraphedForward(GraphedCall):
         return self.replay()
 
 
+class SegmentedForward:
+    """One forward as THREE HIP graphs on two streams (same kernels, same results as `GraphedForward`):
+
+        main stream:  [front: embedding, text encoder, aligner front-end, soft averages] ........ [back: embedding stack,
+                                                                       \                          length regulator,
+        side stream:                                                    [side: MAS, flow predictor]  decoder, to_mel] join
+
+    Inside ONE captured graph HIP replays the side branch late: MAS and the predictor's ~45 small launches end ~0.12 ms
+    after to_mel with the chip otherwise idle (profiles/r02_bf16_timeline.txt); without them the step is 0.15 ms shorter.
+    As a graph of its own, launched on its own stream as soon as the front piece is queued, the branch runs under the
+    decoder.  Still ONE batch in flight: the next replay's front piece is ordered behind this replay's side piece."""
+
+    def __init__(self, model, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor, energy: Tensor,
+                 flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None, warmup: int = 2):
+        b, l = text.shape
+        dev = text.device
+        s = self.static = {"text": text.clone(), "text_len": text_len.clone(), "mel": mel.clone(), "mel_len": mel_len.clone(),
+                           "pitch": pitch.clone(), "energy": energy.clone(),
+                           "flow_noise": flow_noise.clone() if flow_noise is not None else torch.randn(b, l, 3, device=dev),
+                           "flow_time": flow_time.clone() if flow_time is not None else torch.rand(b, device=dev)}
+        self.model, self.side = model, torch.cuda.Stream(device=dev)
+        frames = mel.shape[2]
+        self.g_front = GraphedCall(lambda: model.forward_front(s["text"], s["text_len"], s["mel"], s["mel_len"], s["pitch"],
+                                                               s["energy"]), warmup)
+        st = self.g_front.out
+        self.side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.side):
+            self.g_side = GraphedCall(lambda: model.forward_side(st, s["text_len"], s["mel_len"], s["pitch"], s["energy"],
+                                                                 s["flow_noise"], s["flow_time"]), warmup)
+        torch.cuda.current_stream().wait_stream(self.side)
+        self.g_back = GraphedCall(lambda: model.forward_back(st, s["text_len"], s["mel_len"], frames), warmup)
+        self.out = model.assemble_output(st, self.g_side.out, self.g_back.out)
+        self.front_done, self.side_done = torch.cuda.Event(), torch.cuda.Event()
+
+    def replay(self):
+        main = torch.cuda.current_stream()
+        self.g_front.replay()
+        self.front_done.record(main)
+        self.side.wait_event(self.front_done)
+        with torch.cuda.stream(self.side):
+            self.g_side.replay()
+            self.side_done.record(self.side)
+        self.g_back.replay()
+        main.wait_event(self.side_done)          # the caller's stream sees every output; one batch in flight
+        return self.out
+
+    def __call__(self, **inputs: Tensor):
+        for k, v in inputs.items():
+            self.static[k].copy_(v)
+        return self.replay()
+
+
 class GraphedForwardLanes:
     """Several `GraphedForward` instances ("lanes": own static buffers, own stream) replayed round-robin, so consecutive
     batches overlap on the GPU: while one batch is in its decoder (large, chip-filling launches) the next one runs its

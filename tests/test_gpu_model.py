@@ -596,3 +596,28 @@ def test_batch_ingest_feeds_the_forward(gpu_model):
         out = gpu_model(**got, flow_noise=host[k][0]["flow_x0"].to(DEV), flow_time=host[k][0]["flow_t"].to(DEV))
         ing.done()
         assert torch.equal(out.mel, ref[k]), f"batch {k}"
+
+
+def test_three_graph_forward_equals_the_single_graph(gpu_model):
+    """`graph.SegmentedForward` (front / side branch / back as separate HIP graphs on two streams, built from
+    `AcousticModel.forward_front / forward_side / forward_back`) returns bit-identical outputs to the one-graph forward and
+    to the eager forward, also after the static inputs were replaced."""
+    from isp_tts_amd.graph import GraphedForward, SegmentedForward
+    inp = {k: v.to(DEV) for k, v in _forward_inputs().items()}
+    try:
+        gpu_model.set_compute_dtype(torch.bfloat16)
+        seg, one = SegmentedForward(gpu_model, **inp), GraphedForward(gpu_model, **inp)
+        for trial in range(2):
+            a, b = seg.replay(), one.replay()
+            torch.cuda.synchronize()
+            c = gpu_model(**inp)
+            for x, y, z in ((a.mel, b.mel, c.mel), (a.aligner_output.attn_hard, b.aligner_output.attn_hard, c.aligner_output.attn_hard),
+                            (a.adaptor_output.log_duration, b.adaptor_output.log_duration, c.adaptor_output.log_duration),
+                            (a.adaptor_output.dec_lengths, b.adaptor_output.dec_lengths, c.adaptor_output.dec_lengths),
+                            (a.adaptor_output.pitch_target, b.adaptor_output.pitch_target, c.adaptor_output.pitch_target)):
+                assert torch.equal(x, y) and torch.equal(x, z)
+            inp = {k: (v.flip(0) if v.ndim else v) for k, v in inp.items()}       # other utterance order for the second trial
+            seg(**inp)
+            one(**inp)
+    finally:
+        gpu_model.set_compute_dtype(torch.float32)

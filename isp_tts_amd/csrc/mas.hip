@@ -10,13 +10,18 @@
 //   * Q[i-1][j-1] comes from the neighbouring lane through a DPP wave shift (v_mov_b32_dpp wave_shr:1); the carry
 //     between 64-column chunks is a second DPP (wave_ror:1 of the previous chunk supplies lane 0's value).  No LDS
 //     or barrier inside the row loop.
-//   * the back-pointer of a cell is ONE bit: per row and chunk the wave's ballot (64 bits) is stored in LDS
-//     (M*NC*8 bytes: 8 KB at M=512, L=100; 69 KB at M=1723, L=300).
-//   * logits rows are prefetched R rows ahead into registers, so the dependent chain per row is
-//     DPP -> compare -> select -> add only.
-//   * backtrack: 64 rows at a time, lane r holds the ballot words of row (top - r); the serial walk reads them with
-//     v_readlane (SGPR chain), no LDS round trip per row.
+//   * the back-pointer of a cell is ONE bit, shifted into a per-lane history word (32 rows of the lane's column per word);
+//     a word goes to LDS once per 32 rows: hist[row block][column], M*L/8 bytes (6.4 KB at M=512, L=100).
+//   * logits rows are prefetched R rows ahead into registers through a buffer descriptor (per-lane column offset fixed,
+//     row offset in an SGPR: no vector address arithmetic per row), two register sets swapping roles at compile time, so
+//     the row step is DPP -> compare -> select -> add plus two instructions for the history bit: 19 instructions per row
+//     at L <= 128 (round 1: 37, with a v_writelane pair + 4 wait states per row and chunk).
+//   * backtrack: one history block (32 rows) per pass; lane c holds the word of column j0 - c, a row's decisions across
+//     those columns are one ballot -> SGPR pair, and the serial walk is two scalar instructions per row (s_bitcmp1_b64 on
+//     the current offset, s_addc_u32); the decisions taken are collected in a scalar mask from which every lane counts
+//     its own row's column (popcount) - no per-row vector work.
 //   * the 4 waves of the block then write the one-hot int16 rows (16-B stores), the path and the durations.
+// 40 us at B=64, M=512, L=100 (DP 23, backtrack 8, outputs 9; round 1: 80 = 44 + 25 + 11).
 #include <stdlib.h>
 
 #include "common.h"
@@ -35,30 +40,40 @@ __device__ __forceinline__ float dpp_shr1(float src, float lane0_value) {
                                            0xf, 0xf, false));
 }
 
-// lane `lane` of dst <- the wave-uniform value src (v_writelane_b32; this clang has no builtin for it)
-// lane LANE of (lo, hi) <- the wave-uniform 64-bit value (src_lo, src_hi).  v_writelane_b32 has no builtin in this
-// clang; inside inline asm the compiler's hazard recogniser does not see it, and a v_writelane issued right behind the
-// v_cmp that produced its SGPR operand reads the STALE register (observed: every row stored the previous row's word) -
-// hence the 4 wait states in front.
-template <int LANE>
-__device__ __forceinline__ void writelane64(uint32_t& lo, uint32_t& hi, uint32_t src_lo, uint32_t src_hi) {
-    asm("s_nop 3\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
-        : "+v"(lo), "+v"(hi) : "s"(src_lo), "s"(src_hi), "n"(LANE));
-}
-
 __device__ __forceinline__ float dpp_ror1(float src) {
     // lane l <- lane l-1, lane 0 <- lane 63 (wave_ror:1): carries a chunk's last column to the next chunk's lane 0
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x13C, 0xf, 0xf, false));
 }
 
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+// R DP rows from the prefetched logits `use`.  Per row and 64-column chunk the dependent chain is DPP shift -> compare ->
+// select -> add; the decision bit is shifted into a per-lane history word (one word = kBlk = 32 rows of the lane's
+// column, bit 31 - r <-> row r of the block), which goes to LDS as hist[block][column].
+constexpr int kBlk = 32;
+
+template <int NC, int R>
+__device__ __forceinline__ void mas_rows(float (&q)[NC], const float (&use)[R][NC], uint32_t (&h)[NC], float qnan) {
+    static_for<0, R>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        float left[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) left[c] = dpp_shr1(q[c], c > 0 ? dpp_ror1(q[c - 1]) : qnan);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const bool diag = left[c] >= q[c];       // column 0: NaN >= x is false, no `j > 0` test
+            h[c] = h[c] + h[c] + (diag ? 1u : 0u);   // shift the decision in (one add-with-carry)
+            q[c] = use[r][c] + (diag ? left[c] : q[c]);
+        }
+    });
 }
 
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
-    uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
-    uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane);
-    return ((uint64_t)hi << 32) | lo;
+// One row of the backtrack: if bit d of the row's decision word is set the path moves one column left (d += 1); the
+// decision is shifted into `taken` (rows are visited top down, so after 32 rows bit r belongs to row r of the block).
+__device__ __forceinline__ void walk_step(int& d, uint32_t& taken, uint64_t word) {
+    uint32_t t;
+    asm volatile("s_bitcmp1_b64 %3, %0\n\ts_cselect_b32 %2, 1, 0\n\ts_addc_u32 %0, %0, 0\n\ts_lshl1_add_u32 %1, %1, %2"
+                 : "+s"(d), "+s"(taken), "=&s"(t)
+                 : "s"(word)
+                 : "scc");
 }
 
 template <int NC>
@@ -67,9 +82,10 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
                                                   int64_t* __restrict__ dur, int16_t* __restrict__ path_out, int M_max,
                                                   int L_max, int64_t stride_b, int64_t stride_m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint64_t* bp = reinterpret_cast<uint64_t*>(smem);                        // [M_max][NC]
-    int16_t* path = reinterpret_cast<int16_t*>(smem + (size_t)M_max * NC * 8);  // [M_max] (padded to 16 B)
-    int* cnt = reinterpret_cast<int*>(smem + (size_t)M_max * NC * 8 + (((size_t)M_max * 2 + 15) & ~(size_t)15));
+    const int nblk = (M_max + kBlk - 1) / kBlk;
+    uint32_t* hist = reinterpret_cast<uint32_t*>(smem);                             // [nblk][NC * 64]
+    int16_t* path = reinterpret_cast<int16_t*>(smem + (size_t)nblk * NC * 256);     // [M_max] (padded to 16 B)
+    int* cnt = reinterpret_cast<int*>(smem + (size_t)nblk * NC * 256 + (((size_t)M_max * 2 + 15) & ~(size_t)15));
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -95,92 +111,87 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
         float q[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) q[c] = (lane + 64 * c == 0) ? lp[0] : ninf;
-
-        constexpr int kRowsAhead = rows_ahead<NC>();
-        float cur[kRowsAhead][NC], nxt[kRowsAhead][NC];
-        auto load_rows = [&](float (&dst)[kRowsAhead][NC], int base) {
+        // Logits rows through a buffer descriptor: a per-lane byte offset fixed for the whole kernel (the column, clamped
+        // to m - 1: columns >= m never influence columns < m, any finite value will do) plus a wave-uniform row offset in
+        // an SGPR - no vector address arithmetic per row.  Rows past the end re-read row n - 1 (clamped offset) and their
+        // history bits are never looked at.
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(lp), 0,
+                                                            (int)((int64_t)M_max * stride_m * 4), 0x00020000);
+        int voff[NC];
 #pragma unroll
-            for (int r = 0; r < kRowsAhead; ++r) {
-                int i = base + r;
-                i = i < n ? i : n - 1;
-                const float* row = lp + (int64_t)i * stride_m;
+        for (int c = 0; c < NC; ++c) voff[c] = 4 * min(lane + 64 * c, m - 1);
+        const int row_bytes = (int)(stride_m * 4), last_off = (n - 1) * row_bytes;
+        // kRows rows are in registers ahead of the DP (32 / 16 / 8 by chunk count: 2 * kRows * NC VGPRs for the ping-pong
+        // pair); a trip of the loop below covers 64 rows = two history blocks = an even number of sub-blocks, so the two
+        // buffers swap roles at compile time and no register is ever copied.
+        constexpr int kRows = rows_ahead<NC>(), kSub = kBlk / kRows;
+        float bufa[kRows][NC], bufb[kRows][NC];
+        auto load_rows = [&](float (&dst)[kRows][NC], int base) __attribute__((always_inline)) {
+            int off = base * row_bytes;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const int col = lane + 64 * c;           // (columns >= m never influence columns < m; any finite
-                    dst[r][c] = row[col < m ? col : m - 1];  //  value will do, and a clamped load needs no exec branch)
-                }
+            for (int r = 0; r < kRows; ++r) {
+                const int so = min(off, last_off);
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    dst[r][c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff[c], so, 0));
+                off += row_bytes;
             }
         };
-        load_rows(cur, 1);
-        // Row step, per 64-column chunk: DPP shift, compare, select, add - and nothing else on the dependent chain:
-        //   * the compare's lane mask IS the row's back-pointer word; it is parked in lane r of two VGPRs with
-        //     v_writelane and the wave stores a whole block of kRowsAhead rows to LDS at once (a per-row `if (lane == 0)`
-        //     LDS store costs an exec save / restore and an LDS instruction on every row);
-        //   * column 0 needs no `j > 0` test: its "left neighbour" is NaN, and NaN >= x is false;
-        //   * no per-row `i < n` branch: rows past the end recompute the last row (clamped loads) and are not stored.
         const float qnan = __builtin_nanf("");
-        for (int base = 1; base < n; base += kRowsAhead) {
-            load_rows(nxt, base + kRowsAhead);
-            uint32_t wlo[NC], whi[NC];
+        load_rows(bufa, 1);
+        uint32_t h[NC];
+        for (int base = 1; base < n; base += 2 * kBlk) {
+            static_for<0, 2 * kSub>([&](auto sc) {
+                constexpr int sub = decltype(sc)::value, in_blk = sub % kSub;
+                const int rows_base = base + sub * kRows;
+                if (rows_base < n) {
+                    if (sub % 2 == 0) load_rows(bufb, rows_base + kRows); else load_rows(bufa, rows_base + kRows);
+                    if (in_blk == 0) {
 #pragma unroll
-            for (int c = 0; c < NC; ++c) wlo[c] = whi[c] = 0u;
-            static_for<0, kRowsAhead>([&](auto rc) {
-                constexpr int r = decltype(rc)::value;
-                float left[NC];
+                        for (int c = 0; c < NC; ++c) h[c] = 0u;
+                    }
+                    if (sub % 2 == 0) mas_rows<NC, kRows>(q, bufa, h, qnan); else mas_rows<NC, kRows>(q, bufb, h, qnan);
+                    // the block's word so far, already in its final position (rows not computed yet read as 0): a block
+                    // that the utterance ends in is complete after whichever sub-block was its last
+                    uint32_t* dst = hist + (size_t)((rows_base - 1) / kBlk) * NC * 64 + lane;
 #pragma unroll
-                for (int c = 0; c < NC; ++c) left[c] = dpp_shr1(q[c], c > 0 ? dpp_ror1(q[c - 1]) : qnan);
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                    const bool diag = left[c] >= q[c];
-                    const uint64_t word = __ballot(diag);
-                    q[c] = cur[r][c] + (diag ? left[c] : q[c]);
-                    writelane64<r>(wlo[c], whi[c], (uint32_t)word, (uint32_t)(word >> 32));
+                    for (int c = 0; c < NC; ++c) dst[64 * c] = h[c] << (kRows * (kSub - 1 - in_blk));
                 }
             });
-            if (lane < kRowsAhead && base + lane < n) {
-#pragma unroll
-                for (int c = 0; c < NC; ++c) bp[(size_t)(base + lane) * NC + c] = ((uint64_t)whi[c] << 32) | wlo[c];
-            }
-#pragma unroll
-            for (int r = 0; r < kRowsAhead; ++r)
-#pragma unroll
-                for (int c = 0; c < NC; ++c) cur[r][c] = nxt[r][c];
         }
     }
     __syncthreads();
 
     if (wave == 0 && abl != 1) {
-        // ---------------------------------------------------------------- backtrack, 64 rows per pass
-        int j = m - 1;
-        for (int top = n - 1; top >= 0; top -= 64) {
-            const int myrow = top - lane;
-            const int c_hi = j >> 6;
-            uint64_t w_hi = 0, w_lo = 0;
-            if (myrow >= 1) {
-                w_hi = bp[(size_t)myrow * NC + c_hi];
-                if (c_hi > 0) w_lo = bp[(size_t)myrow * NC + c_hi - 1];
-            }
-            // 16 rows at a time: their ballot words go to SGPRs first (32 independent v_readlane pairs), so the serial
-            // walk itself is scalar arithmetic only - with a readlane inside every step each row waited for a
-            // VALU -> SGPR round trip.  Rows above the top of the utterance hold zero words and leave j unchanged.
-            int myj = -1;
-#pragma unroll 1
-            for (int r0 = 0; r0 < 64; r0 += 16) {
-                uint64_t hi[16], lo[16];
+        // ---------------------------------------------------------------- backtrack, one history block (32 rows) per pass
+        // Lane c holds the history word of column j0 - c (j0 = the path's column at the block's top row); within a block
+        // the path moves left by at most 32, so lanes 0..32 cover it.  Row r's decisions across those columns are one
+        // ballot -> an SGPR word; the serial walk itself is then scalar arithmetic only (d = how far left of j0).
+        int j0 = m - 1;
+        for (int top = n - 1; top >= 1;) {
+            const int blk = (top - 1) / kBlk, base = 1 + blk * kBlk, rows = top - base + 1;   // rows base .. top
+            const int col = j0 - lane;
+            uint32_t w = (col >= 0 && lane <= kBlk) ? hist[(size_t)blk * NC * 64 + col] : 0u;
+            if (rows < kBlk) w &= ~((1u << (kBlk - rows)) - 1u);      // rows above `top`: never computed / not on the path
+            // serial walk, two scalar instructions on the dependent chain per row: test bit d of the row's word, add the
+            // carry.  The decisions taken are collected in `taken` (bit r = row r moved left); lane r then counts the moves
+            // of the rows above it to get its own column - no per-row vector work.
+            int d = 0;
+            uint32_t taken = 0u;
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    hi[u] = readlane_u64(w_hi, r0 + u);
-                    lo[u] = readlane_u64(w_lo, r0 + u);
-                }
+            for (int r0 = kBlk - 16; r0 >= 0; r0 -= 16) {                          // upper 16 rows of the block first
+                uint64_t word[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) {
-                    if (lane == r0 + u) myj = j;
-                    const uint64_t w = (j >> 6) == c_hi ? hi[u] : lo[u];
-                    j -= (int)((w >> (j & 63)) & 1);
-                }
+                for (int u = 0; u < 16; ++u) word[u] = __ballot(((w >> (kBlk - 1 - (r0 + u))) & 1u) != 0u);
+#pragma unroll
+                for (int u = 15; u >= 0; --u) walk_step(d, taken, word[u]);
             }
-            if (myrow >= 0) path[myrow] = (int16_t)myj;
+            const int myj = j0 - __builtin_popcountll((uint64_t)taken >> (lane + 1));   // lanes >= 32: shift clears it
+            if (lane < rows) path[base + lane] = (int16_t)myj;
+            j0 -= d;
+            top = base - 1;
         }
+        if (lane == 0) path[0] = (int16_t)j0;
     }
     __syncthreads();
 
@@ -194,9 +205,18 @@ __global__ __launch_bounds__(256) void mas_kernel(const float* __restrict__ logi
     const int64_t total = (int64_t)M_max * L_max;
     int16_t* out = attn_hard + (int64_t)b * total;
     if ((total & 7) == 0 && (((uintptr_t)attn_hard) & 15) == 0) {
+        // (row, column) of a thread's 8-element group advance by a fixed step: one 32-bit division per thread up front
+        // instead of a 64-bit one per group
+        const uint32_t step_i = 2048u / (uint32_t)L_max, step_c = 2048u % (uint32_t)L_max;
+        int gi = (int)((uint32_t)(tid * 8) / (uint32_t)L_max), gc = (int)((uint32_t)(tid * 8) % (uint32_t)L_max);
         for (int64_t e0 = (int64_t)tid * 8; e0 < total; e0 += 256 * 8) {
-            int i = (int)(e0 / L_max);
-            int col = (int)(e0 - (int64_t)i * L_max);
+            int i = gi, col = gc;
+            gi += (int)step_i;
+            gc += (int)step_c;
+            if (gc >= L_max) {
+                gc -= L_max;
+                ++gi;
+            }
             int hot = i < n ? path[i] : -1;
             uint16_t v[8];
 #pragma unroll
@@ -256,7 +276,9 @@ extern "C" int32_t ispk_mas_f32(const float* logits, const int64_t* text_len, co
     ISPK_REQUIRE(stride_m >= L_max && stride_b >= (int64_t)M_max * 1, ISPK_E_SHAPE, "mas: bad strides");
     if (B == 0) return 0;
     const int nc = (L_max + 63) / 64;
-    const size_t lds = (size_t)M_max * nc * 8 + (((size_t)M_max * 2 + 15) & ~(size_t)15) + (size_t)L_max * 4;
+    const size_t lds = (size_t)((M_max + 31) / 32) * nc * 256 + (((size_t)M_max * 2 + 15) & ~(size_t)15) + (size_t)L_max * 4;
+    ISPK_REQUIRE((int64_t)M_max * stride_m * 4 < ((int64_t)1 << 31), ISPK_E_SHAPE,
+                 "mas: one utterance's logits (M_max * stride_m floats) must span less than 2 GiB");
     ISPK_REQUIRE(lds <= 160 * 1024, ISPK_E_SHAPE, "mas: M_max=%d x L_max=%d needs %zu B of LDS (> 160 KiB)", M_max,
                  L_max, lds);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

@@ -411,40 +411,60 @@ __global__ __launch_bounds__(256) void flow_mix_kernel(const float* __restrict__
 //            batch):  pf = raw * m ;  pred = (x0 + pf) * m ;  dur = max(exp(pred[..., 0]) - 1, 0) ;
 //            ratio[b] = sum_{valid l, c} (pf - flow)^2 / max(C * #valid, 1e-5)   (utils.masked_mean before its .mean()) ;
 //            loss = mean_b ratio[b]                                               (its .mean(), summed in index order)
-// wave w of the 16 handles utterances w, w + 16, ...
+// ONE workgroup (the mean over the batch needs every ratio, and a fixed summation order): 16 lanes per utterance, 64
+// utterances per pass of the 1024 threads; a lane's elements are independent loads (unrolled), the 16 partial sums of an
+// utterance meet in a fixed shuffle tree.  (The first version walked an utterance with one wave, four utterances per wave in
+// turn: 20 dependent load rounds = 36 us for 19,200 elements, all of it at the very end of the forward's side branch.)
 __global__ __launch_bounds__(1024) void flow_finish_kernel(const float* __restrict__ raw, const float* __restrict__ flow,
                                                            const float* __restrict__ x0, const uint8_t* __restrict__ mask,
                                                            float* __restrict__ pred, float* __restrict__ dur,
                                                            float* __restrict__ ratio, float* __restrict__ loss, int B, int L,
                                                            int C) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int b = wave; b < B; b += 16) {
+    __shared__ float sratio[1024];
+    const int tid = threadIdx.x, sub = tid & 15, grp = tid >> 4;
+    const int n = L * C;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + grp;
         float num = 0.f, den = 0.f;
-        for (int e = lane; e < L * C; e += 64) {
-            const int l = e / C, c = e - l * C;
-            const int64_t i = (int64_t)b * L * C + e;
-            const bool m = mask[(int64_t)b * L + l] != 0;
-            const float pf = m ? raw[i] : 0.f;
-            const float pr = m ? x0[i] + pf : 0.f;
-            pred[i] = pr;
-            if (c == 0) dur[(int64_t)b * L + l] = fmaxf(expf(pr) - 1.0f, 0.f);
-            if (m) {
-                const float d = pf - flow[i];
-                num += d * d;
-                den += 1.0f;
+        if (b < B) {
+            const float* rb = raw + (int64_t)b * n;
+            const float* fb = flow + (int64_t)b * n;
+            const float* xb = x0 + (int64_t)b * n;
+            const uint8_t* mb = mask + (int64_t)b * L;
+            float* pb = pred + (int64_t)b * n;
+#pragma unroll 4
+            for (int e = sub; e < n; e += 16) {
+                const int l = e / C, c = e - l * C;
+                const bool m = mb[l] != 0;
+                const float r = rb[e], f = fb[e], x = xb[e];
+                const float pf = m ? r : 0.f;
+                const float pr = m ? x + pf : 0.f;
+                pb[e] = pr;
+                if (c == 0) dur[(int64_t)b * L + l] = fmaxf(expf(pr) - 1.0f, 0.f);
+                const float d = pf - f;
+                num += m ? d * d : 0.f;
+                den += m ? 1.0f : 0.f;
             }
         }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
+        for (int off = 8; off > 0; off >>= 1) {
             num += __shfl_xor(num, off, 64);
             den += __shfl_xor(den, off, 64);
         }
-        if (lane == 0) ratio[b] = num / fmaxf(den, 1e-5f);
+        if (b < B && sub == 0) {
+            const float q = num / fmaxf(den, 1e-5f);
+            ratio[b] = q;
+            if (b < 1024) sratio[b] = q;
+        }
     }
-    __syncthreads();          // (global writes of this workgroup are visible to it after the barrier)
+    __syncthreads();
     if (loss && tid == 0) {
         float s = 0.f;
-        for (int b = 0; b < B; ++b) s += ratio[b];
+        if (B <= 1024) {
+            for (int b = 0; b < B; ++b) s += sratio[b];
+        } else {                                  // (global writes of this workgroup are visible to it after the barrier)
+            for (int b = 0; b < B; ++b) s += ratio[b];
+        }
         loss[0] = s / (float)B;
     }
 }

@@ -528,10 +528,12 @@ def test_bf16_encoder_with_layernorms_inside_the_gemms_matches_separate_layernor
 
 
 def test_config2_encoder_decoder_scope_fp32(gpu_model, state_dict):
-    """BASELINE config 2 scope (TextEncoder + MelDecoder + to_mel on given activations, fp32) against the oracle."""
-    tok = synth._normal("t/c2/tok", (4, 100, 384))
-    dec_in = synth._normal("t/c2/dec", (4, 512, 384))
-    tl, ml = torch.tensor([100, 80, 100, 33]), torch.tensor([512, 512, 301, 77])
+    """BASELINE config 2 (B = 32, TextEncoder + MelDecoder + to_mel on given activations, ragged masks, fp32) against the oracle."""
+    bsz = 32                                          # BASELINE config 2's batch
+    tok = synth._normal("t/c2/tok", (bsz, 100, 384))
+    dec_in = synth._normal("t/c2/dec", (bsz, 512, 384))
+    tl, ml = synth.make_lengths(bsz, 100, 512, variable=True, seed=202)
+    tl[:4], ml[:4] = torch.tensor([100, 80, 100, 33]), torch.tensor([512, 512, 301, 77])
     em = torch.arange(100)[None] < tl[:, None]
     dm = torch.arange(512)[None] < ml[:, None]
     enc_ref, mel_ref = orc.encoder_decoder(state_dict, tok, em, dec_in, dm)

@@ -183,6 +183,21 @@ int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const float* norm_gam
  * units in natural order; no biases.  flags / mask / row_stats as ispk_ffn_bf16_prenorm. */
 int32_t ispk_ffn_chunk_w2_bf16(const uint16_t* W2, int64_t ldw2, int32_t dim, int32_t inner, uint16_t* out,
                                ispk_stream_t stream);
+/* The same block for SMALL batches (the 6,400-row text encoder: 50 row blocks leave most of the 256 CUs idle, and every
+ * workgroup streams all 2.4 MB of weights): the inner dimension is split over `splits` workgroups per row block
+ * (ispk_ffn_bf16_prenorm2_split: parts[s][i][:] = gelu_erf(LN(x[i][:]) W1_s^T) W2_s^T, raw fp32, split s = hidden units
+ * [s * inner / splits, (s + 1) * inner / splits)), then ispk_ffn_combine_ln_f32 adds them in split order:
+ *   y[i][:] = [mask[i]] * (x[i][:] + sum_s parts[s][i][:])                              transformer.py:105-110
+ *   ln_out[i][:] = LN(y[i][:]) [* mask[i] if ln_mask]  (optional: the norm that consumes y - next layer's transformer.py:79
+ *   or the final :205-206; fp32 or bf16), two-pass statistics.  parts: [splits] blocks at part_stride floats, rows x 384 each. */
+int32_t ispk_ffn_bf16_prenorm2_split(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta,
+                                     float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks, float* parts,
+                                     int64_t part_stride, int32_t splits, int32_t rows, int32_t dim, int32_t inner,
+                                     ispk_stream_t stream);
+int32_t ispk_ffn_combine_ln_f32(const float* x, int64_t ldx, const float* parts, int64_t part_stride, int32_t splits,
+                                const uint8_t* mask, float* y, int64_t ldy, const float* ln_gamma, const float* ln_beta,
+                                float ln_eps, int32_t ln_mask, void* ln_out, int64_t ld_ln, int32_t ln_bf16, int32_t rows,
+                                int32_t dim, ispk_stream_t stream);
 int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta, float norm_eps,
                                const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask, float* out, int64_t ldo,
                                int32_t rows, int32_t dim, int32_t inner, uint32_t flags, float* row_stats, float stats_eps,

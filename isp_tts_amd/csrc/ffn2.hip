@@ -64,6 +64,8 @@ struct Ffn2Params {
     uint32_t flags;
     float* stats;
     float stats_eps;
+    int chunk_count = 0;          // split mode (blockIdx.y = split): chunks per split; 0 = the whole inner dimension
+    int64_t part_stride = 0;      // split mode: floats between the splits' partial outputs
     unsigned long long* stamps = nullptr;   // experiments build, ABL == 3: per-wave phase cycle sums [grid * 8][8]
 };
 
@@ -173,9 +175,14 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     const int rg = wave & 3, half = wave >> 2;
     const int l31 = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * 128;
-    const int nchunks = p.inner / kHC;
-    const char* W1b = reinterpret_cast<const char*>(p.W1);
-    const char* W2b = reinterpret_cast<const char*>(p.W2c);
+    // split mode (small batches, ispk_ffn_bf16_prenorm2_split): workgroup (row block, split) walks only its `chunk_count`
+    // chunks of the inner dimension and leaves a raw fp32 partial product; both weight images are chunk-contiguous
+    // (kHC rows of W1 = kHC * kD * 2 bytes = one W2 chunk), so a split is a pointer offset
+    const bool split_mode = p.chunk_count > 0;
+    const int nchunks = split_mode ? p.chunk_count : p.inner / kHC;
+    const int64_t wskip = split_mode ? (int64_t)blockIdx.y * p.chunk_count * (kHC * kD * 2) : 0;
+    const char* W1b = reinterpret_cast<const char*>(p.W1) + wskip;
+    const char* W2b = reinterpret_cast<const char*>(p.W2c) + wskip;
 
     // ---- this lane's part of the wave's DMA instructions (q = wave + 8 j of the group's 49): byte offset inside the chunk
     // in memory.  q < 25: the padded W1 image - 16-byte slot t = 64 q + lane is (row t / 49, piece t % 49), piece 48 and rows
@@ -483,6 +490,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     // ---- epilogue: 64 rows per pass through the fp32 tile; then whole rows: + x, mask, statistics, coalesced stores
     const bool mask_acc = p.flags & ISPK_EP_MASK_ACC, mask_out = p.flags & ISPK_EP_MASK_OUT;
     float* T = reinterpret_cast<float*>(smem);
+    float* outp = p.out + (split_mode ? (int64_t)blockIdx.y * p.part_stride : 0);
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         __syncthreads();
@@ -512,19 +520,21 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             for (int j = 0; j < 3; ++j) {
                 const int c = 4 * (l31 + 32 * j);
                 f32x4 a = *reinterpret_cast<const f32x4*>(T + rl * kLdT + c);
-                const f32x4 xr = *reinterpret_cast<const f32x4*>(p.x + (int64_t)rc * p.ldx + c);
+                if (!split_mode) {       // (split mode: the raw partial product; residual, mask and sums happen in the combine pass)
+                    const f32x4 xr = *reinterpret_cast<const f32x4*>(p.x + (int64_t)rc * p.ldx + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = mask_acc ? a[e] * mk : a[e];
-                    t += xr[e];
-                    a[e] = mask_out ? t * mk : t;
+                    for (int e = 0; e < 4; ++e) {
+                        float t = mask_acc ? a[e] * mk : a[e];
+                        t += xr[e];
+                        a[e] = mask_out ? t * mk : t;
+                    }
                 }
                 y[j] = a;
                 s += (a[0] + a[1]) + (a[2] + a[3]);
             }
             if (live) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(p.out + (int64_t)r * p.ldo + 4 * (l31 + 32 * j)) = y[j];
+                for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(outp + (int64_t)r * p.ldo + 4 * (l31 + 32 * j)) = y[j];
             }
             if (p.stats) {
 #pragma unroll
@@ -582,6 +592,112 @@ extern "C" int32_t ispk_ffn_chunk_w2_bf16(const uint16_t* W2, int64_t ldw2, int3
     const int64_t total = (int64_t)dim * inner / 8;
     hipLaunchKernelGGL(ffn_chunk_w2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), W2, ldw2, out, dim, inner);
+    return ispk_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ small batches: split + combine
+// y = [mask] * (x + sum_s part[s]) in split order, then (optionally) LN(y) for the layer that consumes it.  One row per 32
+// lanes, three float4 per lane (dim 384), two-pass statistics in registers.
+template <typename TOut>
+__global__ __launch_bounds__(256) void ffn_combine_ln_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ part,
+                                                             int64_t part_stride, int splits, const uint8_t* __restrict__ mask,
+                                                             float* __restrict__ y, int64_t ldy, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps, int ln_mask,
+                                                             TOut* __restrict__ ln_out, int64_t ld_ln, int rows) {
+    const int row = blockIdx.x * 8 + (threadIdx.x >> 5), l = threadIdx.x & 31;
+    if (row >= rows) return;
+    const float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
+    f32x4 v[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const f32x4*>(x + (int64_t)row * ldx + 4 * (l + 32 * j));
+    for (int s = 0; s < splits; ++s) {
+        const float* ps = part + (int64_t)s * part_stride + (int64_t)row * kD;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[j] += *reinterpret_cast<const f32x4*>(ps + 4 * (l + 32 * j));
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        v[j] *= mk;
+        *reinterpret_cast<f32x4*>(y + (int64_t)row * ldy + 4 * (l + 32 * j)) = v[j];
+        sum += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    if (!ln_out) return;
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    const float mean = sum * (1.0f / kD);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[j][e] - mean;
+            q = fmaf(d, d, q);
+        }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / kD) + eps), om = ln_mask ? mk : 1.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = 4 * (l + 32 * j);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ((v[j][e] - mean) * rstd * g[e] + bt[e]) * om;
+        if constexpr (std::is_same<TOut, float>::value) {
+            *reinterpret_cast<f32x4*>(ln_out + (int64_t)row * ld_ln + c) = f32x4{o[0], o[1], o[2], o[3]};
+        } else {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+            pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+            *reinterpret_cast<uint2*>(ln_out + (int64_t)row * ld_ln + c) = pk;
+        }
+    }
+}
+
+extern "C" int32_t ispk_ffn_bf16_prenorm2_split(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta,
+                                                float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks, float* parts,
+                                                int64_t part_stride, int32_t splits, int32_t rows, int32_t dim, int32_t inner,
+                                                ispk_stream_t stream) {
+    ISPK_REQUIRE(x && norm_gamma && norm_beta && W1 && W2_chunks && parts, ISPK_E_NULL, "ffn_prenorm2_split: null pointer");
+    ISPK_REQUIRE(dim == kD, ISPK_E_UNSUPPORTED, "ffn_prenorm2_split: dim %d (built for 384)", dim);
+    ISPK_REQUIRE(rows >= 0 && inner >= 32 && inner % 32 == 0 && splits >= 1 && (inner / 32) % splits == 0 &&
+                     (inner / 32) / splits >= 2 && part_stride >= (int64_t)rows * kD,
+                 ISPK_E_SHAPE, "ffn_prenorm2_split: bad shape rows=%d inner=%d splits=%d (chunks of 32 must divide evenly, >= 2 each)",
+                 rows, inner, splits);
+    ISPK_REQUIRE(ldx % 4 == 0 && ldx >= dim && part_stride % 4 == 0 && ispk_aligned(x, 16) && ispk_aligned(parts, 16) &&
+                     ispk_aligned(W1, 16) && ispk_aligned(W2_chunks, 16) && ispk_aligned(norm_gamma, 16) &&
+                     ispk_aligned(norm_beta, 16), ISPK_E_ALIGN, "ffn_prenorm2_split: 16-byte alignment required");
+    if (rows == 0) return 0;
+    Ffn2Params p{x, ldx, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, nullptr, parts, kD, rows, inner, 0u, nullptr, 0.f};
+    p.chunk_count = (inner / 32) / splits;
+    p.part_stride = part_stride;
+    ISPK_RESERVE_LDS((&ffn2_bf16_kernel<0>), kLds, "ffn_prenorm2_split");
+    hipLaunchKernelGGL(ffn2_bf16_kernel<0>, dim3((rows + 127) / 128, splits), dim3(512), kLds,
+                       reinterpret_cast<hipStream_t>(stream), p);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_ffn_combine_ln_f32(const float* x, int64_t ldx, const float* parts, int64_t part_stride, int32_t splits,
+                                           const uint8_t* mask, float* y, int64_t ldy, const float* ln_gamma,
+                                           const float* ln_beta, float ln_eps, int32_t ln_mask, void* ln_out, int64_t ld_ln,
+                                           int32_t ln_bf16, int32_t rows, int32_t dim, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && parts && y, ISPK_E_NULL, "ffn_combine_ln: null pointer");
+    ISPK_REQUIRE(dim == kD && rows >= 0 && splits >= 1 && ldx >= dim && ldy >= dim && ldx % 4 == 0 && ldy % 4 == 0 &&
+                     part_stride % 4 == 0, ISPK_E_SHAPE, "ffn_combine_ln: bad shape rows=%d dim=%d splits=%d", rows, dim, splits);
+    ISPK_REQUIRE(!ln_out || (ln_gamma && ln_beta && ld_ln >= dim && ld_ln % 4 == 0), ISPK_E_NULL,
+                 "ffn_combine_ln: LayerNorm output without gamma / beta");
+    ISPK_REQUIRE(ispk_aligned(x, 16) && ispk_aligned(parts, 16) && ispk_aligned(y, 16) && (!ln_out || ispk_aligned(ln_out, 8)),
+                 ISPK_E_ALIGN, "ffn_combine_ln: 16-byte alignment required");
+    if (rows == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((rows + 7) / 8);
+    if (ln_out && ln_bf16)
+        hipLaunchKernelGGL(ffn_combine_ln_kernel<uint16_t>, grid, dim3(256), 0, s, x, ldx, parts, part_stride, splits, mask, y, ldy,
+                           ln_gamma, ln_beta, ln_eps, ln_mask, static_cast<uint16_t*>(ln_out), ld_ln, rows);
+    else
+        hipLaunchKernelGGL(ffn_combine_ln_kernel<float>, grid, dim3(256), 0, s, x, ldx, parts, part_stride, splits, mask, y, ldy,
+                           ln_gamma, ln_beta, ln_eps, ln_mask, static_cast<float*>(ln_out), ld_ln, rows);
     return ispk_launch_status();
 }
 

@@ -99,6 +99,32 @@ class FeedForward(nn.Module, Constructor):
                 and rows >= self.fused_min_rows and self.net[0].bias is None
                 and not (self.training and self.dropout_p > 0))
 
+    # small batches (text encoder: 6,400 rows = 50 row blocks on 256 CUs): inner dimension split over several workgroups per
+    # row block, partial products combined (+ residual, mask, the consumer's LayerNorm) by a second launch.
+    # 22.4 (FFN2) + 19.8 (FFN1) + 7.1 (LayerNorm) + 5.8 (next LayerNorm) us -> measured in DESIGN.md
+    split_small = True
+
+    def split_ok(self, x: Tensor, norm) -> bool:
+        rows = x.numel() // x.shape[-1]
+        return (self.split_small and self.pair_kernel and isinstance(norm, nn.LayerNorm) and norm.weight is not None
+                and norm.bias is not None and x.dtype == torch.float32 and self.compute_dtype == torch.bfloat16
+                and self.act_flag == runtime.EP_GELU and x.shape[-1] == 384 and 1024 <= rows < self.fused_min_rows
+                and self.net[0].bias is None and self.net[3].bias is None and self.net[0].weight.shape[0] % 64 == 0
+                and not (self.training and self.dropout_p > 0))
+
+    def forward_prenorm_split(self, x: Tensor, norm, *, mask: Optional[Tensor] = None, next_norm: Optional[tuple] = None):
+        """(y, LN_next(y) | None) for small batches: ispk_ffn_bf16_prenorm2_split + ispk_ffn_combine_ln_f32.  `next_norm` =
+        (weight, bias, eps, apply_mask, dtype) of the norm that consumes y."""
+        w1, _ = self._staged(torch.bfloat16)
+        rows, chunks = x.numel() // x.shape[-1], w1.shape[0] // 32
+        blocks = (rows + 127) // 128
+        splits = 1
+        for s in (2, 3, 4, 6, 8):       # as many workgroups as fit one round of the 256 CUs, at least 2 chunks each
+            if chunks % s == 0 and chunks // s >= 2 and blocks * s <= 256:
+                splits = s
+        return runtime.ffn_prenorm2_split(x, norm.weight, norm.bias, w1, self._chunked_w2(), mask, splits, next_norm=next_norm,
+                                          norm_eps=norm.eps)
+
     def prenorm_unfused_ok(self, x: Tensor, norm) -> bool:
         """Two-GEMM path (e.g. an activation the fused kernel lacks): can the first Linear's GEMM apply `norm` itself?
         Only from decoder-sized batches on - below, the separate LayerNorm launch is cheaper (28.8 vs 19.4 + 4.9 us at

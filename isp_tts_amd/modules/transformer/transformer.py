@@ -129,6 +129,14 @@ class TransformerLayer(nn.Module, Constructor):
             y, hn = self.feed_forward.forward_prenorm(x1, self.feed_forward_norm, mask=mask, next_norm=next_norm)
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                           shared_intermediates=shared, next_normed=hn)
+        if (ada is None and (next_norm is None or next_norm[4] == "stats" or next_norm[4] == cdt)
+                and self.feed_forward.split_ok(x1, self.feed_forward_norm)):
+            # small batches: feed_forward_norm + feed-forward split over the inner dimension, then ONE pass that adds the
+            # partial products, the residual and the mask and already applies the norm that consumes the result
+            nn_ = None if next_norm is None else (next_norm[0], next_norm[1], next_norm[2], next_norm[3], cdt)
+            y, hn = self.feed_forward.forward_prenorm_split(x1, self.feed_forward_norm, mask=mask, next_norm=nn_)
+            return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
+                                          shared_intermediates=shared, next_normed=hn)
         if (ada is None and (next_norm is None or next_norm[4] == "stats")
                 and self.feed_forward.prenorm_unfused_ok(x1, self.feed_forward_norm)):
             # small batches (two-GEMM feed-forward): feed_forward_norm inside the first Linear's GEMM

@@ -41,6 +41,8 @@ SIGNATURES = {
                          _U32, _P],
     "ispk_ffn_bf16_prenorm": [_P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
     "ispk_ffn_chunk_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
+    "ispk_ffn_bf16_prenorm2_split": [_P, _I64, _P, _P, _F32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
+    "ispk_ffn_combine_ln_f32": [_P, _I64, _P, _I64, _I32, _P, _P, _I64, _P, _P, _F32, _I32, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_ffn_bf16_prenorm2": [_P, _I64, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
     "ispk_attn_out_ffn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32,
                                _P, _F32, _P],
@@ -438,6 +440,38 @@ def ffn_prenorm2(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, 
             x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w2c.data_ptr(), _ptr(mask),
             out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())
     return (out, stats) if want_stats else out
+
+
+def ffn_prenorm2_split(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2c: Tensor, mask: Optional[Tensor],
+                       splits: int, next_norm: Optional[tuple] = None, norm_eps: float = 1e-5):
+    """Small-batch form of `ffn_prenorm2` (ispk_ffn_bf16_prenorm2_split + ispk_ffn_combine_ln_f32): the inner dimension split
+    over `splits` workgroups per row block, partial products added in split order with the residual and the mask, and -
+    `next_norm` = (weight, bias, eps, apply_mask, dtype) - the LayerNorm that consumes the result from the same pass.
+    -> (y fp32, LN(y) | None)."""
+    _dev(x, norm_weight, norm_bias, w1, w2c, mask)
+    assert x.dtype == torch.float32 and w1.dtype == torch.bfloat16 and w2c.dtype == torch.bfloat16
+    x2 = _rows2d(x)
+    R, D = x2.shape
+    Fi = w1.shape[0]
+    parts = torch.empty((splits, R, D), dtype=torch.float32, device=x.device)   # per call: graph instances may run side by side
+    _launch(f"ffn2_bf16_kernel<0>/split{splits}", 4.0 * R * D * Fi, float(x2.numel() * 4 * splits + (w1.numel() + w2c.numel()) * 2
+                                                                           + splits * R * D * 4),
+            lib().ispk_ffn_bf16_prenorm2_split, x2.data_ptr(), x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(),
+            norm_eps, w1.data_ptr(), w2c.data_ptr(), parts.data_ptr(), R * D, splits, R, D, Fi, _stream())
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+    ln = None
+    nw = nb = None
+    neps, nmask, nbf16 = 1e-5, 0, 0
+    if next_norm is not None:
+        nw, nb, neps, apply_mask, ndtype = next_norm
+        ln = torch.empty(x.shape, dtype=ndtype, device=x.device)
+        nmask, nbf16 = int(bool(apply_mask) and mask is not None), int(ndtype == torch.bfloat16)
+    _launch("ffn_combine_ln_kernel", 0.0, float(R * D * 4 * (2 + splits) + (R * D * ln.element_size() if ln is not None else 0)),
+            lib().ispk_ffn_combine_ln_f32, x2.data_ptr(), x2.stride(0), parts.data_ptr(), R * D, splits, _ptr(mask), y.data_ptr(),
+            D, _ptr(nw), _ptr(nb), neps, nmask, _ptr(ln), D, nbf16, R, D, _stream())
+    return y, ln
 
 
 def attn_out_ffn(o: Tensor, wo: Tensor, x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2p: Tensor,

@@ -468,6 +468,42 @@ def test_eight_wave_ffn_kernel(R, Fi, masked):
     assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("R,splits,masked", [(6400, 4, True), (128 * 9 + 17, 8, True), (1500, 3, False)])
+def test_split_ffn_for_small_batches(R, splits, masked):
+    """ispk_ffn_bf16_prenorm2_split + ispk_ffn_combine_ln_f32 (inner dimension split over workgroups, partials added in split
+    order with residual and mask, consumer LayerNorm from the same pass) against the unsplit eight-wave kernel - the same
+    products, only the fp32 accumulation is cut into `splits` segments - and float64; LayerNorm output against float64 on
+    the kernel's own y; masked rows exactly zero; run-to-run determinism."""
+    D, Fi = 384, 1536
+    x = synth._normal(f"t/ffns/x{R}", (R, D), 1.5, 0.4)
+    w1, w2 = _bf(synth._normal("t/ffns/w1", (Fi, D), D ** -0.5)), _bf(synth._normal("t/ffns/w2", (D, Fi), Fi ** -0.5))
+    g, b = synth._normal("t/ffns/g", (D,), 0.1, 1.0), synth._normal("t/ffns/b", (D,), 0.1)
+    ng, nb = synth._normal("t/ffns/ng", (D,), 0.1, 1.0), synth._normal("t/ffns/nb", (D,), 0.1)
+    mask = (torch.arange(R) % 7 != 3) if masked else None
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    w2c = runtime.ffn_chunk_w2(d(w2))
+    nn_ = (d(ng), d(nb), 1e-5, False, torch.bfloat16)
+    y, hn = runtime.ffn_prenorm2_split(d(x), d(g), d(b), d(w1), w2c, d(mask), splits, next_norm=nn_)
+    y2, hn2 = runtime.ffn_prenorm2_split(d(x), d(g), d(b), d(w1), w2c, d(mask), splits, next_norm=nn_)
+    assert torch.equal(y, y2) and torch.equal(hn, hn2)
+    whole = runtime.ffn_prenorm2(d(x), d(g), d(b), d(w1), w2c, mask=d(mask), flags=runtime.EP_MASK_OUT if masked else 0)
+    e = (y - whole).abs()
+    assert e.max().item() <= 2e-5 * max(1.0, whole.abs().max().item()), e.max().item()   # fp32 sums in another grouping
+    x64 = x.double()
+    h64 = (x64 - x64.mean(1, keepdim=True)) / torch.sqrt(x64.var(1, unbiased=False, keepdim=True) + 1e-5) * g.double() + b.double()
+    ref64 = x64 + F.gelu(h64 @ w1.double().t()) @ w2.double().t()
+    if masked:
+        ref64 = ref64 * mask[:, None]
+        assert y.cpu()[~mask].abs().max().item() == 0.0
+    err = (y.cpu().double() - ref64).abs()
+    assert err.max().item() <= 0.06 and err.pow(2).mean().sqrt().item() <= 6e-3
+    y64 = y.cpu().double()
+    ln64 = (y64 - y64.mean(1, keepdim=True)) / torch.sqrt(y64.var(1, unbiased=False, keepdim=True) + 1e-5) * ng.double() + nb.double()
+    assert (hn.cpu().double() - ln64).abs().max().item() <= 2.0 ** -7 * max(1.0, ln64.abs().max().item())   # bf16 rounding
+    y3, none = runtime.ffn_prenorm2_split(d(x), d(g), d(b), d(w1), w2c, d(mask), splits)
+    assert none is None and torch.equal(y3, y)
+
+
 @pytest.mark.parametrize("R,D,Fi,masked", [(128 * 9 + 17, 384, 1536, True), (300, 256, 1024, True), (128 * 3, 384, 1536, False)])
 def test_fused_ffn_with_layernorm_prologue(R, D, Fi, masked):
     """ispk_ffn_bf16_prenorm == LayerNorm kernel (bf16 out, row mask) -> ispk_ffn_bf16 with the fp32 rows as residual:

@@ -454,7 +454,7 @@ def ffn_prenorm2_split(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Te
     R, D = x2.shape
     Fi = w1.shape[0]
     parts = torch.empty((splits, R, D), dtype=torch.float32, device=x.device)   # per call: graph instances may run side by side
-    _launch(f"ffn2_bf16_kernel<0>/split{splits}", 4.0 * R * D * Fi, float(x2.numel() * 4 * splits + (w1.numel() + w2c.numel()) * 2
+    _launch("ffn2_bf16_kernel<20>", 4.0 * R * D * Fi, float(x2.numel() * 4 * splits + (w1.numel() + w2c.numel()) * 2
                                                                            + splits * R * D * 4),
             lib().ispk_ffn_bf16_prenorm2_split, x2.data_ptr(), x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(),
             norm_eps, w1.data_ptr(), w2c.data_ptr(), parts.data_ptr(), R * D, splits, R, D, Fi, _stream())

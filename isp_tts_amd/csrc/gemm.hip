@@ -1322,6 +1322,13 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
             return N == 384 ? launch_wide<6, 4>(p, s) : launch_wide<4, 4>(p, s);
         }
         const bool w192 = N <= 192 ? N > 128 : N % 192 == 0;
+        // long K with few rows (the aligner's key convolution: 6,656 x 768 x 1920): 64-row blocks make 416 workgroups =
+        // 1.6 rounds, each streaming its 0.7 MB of weights; 128-row blocks are ONE round of 208 that streams them half as often
+        const int blocks128 = ((M + 127) / 128) * (N / 192);
+        if (w192 && N > 192 && p.K >= 1536 && blocks128 >= 160 && blocks128 <= 256) {
+            g_last_bf16_variant = 2000 + 34;
+            return launch_wide<3, 4>(p, s);
+        }
         g_last_bf16_variant = 2000 + (w192 ? 32 : 22);   // 192- or 128-feature column blocks over grid.y
         return w192 ? launch_wide<3, 2>(p, s) : launch_wide<2, 2>(p, s);
     }

@@ -381,6 +381,15 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  * ispk_gelu_f32                a = gelu(u), exact erf (modules/layers.py:29), as a pass of its own: the training forward keeps
  *                              the pre-activation u for the backward (the inference GEMMs apply GELU in their epilogue).
  * ispk_gelu_bwd_f32            du = da * (Phi(u) + u phi(u)): exact-erf GELU (modules/layers.py:29), n % 4 == 0.
+ *                              Dropout (feedforward.py:35, nn.Dropout after the activation; attend.py:118, SDPA dropout_p on the
+ *                              attention probabilities): with dropout_p > 0 ispk_gelu_f32 returns gelu(u) keep / (1 - p),
+ *                              ispk_gelu_bwd_f32 routes the gradient through the same mask, ispk_alibi_mqa_attn_train_f32 is the
+ *                              attention forward with dropped probabilities (it also returns the rows' log-sum-exp, which the
+ *                              backward takes as lse_in instead of recomputing it) and ispk_alibi_mqa_attn_bwd_f32 differentiates
+ *                              through the same mask.  keep = hash(seed, element index) >= p 2^32, a pure function of the seed
+ *                              (element index: flat index of u; ((b H + h) N + query) N + key for attention), so nothing is
+ *                              stored; the draw sequence differs from torch's Philox stream (same Bernoulli(1 - p) law).
+ *                              ispk_dropout_mask_u8 writes keep for indices 0 .. n-1 (tests).
  * ispk_alibi_mqa_attn_bwd_f32  backward of ispk_alibi_mqa_attn_f32 (attend.py:49-122, embeddings.py:51-82, attention.py:128-152):
  *                              qkv / dqkv fp32 [B][N][H*64 + 128] = [Q heads | K | V] at row stride ld_qkv, o / d_o fp32
  *                              [B][N][H*64] at ld_o, slopes [H] = exp(learned_logslopes), key_len int64 [B] or NULL.
@@ -414,12 +423,17 @@ int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int
                                const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
                                float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,
                                float eps, ispk_stream_t stream);
-int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, ispk_stream_t stream);
-int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, ispk_stream_t stream);
+int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
+int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, float dropout_p, uint64_t seed,
+                          ispk_stream_t stream);
+int32_t ispk_dropout_mask_u8(uint8_t* out, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
+int32_t ispk_alibi_mqa_attn_train_f32(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len, float* o,
+                                      int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H, float dropout_p, uint64_t seed,
+                                      ispk_stream_t stream);
 int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
                                     const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
                                     float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
-                                    ispk_stream_t stream);
+                                    const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
                           float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
 int32_t ispk_mel_grad_rows_f32(const float* dmel, const uint8_t* mask, float* g, int32_t B, int32_t C, int32_t T,

@@ -19,6 +19,18 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __b
 // a lane half walks the reduction index when an accumulator is fed back as an MFMA operand (step t <-> register t).
 __device__ __forceinline__ int acc_row(int r, int hf) { return 8 * (r >> 2) + 4 * hf + (r & 3); }
 
+// Dropout masks are a pure function of (seed, element index): forward and backward evaluate the same function instead of
+// storing a mask.  32-bit finaliser-style mix of the 64-bit (seed + golden-ratio * index); an element is KEPT when the hash
+// is >= p * 2^32.  (The reference draws torch's Philox stream: same distribution, another sequence - masks are tested for
+// their rate and forward / backward consistency, gradients against autograd with the exported mask.)
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return (uint32_t)((z ^ (z >> 31)) >> 16);
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) { return drop_hash(seed, idx) >= thresh; }
+
 // ------------------------------------------------------------------------------------------------ transpose
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
                                                         int rows, int cols) {
@@ -235,8 +247,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
 }
 
 // ------------------------------------------------------------------------------------------------ GELU backward
+// With dropout (feedforward.py:35: Linear -> GELU -> Dropout -> Linear): a = gelu(u) * keep / (1 - p), and backward
+// du = da * keep / (1 - p) * gelu'(u); keep = drop_keep(seed, element index).
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ u,
-                                                       float* __restrict__ du, int64_t n4) {
+                                                       float* __restrict__ du, int64_t n4, uint32_t thresh, float inv_keep,
+                                                       uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const f32x4 a = reinterpret_cast<const f32x4*>(da)[i], x = reinterpret_cast<const f32x4*>(u)[i];
@@ -245,17 +260,32 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
     for (int k = 0; k < 4; ++k) {
         const float cdf = 0.5f * (1.f + erff(x[k] * 0.70710678118654752440f));
         const float pdf = 0.39894228040143267794f * expf(-0.5f * x[k] * x[k]);
-        o[k] = a[k] * (cdf + x[k] * pdf);
+        float g = a[k] * (cdf + x[k] * pdf);
+        if (thresh) g = drop_keep(seed, (uint64_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
+        o[k] = g;
     }
     reinterpret_cast<f32x4*>(du)[i] = o;
 }
 
 // the training forward keeps the pre-activation u (for the line above), so its GELU is a pass of its own: a = gelu(u)
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ a, int64_t n4) {
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ a, int64_t n4,
+                                                       uint32_t thresh, float inv_keep, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const f32x4 x = reinterpret_cast<const f32x4*>(u)[i];
-    reinterpret_cast<f32x4*>(a)[i] = f32x4{gelu_erf(x.x), gelu_erf(x.y), gelu_erf(x.z), gelu_erf(x.w)};
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float g = gelu_erf(x[k]);
+        if (thresh) g = drop_keep(seed, (uint64_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
+        o[k] = g;
+    }
+    reinterpret_cast<f32x4*>(a)[i] = o;
+}
+
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t thresh, uint64_t seed) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = drop_keep(seed, (uint64_t)i, thresh) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward
@@ -306,7 +336,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
                                                          const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
                                                          float* __restrict__ dqkv, float* __restrict__ lse,
                                                          float* __restrict__ delta, float* __restrict__ slope_part, int N,
-                                                         int H, float scale) {
+                                                         int H, float scale, const float* __restrict__ lse_in, uint32_t thresh,
+                                                         float inv_keep, uint64_t seed) {
     const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, l = threadIdx.x, c = l & 31, hf = l >> 5;
     const int ntiles = gridDim.x;
     const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
@@ -327,9 +358,10 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
         dl += __shfl_xor(dl, 32, 64);
     }
     const int kt_end = (klen + 31) / 32;
-    // pass 1
+    const uint64_t row_idx = (((uint64_t)b * H + h) * N + (uint64_t)(i < N ? i : 0)) * (uint64_t)N;   // dropout index of (i, 0)
+    // pass 1 (skipped when the training forward kept the row statistics)
     float mx = -INFINITY, sum = 0.f;
-    for (int kt = 0; kt < kt_end; ++kt) {
+    for (int kt = 0; kt < (lse_in ? 0 : kt_end); ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
         const f32x16 s = dot_frags(kf, qf);
         float sv[16], tmax = -INFINITY;
@@ -354,7 +386,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
         sum = hf == 0 ? a + bb : bb + a;
         mx = nm;
     }
-    const float L = sum > 0.f ? mx + logf(sum) : INFINITY;   // no valid key: P = exp(s - inf) = 0
+    float L = sum > 0.f ? mx + logf(sum) : INFINITY;   // no valid key: P = exp(s - inf) = 0
+    if (lse_in) L = i < N ? lse_in[((int64_t)b * H + h) * N + i] : INFINITY;
     if (hf == 0 && i < N) {
         lse[((int64_t)b * H + h) * N + i] = L;
         delta[((int64_t)b * H + h) * N + i] = dl;
@@ -373,7 +406,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
             const int j = kt * 32 + acc_row(r, hf);
             const float dist = fabsf((float)(i - j));
             const float p = (j < klen && i < N) ? expf(s[r] * scale - slope * dist - L) : 0.f;
-            ds[r] = p * (dp[r] - dl);
+            float dpr = dp[r];
+            if (thresh) dpr = drop_keep(seed, row_idx + (uint64_t)j, thresh) ? dpr * inv_keep : 0.f;   // through the dropout
+            ds[r] = p * (dpr - dl);
             gs -= ds[r] * dist;
         }
         // dQ^T[d][i] += sum_j K[j][d] dS^T[j][i]: A = K^T, its reduction index j walked in accumulator-row order
@@ -400,6 +435,82 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
     if (l == 0) slope_part[((int64_t)h * gridDim.z + b) * ntiles + tile] = gs;
 }
 
+// Training forward (attention dropout, attend.py:118 / SDPA dropout_p): the dQ kernel's skeleton - pass 1 row statistics
+// (kept for the backward), pass 2 P, dropout, O^T[d][i] += sum_j V[j][d] Pdrop^T[j][i] with the accumulator fed back as the
+// operand.  fp32, one wave per (32 queries, head, batch item).
+__global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restrict__ qkv, int64_t ld,
+                                                            const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
+                                                            float* __restrict__ o, int64_t ldo, float* __restrict__ lse, int N, int H,
+                                                            float scale, uint32_t thresh, float inv_keep, uint64_t seed) {
+    const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, l = threadIdx.x, c = l & 31, hf = l >> 5;
+    const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
+    const int i = tile * 32 + c;
+    const float* qb = qkv + (int64_t)b * N * ld;
+    const float* kb = qb + H * 64;
+    const float* vb = kb + 64;
+    const float slope = slopes[h];
+    const Frag qf = load_frag(qb + h * 64, ld, i, N, hf);
+    const int kt_end = (klen + 31) / 32;
+    const uint64_t row_idx = (((uint64_t)b * H + h) * N + (uint64_t)(i < N ? i : 0)) * (uint64_t)N;
+    float mx = -INFINITY, sum = 0.f;
+    for (int kt = 0; kt < kt_end; ++kt) {
+        const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
+        const f32x16 s = dot_frags(kf, qf);
+        float sv[16], tmax = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = kt * 32 + acc_row(r, hf);
+            sv[r] = j < klen ? s[r] * scale - slope * fabsf((float)(i - j)) : -INFINITY;
+            tmax = fmaxf(tmax, sv[r]);
+        }
+        const float nm = fmaxf(mx, tmax);
+        float part = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : expf(sv[r] - nm);
+        sum = (mx == -INFINITY ? 0.f : sum * expf(mx - nm)) + part;
+        mx = nm;
+    }
+    {
+        const float om = __shfl_xor(mx, 32, 64), os = __shfl_xor(sum, 32, 64);
+        const float nm = fmaxf(mx, om);
+        const float a = mx == -INFINITY ? 0.f : sum * expf(mx - nm), bb = om == -INFINITY ? 0.f : os * expf(om - nm);
+        sum = hf == 0 ? a + bb : bb + a;
+        mx = nm;
+    }
+    const float L = sum > 0.f ? mx + logf(sum) : INFINITY;
+    if (hf == 0 && i < N) lse[((int64_t)b * H + h) * N + i] = L;
+    f32x16 ot[2] = {zero16(), zero16()};
+    for (int kt = 0; kt < kt_end; ++kt) {
+        const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
+        const f32x16 s = dot_frags(kf, qf);
+        float pd[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = kt * 32 + acc_row(r, hf);
+            float p = (j < klen && i < N) ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
+            if (thresh) p = drop_keep(seed, row_idx + (uint64_t)j, thresh) ? p * inv_keep : 0.f;
+            pd[r] = p;
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int j = kt * 32 + acc_row(t, hf);
+            const float* vr = vb + (int64_t)(j < N ? j : 0) * ld;
+            const float v0 = j < N ? vr[c] : 0.f, v1 = j < N ? vr[32 + c] : 0.f;
+            ot[0] = mfma2(v0, pd[t], ot[0]);
+            ot[1] = mfma2(v1, pd[t], ot[1]);
+        }
+    }
+    if (i < N) {
+        float* dst = o + ((int64_t)b * N + i) * ldo + h * 64;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+                *reinterpret_cast<f32x4*>(dst + 32 * mt + 8 * a + 4 * hf) =
+                    f32x4{ot[mt][4 * a], ot[mt][4 * a + 1], ot[mt][4 * a + 2], ot[mt][4 * a + 3]};
+    }
+}
+
 // dK / dV kernel: one workgroup per (key tile of 32, batch item), one wave per head; a wave loops over the query tiles
 // (S[query][key], key on the lane) with its head's sums in registers, then the H waves add their tiles into one LDS tile in
 // head order (barrier between heads): no atomics, a fixed summation order, one write per element.
@@ -407,7 +518,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                                                             int64_t ldo, const float* __restrict__ slopes,
                                                             const int64_t* __restrict__ key_len, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, float* __restrict__ dqkv, int N,
-                                                            int H, float scale) {
+                                                            int H, float scale, uint32_t thresh, float inv_keep, uint64_t seed) {
     __shared__ float red[2][2][16][64];     // [dk | dv][M tile][register][lane]
     const int kt = blockIdx.x, b = blockIdx.y, h = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, hf = l >> 5;
     const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
@@ -437,7 +548,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                 const bool ok = i < N && j < klen;
                 const float L = i < N ? lh[i] : 0.f, dl = i < N ? dh[i] : 0.f;
                 p[r] = ok ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
-                ds[r] = p[r] * (dp[r] - dl);
+                if (thresh) {
+                    const bool keep = drop_keep(seed, (((uint64_t)b * H + h) * N + (uint64_t)(i < N ? i : 0)) * (uint64_t)N + (uint64_t)j, thresh);
+                    ds[r] = p[r] * ((keep ? dp[r] * inv_keep : 0.f) - dl);
+                    p[r] = keep ? p[r] * inv_keep : 0.f;          // dV takes the DROPPED probabilities
+                } else {
+                    ds[r] = p[r] * (dp[r] - dl);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
@@ -566,30 +683,60 @@ extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const flo
     return ispk_launch_status();
 }
 
-extern "C" int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, ispk_stream_t stream) {
+static inline uint32_t drop_thresh(float p) {   // keep when hash >= thresh; 0 = dropout off
+    if (!(p > 0.f)) return 0u;
+    const double t = (double)p * 4294967296.0;
+    return t >= 4294967295.0 ? 4294967295u : (t < 1.0 ? 1u : (uint32_t)t);
+}
+
+extern "C" int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, float dropout_p, uint64_t seed,
+                                     ispk_stream_t stream) {
     ISPK_REQUIRE(da && u && du, -1, "ispk_gelu_bwd_f32: null pointer");
     ISPK_REQUIRE(n >= 0 && n % 4 == 0 && ispk_aligned(da, 16) && ispk_aligned(u, 16) && ispk_aligned(du, 16), -2,
                  "ispk_gelu_bwd_f32: n must be a multiple of 4 and the arrays 16-byte aligned");
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_bwd_f32: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       da, u, du, n / 4);
+                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
     return ispk_launch_status();
 }
 
-extern "C" int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, ispk_stream_t stream) {
+extern "C" int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream) {
     ISPK_REQUIRE(u && a, -1, "ispk_gelu_f32: null pointer");
     ISPK_REQUIRE(n >= 0 && n % 4 == 0 && ispk_aligned(u, 16) && ispk_aligned(a, 16), -2,
                  "ispk_gelu_f32: n must be a multiple of 4 and the arrays 16-byte aligned");
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_f32: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       u, a, n / 4);
+                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_dropout_mask_u8(uint8_t* out, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream) {
+    ISPK_REQUIRE(out && n >= 0 && dropout_p >= 0.f && dropout_p < 1.f, -1, "ispk_dropout_mask_u8: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       out, n, drop_thresh(dropout_p), seed);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_alibi_mqa_attn_train_f32(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len,
+                                                 float* o, int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H,
+                                                 float dropout_p, uint64_t seed, ispk_stream_t stream) {
+    ISPK_REQUIRE(qkv && slopes && o && lse, -1, "ispk_alibi_mqa_attn_train_f32: null pointer");
+    ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 8 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
+                     ld_o % 4 == 0 && B <= 65535, -2, "ispk_alibi_mqa_attn_train_f32: bad shape B=%d N=%d H=%d", B, N, H);
+    ISPK_REQUIRE(ispk_aligned(qkv, 16) && ispk_aligned(o, 16), -3, "ispk_alibi_mqa_attn_train_f32: arrays must be 16-byte aligned");
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -4, "ispk_alibi_mqa_attn_train_f32: dropout_p must be in [0, 1)");
+    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((N + 31) / 32, H, B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), qkv,
+                       ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
     return ispk_launch_status();
 }
 
 extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
                                                const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
                                                float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
-                                               ispk_stream_t stream) {
+                                               const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream) {
     ISPK_REQUIRE(qkv && o && d_o && slopes && dqkv && workspace, -1, "ispk_alibi_mqa_attn_bwd_f32: null pointer");
     ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 8 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
                      ld_o % 4 == 0, -2, "ispk_alibi_mqa_attn_bwd_f32: bad shape B=%d N=%d H=%d", B, N, H);
@@ -601,10 +748,13 @@ extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv,
     float *lse = workspace, *delta = workspace + stat, *spart = workspace + 2 * stat;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const float scale = 0.125f;
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -5, "ispk_alibi_mqa_attn_bwd_f32: dropout_p must be in [0, 1)");
+    const uint32_t thresh = drop_thresh(dropout_p);
+    const float inv_keep = 1.0f / (1.0f - dropout_p);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse,
-                       delta, spart, N, H, scale);
+                       delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
     hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len, lse, delta,
-                       dqkv, N, H, scale);
+                       dqkv, N, H, scale, thresh, inv_keep, seed);
     if (dlogslopes)
         hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64 * H), 0, s, spart, B * tiles, slopes, dlogslopes, H);
     return ispk_launch_status();

@@ -20,6 +20,7 @@ EP_GELU, EP_SILU, EP_MASK_ACC, EP_MASK_OUT, EP_BIAS_ROW, EP_MASK_COL, EP_OUT_BF1
     1, 2, 4, 8, 16, 32, 64, 128, 256)
 
 _P, _I32, _I64, _U32, _F32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
+_U64 = ctypes.c_uint64
 
 # name -> argtypes; must list EVERY symbol of include/ispk.h (tests/test_abi.py checks header == this table == .so)
 SIGNATURES = {
@@ -64,9 +65,11 @@ SIGNATURES = {
     "ispk_transpose_f32": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ispk_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_layernorm_bwd_f32": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _I64, _I32, _F32, _P],
-    "ispk_gelu_f32": [_P, _P, _I64, _P],
-    "ispk_gelu_bwd_f32": [_P, _P, _P, _I64, _P],
-    "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
+    "ispk_gelu_f32": [_P, _P, _I64, _F32, _U64, _P],
+    "ispk_gelu_bwd_f32": [_P, _P, _P, _I64, _F32, _U64, _P],
+    "ispk_dropout_mask_u8": [_P, _I64, _F32, _U64, _P],
+    "ispk_alibi_mqa_attn_train_f32": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
+    "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
     "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_mel_grad_rows_f32": [_P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_colsum_f32": [_P, _I64, _I64, _I32, _P, _I64, _P, _P],
@@ -874,30 +877,58 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], row_mask: Opti
     return dx, dg, db
 
 
-def gelu(u: Tensor) -> Tensor:
-    """ispk_gelu_f32: exact-erf GELU as its own pass (the training forward keeps u)."""
+def gelu(u: Tensor, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
+    """ispk_gelu_f32: exact-erf GELU as its own pass (the training forward keeps u), optionally followed by dropout."""
     _dev(u)
     assert u.dtype == torch.float32 and u.is_contiguous()
     a = torch.empty_like(u)
-    _launch("gelu_fwd_kernel", 0.0, 8.0 * u.numel(), lib().ispk_gelu_f32, u.data_ptr(), a.data_ptr(), u.numel(), _stream())
+    _launch("gelu_fwd_kernel", 0.0, 8.0 * u.numel(), lib().ispk_gelu_f32, u.data_ptr(), a.data_ptr(), u.numel(), dropout_p,
+            seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return a
 
 
-def gelu_bwd(da: Tensor, u: Tensor, out: Optional[Tensor] = None) -> Tensor:
-    """ispk_gelu_bwd_f32: du = da * gelu'(u) (exact erf); `out` may alias `da`."""
+def dropout_mask(n: int, dropout_p: float, seed: int, device) -> Tensor:
+    """ispk_dropout_mask_u8: the keep mask the kernels evaluate for element indices 0 .. n-1 (bool [n])."""
+    out = torch.empty((n,), dtype=torch.bool, device=device)
+    _dev(out)
+    _check(lib().ispk_dropout_mask_u8(out.data_ptr(), n, dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream()), "ispk_dropout_mask_u8")
+    return out
+
+
+def alibi_mqa_attention_train(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor], dropout_p: float, seed: int):
+    """ispk_alibi_mqa_attn_train_f32 -> (o fp32 [B, N, heads*64], lse fp32 [B, heads, N]): attention with dropped
+    probabilities, row statistics kept for the backward."""
+    _dev(qkv, slopes, key_len)
+    B, N, W = qkv.shape
+    assert W == heads * 64 + 128 and qkv.dtype == torch.float32 and qkv.is_contiguous()
+    slopes = slopes.to(torch.float32).contiguous()
+    if key_len is not None:
+        key_len = key_len.to(torch.int64).contiguous()
+    o = torch.empty((B, N, heads * 64), dtype=torch.float32, device=qkv.device)
+    lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
+    _launch("attn_train_fwd_kernel", 6.0 * B * heads * N * N * 64, 4.0 * (qkv.numel() + o.numel()),
+            lib().ispk_alibi_mqa_attn_train_f32, qkv.data_ptr(), W, slopes.data_ptr(), _ptr(key_len), o.data_ptr(), heads * 64,
+            lse.data_ptr(), B, N, heads, dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    return o, lse
+
+
+def gelu_bwd(da: Tensor, u: Tensor, out: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
+    """ispk_gelu_bwd_f32: du = da * [keep / (1 - p)] * gelu'(u) (exact erf); `out` may alias `da`."""
     _dev(da, u, out)
     assert da.dtype == torch.float32 and u.dtype == torch.float32 and da.is_contiguous() and u.is_contiguous()
     assert da.shape == u.shape
     if out is None:
         out = torch.empty_like(da)
     _launch("gelu_bwd_kernel", 0.0, 12.0 * da.numel(), lib().ispk_gelu_bwd_f32, da.data_ptr(), u.data_ptr(), out.data_ptr(),
-            da.numel(), _stream())
+            da.numel(), dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return out
 
 
-def alibi_mqa_attention_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor]):
-    """ispk_alibi_mqa_attn_bwd_f32 -> (dqkv fp32 like qkv, dlogslopes fp32 [heads])."""
-    _dev(qkv, o, d_o, slopes, key_len)
+def alibi_mqa_attention_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor],
+                            lse: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0):
+    """ispk_alibi_mqa_attn_bwd_f32 -> (dqkv fp32 like qkv, dlogslopes fp32 [heads]).  `lse` (from the training forward)
+    saves the statistics pass; dropout_p / seed must be the forward's."""
+    _dev(qkv, o, d_o, slopes, key_len, lse)
     B, N, W = qkv.shape
     assert W == heads * 64 + 128 and qkv.dtype == torch.float32 and qkv.is_contiguous()
     assert o.shape == (B, N, heads * 64) and d_o.shape == o.shape and o.dtype == torch.float32 and d_o.dtype == torch.float32
@@ -911,7 +942,8 @@ def alibi_mqa_attention_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, heads: int, slo
     ws = workspace(qkv.device, 2 * B * heads * N + heads * B * tiles)
     _launch("attn_bwd_kernels", 10.0 * B * heads * N * N * 64, 4.0 * (2 * qkv.numel() + 2 * o.numel()),
             lib().ispk_alibi_mqa_attn_bwd_f32, qkv.data_ptr(), W, o.data_ptr(), d_o.data_ptr(), heads * 64, slopes.data_ptr(),
-            _ptr(key_len), dqkv.data_ptr(), dls.data_ptr(), ws.data_ptr(), ws.numel(), B, N, heads, _stream())
+            _ptr(key_len), dqkv.data_ptr(), dls.data_ptr(), ws.data_ptr(), ws.numel(), B, N, heads, _ptr(lse), dropout_p,
+            seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return dqkv, dls
 
 

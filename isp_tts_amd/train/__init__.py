@@ -4,13 +4,13 @@
              reference's Optimizer.step (experiments/optimizers.py:230-244) as three launches - squared norm of the decay
              group, AdamW with the clip folded in - and, across ranks, a reduce-scatter of the gradient arena, the update of
              the rank's own slice and an all-gather of the parameters (RCCL over xGMI; optimizer state sharded).
-  stack.py   TransformerStackFunction: a `Transformer` stack (plain LayerNorm, dropout 0, fp32) as ONE autograd node whose
-             backward is the kernels of csrc/backward.hip.
+  stack.py   TransformerStackFunction: a `Transformer` stack (plain LayerNorm, fp32, dropout by in-kernel masks) as ONE
+             autograd node whose backward is the kernels of csrc/backward.hip.
   stack.py   also ToMelFunction (to_mel's Linear + transpose + mask, model.py:167-168) and `mel_decoder_train_forward`.
   loss.py    MelLoss with its gradient as one kernel (models/acoustic/loss.py:22-35).
 
 Not built yet: backward of the aligner front-end, the adaptor (AdaLN stacks, flow matching, length
-regulation), dropout, the CTC / binarisation attention losses, bf16 autocast.
+regulation), the CTC / binarisation attention losses, bf16 autocast.
 """
 from .loss import MelLoss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params

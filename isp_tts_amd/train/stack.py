@@ -2,8 +2,10 @@
 the kernels of csrc/backward.hip plus the forward's own NT GEMM on transposed weights.
 
 Scope of this first cut: plain LayerNorm stacks (TextEncoder, MelDecoder: transformer.py:174-211 with emb_dim == dim),
-fp32, dropout 0 (the recipes train with attention / feed-forward dropout 0.1 - in-kernel Philox masks are not built, so a
-stack with dropout > 0 in training mode raises), ALiBi multi-query attention, exact-erf GELU, no Linear biases.
+fp32, ALiBi multi-query attention, exact-erf GELU, no Linear biases.  Dropout as the recipes train with it (attention
+probabilities and feed-forward activations, p = 0.1): the masks are a hash of (seed, element index) evaluated inside the
+kernels, forward and backward alike - nothing is stored; a step's seeds come from torch's CPU generator (torch.manual_seed
+makes a run reproducible), the draw sequence differs from torch's own dropout kernels.
 
 Forward per layer (transformer.py:62-118 as the inference path launches it, csrc/gemm.hip epilogues), m = row mask:
     h   = LN1(x)                 qkv = h Wqkv^T            o = ALiBi-MQA(qkv)          x1 = x + m (o Wo^T)
@@ -33,8 +35,6 @@ def _check(tr: Transformer) -> None:
         raise NotImplementedError("training backward: adaptive-norm / projected stacks (the temporal adaptor) are not built")
     for layer in tr.layers:
         att, ff = layer.attention, layer.feed_forward
-        if layer.training and (att.attend.dropout > 0 or ff.dropout_p > 0):
-            raise NotImplementedError("training backward: dropout > 0 is not built (set the stack's dropout to 0)")
         if ff.net[0].bias is not None or ff.net[3].bias is not None or ff.act_flag != runtime.EP_GELU:
             raise NotImplementedError("training backward: feed-forward with biases / non-GELU activation is not built")
 
@@ -59,19 +59,27 @@ class TransformerStackFunction(torch.autograd.Function):
         x = x.float().contiguous()
         key_len = mask.sum(dim=1) if mask is not None else None
         tape, out = [], x
-        for layer in tr.layers:
+        base_seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # torch's CPU generator: torch.manual_seed reproduces a run
+        for li, layer in enumerate(tr.layers):
             att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
             wqkv, wo, slopes = att._staged(torch.float32)
             w1, w2 = ff._staged(torch.float32)
             h = runtime.layernorm(out, an.weight, an.bias, eps=an.eps)
             qkv = runtime.gemm(h, wqkv)
-            o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
+            p_att = float(att.attend.dropout) if layer.training else 0.0
+            p_ff = float(ff.dropout_p) if layer.training else 0.0
+            seed_att, seed_ff = base_seed + 2 * li, base_seed + 2 * li + 1
+            lse = None
+            if p_att > 0:   # dropped attention probabilities (attend.py:118); the rows' log-sum-exp is kept for the backward
+                o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att)
+            else:
+                o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
             x1 = runtime.gemm(o, wo, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
             h2 = runtime.layernorm(x1, fn.weight, fn.bias, row_mask=mask, eps=fn.eps)
             u = runtime.gemm(h2, w1)
-            a = runtime.gelu(u)
+            a = runtime.gelu(u, p_ff, seed_ff)                       # GELU, then nn.Dropout (feedforward.py:35)
             y = runtime.gemm(a, w2, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
-            tape.append((out, h, qkv, o, x1, h2, u, a))
+            tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
         final = runtime.layernorm(out, tr.norm.weight, tr.norm.bias, row_mask=mask, eps=tr.norm.eps)
         ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last = tr, mask, key_len, tape, out
@@ -84,7 +92,8 @@ class TransformerStackFunction(torch.autograd.Function):
         grads: list = []
         dy, dgf, dbf = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask,
                                              eps=tr.norm.eps)
-        for layer, (xin, h, qkv, o, x1, h2, u, a) in zip(reversed(tr.layers), reversed(ctx.tape)):
+        for layer, (xin, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff) in zip(reversed(tr.layers),
+                                                                                               reversed(ctx.tape)):
             att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
             wqkv, wo, slopes = att._staged(torch.float32)
             w1, w2 = ff._staged(torch.float32)
@@ -95,14 +104,15 @@ class TransformerStackFunction(torch.autograd.Function):
             # feed-forward block
             dw2 = runtime.gemm_tn(dy, a, row_mask=mask)                         # [dim, inner]
             da = runtime.gemm(dy, w2_t, mask=mask, flags=mflag)                  # (m dy) W2
-            du = runtime.gelu_bwd(da, u, out=da)
+            du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
             dw1 = runtime.gemm_tn(du, h2)                                        # [inner, dim]
             dh2 = runtime.gemm(du, w1_t)
             dx1, dg2, db2 = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps)
             # attention block
             dwo = runtime.gemm_tn(dx1, o, row_mask=mask)                         # [dim, heads*64]
             d_o = runtime.gemm(dx1, wo_t, mask=mask, flags=mflag)
-            dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len)
+            dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
+                                                        seed=seed_att)
             dwqkv = runtime.gemm_tn(dqkv, h)                                     # [heads*64 + 128, dim]
             dh = runtime.gemm(dqkv, wqkv_t)
             dy, dg1, db1 = runtime.layernorm_bwd(xin, dh, an.weight, dx=dx1, add_to_dx=True, eps=an.eps)

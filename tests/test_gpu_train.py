@@ -307,3 +307,100 @@ def test_decoder_to_mel_loss_training_step_matches_reference_step(state_dict):
     for k in names:
         d = (got[k].detach().cpu() - sd[k].detach()).abs()
         assert float(d.max()) <= 0.1 * lr and float(d.mean()) <= 2e-3 * lr, (k, float(d.max()), float(d.mean()))
+
+
+# ------------------------------------------------------------------------------------------------ dropout
+def test_dropout_mask_rate_and_gelu_dropout():
+    """The in-kernel mask: keep rate 1 - p within 4 sigma, different seeds give different masks, the same seed the same;
+    GELU + dropout forward / backward equal float64 with the exported mask."""
+    n, p = 1 << 20, 0.1
+    m1, m2 = runtime.dropout_mask(n, p, 1234, DEV), runtime.dropout_mask(n, p, 1235, DEV)
+    assert torch.equal(m1, runtime.dropout_mask(n, p, 1234, DEV)) and not torch.equal(m1, m2)
+    for m in (m1, m2):
+        assert abs(float(m.float().mean()) - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5
+    assert bool(runtime.dropout_mask(1000, 0.0, 7, DEV).all())
+    u = _rand((2048, 16), 80, 2.0).requires_grad_()
+    da = _rand((2048, 16), 81)
+    keep = runtime.dropout_mask(u.numel(), 0.3, 99, DEV).cpu().view_as(u)
+    ref = F.gelu(u.double()) * keep / 0.7
+    ref.backward(da.double())
+    _close(runtime.gelu(u.detach().to(DEV), 0.3, 99), ref, 1e-6, "gelu + dropout")
+    _close(runtime.gelu_bwd(da.to(DEV), u.detach().to(DEV), dropout_p=0.3, seed=99), u.grad, 2e-6, "gelu + dropout backward")
+
+
+@pytest.mark.parametrize("B,N,H,lens,p", [(2, 100, 6, (100, 61), 0.1), (1, 160, 4, None, 0.3)])
+def test_attention_dropout_forward_backward(B, N, H, lens, p):
+    """ispk_alibi_mqa_attn_train_f32 / _bwd_f32 with dropout on the attention probabilities against float64 autograd that
+    applies the SAME mask (exported by ispk_dropout_mask_u8, index ((b H + h) N + i) N + j); the training forward with p = 0
+    equals the inference kernel; the backward with the forward's log-sum-exp equals the one that recomputes it."""
+    W = H * 64 + 128
+    qkv = _rand((B, N, W), 90, 0.7)
+    d_o = _rand((B, N, H * 64), 91)
+    logs = torch.log(torch.tensor([2.0 ** (-(i + 1) * 8.0 / H) for i in range(H)]))
+    key_len = torch.tensor(lens) if lens is not None else None
+    idx = torch.arange(N)
+    if key_len is not None:
+        d_o = d_o * (idx[None, :] < key_len[:, None])[..., None]
+    seed = 4242
+    keep = runtime.dropout_mask(B * H * N * N, p, seed, DEV).cpu().view(B, H, N, N)
+    q64 = qkv.double().requires_grad_()
+    l64 = logs.double().requires_grad_()
+    q = q64[..., :H * 64].view(B, N, H, 64).transpose(1, 2)
+    k, v = q64[..., H * 64:H * 64 + 64], q64[..., H * 64 + 64:]
+    bias = -(idx[None, :] - idx[:, None]).abs().double()[None] * l64.exp()[:, None, None]
+    s = torch.einsum("bhid,bjd->bhij", q, k) / 8.0 + bias[None]
+    if key_len is not None:
+        s = s.masked_fill(~(idx[None, :] < key_len[:, None])[:, None, None, :], float("-inf"))
+    pd = s.softmax(-1) * keep / (1 - p)
+    o = torch.einsum("bhij,bjd->bhid", pd, v).transpose(1, 2).reshape(B, N, H * 64)
+    o.backward(d_o.double())
+    qd, sd = qkv.to(DEV), logs.exp().to(DEV)
+    kd = key_len.to(DEV) if key_len is not None else None
+    o_gpu, lse = runtime.alibi_mqa_attention_train(qd, H, sd, kd, p, seed)
+    valid = (idx[None, :] < key_len[:, None])[..., None] if key_len is not None else torch.ones(B, N, 1, dtype=torch.bool)
+    _close(o_gpu.cpu() * valid, o.detach() * valid, 5e-6, "forward with dropout")
+    dqkv, dls = runtime.alibi_mqa_attention_bwd(qd, o_gpu, d_o.to(DEV), H, sd, kd, lse=lse, dropout_p=p, seed=seed)
+    _close(dqkv, q64.grad, 3e-5, "dqkv with dropout")
+    _close(dls, l64.grad, 1e-4, "dlogslopes with dropout")
+    dqkv2, dls2 = runtime.alibi_mqa_attention_bwd(qd, o_gpu, d_o.to(DEV), H, sd, kd, dropout_p=p, seed=seed)
+    _close(dqkv2, dqkv, 1e-6, "backward with recomputed statistics")
+    o0, _ = runtime.alibi_mqa_attention_train(qd, H, sd, kd, 0.0, 0)
+    _close(o0.cpu() * valid, runtime.alibi_mqa_attention(qd, H, sd, kd).cpu() * valid, 5e-6, "training forward, p = 0")
+
+
+def test_stack_training_with_the_recipes_dropout(state_dict):
+    """The decoder stack in training mode with the recipes' dropout (0.1 / 0.1): a step is reproducible under
+    torch.manual_seed, differs between seeds, equals the dropout-free step when p = 0, and the loss falls over 8 steps."""
+    tr = _decoder_stack(state_dict, 2)
+    for layer in tr.layers:
+        layer.attention.attend.dropout = 0.1
+        layer.feed_forward.dropout_p = 0.1
+    B, N = 3, 64
+    x = _rand((B, N, 384), 95).to(DEV)
+    mask = (torch.arange(N)[None, :] < torch.tensor([64, 40, 57])[:, None]).to(DEV)
+    dout = _rand((B, N, 384), 96).to(DEV)
+
+    def run(seed):
+        torch.manual_seed(seed)
+        xg = x.clone().requires_grad_()
+        out = train.transformer_train_forward(tr, xg, mask)
+        out.backward(dout)
+        g = tr.layers[0].feed_forward.net[0].weight.grad.clone()
+        tr.zero_grad(set_to_none=True)
+        return out.detach().clone(), xg.grad.clone(), g
+    a, b, c = run(5), run(5), run(6)
+    assert all(torch.equal(p, q) for p, q in zip(a, b)), "same seed, different step"
+    assert not torch.equal(a[0], c[0])
+    tr.eval()
+    assert torch.equal(run(5)[0], run(6)[0]), "eval mode must not drop anything"
+    tr.train()
+    opt = train.FlatAdamW(tr, lr=1e-3, weight_decay=1e-2, grad_clip=1.0)
+    target = _rand((B, N, 384), 97, 0.5).to(DEV)
+    torch.manual_seed(0)
+    losses = []
+    for _ in range(8):
+        out = train.transformer_train_forward(tr, x, mask)
+        loss = (((out - target) * mask[..., None]) ** 2).mean()
+        losses.append(float(loss.detach()))
+        opt.step(loss)
+    assert losses[-1] < 0.9 * losses[0], losses

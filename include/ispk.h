@@ -387,7 +387,7 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              attention forward with dropped probabilities (it also returns the rows' log-sum-exp, which the
  *                              backward takes as lse_in instead of recomputing it) and ispk_alibi_mqa_attn_bwd_f32 differentiates
  *                              through the same mask.  keep = hash(seed, element index) >= p 2^32, a pure function of the seed
- *                              (element index: flat index of u; ((b H + h) N + query) N + key for attention), so nothing is
+ *                              (element index modulo 2^32: flat index of u; ((b H + h) N + query) N + key for attention), so nothing is
  *                              stored; the draw sequence differs from torch's Philox stream (same Bernoulli(1 - p) law).
  *                              ispk_dropout_mask_u8 writes keep for indices 0 .. n-1 (tests).
  * ispk_alibi_mqa_attn_bwd_f32  backward of ispk_alibi_mqa_attn_f32 (attend.py:49-122, embeddings.py:51-82, attention.py:128-152):

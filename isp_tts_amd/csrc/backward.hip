@@ -20,16 +20,22 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __b
 __device__ __forceinline__ int acc_row(int r, int hf) { return 8 * (r >> 2) + 4 * hf + (r & 3); }
 
 // Dropout masks are a pure function of (seed, element index): forward and backward evaluate the same function instead of
-// storing a mask.  32-bit finaliser-style mix of the 64-bit (seed + golden-ratio * index); an element is KEPT when the hash
-// is >= p * 2^32.  (The reference draws torch's Philox stream: same distribution, another sequence - masks are tested for
+// storing a mask.  Two rounds of a 32-bit multiply-xorshift mix over (seed, index); an element is KEPT when the hash is
+// >= p * 2^32.  (The reference draws torch's Philox stream: same distribution, another sequence - masks are tested for
 // their rate and forward / backward consistency, gradients against autograd with the exported mask.)
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return (uint32_t)((z ^ (z >> 31)) >> 16);
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32": two multiply-xorshift rounds, 32-bit arithmetic only
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
 }
-__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) { return drop_hash(seed, idx) >= thresh; }
+__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t idx) {
+    // (a 64-bit finaliser costs ~30 VALU instructions per element; this is 14.  The element index enters modulo 2^32.)
+    return mix32(mix32(idx ^ (uint32_t)seed) + (uint32_t)(seed >> 32));
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t idx, uint32_t thresh) { return drop_hash(seed, idx) >= thresh; }
 
 // ------------------------------------------------------------------------------------------------ transpose
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
@@ -261,7 +267,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
         const float cdf = 0.5f * (1.f + erff(x[k] * 0.70710678118654752440f));
         const float pdf = 0.39894228040143267794f * expf(-0.5f * x[k] * x[k]);
         float g = a[k] * (cdf + x[k] * pdf);
-        if (thresh) g = drop_keep(seed, (uint64_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
+        if (thresh) g = drop_keep(seed, (uint32_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
         o[k] = g;
     }
     reinterpret_cast<f32x4*>(du)[i] = o;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         float g = gelu_erf(x[k]);
-        if (thresh) g = drop_keep(seed, (uint64_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
+        if (thresh) g = drop_keep(seed, (uint32_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
         o[k] = g;
     }
     reinterpret_cast<f32x4*>(a)[i] = o;
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__
 
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t thresh, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = drop_keep(seed, (uint64_t)i, thresh) ? 1 : 0;
+    if (i < n) out[i] = drop_keep(seed, (uint32_t)i, thresh) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------------ attention backward
@@ -331,6 +337,7 @@ __device__ __forceinline__ f32x16 dot_frags(const Frag& a, const Frag& b) {
 // dQ kernel: one wave per (query tile of 32, head, batch item), transposed orientation S^T[key][query] (query on the lane).
 // Pass 1: row maxima / sums -> LSE (kept, and written for the dK/dV kernel together with delta).  Pass 2: P, dP, dS,
 // dQ^T += K^T dS^T, slope partial.
+template <bool kDrop>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ o,
                                                          const float* __restrict__ dout, int64_t ldo,
                                                          const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
         dl += __shfl_xor(dl, 32, 64);
     }
     const int kt_end = (klen + 31) / 32;
-    const uint64_t row_idx = (((uint64_t)b * H + h) * N + (uint64_t)(i < N ? i : 0)) * (uint64_t)N;   // dropout index of (i, 0)
+    const uint32_t row_idx = (((uint32_t)b * H + h) * N + (uint32_t)(i < N ? i : 0)) * (uint32_t)N;   // dropout index of (i, 0)
     // pass 1 (skipped when the training forward kept the row statistics)
     float mx = -INFINITY, sum = 0.f;
     for (int kt = 0; kt < (lse_in ? 0 : kt_end); ++kt) {
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
             const float dist = fabsf((float)(i - j));
             const float p = (j < klen && i < N) ? expf(s[r] * scale - slope * dist - L) : 0.f;
             float dpr = dp[r];
-            if (thresh) dpr = drop_keep(seed, row_idx + (uint64_t)j, thresh) ? dpr * inv_keep : 0.f;   // through the dropout
+            if constexpr (kDrop) dpr = drop_keep(seed, row_idx + (uint32_t)j, thresh) ? dpr * inv_keep : 0.f;   // through the dropout
             ds[r] = p * (dpr - dl);
             gs -= ds[r] * dist;
         }
@@ -451,7 +458,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
     const float slope = slopes[h];
     const Frag qf = load_frag(qb + h * 64, ld, i, N, hf);
     const int kt_end = (klen + 31) / 32;
-    const uint64_t row_idx = (((uint64_t)b * H + h) * N + (uint64_t)(i < N ? i : 0)) * (uint64_t)N;
+    const uint32_t row_idx = (((uint32_t)b * H + h) * N + (uint32_t)(i < N ? i : 0)) * (uint32_t)N;
     float mx = -INFINITY, sum = 0.f;
     for (int kt = 0; kt < kt_end; ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
@@ -488,7 +495,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
             const int j = kt * 32 + acc_row(r, hf);
             float p = (j < klen && i < N) ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
-            if (thresh) p = drop_keep(seed, row_idx + (uint64_t)j, thresh) ? p * inv_keep : 0.f;
+            if (thresh) p = drop_keep(seed, row_idx + (uint32_t)j, thresh) ? p * inv_keep : 0.f;
             pd[r] = p;
         }
 #pragma unroll
@@ -514,6 +521,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
 // dK / dV kernel: one workgroup per (key tile of 32, batch item), one wave per head; a wave loops over the query tiles
 // (S[query][key], key on the lane) with its head's sums in registers, then the H waves add their tiles into one LDS tile in
 // head order (barrier between heads): no atomics, a fixed summation order, one write per element.
+template <bool kDrop>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ dout,
                                                             int64_t ldo, const float* __restrict__ slopes,
                                                             const int64_t* __restrict__ key_len, const float* __restrict__ lse,
@@ -548,8 +556,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                 const bool ok = i < N && j < klen;
                 const float L = i < N ? lh[i] : 0.f, dl = i < N ? dh[i] : 0.f;
                 p[r] = ok ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
-                if (thresh) {
-                    const bool keep = drop_keep(seed, (((uint64_t)b * H + h) * N + (uint64_t)(i < N ? i : 0)) * (uint64_t)N + (uint64_t)j, thresh);
+                if constexpr (kDrop) {
+                    const bool keep = drop_keep(seed, (((uint32_t)b * H + h) * N + (uint32_t)(i < N ? i : 0)) * (uint32_t)N + (uint32_t)j, thresh);
                     ds[r] = p[r] * ((keep ? dp[r] * inv_keep : 0.f) - dl);
                     p[r] = keep ? p[r] * inv_keep : 0.f;          // dV takes the DROPPED probabilities
                 } else {
@@ -751,10 +759,17 @@ extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv,
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -5, "ispk_alibi_mqa_attn_bwd_f32: dropout_p must be in [0, 1)");
     const uint32_t thresh = drop_thresh(dropout_p);
     const float inv_keep = 1.0f / (1.0f - dropout_p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse,
-                       delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len, lse, delta,
-                       dqkv, N, H, scale, thresh, inv_keep, seed);
+    if (thresh) {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len,
+                           dqkv, lse, delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len,
+                           lse, delta, dqkv, N, H, scale, thresh, inv_keep, seed);
+    } else {
+        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len,
+                           dqkv, lse, delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
+        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len,
+                           lse, delta, dqkv, N, H, scale, thresh, inv_keep, seed);
+    }
     if (dlogslopes)
         hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64 * H), 0, s, spart, B * tiles, slopes, dlogslopes, H);
     return ispk_launch_status();

@@ -660,8 +660,10 @@ def worker(args) -> int:
             mask = torch.arange(M, device=dev)[None, :] < mlen[:, None]
             prof = runtime.LaunchProfiler() if rank == 0 else None
 
+            amp = [True]
+
             def st():
-                mel = train.mel_decoder_train_forward(model, x, mask)
+                mel = train.mel_decoder_train_forward(model, x, mask, amp=amp[0])
                 opt.step(crit(mel, target, mlen))
             try:
                 n = max(3, args.steps // 4)
@@ -673,6 +675,16 @@ def worker(args) -> int:
                     st()
                 fence()
                 el = max_over_ranks(time.perf_counter() - t0)
+                amp[0] = False                       # the all-fp32 step beside it
+                for _ in range(2):
+                    st()
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    st()
+                fence()
+                el32 = max_over_ranks(time.perf_counter() - t0)
+                amp[0] = True
                 kern = None
                 if prof is not None:
                     runtime.set_profiler(prof)
@@ -690,7 +702,8 @@ def worker(args) -> int:
             frames = world * B * M
             # forward 2 N K per Linear + attention 4 N^2 64 H; backward = 2 x the Linears' + 2.5 x the attention's
             res = {"value": round(frames * n / el, 1), "unit": "mel-frames/s", "ms_per_step": round(1e3 * el / n, 3), "steps": n,
-                   "dtype": "f32", "global_batch": world * B, "parameters": opt.flat.total,
+                   "dtype": "bf16 operands for the Linear GEMMs (AMP), fp32 everything else and master weights",
+                   "ms_per_step_all_fp32": round(1e3 * el32 / n, 3), "global_batch": world * B, "parameters": opt.flat.total,
                    "optimizer": f"flat AdamW, clip 1.0, {'reduce-scatter + all-gather over RCCL, moments sharded' if world > 1 else 'single rank'}",
                    "workload": "BASELINE config 5 restricted to MelDecoder + to_mel under the mel loss (forward with dropout 0.1 + "
                                "backward + clip + AdamW), eager launches"}

@@ -50,11 +50,22 @@ def stack_parameters(tr: Transformer) -> list:
     return ps + [tr.norm.weight, tr.norm.bias]
 
 
+def _mm(a32: Tensor, w32: Tensor, w16: Optional[Tensor], **kw) -> Tensor:
+    """a . w^T -> fp32.  `w16` given (bf16 AMP): operands rounded to bf16 (one cast launch for the activation), fp32
+    accumulation and output; residual / mask epilogues as in the fp32 GEMM."""
+    if w16 is None:
+        return runtime.gemm(a32, w32, **kw)
+    return runtime.gemm(runtime.cast_bf16(a32), w16, out_dtype=torch.float32, **kw)
+
+
 class TransformerStackFunction(torch.autograd.Function):
-    """out = Transformer(x, mask).out with every parameter of the stack as a differentiable input."""
+    """out = Transformer(x, mask).out with every parameter of the stack as a differentiable input.  `amp`: the eight
+    Linear GEMMs of a layer (forward and the dX ones of the backward) take bf16 operands - the reference trains under
+    autocast (recipes/default.yaml:56) - while LayerNorm, attention, GELU, every weight gradient and the residual stream stay
+    fp32."""
 
     @staticmethod
-    def forward(ctx, tr: Transformer, x: Tensor, mask: Optional[Tensor], *params: Tensor):
+    def forward(ctx, tr: Transformer, x: Tensor, mask: Optional[Tensor], amp: bool, *params: Tensor):
         _check(tr)
         x = x.float().contiguous()
         key_len = mask.sum(dim=1) if mask is not None else None
@@ -64,8 +75,10 @@ class TransformerStackFunction(torch.autograd.Function):
             att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
             wqkv, wo, slopes = att._staged(torch.float32)
             w1, w2 = ff._staged(torch.float32)
+            wqkv16, wo16, _ = att._staged(torch.bfloat16) if amp else (None, None, None)
+            w116, w216 = ff._staged(torch.bfloat16) if amp else (None, None)
             h = runtime.layernorm(out, an.weight, an.bias, eps=an.eps)
-            qkv = runtime.gemm(h, wqkv)
+            qkv = _mm(h, wqkv, wqkv16)
             p_att = float(att.attend.dropout) if layer.training else 0.0
             p_ff = float(ff.dropout_p) if layer.training else 0.0
             seed_att, seed_ff = base_seed + 2 * li, base_seed + 2 * li + 1
@@ -74,20 +87,20 @@ class TransformerStackFunction(torch.autograd.Function):
                 o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att)
             else:
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
-            x1 = runtime.gemm(o, wo, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
+            x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
             h2 = runtime.layernorm(x1, fn.weight, fn.bias, row_mask=mask, eps=fn.eps)
-            u = runtime.gemm(h2, w1)
+            u = _mm(h2, w1, w116)
             a = runtime.gelu(u, p_ff, seed_ff)                       # GELU, then nn.Dropout (feedforward.py:35)
-            y = runtime.gemm(a, w2, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
+            y = _mm(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
             tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
         final = runtime.layernorm(out, tr.norm.weight, tr.norm.bias, row_mask=mask, eps=tr.norm.eps)
-        ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last = tr, mask, key_len, tape, out
+        ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last, ctx.amp = tr, mask, key_len, tape, out, amp
         return final
 
     @staticmethod
     def backward(ctx, dfinal: Tensor):
-        tr, mask, key_len = ctx.tr, ctx.mask, ctx.key_len
+        tr, mask, key_len, amp = ctx.tr, ctx.mask, ctx.key_len, ctx.amp
         mflag = runtime.EP_MASK_OUT if mask is not None else 0
         grads: list = []
         dy, dgf, dbf = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask,
@@ -101,31 +114,37 @@ class TransformerStackFunction(torch.autograd.Function):
                                           lambda: (runtime.transpose(wqkv), runtime.transpose(wo)))
             w1_t, w2_t = ff._cache.get("t32", (ff.net[0].weight, ff.net[3].weight),
                                        lambda: (runtime.transpose(w1), runtime.transpose(w2)))
+            t16 = lambda *ws: tuple(runtime.cast_bf16(w) for w in ws)                      # noqa: E731
+            wqkv_t16, wo_t16 = att._cache.get("t16", (att.to_q.weight, att.to_kv.weight, att.to_out.weight),
+                                              lambda: t16(wqkv_t, wo_t)) if amp else (None, None)
+            w1_t16, w2_t16 = ff._cache.get("t16", (ff.net[0].weight, ff.net[3].weight),
+                                           lambda: t16(w1_t, w2_t)) if amp else (None, None)
             # feed-forward block
             dw2 = runtime.gemm_tn(dy, a, row_mask=mask)                         # [dim, inner]
-            da = runtime.gemm(dy, w2_t, mask=mask, flags=mflag)                  # (m dy) W2
+            da = _mm(dy, w2_t, w2_t16, mask=mask, flags=mflag)                   # (m dy) W2
             du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
             dw1 = runtime.gemm_tn(du, h2)                                        # [inner, dim]
-            dh2 = runtime.gemm(du, w1_t)
+            dh2 = _mm(du, w1_t, w1_t16)
             dx1, dg2, db2 = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps)
             # attention block
             dwo = runtime.gemm_tn(dx1, o, row_mask=mask)                         # [dim, heads*64]
-            d_o = runtime.gemm(dx1, wo_t, mask=mask, flags=mflag)
+            d_o = _mm(dx1, wo_t, wo_t16, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
                                                         seed=seed_att)
             dwqkv = runtime.gemm_tn(dqkv, h)                                     # [heads*64 + 128, dim]
-            dh = runtime.gemm(dqkv, wqkv_t)
+            dh = _mm(dqkv, wqkv_t, wqkv_t16)
             dy, dg1, db1 = runtime.layernorm_bwd(xin, dh, an.weight, dx=dx1, add_to_dx=True, eps=an.eps)
             hq = att.heads * 64
             ls = att.rel_pos.learned_logslopes
             grads = [dg1, db1, dwqkv[:hq], dwqkv[hq:], dls[:ls.numel()].view_as(ls), dwo, dg2, db2, dw1, dw2] + grads
         ctx.tape = None
-        return (None, dy, None, *grads, dgf, dbf)
+        return (None, dy, None, None, *grads, dgf, dbf)
 
 
-def transformer_train_forward(tr: Transformer, x: Tensor, mask: Optional[Tensor] = None) -> Tensor:
-    """`tr(x, mask).out` as a differentiable node (gradients reach x and every parameter of the stack)."""
-    return TransformerStackFunction.apply(tr, x, mask, *stack_parameters(tr))
+def transformer_train_forward(tr: Transformer, x: Tensor, mask: Optional[Tensor] = None, amp: bool = False) -> Tensor:
+    """`tr(x, mask).out` as a differentiable node (gradients reach x and every parameter of the stack); `amp` = bf16
+    operands for the Linear GEMMs (see TransformerStackFunction)."""
+    return TransformerStackFunction.apply(tr, x, mask, amp, *stack_parameters(tr))
 
 
 class ToMelFunction(torch.autograd.Function):
@@ -148,7 +167,7 @@ class ToMelFunction(torch.autograd.Function):
         return d_dec, dw, runtime.colsum(g), None
 
 
-def mel_decoder_train_forward(model, dec_in: Tensor, dec_mask: Optional[Tensor]) -> Tensor:
+def mel_decoder_train_forward(model, dec_in: Tensor, dec_mask: Optional[Tensor], amp: bool = False) -> Tensor:
     """MelDecoder + to_mel of `AcousticModel` (model.py:165-168) as differentiable nodes: dec_in [B, T, dim] -> mel [B, 80, T]."""
-    dec = transformer_train_forward(model.decoder, dec_in, dec_mask)
+    dec = transformer_train_forward(model.decoder, dec_in, dec_mask, amp)
     return ToMelFunction.apply(dec, model.to_mel.weight, model.to_mel.bias, dec_mask)

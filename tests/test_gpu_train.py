@@ -404,3 +404,30 @@ def test_stack_training_with_the_recipes_dropout(state_dict):
         losses.append(float(loss.detach()))
         opt.step(loss)
     assert losses[-1] < 0.9 * losses[0], losses
+
+
+def test_stack_gradients_under_bf16_amp(state_dict):
+    """`amp=True`: the Linear GEMMs (forward and dX) take bf16 operands, everything else stays fp32.  Against the fp32
+    kernels on the same input: output and gradients agree to bf16 accuracy (relative RMS, stated per quantity)."""
+    tr = _decoder_stack(state_dict, 2)
+    B, N = 3, 70
+    x = _rand((B, N, 384), 20).to(DEV)
+    mask = (torch.arange(N)[None, :] < torch.tensor([70, 41, 64])[:, None]).to(DEV)
+    dout = _rand((B, N, 384), 21).to(DEV)
+
+    def run(amp):
+        xg = x.clone().requires_grad_()
+        out = train.transformer_train_forward(tr, xg, mask, amp=amp)
+        out.backward(dout)
+        g = {n: p.grad.clone() for n, p in tr.named_parameters()}
+        tr.zero_grad(set_to_none=True)
+        return out.detach(), xg.grad, g
+    o32, dx32, g32 = run(False)
+    o16, dx16, g16 = run(True)
+
+    def rel(a, b):
+        return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+    assert rel(o16, o32) < 1e-2 and rel(dx16, dx32) < 3e-2, (rel(o16, o32), rel(dx16, dx32))
+    for n in g32:
+        assert rel(g16[n], g32[n]) < 5e-2, (n, rel(g16[n], g32[n]))
+    assert not torch.equal(o16, o32)

@@ -46,6 +46,7 @@ def test_mas_golden_vectors():
     (4, 700, 300, True, "realistic"), (2, 1723, 300, True, "realistic"),                      # recipe maxima
     (3, 90, 400, True, "realistic"), (2, 64, 512, False, "ties"),                             # n < m, max L
     (64, 512, 100, False, "realistic"), (37, 512, 100, True, "realistic"),
+    (1, 4096, 200, True, "realistic"), (2, 2048, 512, True, "ties"),                          # the ABI's M / L maxima
 ])
 def test_mas_matches_oracle(B, M, L, var, kind):
     x, tl, ml = synth.make_mas_logits(B, M, L, var, kind)

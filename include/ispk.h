@@ -400,6 +400,10 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              ratio[b] = sum over (c, t < mel_len[b]) of (out - target)^2 / max(C * len_b, 1e-5)
  *                              (utils/functions.py:44-58), loss[0] = mean_b ratio[b]; grad (or NULL) = d loss / d mel_out *
  *                              grad_out, zero on padded frames.  mel fp32 [B][C][T].
+ * ispk_attn_bin_loss_f32       models/acoustic/loss.py:90-107 (AttentionBinarizationLoss, weight folded into grad_out):
+ *                              loss[0] = -sum over the cells of the hard alignment of log(clamp(attn_soft, eps)) / loss[1],
+ *                              loss[1] = the number of such cells; attn_hard = the int16 one-hot MAS output [B][M][L].  grad
+ *                              (or NULL; must arrive zeroed) = d loss / d attn_soft * grad_out.  workspace: 2048 floats.
  * ispk_mel_grad_rows_f32       first step of the backward of `to_mel` (Linear + transpose + mask, model.py:167-168):
  *                              g[(b, t)][c] = mask[b][t] * dmel[b][c][t], frames as rows for the two GEMMs that follow
  *                              (d dec = g W through ispk_gemm_f32 on W^T, dW = g^T dec through ispk_gemm_tn_f32).
@@ -436,6 +440,8 @@ int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const floa
                                     const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
                           float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
+int32_t ispk_attn_bin_loss_f32(const float* attn_soft, const int16_t* attn_hard, float eps, float* workspace, float* loss,
+                               float* grad, float grad_out, int32_t B, int32_t M, int32_t L, ispk_stream_t stream);
 int32_t ispk_mel_grad_rows_f32(const float* dmel, const uint8_t* mask, float* g, int32_t B, int32_t C, int32_t T,
                                ispk_stream_t stream);
 int32_t ispk_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t cols, float* workspace, int64_t workspace_floats,

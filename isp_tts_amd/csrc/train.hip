@@ -183,7 +183,87 @@ __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restr
     out[c] = s;
 }
 
+// ------------------------------------------------------------------------------------------------ binarisation loss
+// loss.py:90-107 (AttentionBinarizationLoss): -sum over the hard path of log(clamp(soft, eps)) / (number of path cells).
+// One wave per (utterance, frame) row finds the row's hot column in the int16 one-hot MAS output (rows past mel_len are all
+// zero and contribute nothing), stage 1 leaves one (sum of logs, count) pair per workgroup, stage 2 adds them in order.
+// The gradient wrt soft is -go / (count * soft) at the hot cell where soft > eps (clamp: zero below), written by a second
+// pass once the count is known (grad must be zero-initialised by the caller, or NULL).
+constexpr int kBinParts = 1024;
+__global__ __launch_bounds__(256) void bin_loss_stage1_kernel(const float* __restrict__ soft, const int16_t* __restrict__ hard,
+                                                              int64_t rows, int L, float eps, float* __restrict__ part) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float lsum = 0.f, cnt = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)kBinParts * 4) {
+        for (int j = lane; j < L; j += 64)
+            if (hard[r * L + j] != 0) {
+                lsum += logf(fmaxf(soft[r * L + j], eps));
+                cnt += 1.f;
+            }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        lsum += __shfl_down(lsum, off, 64);
+        cnt += __shfl_down(cnt, off, 64);
+    }
+    __shared__ float w[4][2];
+    if (lane == 0) {
+        w[wave][0] = lsum;
+        w[wave][1] = cnt;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[2 * blockIdx.x] = (w[0][0] + w[1][0]) + (w[2][0] + w[3][0]);
+        part[2 * blockIdx.x + 1] = (w[0][1] + w[1][1]) + (w[2][1] + w[3][1]);
+    }
+}
+
+__global__ __launch_bounds__(1024) void bin_loss_stage2_kernel(const float* __restrict__ part, float* __restrict__ out) {
+    __shared__ float s[kBinParts], c[kBinParts];
+    s[threadIdx.x] = part[2 * threadIdx.x];
+    c[threadIdx.x] = part[2 * threadIdx.x + 1];
+    __syncthreads();
+    for (int half = kBinParts / 2; half > 0; half >>= 1) {
+        if ((int)threadIdx.x < half) {
+            s[threadIdx.x] += s[threadIdx.x + half];
+            c[threadIdx.x] += c[threadIdx.x + half];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = -s[0] / c[0];      // (no path cell at all: 0 / 0 = NaN, as the reference)
+        out[1] = c[0];
+    }
+}
+
+__global__ __launch_bounds__(256) void bin_loss_grad_kernel(const float* __restrict__ soft, const int16_t* __restrict__ hard,
+                                                            int64_t rows, int L, float eps, const float* __restrict__ loss_cnt,
+                                                            float grad_out, float* __restrict__ grad) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const float scale = -grad_out / loss_cnt[1];
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < rows; r += (int64_t)gridDim.x * 4)
+        for (int j = lane; j < L; j += 64)
+            if (hard[r * L + j] != 0) {
+                const float v = soft[r * L + j];
+                grad[r * L + j] = v > eps ? scale / v : 0.f;
+            }
+}
+
 }  // namespace
+
+extern "C" int32_t ispk_attn_bin_loss_f32(const float* attn_soft, const int16_t* attn_hard, float eps, float* workspace,
+                                          float* loss, float* grad, float grad_out, int32_t B, int32_t M, int32_t L,
+                                          ispk_stream_t stream) {
+    ISPK_REQUIRE(attn_soft && attn_hard && workspace && loss, -1, "ispk_attn_bin_loss_f32: null pointer");
+    ISPK_REQUIRE(B >= 1 && M >= 1 && L >= 1, -2, "ispk_attn_bin_loss_f32: bad shape B=%d M=%d L=%d", B, M, L);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t rows = (int64_t)B * M;
+    hipLaunchKernelGGL(bin_loss_stage1_kernel, dim3(kBinParts), dim3(256), 0, s, attn_soft, attn_hard, rows, L, eps, workspace);
+    hipLaunchKernelGGL(bin_loss_stage2_kernel, dim3(1), dim3(kBinParts), 0, s, workspace, loss);
+    if (grad)
+        hipLaunchKernelGGL(bin_loss_grad_kernel, dim3(1024), dim3(256), 0, s, attn_soft, attn_hard, rows, L, eps, loss, grad_out,
+                           grad);
+    return ispk_launch_status();
+}
 
 extern "C" int32_t ispk_mel_grad_rows_f32(const float* dmel, const uint8_t* mask, float* g, int32_t B, int32_t C, int32_t T,
                                           ispk_stream_t stream) {

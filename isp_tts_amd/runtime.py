@@ -71,6 +71,7 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_train_f32": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
     "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
     "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
+    "ispk_attn_bin_loss_f32": [_P, _P, _F32, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_mel_grad_rows_f32": [_P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_colsum_f32": [_P, _I64, _I64, _I32, _P, _I64, _P, _P],
     "ispk_grad_sqnorm_f32": [_P, _I64, _P, _P, _P],
@@ -960,6 +961,20 @@ def mel_loss(mel_out: Tensor, mel_target: Tensor, mel_len: Tensor, want_grad: bo
     _launch("mel_loss_kernel", 0.0, 4.0 * mel_out.numel() * (2 + int(want_grad)), lib().ispk_mel_loss_f32, mel_out.data_ptr(),
             mel_target.data_ptr(), mel_len.data_ptr(), ratio.data_ptr(), loss.data_ptr(), _ptr(grad), grad_out, B, C, T,
             _stream())
+    return loss, grad
+
+
+def attn_bin_loss(attn_soft: Tensor, attn_hard: Tensor, eps: float = 1e-6, want_grad: bool = False, grad_out: float = 1.0):
+    """ispk_attn_bin_loss_f32 -> (loss fp32 [2] = (loss, number of path cells), grad fp32 like attn_soft | None)."""
+    _dev(attn_soft, attn_hard)
+    assert attn_soft.dtype == torch.float32 and attn_hard.dtype == torch.int16 and attn_soft.shape == attn_hard.shape
+    attn_soft, attn_hard = attn_soft.contiguous(), attn_hard.contiguous()
+    B, M, L = attn_soft.shape[0], attn_soft.shape[-2], attn_soft.shape[-1]
+    loss = torch.empty((2,), dtype=torch.float32, device=attn_soft.device)
+    grad = torch.zeros_like(attn_soft) if want_grad else None
+    ws = workspace(attn_soft.device, 2048)
+    _launch("bin_loss_kernels", 0.0, 6.0 * attn_soft.numel(), lib().ispk_attn_bin_loss_f32, attn_soft.data_ptr(),
+            attn_hard.data_ptr(), eps, ws.data_ptr(), loss.data_ptr(), _ptr(grad), grad_out, B, M, L, _stream())
     return loss, grad
 
 

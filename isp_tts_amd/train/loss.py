@@ -33,3 +33,32 @@ class MelLoss(torch.nn.Module):
         if step is not None and step < self.skip_steps:
             return 0.
         return self.weight * _MelLossFunction.apply(mels_out, mels_target, mel_lengths)
+
+
+class _BinLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, soft: Tensor, hard: Tensor, eps: float):
+        loss, grad = runtime.attn_bin_loss(soft, hard, eps, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, grad_loss: Tensor):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_loss, None, None
+
+
+class AttentionBinarizationLoss(torch.nn.Module):
+    """loss.py:80-107: -log(clamp(attn_soft[attn_hard == 1], eps)).sum() / attn_hard.sum(), times `weight`;
+    `attn_hard` is the aligner's int16 one-hot MAS output."""
+
+    def __init__(self, weight: float = 1.0, skip_steps: int = 0, eps: float = 1e-6):
+        super().__init__()
+        self.weight, self.skip_steps, self.eps = weight, skip_steps, eps
+
+    def forward(self, soft_attention: Tensor, hard_attention: Tensor, step=None):
+        if step is not None and step < self.skip_steps:
+            return 0.
+        soft = soft_attention.reshape(-1, *soft_attention.shape[-2:])
+        hard = hard_attention.reshape(-1, *hard_attention.shape[-2:])
+        return self.weight * _BinLossFunction.apply(soft, hard, self.eps)

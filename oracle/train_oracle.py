@@ -59,6 +59,12 @@ def mel_loss(mel_out: Tensor, mel_target: Tensor, mel_len: Tensor) -> Tensor:
     return (num / den.clamp(min=1e-5)).mean()
 
 
+def attention_binarization_loss(soft: Tensor, hard: Tensor, eps: float = 1e-6) -> Tensor:
+    """loss.py:100-107."""
+    log_sum = torch.log(torch.clamp(soft[hard == 1], min=eps)).sum()
+    return -log_sum / hard.sum()
+
+
 def sqnorm_flat(g: Tensor, out: Tensor) -> Tensor:
     out.copy_((g.double() ** 2).sum().float().reshape(1))
     return out

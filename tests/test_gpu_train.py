@@ -431,3 +431,22 @@ def test_stack_gradients_under_bf16_amp(state_dict):
     for n in g32:
         assert rel(g16[n], g32[n]) < 5e-2, (n, rel(g16[n], g32[n]))
     assert not torch.equal(o16, o32)
+
+
+def test_attention_binarization_loss():
+    """AttentionBinarizationLoss (loss.py:80-107) on a real MAS output: value and d / d attn_soft against the reference's
+    expression under autograd (float64), including cells clamped at eps (zero gradient) and ragged utterances."""
+    B, M, L = 5, 200, 60
+    x, tl, ml = synth.make_mas_logits(B, M, L, True, "realistic")
+    hard = runtime.mas(x.to(DEV), tl.to(DEV), ml.to(DEV))[0]
+    soft = torch.softmax(x, dim=-1)
+    soft[0, :20] = 1e-9                                    # below eps: clamped, no gradient
+    s64 = soft.double().requires_grad_()
+    ref = 0.5 * torc.attention_binarization_loss(s64, hard.cpu().long(), 1e-6)
+    ref.backward()
+    sg = soft.to(DEV).requires_grad_()
+    loss = train.AttentionBinarizationLoss(weight=0.5)(sg, hard)
+    _close(loss, ref, 2e-6, "binarisation loss")
+    loss.backward()
+    _close(sg.grad, s64.grad, 2e-6, "d attn_soft")
+    assert int(runtime.attn_bin_loss(soft.to(DEV), hard)[0][1]) == int(ml.sum())

@@ -400,6 +400,12 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              ratio[b] = sum over (c, t < mel_len[b]) of (out - target)^2 / max(C * len_b, 1e-5)
  *                              (utils/functions.py:44-58), loss[0] = mean_b ratio[b]; grad (or NULL) = d loss / d mel_out *
  *                              grad_out, zero on padded frames.  mel fp32 [B][C][T].
+ * ispk_attn_ctc_loss_f32       models/acoustic/loss.py:39-77 (AttentionCTCLoss, weight folded into grad_out): attn_logits fp32
+ *                              [B][M][L] -> a blank class with logit blank_logprob in front, log-softmax over the L + 1 classes,
+ *                              nn.CTCLoss(blank 0, zero_infinity, reduction "mean") against the targets 1 .. text_len[b] with
+ *                              mel_len[b] frames: loss[0] = mean_b nll_b / max(text_len[b], 1) (inf -> 0); grad (or NULL) =
+ *                              d loss / d attn_logits * grad_out (what autograd gives through the pad and the log-softmax).
+ *                              workspace >= B*M + B + 2*B*M*S floats, S = 2L + 1 rounded up to a multiple of 64.
  * ispk_attn_bin_loss_f32       models/acoustic/loss.py:90-107 (AttentionBinarizationLoss, weight folded into grad_out):
  *                              loss[0] = -sum over the cells of the hard alignment of log(clamp(attn_soft, eps)) / loss[1],
  *                              loss[1] = the number of such cells; attn_hard = the int16 one-hot MAS output [B][M][L].  grad
@@ -440,6 +446,9 @@ int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const floa
                                     const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
                           float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
+int32_t ispk_attn_ctc_loss_f32(const float* attn_logits, const int64_t* text_len, const int64_t* mel_len, float blank_logprob,
+                               float* workspace, int64_t workspace_floats, float* loss, float* grad, float grad_out, int32_t B,
+                               int32_t M, int32_t L, ispk_stream_t stream);
 int32_t ispk_attn_bin_loss_f32(const float* attn_soft, const int16_t* attn_hard, float eps, float* workspace, float* loss,
                                float* grad, float grad_out, int32_t B, int32_t M, int32_t L, ispk_stream_t stream);
 int32_t ispk_mel_grad_rows_f32(const float* dmel, const uint8_t* mask, float* g, int32_t B, int32_t C, int32_t T,

@@ -248,7 +248,160 @@ __global__ __launch_bounds__(256) void bin_loss_grad_kernel(const float* __restr
             }
 }
 
+// ------------------------------------------------------------------------------------------------ attention CTC loss
+// loss.py:39-77 (AttentionCTCLoss): the aligner's logits [B][M][L] get a blank class in front (logit `blank`, -1 in the
+// recipes), log-softmax over the L + 1 classes, then nn.CTCLoss(blank = 0, zero_infinity = True, reduction "mean") with
+// the targets 1 .. text_len[b] (every text token once, in order) and mel_len[b] input frames.
+//   extended targets l'_s, s = 0 .. 2U: blank for even s, token (s + 1) / 2 for odd s (all tokens distinct, so the skip
+//   s - 2 -> s is always allowed for odd s >= 3);
+//   alpha_t(s) = lp_t(l'_s) + lse(alpha_{t-1}(s), alpha_{t-1}(s-1), [odd s >= 3] alpha_{t-1}(s-2)); beta mirrored;
+//   nll = -lse(alpha_{T-1}(2U), alpha_{T-1}(2U-1));  loss = mean_b nll_b / max(U_b, 1)  (inf -> 0: zero_infinity);
+//   d loss / d logit_t(c) = w_b (softmax_t(c) - exp(lse_{s: l'_s = c}(alpha_t(s) + beta_t(s)) + nll - lp_t(c))),  t < T,
+//   with w_b = go / (B max(U_b, 1)) - the gradient torch's ctc_loss_backward returns for log-softmax'ed inputs.
+// Three launches: row normalisers (one wave per frame), the two recursions (one 512-thread workgroup per utterance: waves
+// 0-3 walk alpha forwards while waves 4-7 walk beta backwards, one barrier per frame; tables in a workspace), then the
+// gradient with one wave per frame.  fp32 log domain; a first correct cut, not tuned.
+__device__ __forceinline__ float lse2(float a, float b) {
+    const float m = fmaxf(a, b);
+    return m == -INFINITY ? -INFINITY : m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    return m == -INFINITY ? -INFINITY : m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+__global__ __launch_bounds__(256) void ctc_row_lse_kernel(const float* __restrict__ logits, float blank, int64_t rows, int L,
+                                                          float* __restrict__ row_lse) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float m = blank;
+    for (int j = lane; j < L; j += 64) m = fmaxf(m, logits[r * L + j]);
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float sum = lane == 0 ? expf(blank - m) : 0.f;
+    for (int j = lane; j < L; j += 64) sum += expf(logits[r * L + j] - m);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) row_lse[r] = m + logf(sum);
+}
+
+__global__ __launch_bounds__(512) void ctc_alpha_beta_kernel(const float* __restrict__ logits, const float* __restrict__ row_lse,
+                                                             float blank, const int64_t* __restrict__ text_len,
+                                                             const int64_t* __restrict__ mel_len, float* __restrict__ alpha,
+                                                             float* __restrict__ beta, float* __restrict__ nll, int M, int L,
+                                                             int S_pad) {
+    extern __shared__ float sm[];                 // [2 tables][2 buffers][S_pad + 2]: two -inf guard cells on either side
+    const int b = blockIdx.x, tid = threadIdx.x, back = tid >> 8, t8 = tid & 255;
+    const int U = (int)min((int64_t)L, max((int64_t)0, text_len[b])), T = (int)min((int64_t)M, max((int64_t)0, mel_len[b]));
+    const int S = 2 * U + 1;
+    float* tab = sm + back * 2 * (S_pad + 4);
+    const float* lg = logits + (int64_t)b * M * L;
+    const float* rl = row_lse + (int64_t)b * M;
+    float* out = (back ? beta : alpha) + (int64_t)b * M * S_pad;
+    for (int i = t8; i < 2 * (S_pad + 4); i += 256) tab[i] = -INFINITY;
+    __syncthreads();
+    if (T == 0) {
+        if (tid == 0) nll[b] = INFINITY;
+        return;
+    }
+    auto lp = [&](int t, int s) {                 // log-probability of the extended target's class at position s, frame t
+        const float v = (s & 1) ? lg[(int64_t)t * L + (s >> 1)] : blank;
+        return v - rl[t];
+    };
+    for (int step = 0; step < T; ++step) {
+        const int t = back ? T - 1 - step : step;
+        float* cur = tab + (step & 1) * (S_pad + 4) + 2;
+        const float* prev = tab + ((step & 1) ^ 1) * (S_pad + 4) + 2;
+        for (int s = t8; s < S; s += 256) {
+            float v;
+            if (step == 0) {
+                const bool start = back ? (s >= S - 2) : (s <= 1);
+                v = start ? lp(t, s) : -INFINITY;
+            } else if (!back) {
+                const float skip = ((s & 1) && s >= 3) ? prev[s - 2] : -INFINITY;
+                v = lse3(prev[s], prev[s - 1], skip);
+                v = v == -INFINITY ? v : v + lp(t, s);
+            } else {
+                const float nxt = s + 1 < S ? prev[s + 1] : -INFINITY;
+                const float skip = ((s & 1) && s + 2 < S) ? prev[s + 2] : -INFINITY;
+                v = lse3(prev[s], nxt, skip);
+                v = v == -INFINITY ? v : v + lp(t, s);
+            }
+            cur[s] = v;
+            out[(int64_t)t * S_pad + s] = v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float* last = sm + ((T - 1) & 1) * (S_pad + 4) + 2;     // the alpha table's final buffer
+        nll[b] = -lse2(last[S - 1], S >= 2 ? last[S - 2] : -INFINITY);
+    }
+}
+
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logits, const float* __restrict__ row_lse,
+                                                       float blank, const int64_t* __restrict__ text_len,
+                                                       const int64_t* __restrict__ mel_len, const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta, const float* __restrict__ nll,
+                                                       float grad_out, float* __restrict__ grad, int B, int M, int L, int S_pad) {
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= (int64_t)B * M) return;
+    const int b = (int)(r / M), t = (int)(r - (int64_t)b * M);
+    const int U = (int)min((int64_t)L, max((int64_t)0, text_len[b])), T = (int)min((int64_t)M, max((int64_t)0, mel_len[b]));
+    const float n = nll[b];
+    float* g = grad + r * L;
+    if (t >= T || !(n < INFINITY)) {              // frames past the input length, or an impossible alignment (zero_infinity)
+        for (int j = lane; j < L; j += 64) g[j] = 0.f;
+        return;
+    }
+    const float w = grad_out / ((float)B * (float)max(U, 1));
+    const float* a = alpha + r * S_pad;
+    const float* be = beta + r * S_pad;
+    const float lse_t = row_lse[r];
+    for (int j = lane; j < L; j += 64) {          // class j + 1: one extended position (2 j + 1) when j < U, none otherwise
+        const float lpv = logits[r * L + j] - lse_t;
+        float v = expf(lpv);
+        if (j < U) v -= expf(a[2 * j + 1] + be[2 * j + 1] + n - lpv);
+        g[j] = w * v;
+    }
+}
+
+__global__ __launch_bounds__(64) void ctc_mean_kernel(const float* __restrict__ nll, const int64_t* __restrict__ text_len, int B,
+                                                      int L, float* __restrict__ loss) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const int U = (int)min((int64_t)L, max((int64_t)0, text_len[b]));
+            const float v = nll[b];
+            s += (v < INFINITY) ? v / (float)max(U, 1) : 0.f;
+        }
+        loss[0] = s / (float)B;
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t ispk_attn_ctc_loss_f32(const float* attn_logits, const int64_t* text_len, const int64_t* mel_len,
+                                          float blank_logprob, float* workspace, int64_t workspace_floats, float* loss,
+                                          float* grad, float grad_out, int32_t B, int32_t M, int32_t L, ispk_stream_t stream) {
+    ISPK_REQUIRE(attn_logits && text_len && mel_len && workspace && loss, -1, "ispk_attn_ctc_loss_f32: null pointer");
+    ISPK_REQUIRE(B >= 1 && M >= 1 && L >= 1 && L <= 2048, -2, "ispk_attn_ctc_loss_f32: bad shape B=%d M=%d L=%d", B, M, L);
+    const int S_pad = (2 * L + 1 + 63) / 64 * 64;
+    const int64_t rows = (int64_t)B * M, need = rows + B + 2 * rows * S_pad;
+    ISPK_REQUIRE(workspace_floats >= need, -3, "ispk_attn_ctc_loss_f32: workspace needs %lld floats", (long long)need);
+    float *row_lse = workspace, *nll = workspace + rows, *alpha = nll + B, *beta = alpha + rows * S_pad;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(ctc_row_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, attn_logits, blank_logprob, rows, L,
+                       row_lse);
+    const size_t lds = (size_t)4 * (S_pad + 4) * sizeof(float);
+    ISPK_RESERVE_LDS(ctc_alpha_beta_kernel, lds, "ispk_attn_ctc_loss_f32");
+    hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(B), dim3(512), lds, s, attn_logits, row_lse, blank_logprob, text_len, mel_len,
+                       alpha, beta, nll, M, L, S_pad);
+    hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, s, nll, text_len, B, L, loss);
+    if (grad)
+        hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, attn_logits, row_lse, blank_logprob,
+                           text_len, mel_len, alpha, beta, nll, grad_out, grad, B, M, L, S_pad);
+    return ispk_launch_status();
+}
 
 extern "C" int32_t ispk_attn_bin_loss_f32(const float* attn_soft, const int16_t* attn_hard, float eps, float* workspace,
                                           float* loss, float* grad, float grad_out, int32_t B, int32_t M, int32_t L,

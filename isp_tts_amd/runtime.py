@@ -71,6 +71,7 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_train_f32": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
     "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
     "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
+    "ispk_attn_ctc_loss_f32": [_P, _P, _P, _F32, _P, _I64, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_attn_bin_loss_f32": [_P, _P, _F32, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_mel_grad_rows_f32": [_P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_colsum_f32": [_P, _I64, _I64, _I32, _P, _I64, _P, _P],
@@ -962,6 +963,24 @@ def mel_loss(mel_out: Tensor, mel_target: Tensor, mel_len: Tensor, want_grad: bo
             mel_target.data_ptr(), mel_len.data_ptr(), ratio.data_ptr(), loss.data_ptr(), _ptr(grad), grad_out, B, C, T,
             _stream())
     return loss, grad
+
+
+def attn_ctc_loss(attn_logits: Tensor, text_len: Tensor, mel_len: Tensor, blank_logprob: float = -1.0,
+                  want_grad: bool = False, grad_out: float = 1.0):
+    """ispk_attn_ctc_loss_f32 -> (loss fp32 [1], grad fp32 like attn_logits | None)."""
+    _dev(attn_logits, text_len, mel_len)
+    assert attn_logits.dtype == torch.float32
+    lg = attn_logits.reshape(-1, *attn_logits.shape[-2:]).contiguous()
+    B, M, L = lg.shape
+    text_len, mel_len = text_len.to(torch.int64).contiguous(), mel_len.to(torch.int64).contiguous()
+    s_pad = (2 * L + 1 + 63) // 64 * 64
+    ws = workspace(lg.device, B * M + B + 2 * B * M * s_pad)
+    loss = torch.empty((1,), dtype=torch.float32, device=lg.device)
+    grad = torch.empty_like(lg) if want_grad else None
+    _launch("ctc_loss_kernels", 0.0, 4.0 * (lg.numel() * (2 + int(want_grad)) + 4 * B * M * s_pad), lib().ispk_attn_ctc_loss_f32,
+            lg.data_ptr(), text_len.data_ptr(), mel_len.data_ptr(), blank_logprob, ws.data_ptr(), ws.numel(), loss.data_ptr(),
+            _ptr(grad), grad_out, B, M, L, _stream())
+    return loss, (grad.view(attn_logits.shape) if grad is not None else None)
 
 
 def attn_bin_loss(attn_soft: Tensor, attn_hard: Tensor, eps: float = 1e-6, want_grad: bool = False, grad_out: float = 1.0):

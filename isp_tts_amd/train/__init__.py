@@ -7,14 +7,15 @@
   stack.py   TransformerStackFunction: a `Transformer` stack (plain LayerNorm, fp32, dropout by in-kernel masks) as ONE
              autograd node whose backward is the kernels of csrc/backward.hip.
   stack.py   also ToMelFunction (to_mel's Linear + transpose + mask, model.py:167-168) and `mel_decoder_train_forward`.
-  loss.py    MelLoss (models/acoustic/loss.py:22-35) and AttentionBinarizationLoss (:80-107), value and gradient by kernels.
+  loss.py    MelLoss (models/acoustic/loss.py:22-35), AttentionCTCLoss (:39-77) and AttentionBinarizationLoss (:80-107), value
+             and gradient by kernels.
 
 Not built yet: backward of the aligner front-end, the adaptor (AdaLN stacks, flow matching, length
-regulation), the CTC attention loss, bf16 autocast.
+regulation), bf16 attention / weight-gradient kernels.
 """
-from .loss import AttentionBinarizationLoss, MelLoss
+from .loss import AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params
 from .stack import ToMelFunction, TransformerStackFunction, mel_decoder_train_forward, transformer_train_forward
 
-__all__ = ["AttentionBinarizationLoss", "FlatAdamW", "FlatParameters", "MelLoss", "ToMelFunction", "TransformerStackFunction",
+__all__ = ["AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "MelLoss", "ToMelFunction", "TransformerStackFunction",
            "group_weight_decayable_params", "mel_decoder_train_forward", "transformer_train_forward"]

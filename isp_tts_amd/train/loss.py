@@ -62,3 +62,30 @@ class AttentionBinarizationLoss(torch.nn.Module):
         soft = soft_attention.reshape(-1, *soft_attention.shape[-2:])
         hard = hard_attention.reshape(-1, *hard_attention.shape[-2:])
         return self.weight * _BinLossFunction.apply(soft, hard, self.eps)
+
+
+class _CTCLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits: Tensor, text_len: Tensor, mel_len: Tensor, blank: float):
+        loss, grad = runtime.attn_ctc_loss(logits, text_len, mel_len, blank, want_grad=True)
+        ctx.save_for_backward(grad)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_loss: Tensor):
+        (grad,) = ctx.saved_tensors
+        return grad * grad_loss, None, None, None
+
+
+class AttentionCTCLoss(torch.nn.Module):
+    """loss.py:39-77: CTC ("forward-sum") loss of the aligner's logits against the text positions 1 .. text_len, a blank class
+    with logit `blank_logprob` in front, nn.CTCLoss(zero_infinity=True) semantics, times `weight`."""
+
+    def __init__(self, blank_logprob: float = -1, weight: float = 1.0, skip_steps: int = 0):
+        super().__init__()
+        self.blank_logprob, self.weight, self.skip_steps = blank_logprob, weight, skip_steps
+
+    def forward(self, attn_logits: Tensor, text_lengths: Tensor, mel_lengths: Tensor, step=None):
+        if step is not None and step < self.skip_steps:
+            return 0.
+        return self.weight * _CTCLossFunction.apply(attn_logits, text_lengths, mel_lengths, float(self.blank_logprob))

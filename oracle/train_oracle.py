@@ -59,6 +59,16 @@ def mel_loss(mel_out: Tensor, mel_target: Tensor, mel_len: Tensor) -> Tensor:
     return (num / den.clamp(min=1e-5)).mean()
 
 
+def attention_ctc_loss(attn_logits: Tensor, text_len: Tensor, mel_len: Tensor, blank_logprob: float = -1) -> Tensor:
+    """loss.py:56-77: pad a blank class in front, log-softmax over classes, [T, B, C] layout, targets 1 .. len padded with
+    0, nn.CTCLoss(zero_infinity=True) with its default "mean" reduction."""
+    padded = F.pad(attn_logits, pad=(1, 0), value=blank_logprob)
+    logprob = F.log_softmax(padded, dim=2).transpose(0, 1)
+    ids = torch.arange(1, int(text_len.max()) + 1)[None].expand(text_len.numel(), -1).clone()
+    ids[ids > text_len.unsqueeze(1)] = 0
+    return torch.nn.CTCLoss(zero_infinity=True)(log_probs=logprob, targets=ids, input_lengths=mel_len, target_lengths=text_len)
+
+
 def attention_binarization_loss(soft: Tensor, hard: Tensor, eps: float = 1e-6) -> Tensor:
     """loss.py:100-107."""
     log_sum = torch.log(torch.clamp(soft[hard == 1], min=eps)).sum()

@@ -450,3 +450,30 @@ def test_attention_binarization_loss():
     loss.backward()
     _close(sg.grad, s64.grad, 2e-6, "d attn_soft")
     assert int(runtime.attn_bin_loss(soft.to(DEV), hard)[0][1]) == int(ml.sum())
+
+
+@pytest.mark.parametrize("B,M,L,kind", [(5, 120, 40, "ragged"), (3, 64, 100, "impossible"), (2, 300, 129, "ragged")])
+def test_attention_ctc_loss(B, M, L, kind):
+    """AttentionCTCLoss (loss.py:39-77) against the reference's expression (pad + log_softmax + nn.CTCLoss, float64) under
+    autograd: value and d / d attn_logits; ragged lengths, frames past mel_len (zero gradient), and an utterance with fewer
+    frames than tokens (infinite loss -> 0 with zero gradient: zero_infinity)."""
+    logits = _rand((B, M, L), 110, 2.0)
+    text_len, mel_len = synth.make_lengths(B, L, M, variable=True, seed=111)
+    text_len, mel_len = text_len.clamp(min=1), mel_len.clamp(min=1)
+    if kind == "impossible":
+        text_len[0], mel_len[0] = 90, 50            # cannot emit 90 tokens in 50 frames
+        text_len[1], mel_len[1] = L, M
+    l64 = logits.double().requires_grad_()
+    ref = 0.7 * torc.attention_ctc_loss(l64, text_len, mel_len, -1)
+    ref.backward()
+    lg = logits.to(DEV).requires_grad_()
+    loss = train.AttentionCTCLoss(blank_logprob=-1, weight=0.7)(lg, text_len.to(DEV), mel_len.to(DEV))
+    _close(loss, ref, 2e-5, "CTC loss")
+    loss.backward()
+    # (fp32 log-domain recursions: alpha + beta + nll are O(10^3) in magnitude, so their fp32 rounding (1e-4 absolute) is
+    # the relative error of the posterior that the gradient subtracts)
+    _close(lg.grad, l64.grad, 2e-3, "d attn_logits")
+    for b in range(B):
+        assert float(lg.grad[b, int(mel_len[b]):].abs().max()) == 0.0 if int(mel_len[b]) < M else True
+    if kind == "impossible":
+        assert float(lg.grad[0].abs().max()) == 0.0

@@ -13,9 +13,9 @@
 Not built yet: backward of the aligner front-end, the adaptor (AdaLN stacks, flow matching, length
 regulation), bf16 attention / weight-gradient kernels.
 """
-from .loss import AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
+from .loss import AcousticModelLoss, AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params
 from .stack import ToMelFunction, TransformerStackFunction, mel_decoder_train_forward, transformer_train_forward
 
-__all__ = ["AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "MelLoss", "ToMelFunction", "TransformerStackFunction",
+__all__ = ["AcousticModelLoss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "MelLoss", "ToMelFunction", "TransformerStackFunction",
            "group_weight_decayable_params", "mel_decoder_train_forward", "transformer_train_forward"]

@@ -1,5 +1,7 @@
-"""`MelLoss` (models/acoustic/loss.py:22-35) with forward value and gradient from one kernel."""
+"""The loss terms of `AcousticModelLoss` (models/acoustic/loss.py:22-182), value and gradient of each from kernels."""
 from __future__ import annotations
+
+from typing import Optional
 
 import torch
 from torch import Tensor
@@ -89,3 +91,37 @@ class AttentionCTCLoss(torch.nn.Module):
         if step is not None and step < self.skip_steps:
             return 0.
         return self.weight * _CTCLossFunction.apply(attn_logits, text_lengths, mel_lengths, float(self.blank_logprob))
+
+
+class AcousticModelLoss(torch.nn.Module):
+    """`AcousticModelLoss` of models/acoustic/loss.py:122-182: mel loss + the adaptor's own losses (the flow loss) + attention CTC
+    loss + attention binarisation loss, each a kernel; returns (loss, {"model/mel_loss", "adaptor/...", "aligner/attention_loss",
+    "aligner/kl_loss"}) like the reference.  `inputs` needs `.mel`, `.mel_len`, `.text_len` (a dict or any object with those
+    attributes: the collator's batch through `AcousticModel.prepare_inputs`); `outputs` is the model's `AcousticModelOutput`."""
+
+    def __init__(self, mel_loss: Optional[dict] = None, attention_loss: Optional[dict] = None,
+                 attention_kl_loss: Optional[dict] = None, use_attention_loss: bool = True, use_attention_kl_loss: bool = True):
+        super().__init__()
+        self.mel_criterion = MelLoss(**(mel_loss or {}))
+        self.attention_criterion = AttentionCTCLoss(**(attention_loss or {})) if use_attention_loss else None
+        self.attention_kl_criterion = AttentionBinarizationLoss(**(attention_kl_loss or {})) if use_attention_kl_loss else None
+
+    def forward(self, inputs, outputs, step=None):
+        get = (lambda k: inputs[k]) if isinstance(inputs, dict) else (lambda k: getattr(inputs, k))
+        loss, losses = 0., {}
+        mel_loss = self.mel_criterion(outputs.mel, get("mel"), get("mel_len"), step=step)
+        losses["model/mel_loss"] = mel_loss
+        loss = loss + mel_loss
+        if outputs.adaptor_output.losses is not None:
+            for key, loss_i in outputs.adaptor_output.losses.items():
+                losses[f"adaptor/{key}"] = loss_i
+                loss = loss + loss_i
+        if self.attention_criterion is not None:
+            attn_loss = self.attention_criterion(outputs.aligner_output.attn_logits, get("text_len"), get("mel_len"), step=step)
+            losses["aligner/attention_loss"] = attn_loss
+            loss = loss + attn_loss
+        if self.attention_kl_criterion is not None:
+            kl = self.attention_kl_criterion(outputs.aligner_output.attn_soft, outputs.aligner_output.attn_hard, step=step)
+            losses["aligner/kl_loss"] = kl
+            loss = loss + kl
+        return loss, losses

@@ -477,3 +477,23 @@ def test_attention_ctc_loss(B, M, L, kind):
         assert float(lg.grad[b, int(mel_len[b]):].abs().max()) == 0.0 if int(mel_len[b]) < M else True
     if kind == "impossible":
         assert float(lg.grad[0].abs().max()) == 0.0
+
+
+def test_acoustic_model_loss_on_a_forward(gpu_model, state_dict):
+    """`train.AcousticModelLoss` (loss.py:122-182) on the outputs of a real forward: every term and the total against the
+    reference's expressions evaluated on the ORACLE's outputs for the same batch (float32 CPU)."""
+    inp = synth.make_inputs(3, 60, 200, variable=True, seed=7)
+    args = (inp["text"], inp["text_len"], inp["mel"], inp["mel_len"], inp["pitch"], inp["energy"])
+    ref = orc.acoustic_forward(state_dict, *args, inp["flow_x0"], inp["flow_t"])
+    out = gpu_model(*[a.to(DEV) for a in args], flow_noise=inp["flow_x0"].to(DEV), flow_time=inp["flow_t"].to(DEV))
+    crit = train.AcousticModelLoss()
+    total, terms = crit({"mel": inp["mel"].to(DEV), "mel_len": inp["mel_len"].to(DEV), "text_len": inp["text_len"].to(DEV)}, out)
+    want = {"model/mel_loss": torc.mel_loss(ref.mel, inp["mel"], inp["mel_len"]),
+            "aligner/attention_loss": torc.attention_ctc_loss(ref.aligner.attn_logits.reshape(3, 200, 60), inp["text_len"], inp["mel_len"]),
+            "aligner/kl_loss": torc.attention_binarization_loss(ref.aligner.attn_soft, ref.aligner.attn_hard)}
+    for k, v in want.items():
+        _close(terms[k], v, 1e-4, k)
+    flow = [v for k, v in terms.items() if k.startswith("adaptor/")]
+    assert len(flow) == 1
+    _close(flow[0], ref.adaptor.flow_loss, 1e-4, "adaptor flow loss")
+    _close(total, sum(want.values()) + ref.adaptor.flow_loss, 1e-4, "total loss")

@@ -429,6 +429,13 @@ int32_t ispk_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, i
 int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
                          int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
                          int64_t workspace_floats, ispk_stream_t stream);
+/* The same product for `batch` independent pairs (A_b, B_b) at element strides stride_a / stride_b, C_b at stride_c - e.g. the
+ * backward of the length regulator (temporal_adaptor.py:419-421: out_b = A_b x_b): d x_b = A_b^T d out_b per utterance.
+ * row_mask (or NULL) is [batch][M]; workspace >= batch * N1 * N2 floats. */
+int32_t ispk_gemm_tn_batched_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b,
+                                 float* C, int64_t ldc, int64_t stride_c, int32_t batch, int32_t M, int32_t N1, int32_t N2,
+                                 const uint8_t* row_mask, int32_t accumulate, float* workspace, int64_t workspace_floats,
+                                 ispk_stream_t stream);
 int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
                                const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
                                float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,

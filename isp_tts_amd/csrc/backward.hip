@@ -63,13 +63,18 @@ constexpr int kTnStage = 2 * kTnRows * kTnLd;   // floats per stage: A chunk + B
 template <bool kMask>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
                                                       int64_t ldb, float* __restrict__ part, int M, int N1, int N2,
-                                                      int rows_per_split, const uint8_t* __restrict__ mask) {
+                                                      int rows_per_split, const uint8_t* __restrict__ mask, int splits,
+                                                      int64_t stride_a, int64_t stride_b) {
     // Staging: thread (r = tid / 32, q = tid % 32) fetches float4 q of rows r, r + 8, r + 16, r + 24 of the A chunk and of the
     // B chunk (512 contiguous bytes per row and wave half), one chunk ahead of the MFMAs, double-buffered in LDS.
     extern __shared__ float lds[];
     const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, c = l & 31, hf = l >> 5;
     const int n1 = blockIdx.x * 128, n2 = blockIdx.y * 128, wa = (wave >> 1) * 64, wb = (wave & 1) * 64;
-    const int split = blockIdx.z;
+    // blockIdx.z = batch item * splits + row range (batched form: independent products A_b^T B_b, e.g. one per utterance)
+    const int bz = blockIdx.z / splits, split = blockIdx.z - bz * splits;
+    A += (int64_t)bz * stride_a;
+    B += (int64_t)bz * stride_b;
+    if (kMask) mask += (int64_t)bz * M;
     const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
     const int sr = tid >> 5, sq = (tid & 31) * 4;
     const bool a_ok = n1 + sq < N1, b_ok = n2 + sq < N2;     // (N1, N2 are multiples of 4: a float4 is in or out as a whole)
@@ -125,7 +130,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         __syncthreads();
         buf ^= 1;
     }
-    float* out = part + (int64_t)split * N1 * N2;
+    float* out = part + (int64_t)blockIdx.z * N1 * N2;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -141,12 +146,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int splits, int64_t n, int cols,
-                                                           float* __restrict__ C, int64_t ldc, int accumulate) {
+                                                           float* __restrict__ C, int64_t ldc, int accumulate, int64_t stride_c) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    part += (int64_t)blockIdx.y * splits * n;       // blockIdx.y = batch item
     float s = 0.f;
     for (int k = 0; k < splits; ++k) s += part[(int64_t)k * n + i];
-    float* dst = C + (i / cols) * ldc + (i % cols);
+    float* dst = C + (int64_t)blockIdx.y * stride_c + (i / cols) * ldc + (i % cols);
     *dst = accumulate ? *dst + s : s;
 }
 
@@ -629,41 +635,57 @@ extern "C" int32_t ispk_transpose_f32(const float* x, int64_t ldx, float* y, int
     return ispk_launch_status();
 }
 
-extern "C" int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
-                                    int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
-                                    int64_t workspace_floats, ispk_stream_t stream) {
-    ISPK_REQUIRE(A && B && C && workspace, -1, "ispk_gemm_tn_f32: null pointer");
-    ISPK_REQUIRE(M >= 1 && N1 >= 4 && N2 >= 4 && N1 % 4 == 0 && N2 % 4 == 0 && lda >= N1 && ldb >= N2 && ldc >= N2 &&
-                     lda % 4 == 0 && ldb % 4 == 0 && ispk_aligned(A, 16) && ispk_aligned(B, 16), -2,
-                 "ispk_gemm_tn_f32: bad shape M=%d N1=%d N2=%d (N1, N2, lda, ldb multiples of 4, 16-byte aligned operands)", M,
-                 N1, N2);
+static int32_t gemm_tn_launch(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b, float* C,
+                              int64_t ldc, int64_t stride_c, int batch, int M, int N1, int N2, const uint8_t* row_mask,
+                              int accumulate, float* workspace, int64_t workspace_floats, hipStream_t s, const char* who) {
+    ISPK_REQUIRE(A && B && C && workspace, -1, "%s: null pointer", who);
+    ISPK_REQUIRE(batch >= 1 && M >= 1 && N1 >= 4 && N2 >= 4 && N1 % 4 == 0 && N2 % 4 == 0 && lda >= N1 && ldb >= N2 && ldc >= N2 &&
+                     lda % 4 == 0 && ldb % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0 && ispk_aligned(A, 16) &&
+                     ispk_aligned(B, 16), -2,
+                 "%s: bad shape batch=%d M=%d N1=%d N2=%d (N1, N2, leading dimensions and batch strides multiples of 4, 16-byte "
+                 "aligned operands)", who, batch, M, N1, N2);
     const int64_t tile = (int64_t)N1 * N2;
-    ISPK_REQUIRE(workspace_floats >= tile, -3, "ispk_gemm_tn_f32: workspace holds %lld floats, one partial needs %lld",
-                 (long long)workspace_floats, (long long)tile);
+    ISPK_REQUIRE(workspace_floats >= tile * batch, -3, "%s: workspace holds %lld floats, one partial per batch item needs %lld",
+                 who, (long long)workspace_floats, (long long)(tile * batch));
     // row ranges: enough workgroups to fill the chip (>= 1024), at least 64 rows each, bounded by the workspace
-    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128);
+    const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128) * batch;
     int64_t splits = (1024 + tiles - 1) / tiles;
     splits = splits < (M + 63) / 64 ? splits : (M + 63) / 64;
-    splits = splits < workspace_floats / tile ? splits : workspace_floats / tile;
+    splits = splits < workspace_floats / (tile * batch) ? splits : workspace_floats / (tile * batch);
     splits = splits < 1 ? 1 : (splits > 256 ? 256 : splits);
     int rows_per = (int)((M + splits - 1) / splits);
     rows_per = (rows_per + kTnRows - 1) / kTnRows * kTnRows;
     splits = (M + rows_per - 1) / rows_per;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((N1 + 127) / 128, (N2 + 127) / 128, (unsigned)splits);
+    ISPK_REQUIRE(splits * batch <= 65535, -4, "%s: batch %d x %lld row ranges exceed the grid limit", who, batch, (long long)splits);
+    const dim3 grid((N1 + 127) / 128, (N2 + 127) / 128, (unsigned)(splits * batch));
     constexpr size_t lds_bytes = 2 * kTnStage * sizeof(float);   // 80 KB: two workgroups per CU
     if (row_mask) {
         ISPK_RESERVE_LDS(gemm_tn_kernel<true>, lds_bytes, "ispk_gemm_tn_f32");
         hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), lds_bytes, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
-                           row_mask);
+                           row_mask, (int)splits, stride_a, stride_b);
     } else {
         ISPK_RESERVE_LDS(gemm_tn_kernel<false>, lds_bytes, "ispk_gemm_tn_f32");
         hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), lds_bytes, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
-                           row_mask);
+                           row_mask, (int)splits, stride_a, stride_b);
     }
-    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((tile + 255) / 256)), dim3(256), 0, s, workspace, (int)splits, tile,
-                       N2, C, ldc, accumulate);
+    hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((tile + 255) / 256), batch), dim3(256), 0, s, workspace, (int)splits,
+                       tile, N2, C, ldc, accumulate, stride_c);
     return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
+                                    int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
+                                    int64_t workspace_floats, ispk_stream_t stream) {
+    return gemm_tn_launch(A, lda, 0, B, ldb, 0, C, ldc, 0, 1, M, N1, N2, row_mask, accumulate, workspace, workspace_floats,
+                          reinterpret_cast<hipStream_t>(stream), "ispk_gemm_tn_f32");
+}
+
+extern "C" int32_t ispk_gemm_tn_batched_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb,
+                                            int64_t stride_b, float* C, int64_t ldc, int64_t stride_c, int32_t batch, int32_t M,
+                                            int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
+                                            int64_t workspace_floats, ispk_stream_t stream) {
+    return gemm_tn_launch(A, lda, stride_a, B, ldb, stride_b, C, ldc, stride_c, batch, M, N1, N2, row_mask, accumulate, workspace,
+                          workspace_floats, reinterpret_cast<hipStream_t>(stream), "ispk_gemm_tn_batched_f32");
 }
 
 extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ispk_soft_average_f32": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_transpose_f32": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ispk_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
+    "ispk_gemm_tn_batched_f32": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_layernorm_bwd_f32": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _I64, _I32, _F32, _P],
     "ispk_gelu_f32": [_P, _P, _I64, _F32, _U64, _P],
     "ispk_gelu_bwd_f32": [_P, _P, _P, _I64, _F32, _U64, _P],
@@ -848,6 +849,21 @@ def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Option
     _launch(f"gemm_tn_kernel<{N1}x{N2}>", 2.0 * M * N1 * N2, 4.0 * (a2.numel() + b2.numel() + out.numel()),
             lib().ispk_gemm_tn_f32, a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), out.data_ptr(), out.stride(0), M,
             N1, N2, _ptr(row_mask), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def gemm_tn_batched(a: Tensor, b: Tensor) -> Tensor:
+    """ispk_gemm_tn_batched_f32: C[i] = a[i]^T b[i] for a [batch, M, N1], b [batch, M, N2] (fp32, contiguous) -> [batch, N1, N2]."""
+    _dev(a, b)
+    assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.ndim == 3 and b.ndim == 3 and a.shape[:2] == b.shape[:2]
+    a, b = a.contiguous(), b.contiguous()
+    batch, M, N1 = a.shape
+    N2 = b.shape[2]
+    out = torch.empty((batch, N1, N2), dtype=torch.float32, device=a.device)
+    ws = workspace(a.device, batch * N1 * N2)
+    _launch("gemm_tn_kernel<batched>", 2.0 * batch * M * N1 * N2, 4.0 * (a.numel() + b.numel() + out.numel()),
+            lib().ispk_gemm_tn_batched_f32, a.data_ptr(), N1, M * N1, b.data_ptr(), N2, M * N2, out.data_ptr(), N2, N1 * N2, batch,
+            M, N1, N2, None, 0, ws.data_ptr(), ws.numel(), _stream())
     return out
 
 

@@ -171,3 +171,21 @@ def mel_decoder_train_forward(model, dec_in: Tensor, dec_mask: Optional[Tensor],
     """MelDecoder + to_mel of `AcousticModel` (model.py:165-168) as differentiable nodes: dec_in [B, T, dim] -> mel [B, 80, T]."""
     dec = transformer_train_forward(model.decoder, dec_in, dec_mask, amp)
     return ToMelFunction.apply(dec, model.to_mel.weight, model.to_mel.bias, dec_mask)
+
+
+class LengthRegulateFunction(torch.autograd.Function):
+    """out[b] = A[b] x[b] (LengthRegulator, soft branch: temporal_adaptor.py:411-436; forward = `runtime.length_regulate`).
+    Backward for x: d x[b] = A[b]^T d out[b], one batched product.  The alignment is treated as a constant here (its
+    gradient - d A[b] = d out[b] x[b]^T, the path by which the mel loss reaches the aligner - is not built yet)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, alignment: Tensor, durations: Tensor, frames: int):
+        out, dec_len, dec_mask = runtime.length_regulate(x, durations, alignment, frames, max_len=frames)
+        ctx.save_for_backward(alignment)
+        ctx.mark_non_differentiable(dec_len, dec_mask)
+        return out, dec_len, dec_mask
+
+    @staticmethod
+    def backward(ctx, d_out: Tensor, _dl, _dm):
+        (alignment,) = ctx.saved_tensors
+        return runtime.gemm_tn_batched(alignment, d_out.float().contiguous()), None, None, None

@@ -497,3 +497,27 @@ def test_acoustic_model_loss_on_a_forward(gpu_model, state_dict):
     assert len(flow) == 1
     _close(flow[0], ref.adaptor.flow_loss, 1e-4, "adaptor flow loss")
     _close(total, sum(want.values()) + ref.adaptor.flow_loss, 1e-4, "total loss")
+
+
+def test_length_regulator_backward_and_batched_gemm_tn():
+    """LengthRegulateFunction: out[b] = A[b] x[b] and d x[b] = A[b]^T d out[b] against float64 autograd (B = 5, ragged);
+    the batched transposed GEMM on its own against torch.bmm; L not a multiple of the tiles (L = 100)."""
+    B, M, L, D = 5, 200, 100, 384
+    a = torch.softmax(_rand((B, M, L), 120, 2.0), dim=-1)
+    mel_len = torch.tensor([200, 133, 64, 200, 97])
+    a = a * (torch.arange(M)[None, :] < mel_len[:, None])[..., None]
+    x = _rand((B, L, D), 121).requires_grad_()
+    d_out = _rand((B, M, D), 122)
+    ref = torch.bmm(a.double(), x.double())
+    ref.backward(d_out.double())
+    xg = x.detach().to(DEV).requires_grad_()
+    out, dec_len, dec_mask = train.LengthRegulateFunction.apply(xg, a.to(DEV), mel_len.view(-1, 1).to(DEV), M)
+    valid = (torch.arange(M)[None, :] < mel_len[:, None])[..., None]
+    _close(out.cpu() * valid, ref.detach() * valid, 5e-6, "regulated output")
+    assert torch.equal(dec_len.cpu(), mel_len)
+    out.backward((d_out * valid).to(DEV))
+    x.grad = None
+    torch.bmm(a.double(), x.double()).backward((d_out * valid).double())
+    _close(xg.grad, x.grad, 2e-5, "d x")
+    p, q = _rand((7, 130, 100), 123), _rand((7, 130, 36), 124)
+    _close(runtime.gemm_tn_batched(p.to(DEV), q.to(DEV)), torch.bmm(p.double().transpose(1, 2), q.double()), 2e-6, "batched A^T B")

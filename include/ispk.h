@@ -413,7 +413,11 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  * ispk_mel_grad_rows_f32       first step of the backward of `to_mel` (Linear + transpose + mask, model.py:167-168):
  *                              g[(b, t)][c] = mask[b][t] * dmel[b][c][t], frames as rows for the two GEMMs that follow
  *                              (d dec = g W through ispk_gemm_f32 on W^T, dW = g^T dec through ispk_gemm_tn_f32).
- * ispk_colsum_f32              out[c] = sum_r x[r][c] (bias gradients), fixed summation order; workspace >= 256 * cols floats.
+ * ispk_colsum_f32              out[c] = sum_r [mask[r]] x[r][c] (bias gradients), fixed summation order; workspace >= 256 * cols floats.
+ * ispk_smallk_wgrad_f32        out[n][k] = sum_r g[r][n] x[r][k], k < K <= 8: weight gradient of a Linear with a handful of input
+ *                              features (the adaptor's 2 -> 256 embedding projection, transformer.py:170); workspace >= 256 N K.
+ * ispk_embedding_bwd_f32       backward of nn.Embedding (model.py:131): d_table[v][:] = sum of d_emb rows whose id is v, in row order;
+ *                              row padding_idx gets zeros.
  * ispk_grad_sqnorm_f32         out[0] = sum g[i]^2 over a flat gradient arena (what clip_grad_norm_ needs,
  *                              experiments/optimizers.py:236-237); partial = 2048 floats (8 KB, 8-byte aligned) of scratch;
  *                              fp64 accumulation in a fixed order.
@@ -460,8 +464,12 @@ int32_t ispk_attn_bin_loss_f32(const float* attn_soft, const int16_t* attn_hard,
                                float* grad, float grad_out, int32_t B, int32_t M, int32_t L, ispk_stream_t stream);
 int32_t ispk_mel_grad_rows_f32(const float* dmel, const uint8_t* mask, float* g, int32_t B, int32_t C, int32_t T,
                                ispk_stream_t stream);
-int32_t ispk_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t cols, float* workspace, int64_t workspace_floats,
-                        float* out, ispk_stream_t stream);
+int32_t ispk_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t cols, const uint8_t* row_mask, float* workspace,
+                        int64_t workspace_floats, float* out, ispk_stream_t stream);
+int32_t ispk_smallk_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t rows, int32_t N, int32_t K,
+                              float* workspace, int64_t workspace_floats, float* out, ispk_stream_t stream);
+int32_t ispk_embedding_bwd_f32(const int64_t* ids, const float* d_emb, int64_t rows, int32_t dim, int32_t vocab,
+                               int32_t padding_idx, float* d_table, int64_t ld_table, ispk_stream_t stream);
 int32_t ispk_grad_sqnorm_f32(const float* g, int64_t n, float* partial, float* out, ispk_stream_t stream);
 int32_t ispk_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int32_t step, const float* grad_sqnorm, float max_norm,

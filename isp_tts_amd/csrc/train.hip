@@ -167,11 +167,42 @@ __global__ __launch_bounds__(256) void mel_grad_rows_kernel(const float* __restr
 // column sums of a [rows][cols] matrix (bias gradients), two stages with a fixed order: block k adds rows k, k + P, ...
 constexpr int kColParts = 256;
 __global__ __launch_bounds__(256) void colsum_stage1_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int cols,
-                                                            float* __restrict__ part) {
+                                                            const uint8_t* __restrict__ mask, float* __restrict__ part) {
     for (int c = threadIdx.x; c < cols; c += 256) {
         float s = 0.f;
-        for (int64_t r = blockIdx.x; r < rows; r += kColParts) s += x[r * ld + c];
+        for (int64_t r = blockIdx.x; r < rows; r += kColParts)
+            if (!mask || mask[r]) s += x[r * ld + c];
         part[(int64_t)blockIdx.x * cols + c] = s;
+    }
+}
+
+// Weight gradient of a Linear with a handful of input features (the adaptor's 2 -> 256 embedding projection):
+// out[n][k] = sum_r g[r][n] x[r][k], k < K <= 8.  Same two stages as the column sums.
+__global__ __launch_bounds__(256) void smallk_wgrad_stage1_kernel(const float* __restrict__ g, int64_t ldg,
+                                                                  const float* __restrict__ x, int64_t ldx, int64_t rows, int N,
+                                                                  int K, float* __restrict__ part) {
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int64_t r = blockIdx.x; r < rows; r += kColParts) {
+            const float gv = g[r * ldg + n];
+            for (int k = 0; k < K; ++k) s[k] += gv * x[r * ldx + k];
+        }
+        for (int k = 0; k < K; ++k) part[((int64_t)blockIdx.x * N + n) * K + k] = s[k];
+    }
+}
+
+// d table[v][:] = sum over the token positions r with ids[r] == v of d_emb[r][:], rows visited in index order (nn.Embedding's
+// backward, model.py:131; the padding row gets no gradient).  One workgroup per vocabulary row.
+__global__ __launch_bounds__(128) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ d_emb,
+                                                            int64_t rows, int D, int padding_idx, float* __restrict__ d_table,
+                                                            int64_t ld_table) {
+    const int v = blockIdx.x;
+    for (int c = threadIdx.x; c < D; c += 128) {
+        float s = 0.f;
+        if (v != padding_idx)
+            for (int64_t r = 0; r < rows; ++r)
+                if (ids[r] == v) s += d_emb[r * D + c];
+        d_table[(int64_t)v * ld_table + c] = s;
     }
 }
 
@@ -427,14 +458,36 @@ extern "C" int32_t ispk_mel_grad_rows_f32(const float* dmel, const uint8_t* mask
     return ispk_launch_status();
 }
 
-extern "C" int32_t ispk_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t cols, float* workspace,
+extern "C" int32_t ispk_smallk_wgrad_f32(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t rows, int32_t N, int32_t K,
+                                         float* workspace, int64_t workspace_floats, float* out, ispk_stream_t stream) {
+    ISPK_REQUIRE(g && x && workspace && out, -1, "ispk_smallk_wgrad_f32: null pointer");
+    ISPK_REQUIRE(rows >= 1 && N >= 1 && K >= 1 && K <= 8 && ldg >= N && ldx >= K && workspace_floats >= (int64_t)kColParts * N * K, -2,
+                 "ispk_smallk_wgrad_f32: rows=%lld N=%d K=%d (K <= 8), workspace needs %lld floats", (long long)rows, N, K,
+                 (long long)kColParts * N * K);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(smallk_wgrad_stage1_kernel, dim3(kColParts), dim3(256), 0, s, g, ldg, x, ldx, rows, N, K, workspace);
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((N * K + 255) / 256), dim3(256), 0, s, workspace, N * K, out);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_embedding_bwd_f32(const int64_t* ids, const float* d_emb, int64_t rows, int32_t dim, int32_t vocab,
+                                          int32_t padding_idx, float* d_table, int64_t ld_table, ispk_stream_t stream) {
+    ISPK_REQUIRE(ids && d_emb && d_table, -1, "ispk_embedding_bwd_f32: null pointer");
+    ISPK_REQUIRE(rows >= 0 && dim >= 1 && vocab >= 1 && ld_table >= dim, -2, "ispk_embedding_bwd_f32: bad shape rows=%lld dim=%d vocab=%d",
+                 (long long)rows, dim, vocab);
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3(vocab), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), ids, d_emb, rows, dim,
+                       padding_idx, d_table, ld_table);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_colsum_f32(const float* x, int64_t ldx, int64_t rows, int32_t cols, const uint8_t* row_mask, float* workspace,
                                    int64_t workspace_floats, float* out, ispk_stream_t stream) {
     ISPK_REQUIRE(x && workspace && out, -1, "ispk_colsum_f32: null pointer");
     ISPK_REQUIRE(rows >= 1 && cols >= 1 && ldx >= cols && workspace_floats >= (int64_t)kColParts * cols, -2,
                  "ispk_colsum_f32: rows=%lld cols=%d, workspace needs %lld floats", (long long)rows, cols,
                  (long long)kColParts * cols);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(kColParts), dim3(256), 0, s, x, ldx, rows, cols, workspace);
+    hipLaunchKernelGGL(colsum_stage1_kernel, dim3(kColParts), dim3(256), 0, s, x, ldx, rows, cols, row_mask, workspace);
     hipLaunchKernelGGL(colsum_stage2_kernel, dim3((cols + 255) / 256), dim3(256), 0, s, workspace, cols, out);
     return ispk_launch_status();
 }

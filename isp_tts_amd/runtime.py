@@ -75,7 +75,9 @@ SIGNATURES = {
     "ispk_attn_ctc_loss_f32": [_P, _P, _P, _F32, _P, _I64, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_attn_bin_loss_f32": [_P, _P, _F32, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_mel_grad_rows_f32": [_P, _P, _P, _I32, _I32, _I32, _P],
-    "ispk_colsum_f32": [_P, _I64, _I64, _I32, _P, _I64, _P, _P],
+    "ispk_colsum_f32": [_P, _I64, _I64, _I32, _P, _P, _I64, _P, _P],
+    "ispk_smallk_wgrad_f32": [_P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I64, _P, _P],
+    "ispk_embedding_bwd_f32": [_P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "ispk_grad_sqnorm_f32": [_P, _I64, _P, _P, _P],
     "ispk_adamw_f32": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _P, _F32, _F32, _P],
 }
@@ -1028,16 +1030,45 @@ def mel_grad_rows(dmel: Tensor, mask: Optional[Tensor]) -> Tensor:
     return g
 
 
-def colsum(x: Tensor) -> Tensor:
-    """ispk_colsum_f32: column sums of a [rows, cols] fp32 matrix (bias gradients), fixed order."""
-    _dev(x)
+def colsum(x: Tensor, row_mask: Optional[Tensor] = None) -> Tensor:
+    """ispk_colsum_f32: column sums of a [rows, cols] fp32 matrix (bias gradients) over the rows `row_mask` keeps, fixed order."""
+    _dev(x, row_mask)
     x2 = _rows2d(x)
     assert x2.dtype == torch.float32
     rows, cols = x2.shape
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).contiguous()
+        assert row_mask.dtype == torch.bool and row_mask.numel() == rows
     out = torch.empty((cols,), dtype=torch.float32, device=x.device)
     ws = workspace(x.device, 256 * cols)
     _launch("colsum_kernels", 0.0, 4.0 * x2.numel(), lib().ispk_colsum_f32, x2.data_ptr(), x2.stride(0), rows, cols,
-            ws.data_ptr(), ws.numel(), out.data_ptr(), _stream())
+            _ptr(row_mask), ws.data_ptr(), ws.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def smallk_wgrad(g: Tensor, x: Tensor) -> Tensor:
+    """ispk_smallk_wgrad_f32: out[n, k] = sum_r g[r, n] x[r, k] for a Linear with K <= 8 input features."""
+    _dev(g, x)
+    g2, x2 = _rows2d(g), _rows2d(x)
+    assert g2.dtype == torch.float32 and x2.dtype == torch.float32 and g2.shape[0] == x2.shape[0] and x2.shape[1] <= 8
+    rows, N = g2.shape
+    K = x2.shape[1]
+    out = torch.empty((N, K), dtype=torch.float32, device=g.device)
+    ws = workspace(g.device, 256 * N * K)
+    _launch("smallk_wgrad_kernels", 2.0 * rows * N * K, 4.0 * (g2.numel() + x2.numel()), lib().ispk_smallk_wgrad_f32, g2.data_ptr(),
+            g2.stride(0), x2.data_ptr(), x2.stride(0), rows, N, K, ws.data_ptr(), ws.numel(), out.data_ptr(), _stream())
+    return out
+
+
+def embedding_bwd(ids: Tensor, d_emb: Tensor, vocab: int, padding_idx: int = 0) -> Tensor:
+    """ispk_embedding_bwd_f32 -> d_table fp32 [vocab, D]."""
+    _dev(ids, d_emb)
+    ids = ids.reshape(-1).to(torch.int64).contiguous()
+    d2 = _rows2d(d_emb).contiguous()
+    assert d2.dtype == torch.float32 and d2.shape[0] == ids.numel()
+    out = torch.empty((vocab, d2.shape[1]), dtype=torch.float32, device=d_emb.device)
+    _launch("embedding_bwd_kernel", 0.0, 4.0 * d2.numel(), lib().ispk_embedding_bwd_f32, ids.data_ptr(), d2.data_ptr(), ids.numel(),
+            d2.shape[1], vocab, padding_idx, out.data_ptr(), out.stride(0), _stream())
     return out
 
 

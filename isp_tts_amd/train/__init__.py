@@ -15,7 +15,7 @@ regulation), bf16 attention / weight-gradient kernels.
 """
 from .loss import AcousticModelLoss, AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params
-from .stack import LengthRegulateFunction, ToMelFunction, TransformerStackFunction, mel_decoder_train_forward, transformer_train_forward
+from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction, TransformerStackFunction, acoustic_mel_train_forward, mel_decoder_train_forward, transformer_train_forward)
 
-__all__ = ["AcousticModelLoss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
+__all__ = ["AcousticModelLoss", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
            "group_weight_decayable_params", "mel_decoder_train_forward", "transformer_train_forward"]

@@ -31,8 +31,10 @@ from ..modules.transformer.transformer import Transformer
 
 
 def _check(tr: Transformer) -> None:
-    if tr.adaptive_norm or not isinstance(tr.project_emb, torch.nn.Identity):
-        raise NotImplementedError("training backward: adaptive-norm / projected stacks (the temporal adaptor) are not built")
+    if tr.adaptive_norm:
+        raise NotImplementedError("training backward: adaptive-norm stacks (the flow predictor) are not built")
+    if not isinstance(tr.project_emb, torch.nn.Identity) and tr.project_emb.in_features > 8:
+        raise NotImplementedError("training backward: input projections with more than 8 features are not built")
     for layer in tr.layers:
         att, ff = layer.attention, layer.feed_forward
         if ff.net[0].bias is not None or ff.net[3].bias is not None or ff.act_flag != runtime.EP_GELU:
@@ -41,7 +43,7 @@ def _check(tr: Transformer) -> None:
 
 def stack_parameters(tr: Transformer) -> list:
     """The parameters the node differentiates, in the order `TransformerStackFunction` takes and returns them."""
-    ps = []
+    ps = [] if isinstance(tr.project_emb, torch.nn.Identity) else [tr.project_emb.weight, tr.project_emb.bias]
     for layer in tr.layers:
         att, ff = layer.attention, layer.feed_forward
         ps += [layer.attention_norm.weight, layer.attention_norm.bias, att.to_q.weight, att.to_kv.weight,
@@ -69,6 +71,10 @@ class TransformerStackFunction(torch.autograd.Function):
         _check(tr)
         x = x.float().contiguous()
         key_len = mask.sum(dim=1) if mask is not None else None
+        proj = not isinstance(tr.project_emb, torch.nn.Identity)
+        if proj:      # transformer.py:170, :189: a Linear from the few input features (the adaptor's pitch / energy pair)
+            ctx.proj_in = x
+            x = runtime.linear(x, tr.project_emb.weight, tr.project_emb.bias)
         tape, out = [], x
         base_seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # torch's CPU generator: torch.manual_seed reproduces a run
         for li, layer in enumerate(tr.layers):
@@ -138,6 +144,11 @@ class TransformerStackFunction(torch.autograd.Function):
             ls = att.rel_pos.learned_logslopes
             grads = [dg1, db1, dwqkv[:hq], dwqkv[hq:], dls[:ls.numel()].view_as(ls), dwo, dg2, db2, dw1, dw2] + grads
         ctx.tape = None
+        if not isinstance(tr.project_emb, torch.nn.Identity):
+            # dy is the gradient of the projected input: d W = dy^T x over a handful of input features, d b = column sums;
+            # the raw features are targets (no gradient wanted)
+            grads = [runtime.smallk_wgrad(dy, ctx.proj_in), runtime.colsum(dy)] + grads
+            dy = None
         return (None, dy, None, None, *grads, dgf, dbf)
 
 
@@ -189,3 +200,63 @@ class LengthRegulateFunction(torch.autograd.Function):
     def backward(ctx, d_out: Tensor, _dl, _dm):
         (alignment,) = ctx.saved_tensors
         return runtime.gemm_tn_batched(alignment, d_out.float().contiguous()), None, None, None
+
+
+class MaskedLinearResidualFunction(torch.autograd.Function):
+    """out = residual + mask * (h W^T + b): the output Linear of the adaptor's `TransformerTemporalModule`
+    (temporal_adaptor.py:43-59) fused with the caller's `enc_out + embedding(...)` (:297), as the forward path launches it."""
+
+    @staticmethod
+    def forward(ctx, h: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor], residual: Tensor):
+        h = h.float().contiguous()
+        ctx.save_for_backward(h, weight)
+        ctx.mask = mask
+        return runtime.gemm(h, weight.detach(), bias=bias.detach(), mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0,
+                            resid=residual)
+
+    @staticmethod
+    def backward(ctx, dy: Tensor):
+        h, weight = ctx.saved_tensors
+        dy, mask = dy.float().contiguous(), ctx.mask
+        dh = runtime.gemm(dy, runtime.transpose(weight.detach()), mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
+        return dh, runtime.gemm_tn(dy, h, row_mask=mask), runtime.colsum(dy, mask), None, dy
+
+
+class EmbedTokensFunction(torch.autograd.Function):
+    """emb = table[text] (model.py:131, nn.Embedding with padding_idx 0) - forward by `runtime.embed_tokens`, backward a
+    deterministic row gather-sum per vocabulary entry (no gradient for the padding row)."""
+
+    @staticmethod
+    def forward(ctx, text: Tensor, table: Tensor, text_len: Tensor):
+        emb, mask = runtime.embed_tokens(text, table.detach(), text_len)
+        ctx.save_for_backward(text)
+        ctx.vocab = table.shape[0]
+        ctx.mark_non_differentiable(mask)
+        return emb, mask
+
+    @staticmethod
+    def backward(ctx, d_emb: Tensor, _dm):
+        (text,) = ctx.saved_tensors
+        return None, runtime.embedding_bwd(text, d_emb.float().contiguous(), ctx.vocab, padding_idx=0), None
+
+
+def acoustic_mel_train_forward(model, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor, energy: Tensor,
+                               amp: bool = False) -> Tensor:
+    """The teacher-forced forward of `AcousticModel` (model.py:116-174) as a differentiable chain for the MEL loss:
+    text embedding -> TextEncoder -> [aligner, frozen] -> adaptor embedding stack + length regulator -> MelDecoder -> to_mel.
+    Gradients reach the text embedding table, the encoder, the adaptor's embedding module, the decoder and to_mel - every
+    parameter the mel loss reaches outside the aligner (which the reference feeds a DETACHED encoder output, model.py:139,
+    and trains through attn_soft: that path, d A = d out x^T, is not built) and the flow predictor (whose outputs the
+    mel loss does not see).  -> mel [B, 80, M]."""
+    ad = model.temporal_adaptor
+    emb, enc_mask = EmbedTokensFunction.apply(text, model.text_embedding.weight, text_len)
+    enc_out = transformer_train_forward(model.encoder, emb, enc_mask, amp)
+    with torch.no_grad():
+        attn_soft, _ = model.aligner.attention(mel, enc_out.detach().transpose(1, 2), mel_len, text_len)
+        feats = runtime.soft_average(attn_soft, pitch, energy, None, text_len)        # pitch / energy targets (:257-269)
+    emod = ad.embedding
+    h = transformer_train_forward(emod.transformer, feats[..., 1:3], enc_mask, amp)
+    x = MaskedLinearResidualFunction.apply(h, emod.linear_layer.weight, emod.linear_layer.bias, enc_mask, enc_out)
+    dec_in, dec_len, dec_mask = LengthRegulateFunction.apply(x, attn_soft, mel_len.view(-1, 1), mel.shape[2])
+    dec = transformer_train_forward(model.decoder, dec_in, dec_mask, amp)
+    return ToMelFunction.apply(dec, model.to_mel.weight, model.to_mel.bias, dec_mask)

@@ -521,3 +521,48 @@ def test_length_regulator_backward_and_batched_gemm_tn():
     _close(xg.grad, x.grad, 2e-5, "d x")
     p, q = _rand((7, 130, 100), 123), _rand((7, 130, 36), 124)
     _close(runtime.gemm_tn_batched(p.to(DEV), q.to(DEV)), torch.bmm(p.double().transpose(1, 2), q.double()), 2e-6, "batched A^T B")
+
+
+def test_mel_loss_gradients_of_the_whole_chain_match_autograd(state_dict):
+    """`train.acoustic_mel_train_forward` + MelLoss: the mel loss's gradient for EVERY parameter it reaches outside the aligner
+    (text embedding table, TextEncoder, the adaptor's embedding module, MelDecoder, to_mel) against torch autograd over the
+    oracle's forward, composed as the reference composes it (aligner fed the detached encoder output, model.py:139; the
+    alignment itself a constant here).  B = 2, ragged."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    inp = synth.make_inputs(2, 40, 150, variable=True, seed=31)
+    text, text_len, mel, mel_len, pitch, energy = (inp[k] for k in ("text", "text_len", "mel", "mel_len", "pitch", "energy"))
+    keep = ("text_embedding.", "encoder.", "temporal_adaptor.embedding.", "decoder.", "to_mel.")
+    sd = {k: (v.clone().requires_grad_() if k.startswith(keep) else v.clone()) for k, v in state_dict.items()}
+    emb = F.embedding(text, sd["text_embedding.weight"], padding_idx=0)
+    enc_mask = torch.arange(text.shape[1])[None, :] < text_len[:, None]
+    enc_out = orc.transformer(sd, "encoder", emb, enc_mask)
+    with torch.no_grad():
+        al = orc.aligner(sd, mel, enc_out.detach().transpose(1, 2), mel_len, text_len)
+    ad = orc.adaptor_forward(sd, enc_out, enc_mask, mel.shape[2], al.attn_hard_duration, al.attn_soft, pitch, energy,
+                             inp["flow_x0"], inp["flow_t"])
+    dec_mask = torch.arange(mel.shape[2])[None, :] < ad.dec_lengths[:, None]
+    dec = orc.transformer(sd, "decoder", ad.enc_out, dec_mask)
+    mel_ref = F.linear(dec, sd["to_mel.weight"], sd["to_mel.bias"]).transpose(1, 2) * dec_mask[:, None]
+    loss_ref = torc.mel_loss(mel_ref, mel, mel_len)
+    loss_ref.backward()
+
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model = model.to(DEV).eval()                      # eval: no dropout, so the two sides compute the same function
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    out = train.acoustic_mel_train_forward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"])
+    _close(out, mel_ref, 2e-4, "mel")
+    loss = train.MelLoss()(out, d["mel"], d["mel_len"])
+    _close(loss, loss_ref, 1e-5, "mel loss")
+    loss.backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if not name.startswith(keep):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        assert p.grad is not None, name
+        _close(p.grad, sd[name].grad, 1e-3, f"d {name}")
+        checked += 1
+    assert checked == sum(1 for k in state_dict if k.startswith(keep))          # 143 tensors
+    assert float(model.text_embedding.weight.grad[0].abs().max()) == 0.0     # padding row

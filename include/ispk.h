@@ -400,6 +400,13 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              ratio[b] = sum over (c, t < mel_len[b]) of (out - target)^2 / max(C * len_b, 1e-5)
  *                              (utils/functions.py:44-58), loss[0] = mean_b ratio[b]; grad (or NULL) = d loss / d mel_out *
  *                              grad_out, zero on padded frames.  mel fp32 [B][C][T].
+ * ispk_flow_loss_bwd_f32       d (flow loss) / d pred_raw of ispk_flow_finish_f32 (temporal_adaptor.py:145-146): go 2 m (raw m - flow) /
+ *                              (max(C n_b, 1e-5) B), n_b = valid positions of utterance b.
+ * ispk_adaln_bwd_f32           backward of AdaptiveLayerNorm (normalization.py:37-61) as ispk_layernorm_f32 applies it with per-
+ *                              utterance scale / shift rows: dx (=) or (+=), dscale[b][:] = sum_rows dy mask xhat, dshift[b][:] =
+ *                              sum_rows dy mask (rows of utterance b: rows_per_batch consecutive rows); dim 256 / 384.
+ * ispk_time_embedding_bwd_f32  backward of ispk_time_embedding_f32 for its four parameters (the time value gets no gradient):
+ *                              dw0 [emb_dim][1 + 2 half_dim], db0, dw1 [emb_dim][emb_dim], db1 from d_out [n][emb_dim].
  * ispk_attn_ctc_loss_f32       models/acoustic/loss.py:39-77 (AttentionCTCLoss, weight folded into grad_out): attn_logits fp32
  *                              [B][M][L] -> a blank class with logit blank_logprob in front, log-softmax over the L + 1 classes,
  *                              nn.CTCLoss(blank 0, zero_infinity, reduction "mean") against the targets 1 .. text_len[b] with
@@ -457,6 +464,14 @@ int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const floa
                                     const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
                           float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
+int32_t ispk_flow_loss_bwd_f32(const float* pred_raw, const float* flow, const uint8_t* mask, float grad_out, float* d_raw, int32_t B,
+                               int32_t L, int32_t C, ispk_stream_t stream);
+int32_t ispk_adaln_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* scale, int64_t ld_scale,
+                           const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dscale, float* dshift,
+                           int64_t ld_out, int32_t B, int32_t rows_per_batch, int32_t dim, float eps, ispk_stream_t stream);
+int32_t ispk_time_embedding_bwd_f32(const float* t, int32_t n, const float* inv_freq, const float* freq_scale, int32_t half_dim,
+                                    const float* w0, const float* b0, const float* w1, int32_t emb_dim, const float* d_out,
+                                    float* dw0, float* db0, float* dw1, float* db1, ispk_stream_t stream);
 int32_t ispk_attn_ctc_loss_f32(const float* attn_logits, const int64_t* text_len, const int64_t* mel_len, float blank_logprob,
                                float* workspace, int64_t workspace_floats, float* loss, float* grad, float grad_out, int32_t B,
                                int32_t M, int32_t L, ispk_stream_t stream);

@@ -409,7 +409,198 @@ __global__ __launch_bounds__(64) void ctc_mean_kernel(const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ flow predictor, backward pieces
+// Flow loss (temporal_adaptor.py:145-146, utils/functions.py:44-58): loss = mean_b sum_{valid l, c} (raw m - flow)^2 / max(C n_b, 1e-5);
+// d loss / d raw[b][l][c] = go 2 m (raw m - flow) / (max(C n_b, 1e-5) B).  One workgroup per utterance (it counts n_b first).
+__global__ __launch_bounds__(256) void flow_loss_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ flow,
+                                                            const uint8_t* __restrict__ mask, float grad_out, float* __restrict__ d_raw,
+                                                            int B, int L, int C) {
+    const int b = blockIdx.x;
+    __shared__ int cnt[4];
+    int n = 0;
+    for (int l = threadIdx.x; l < L; l += 256) n += mask[(int64_t)b * L + l] ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_down(n, off, 64);
+    if ((threadIdx.x & 63) == 0) cnt[threadIdx.x >> 6] = n;
+    __syncthreads();
+    const int valid = (cnt[0] + cnt[1]) + (cnt[2] + cnt[3]);
+    const float w = 2.f * grad_out / (fmaxf((float)(C * valid), 1e-5f) * (float)B);
+    for (int e = threadIdx.x; e < L * C; e += 256) {
+        const int64_t i = (int64_t)b * L * C + e;
+        const bool m = mask[(int64_t)b * L + e / C] != 0;
+        d_raw[i] = m ? w * (raw[i] - flow[i]) : 0.f;
+    }
+}
+
+// AdaptiveLayerNorm backward (normalization.py:37-61): y = xhat * scale_b + shift_b [* mask], xhat = (x - mean) rstd without
+// affine; per utterance b (rows_per_batch rows): dx = rstd (g - mean(g) - xhat mean(g xhat)) with g = dy mask scale_b,
+// d scale_b = sum_rows dy mask xhat, d shift_b = sum_rows dy mask.  One workgroup per utterance, rows over its 4 waves, a
+// fixed-order cross-wave sum: [B][D] outputs with no second stage.  D = 64 * NPL.
+template <int NPL>
+__global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                        int64_t lddy, const float* __restrict__ scale, int64_t ld_scale,
+                                                        const uint8_t* __restrict__ mask, float* __restrict__ dx, int64_t lddx,
+                                                        int add_to_dx, float* __restrict__ dscale, float* __restrict__ dshift,
+                                                        int64_t ld_out, int rows_per_batch, float eps) {
+    constexpr int D = NPL * 64;
+    const int b = blockIdx.x, wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    float sc[NPL], ds[NPL], dt[NPL];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        sc[k] = scale[(int64_t)b * ld_scale + l + 64 * k];
+        ds[k] = 0.f;
+        dt[k] = 0.f;
+    }
+    for (int rr = wave; rr < rows_per_batch; rr += 4) {
+        const int64_t row = (int64_t)b * rows_per_batch + rr;
+        const float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
+        float xv[NPL], gv[NPL];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            xv[k] = x[row * ldx + l + 64 * k];
+            gv[k] = dy[row * lddy + l + 64 * k] * mk;
+            s += xv[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        const float mean = s * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            xv[k] -= mean;
+            q += xv[k] * xv[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+        const float rstd = 1.f / sqrtf(q * (1.f / D) + eps);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            xv[k] *= rstd;
+            ds[k] += gv[k] * xv[k];
+            dt[k] += gv[k];
+            gv[k] *= sc[k];
+            c1 += gv[k];
+            c2 += gv[k] * xv[k];
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            c1 += __shfl_xor(c1, off, 64);
+            c2 += __shfl_xor(c2, off, 64);
+        }
+        c1 *= (1.f / D);
+        c2 *= (1.f / D);
+#pragma unroll
+        for (int k = 0; k < NPL; ++k) {
+            const float v = rstd * (gv[k] - c1 - xv[k] * c2);
+            float* d = dx + row * lddx + l + 64 * k;
+            *d = add_to_dx ? *d + v : v;
+        }
+    }
+    __shared__ float red[4][2][D];
+#pragma unroll
+    for (int k = 0; k < NPL; ++k) {
+        red[wave][0][l + 64 * k] = ds[k];
+        red[wave][1][l + 64 * k] = dt[k];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < D; i += 256) {
+        dscale[(int64_t)b * ld_out + i] = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
+        dshift[(int64_t)b * ld_out + i] = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+    }
+}
+
+// Time embedding backward (embeddings.py:131-157 as ispk_time_embedding_f32 computes it: f = [t, sin, cos], h = silu(W0 f + b0),
+// out = W1 h + b1; t itself gets no gradient).  ONE wave: lane j owns hidden unit / output j; the n time values are walked in
+// order, so every sum has a fixed order.  E <= 64, 1 + 2H <= 160.
+__global__ __launch_bounds__(64) void time_embedding_bwd_kernel(const float* __restrict__ t, int n, const float* __restrict__ inv_freq,
+                                                                const float* __restrict__ freq_scale, int H,
+                                                                const float* __restrict__ w0, const float* __restrict__ b0,
+                                                                const float* __restrict__ w1, int E, const float* __restrict__ d_out,
+                                                                float* __restrict__ dw0, float* __restrict__ db0,
+                                                                float* __restrict__ dw1, float* __restrict__ db1) {
+#pragma clang fp contract(off)
+    __shared__ float f[160], h[64], go[64];
+    const int j = threadIdx.x, K0 = 1 + 2 * H;
+    float aw0[160], aw1[64], ab0 = 0.f, ab1 = 0.f;
+    for (int k = 0; k < K0; ++k) aw0[k] = 0.f;
+    for (int k = 0; k < E; ++k) aw1[k] = 0.f;
+    const float fs = freq_scale[0];
+    for (int i = 0; i < n; ++i) {
+        const float pos = t[i];
+        if (j == 0) f[0] = pos;
+        for (int k = j; k < H; k += 64) {
+            const float a = pos * fs * inv_freq[k];
+            f[1 + k] = sinf(a);
+            f[1 + H + k] = cosf(a);
+        }
+        if (j < E) go[j] = d_out[(int64_t)i * E + j];
+        __syncthreads();
+        float pre = 0.f;
+        if (j < E) {
+            pre = b0[j];
+            for (int k = 0; k < K0; ++k) pre = fmaf(f[k], w0[(int64_t)j * K0 + k], pre);
+            h[j] = pre / (1.0f + expf(-pre));
+        }
+        __syncthreads();
+        if (j < E) {
+            float dh = 0.f;                                   // d loss / d h_j = sum_k go[k] W1[k][j]
+            for (int k = 0; k < E; ++k) dh = fmaf(go[k], w1[(int64_t)k * E + j], dh);
+            const float sg = 1.0f / (1.0f + expf(-pre));
+            const float dpre = dh * (sg * (1.0f + pre * (1.0f - sg)));      // silu'(pre)
+            for (int k = 0; k < E; ++k) aw1[k] += go[j] * h[k];             // row j of dW1
+            ab1 += go[j];
+            for (int k = 0; k < K0; ++k) aw0[k] += dpre * f[k];             // row j of dW0
+            ab0 += dpre;
+        }
+        __syncthreads();
+    }
+    if (j < E) {
+        for (int k = 0; k < K0; ++k) dw0[(int64_t)j * K0 + k] = aw0[k];
+        for (int k = 0; k < E; ++k) dw1[(int64_t)j * E + k] = aw1[k];
+        db0[j] = ab0;
+        db1[j] = ab1;
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t ispk_flow_loss_bwd_f32(const float* pred_raw, const float* flow, const uint8_t* mask, float grad_out, float* d_raw,
+                                          int32_t B, int32_t L, int32_t C, ispk_stream_t stream) {
+    ISPK_REQUIRE(pred_raw && flow && mask && d_raw, -1, "ispk_flow_loss_bwd_f32: null pointer");
+    ISPK_REQUIRE(B >= 1 && L >= 1 && C >= 1 && B <= 65535, -2, "ispk_flow_loss_bwd_f32: bad shape B=%d L=%d C=%d", B, L, C);
+    hipLaunchKernelGGL(flow_loss_bwd_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), pred_raw, flow, mask,
+                       grad_out, d_raw, B, L, C);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_adaln_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* scale, int64_t ld_scale,
+                                      const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dscale,
+                                      float* dshift, int64_t ld_out, int32_t B, int32_t rows_per_batch, int32_t dim, float eps,
+                                      ispk_stream_t stream) {
+    ISPK_REQUIRE(x && dy && scale && dx && dscale && dshift, -1, "ispk_adaln_bwd_f32: null pointer");
+    ISPK_REQUIRE(B >= 1 && rows_per_batch >= 1 && (dim == 256 || dim == 384) && ldx >= dim && lddy >= dim && lddx >= dim &&
+                     ld_scale >= dim && ld_out >= dim && B <= 65535, -2,
+                 "ispk_adaln_bwd_f32: bad shape B=%d rows_per_batch=%d dim=%d (dim 256 or 384)", B, rows_per_batch, dim);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dim == 256)
+        hipLaunchKernelGGL(adaln_bwd_kernel<4>, dim3(B), dim3(256), 0, s, x, ldx, dy, lddy, scale, ld_scale, row_mask, dx, lddx,
+                           add_to_dx, dscale, dshift, ld_out, rows_per_batch, eps);
+    else
+        hipLaunchKernelGGL(adaln_bwd_kernel<6>, dim3(B), dim3(256), 0, s, x, ldx, dy, lddy, scale, ld_scale, row_mask, dx, lddx,
+                           add_to_dx, dscale, dshift, ld_out, rows_per_batch, eps);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_time_embedding_bwd_f32(const float* t, int32_t n, const float* inv_freq, const float* freq_scale,
+                                               int32_t half_dim, const float* w0, const float* b0, const float* w1, int32_t emb_dim,
+                                               const float* d_out, float* dw0, float* db0, float* dw1, float* db1,
+                                               ispk_stream_t stream) {
+    ISPK_REQUIRE(t && inv_freq && freq_scale && w0 && b0 && w1 && d_out && dw0 && db0 && dw1 && db1, -1,
+                 "ispk_time_embedding_bwd_f32: null pointer");
+    ISPK_REQUIRE(n >= 1 && half_dim >= 1 && 1 + 2 * half_dim <= 160 && emb_dim >= 1 && emb_dim <= 64, -2,
+                 "ispk_time_embedding_bwd_f32: bad shape n=%d half_dim=%d emb_dim=%d", n, half_dim, emb_dim);
+    hipLaunchKernelGGL(time_embedding_bwd_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), t, n, inv_freq, freq_scale,
+                       half_dim, w0, b0, w1, emb_dim, d_out, dw0, db0, dw1, db1);
+    return ispk_launch_status();
+}
 
 extern "C" int32_t ispk_attn_ctc_loss_f32(const float* attn_logits, const int64_t* text_len, const int64_t* mel_len,
                                           float blank_logprob, float* workspace, int64_t workspace_floats, float* loss,

@@ -72,6 +72,9 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_train_f32": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
     "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
     "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
+    "ispk_flow_loss_bwd_f32": [_P, _P, _P, _F32, _P, _I32, _I32, _I32, _P],
+    "ispk_adaln_bwd_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
+    "ispk_time_embedding_bwd_f32": [_P, _I32, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P],
     "ispk_attn_ctc_loss_f32": [_P, _P, _P, _F32, _P, _I64, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_attn_bin_loss_f32": [_P, _P, _F32, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_mel_grad_rows_f32": [_P, _P, _P, _I32, _I32, _I32, _P],
@@ -981,6 +984,51 @@ def mel_loss(mel_out: Tensor, mel_target: Tensor, mel_len: Tensor, want_grad: bo
             mel_target.data_ptr(), mel_len.data_ptr(), ratio.data_ptr(), loss.data_ptr(), _ptr(grad), grad_out, B, C, T,
             _stream())
     return loss, grad
+
+
+def flow_loss_bwd(pred_raw: Tensor, flow: Tensor, mask: Tensor, grad_out: float = 1.0) -> Tensor:
+    """ispk_flow_loss_bwd_f32: gradient of the flow loss wrt the predictor's raw output [B, L, C]."""
+    _dev(pred_raw, flow, mask)
+    pred_raw, flow, mask = pred_raw.contiguous(), flow.contiguous(), mask.contiguous()
+    B, L, C = pred_raw.shape
+    assert mask.dtype == torch.bool and mask.shape == (B, L) and flow.shape == pred_raw.shape
+    d = torch.empty_like(pred_raw)
+    _launch("flow_loss_bwd_kernel", 0.0, 12.0 * pred_raw.numel(), lib().ispk_flow_loss_bwd_f32, pred_raw.data_ptr(), flow.data_ptr(),
+            mask.data_ptr(), grad_out, d.data_ptr(), B, L, C, _stream())
+    return d
+
+
+def adaln_bwd(x: Tensor, dy: Tensor, scale: Tensor, row_mask: Optional[Tensor], dx: Optional[Tensor], add_to_dx: bool,
+              dscale: Tensor, dshift: Tensor, eps: float = 1e-5) -> Tensor:
+    """ispk_adaln_bwd_f32: x, dy [B, L, D]; scale / dscale / dshift [B, D] rows (any row stride, unit column stride)."""
+    _dev(x, dy, scale, row_mask, dx, dscale, dshift)
+    B, L, D = x.shape
+    x2, dy2 = _rows2d(x), _rows2d(dy)
+    if dx is None:
+        assert not add_to_dx
+        dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dx2 = _rows2d(dx)
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).contiguous()
+    assert scale.stride(1) == 1 and dscale.stride(1) == 1 and dshift.stride(1) == 1 and dscale.stride(0) == dshift.stride(0)
+    _launch(f"adaln_bwd_kernel<{D // 64}>", 0.0, 4.0 * x2.numel() * (3 + int(add_to_dx)), lib().ispk_adaln_bwd_f32, x2.data_ptr(),
+            x2.stride(0), dy2.data_ptr(), dy2.stride(0), scale.data_ptr(), scale.stride(0), _ptr(row_mask), dx2.data_ptr(),
+            dx2.stride(0), int(add_to_dx), dscale.data_ptr(), dshift.data_ptr(), dscale.stride(0), B, L, D, eps, _stream())
+    return dx
+
+
+def time_embedding_bwd(t: Tensor, inv_freq: Tensor, freq_scale: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, d_out: Tensor):
+    """ispk_time_embedding_bwd_f32 -> (dw0, db0, dw1, db1)."""
+    _dev(t, inv_freq, freq_scale, w0, b0, w1, d_out)
+    t = t.reshape(-1).float().contiguous()
+    d_out = d_out.reshape(t.numel(), -1).float().contiguous()
+    E, H = w1.shape[0], inv_freq.numel()
+    dw0, db0 = torch.empty_like(w0, dtype=torch.float32), torch.empty((E,), dtype=torch.float32, device=t.device)
+    dw1, db1 = torch.empty((E, E), dtype=torch.float32, device=t.device), torch.empty((E,), dtype=torch.float32, device=t.device)
+    _launch("time_embedding_bwd_kernel", 0.0, 0.0, lib().ispk_time_embedding_bwd_f32, t.data_ptr(), t.numel(),
+            inv_freq.contiguous().data_ptr(), freq_scale.data_ptr(), H, w0.contiguous().data_ptr(), b0.data_ptr(),
+            w1.contiguous().data_ptr(), E, d_out.data_ptr(), dw0.data_ptr(), db0.data_ptr(), dw1.data_ptr(), db1.data_ptr(), _stream())
+    return dw0, db0, dw1, db1
 
 
 def attn_ctc_loss(attn_logits: Tensor, text_len: Tensor, mel_len: Tensor, blank_logprob: float = -1.0,

@@ -7,6 +7,8 @@
   stack.py   TransformerStackFunction: a `Transformer` stack (plain LayerNorm, fp32, dropout by in-kernel masks) as ONE
              autograd node whose backward is the kernels of csrc/backward.hip.
   stack.py   also ToMelFunction (to_mel's Linear + transpose + mask, model.py:167-168) and `mel_decoder_train_forward`.
+  predictor.py  the flow predictor (time embedding, AdaptiveLayerNorm projections, split input projection, adaptive-norm stack,
+             output Linear, flow loss) as autograd nodes: `flow_predictor_loss`.
   loss.py    MelLoss (models/acoustic/loss.py:22-35), AttentionCTCLoss (:39-77) and AttentionBinarizationLoss (:80-107), value
              and gradient by kernels.
 
@@ -14,8 +16,9 @@ Not built yet: backward of the aligner front-end, the adapto
 regulation), bf16 attention / weight-gradient kernels.
 """
 from .loss import AcousticModelLoss, AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
+from .predictor import flow_predictor_loss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params
 from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction, TransformerStackFunction, acoustic_mel_train_forward, mel_decoder_train_forward, transformer_train_forward)
 
-__all__ = ["AcousticModelLoss", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
+__all__ = ["AcousticModelLoss", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "flow_predictor_loss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
            "group_weight_decayable_params", "mel_decoder_train_forward", "transformer_train_forward"]

@@ -566,3 +566,39 @@ def test_mel_loss_gradients_of_the_whole_chain_match_autograd(state_dict):
         checked += 1
     assert checked == sum(1 for k in state_dict if k.startswith(keep))          # 143 tensors
     assert float(model.text_embedding.weight.grad[0].abs().max()) == 0.0     # padding row
+
+
+def test_flow_predictor_loss_gradients_match_autograd(state_dict):
+    """`train.flow_predictor_loss` (time embedding -> AdaLN projections -> split input projection -> 3 x 256 adaptive-norm
+    stack -> output Linear -> flow loss): value, the gradient of every predictor parameter and of the conditioning encoder
+    output against torch autograd over the oracle's `predictor_forward`."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    B, L = 3, 50
+    cond = _rand((B, L, 384), 130)
+    targets = _rand((B, L, 3), 131)
+    x0, t = _rand((B, L, 3), 132), torch.tensor([0.13, 0.71, 0.42])
+    lens = torch.tensor([50, 31, 44])
+    mask = torch.arange(L)[None, :] < lens[:, None]
+    pre = "temporal_adaptor.predictor."
+    sd = {k: (v.clone().requires_grad_() if k.startswith(pre) else v.clone()) for k, v in state_dict.items()}
+    c64 = cond.clone().requires_grad_()
+    _, loss_ref = orc.predictor_forward(sd, c64, targets, mask, x0, t)
+    loss_ref.backward()
+
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model = model.to(DEV).eval()
+    pred = model.temporal_adaptor.predictor
+    cg = cond.to(DEV).requires_grad_()
+    loss = train.flow_predictor_loss(pred, cg, targets.to(DEV), mask.to(DEV), x0.to(DEV), t.to(DEV))
+    _close(loss, loss_ref, 2e-5, "flow loss")
+    loss.backward()
+    _close(cg.grad, c64.grad, 1e-3, "d cond")
+    n = 0
+    for name, p in pred.named_parameters():
+        ref = sd[pre + name].grad
+        assert p.grad is not None and ref is not None, name
+        _close(p.grad, ref, 1e-3, f"d {name}")
+        n += 1
+    assert n == sum(1 for k in state_dict if k.startswith(pre) and not k.endswith("freq_scale"))      # 52 (freq_scale: a buffer)

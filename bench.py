@@ -641,30 +641,29 @@ def worker(args) -> int:
     # ---------------------------------------------------------------------------------------------- training step (all ranks)
     if not args.no_extras:
         def train_line():
-            """SURVEY row f2, first cut: one optimizer step under the MEL loss over everything that loss reaches outside the
-            aligner - text embedding, TextEncoder, the adaptor's embedding module, length regulator, MelDecoder, to_mel
-            (train.acoustic_mel_train_forward; aligner and flow predictor frozen) - with the recipes' dropout, bf16 AMP
-            for the Linear GEMMs, sharded flat AdamW; B utterances x M frames per GPU of the headline's synthetic batch."""
+            """SURVEY row f2, first cut: one optimizer step under the mel + flow losses over every parameter outside the
+            aligner - text embedding, TextEncoder, the adaptor's embedding module and flow predictor, length regulator,
+            MelDecoder, to_mel (train.acoustic_train_forward; the aligner is frozen, its CTC / binarisation losses are
+            evaluated as values) - with the recipes' dropout, bf16 AMP for the Linear GEMMs, sharded flat AdamW; B
+            utterances x M frames per GPU of the headline's synthetic batch."""
             from isp_tts_amd import train
             model.train()                       # training mode: the recipes' dropout on attention and feed-forward
             for p in model.parameters():
                 p.requires_grad_(False)
-            trained = [p for nm, p in model.named_parameters()
-                       if not nm.startswith(("aligner.", "temporal_adaptor.predictor."))]
+            trained = [p for nm, p in model.named_parameters() if not nm.startswith("aligner.")]
             for p in trained:
                 p.requires_grad_(True)
             model.set_compute_dtype(torch.float32)
             opt = train.FlatAdamW(trained, lr=2e-4, weight_decay=1e-2, grad_clip=1.0)
             opt.check_finite = False
-            crit = train.MelLoss()
             prof = runtime.LaunchProfiler() if rank == 0 else None
 
             amp = [True]
 
             def st():
-                mel = train.acoustic_mel_train_forward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"],
-                                                       d["energy"], amp=amp[0])
-                opt.step(crit(mel, d["mel"], d["mel_len"]))
+                _, total, _ = train.acoustic_train_forward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"],
+                                                           d["energy"], flow_noise=d["flow_x0"], flow_time=d["flow_t"], amp=amp[0])
+                opt.step(total)
             try:
                 n = max(3, args.steps // 4)
                 for _ in range(2):
@@ -705,13 +704,13 @@ def worker(args) -> int:
                    "dtype": "bf16 operands for the Linear GEMMs (AMP), fp32 everything else and master weights",
                    "ms_per_step_all_fp32": round(1e3 * el32 / n, 3), "global_batch": world * B, "parameters": opt.flat.total,
                    "optimizer": f"flat AdamW, clip 1.0, {'reduce-scatter + all-gather over RCCL, moments sharded' if world > 1 else 'single rank'}",
-                   "workload": "BASELINE config 5 restricted to the MEL loss: text embedding + TextEncoder + adaptor embedding "
-                               "module + length regulator + MelDecoder + to_mel trained (aligner, flow predictor frozen), "
-                               "forward with the recipes' dropout + backward + clip + AdamW, eager launches"}
+                   "workload": "BASELINE config 5 with the aligner frozen: mel + flow losses, every parameter outside the aligner "
+                               "trained (text embedding, TextEncoder, adaptor embedding module + flow predictor, MelDecoder, "
+                               "to_mel); forward with the recipes' dropout + backward + clip + AdamW, eager launches"}
             if kern:
                 res["ms_by_kernel_one_step"] = kern
             return res
-        extra("train_step_mel_loss", train_line)
+        extra("train_step", train_line)
 
     if rank == 0:
         os.write(json_fd, (json.dumps(line) + "\n").encode())

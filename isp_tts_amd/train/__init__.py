@@ -9,6 +9,7 @@
   stack.py   also ToMelFunction (to_mel's Linear + transpose + mask, model.py:167-168) and `mel_decoder_train_forward`.
   predictor.py  the flow predictor (time embedding, AdaptiveLayerNorm projections, split input projection, adaptive-norm stack,
              output Linear, flow loss) as autograd nodes: `flow_predictor_loss`.
+  model.py   `acoustic_train_forward`: the whole teacher-forced forward with the mel and flow losses differentiable (aligner frozen).
   loss.py    MelLoss (models/acoustic/loss.py:22-35), AttentionCTCLoss (:39-77) and AttentionBinarizationLoss (:80-107), value
              and gradient by kernels.
 
@@ -16,9 +17,10 @@ Not built yet: backward of the aligner front-end, the adapto
 regulation), bf16 attention / weight-gradient kernels.
 """
 from .loss import AcousticModelLoss, AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
+from .model import acoustic_train_forward
 from .predictor import flow_predictor_loss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params
 from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction, TransformerStackFunction, acoustic_mel_train_forward, mel_decoder_train_forward, transformer_train_forward)
 
-__all__ = ["AcousticModelLoss", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "flow_predictor_loss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
+__all__ = ["AcousticModelLoss", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "acoustic_train_forward", "flow_predictor_loss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
            "group_weight_decayable_params", "mel_decoder_train_forward", "transformer_train_forward"]

@@ -602,3 +602,49 @@ def test_flow_predictor_loss_gradients_match_autograd(state_dict):
         _close(p.grad, ref, 1e-3, f"d {name}")
         n += 1
     assert n == sum(1 for k in state_dict if k.startswith(pre) and not k.endswith("freq_scale"))      # 52 (freq_scale: a buffer)
+
+
+def test_mel_plus_flow_loss_gradients_of_the_model_match_autograd(state_dict):
+    """`train.acoustic_train_forward`: mel + flow loss; the gradient of EVERY parameter outside the aligner (195 tensors: text
+    embedding, TextEncoder, embedding module, flow predictor, MelDecoder, to_mel) against torch autograd over the oracle's
+    forward composed as the reference composes it (aligner on the detached encoder output, alignment constant); the CTC and
+    binarisation terms against the reference's expressions as values."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    inp = synth.make_inputs(2, 40, 150, variable=True, seed=33)
+    text, text_len, mel, mel_len, pitch, energy = (inp[k] for k in ("text", "text_len", "mel", "mel_len", "pitch", "energy"))
+    frozen = ("aligner.",)
+    sd = {k: (v.clone() if k.startswith(frozen) or not v.is_floating_point() or k.endswith("freq_scale") else v.clone().requires_grad_())
+          for k, v in state_dict.items()}
+    emb = F.embedding(text, sd["text_embedding.weight"], padding_idx=0)
+    enc_mask = torch.arange(text.shape[1])[None, :] < text_len[:, None]
+    enc_out = orc.transformer(sd, "encoder", emb, enc_mask)
+    with torch.no_grad():
+        al = orc.aligner(sd, mel, enc_out.detach().transpose(1, 2), mel_len, text_len)
+    ad = orc.adaptor_forward(sd, enc_out, enc_mask, mel.shape[2], al.attn_hard_duration, al.attn_soft, pitch, energy,
+                             inp["flow_x0"], inp["flow_t"])
+    dec_mask = torch.arange(mel.shape[2])[None, :] < ad.dec_lengths[:, None]
+    dec = orc.transformer(sd, "decoder", ad.enc_out, dec_mask)
+    mel_ref = F.linear(dec, sd["to_mel.weight"], sd["to_mel.bias"]).transpose(1, 2) * dec_mask[:, None]
+    total_ref = torc.mel_loss(mel_ref, mel, mel_len) + ad.flow_loss
+    total_ref.backward()
+
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model = model.to(DEV).eval()
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    mel_out, total, losses = train.acoustic_train_forward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"],
+                                                          d["energy"], flow_noise=d["flow_x0"], flow_time=d["flow_t"])
+    _close(total, total_ref, 2e-5, "mel + flow loss")
+    _close(losses["adaptor/flow_loss"], ad.flow_loss, 2e-5, "flow loss")
+    _close(losses["aligner/attention_loss"], torc.attention_ctc_loss(al.attn_logits.reshape(2, 150, 40), text_len, mel_len), 1e-4, "CTC value")
+    _close(losses["aligner/kl_loss"], torc.attention_binarization_loss(al.attn_soft, al.attn_hard), 1e-4, "binarisation value")
+    total.backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        if name.startswith(frozen):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, name
+            continue
+        _close(p.grad, sd[name].grad, 1e-3, f"d {name}")
+        checked += 1
+    assert checked == 195, checked

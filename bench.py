@@ -641,16 +641,14 @@ def worker(args) -> int:
     # ---------------------------------------------------------------------------------------------- training step (all ranks)
     if not args.no_extras:
         def train_line():
-            """SURVEY row f2, first cut: one optimizer step under the mel + flow losses over every parameter outside the
-            aligner - text embedding, TextEncoder, the adaptor's embedding module and flow predictor, length regulator,
-            MelDecoder, to_mel (train.acoustic_train_forward; the aligner is frozen, its CTC / binarisation losses are
-            evaluated as values) - with the recipes' dropout, bf16 AMP for the Linear GEMMs, sharded flat AdamW; B
-            utterances x M frames per GPU of the headline's synthetic batch."""
+            """one optimizer step of BASELINE config 5 under the reference's total loss (mel + flow + CTC +
+            binarisation, loss.py:140-182) over every parameter of the model - text embedding, TextEncoder, aligner
+            front-end, the adaptor's embedding module and flow predictor, MelDecoder, to_mel (train.acoustic_train_forward)
+            - with the recipes' dropout, bf16 AMP for the Linear GEMMs, sharded flat AdamW; B utterances x M frames per
+            GPU of the headline's synthetic batch."""
             from isp_tts_amd import train
             model.train()                       # training mode: the recipes' dropout on attention and feed-forward
-            for p in model.parameters():
-                p.requires_grad_(False)
-            trained = [p for nm, p in model.named_parameters() if not nm.startswith("aligner.")]
+            trained = list(model.parameters())
             for p in trained:
                 p.requires_grad_(True)
             model.set_compute_dtype(torch.float32)
@@ -704,9 +702,9 @@ def worker(args) -> int:
                    "dtype": "bf16 operands for the Linear GEMMs (AMP), fp32 everything else and master weights",
                    "ms_per_step_all_fp32": round(1e3 * el32 / n, 3), "global_batch": world * B, "parameters": opt.flat.total,
                    "optimizer": f"flat AdamW, clip 1.0, {'reduce-scatter + all-gather over RCCL, moments sharded' if world > 1 else 'single rank'}",
-                   "workload": "BASELINE config 5 with the aligner frozen: mel + flow losses, every parameter outside the aligner "
-                               "trained (text embedding, TextEncoder, adaptor embedding module + flow predictor, MelDecoder, "
-                               "to_mel); forward with the recipes' dropout + backward + clip + AdamW, eager launches"}
+                   "workload": "BASELINE config 5: mel + flow + CTC + binarisation losses, every parameter trained (text embedding, "
+                               "TextEncoder, aligner, adaptor embedding module + flow predictor, MelDecoder, to_mel); forward "
+                               "with the recipes' dropout + backward + clip + AdamW, eager launches"}
             if kern:
                 res["ms_by_kernel_one_step"] = kern
             return res

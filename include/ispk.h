@@ -372,7 +372,8 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              (autograd of F.linear).  Rows are split into ranges whose partial products go to `workspace`
  *                              (>= N1*N2 floats; more = more ranges, up to 256) and are added in range order: deterministic.
  *                              row_mask uint8 [M] or NULL; accumulate != 0 adds to C.  N1, N2, lda, ldb multiples of 4,
- *                              A and B 16-byte aligned.
+ *                              A and B 16-byte aligned; ldb < N2 is allowed (overlapping rows: the windows of a padded
+ *                              convolution input, for the convolution's weight gradient).
  * ispk_layernorm_bwd_f32       backward of modules/transformer/normalization.py:20-31 followed by `* mask` (transformer.py:102):
  *                              dx (=) or (+=, add_to_dx) rstd (g - mean(g) - xhat mean(g xhat)), g = dy mask gamma;
  *                              dgamma = sum_rows dy mask xhat, dbeta = sum_rows dy mask (either may be NULL; both NULL needs no
@@ -400,6 +401,15 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              ratio[b] = sum over (c, t < mel_len[b]) of (out - target)^2 / max(C * len_b, 1e-5)
  *                              (utils/functions.py:44-58), loss[0] = mean_b ratio[b]; grad (or NULL) = d loss / d mel_out *
  *                              grad_out, zero on padded frames.  mel fp32 [B][C][T].
+ * ispk_aligner_scores_bwd_f32  backward of ispk_aligner_scores_f32 (alignment.py:187-208) from d attn_soft and / or d attn_logits
+ *                              (either may be NULL): the gradient of the UNSCALED q . k products, as dS [B][M][ld_s] and its
+ *                              transpose dSt [B][L][ld_t] (padding columns must arrive zeroed) - the operands of the two batched
+ *                              products d q_enc = dS k_enc, d k_enc = dS^T q_enc.  The diagonal prior is recomputed.
+ * ispk_masked_instnorm_bwd_f32 backward of ispk_masked_instnorm_f32 (modules/normalization.py:160-208): y / d_out / d_y are
+ *                              [B][T+4][C] with row t = frame t; d_y is zero past each utterance's length; d_weight / d_bias
+ *                              summed over utterances in order.  workspace >= 2 B C floats.
+ * ispk_soft_average_bwd_f32    d attn_soft (=) or (+=) from d feats [B][L][3] of ispk_soft_average_f32 (temporal_adaptor.py:446-449;
+ *                              column 0, the log1p duration, carries no gradient).  workspace >= 3 B L floats.
  * ispk_flow_loss_bwd_f32       d (flow loss) / d pred_raw of ispk_flow_finish_f32 (temporal_adaptor.py:145-146): go 2 m (raw m - flow) /
  *                              (max(C n_b, 1e-5) B), n_b = valid positions of utterance b.
  * ispk_adaln_bwd_f32           backward of AdaptiveLayerNorm (normalization.py:37-61) as ispk_layernorm_f32 applies it with per-
@@ -464,6 +474,15 @@ int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const floa
                                     const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
                           float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
+int32_t ispk_aligner_scores_bwd_f32(const float* attn_logits, const float* attn_soft, const float* d_soft, const float* d_logits,
+                                    const int64_t* text_len, const int64_t* mel_len, float* dS, int64_t ld_s, float* dSt,
+                                    int64_t ld_t, int32_t B, int32_t M, int32_t L, float scale, ispk_stream_t stream);
+int32_t ispk_masked_instnorm_bwd_f32(const float* y, const float* d_out, const float* weight, const int64_t* lengths, float* d_y,
+                                     float* d_weight, float* d_bias, float* workspace, int64_t workspace_floats, int32_t B,
+                                     int32_t T, int32_t C, float eps, ispk_stream_t stream);
+int32_t ispk_soft_average_bwd_f32(const float* attn_soft, const float* pitch, const float* energy, const float* d_feats,
+                                  const int64_t* text_len, float* workspace, int64_t workspace_floats, float* d_attn,
+                                  int32_t accumulate, int32_t B, int32_t M, int32_t L, ispk_stream_t stream);
 int32_t ispk_flow_loss_bwd_f32(const float* pred_raw, const float* flow, const uint8_t* mask, float grad_out, float* d_raw, int32_t B,
                                int32_t L, int32_t C, ispk_stream_t stream);
 int32_t ispk_adaln_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* scale, int64_t ld_scale,

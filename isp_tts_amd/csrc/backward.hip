@@ -639,7 +639,8 @@ static int32_t gemm_tn_launch(const float* A, int64_t lda, int64_t stride_a, con
                               int64_t ldc, int64_t stride_c, int batch, int M, int N1, int N2, const uint8_t* row_mask,
                               int accumulate, float* workspace, int64_t workspace_floats, hipStream_t s, const char* who) {
     ISPK_REQUIRE(A && B && C && workspace, -1, "%s: null pointer", who);
-    ISPK_REQUIRE(batch >= 1 && M >= 1 && N1 >= 4 && N2 >= 4 && N1 % 4 == 0 && N2 % 4 == 0 && lda >= N1 && ldb >= N2 && ldc >= N2 &&
+    // (ldb < N2 is allowed: overlapping rows, i.e. the 5-tap windows of a padded convolution input)
+    ISPK_REQUIRE(batch >= 1 && M >= 1 && N1 >= 4 && N2 >= 4 && N1 % 4 == 0 && N2 % 4 == 0 && lda >= N1 && ldb >= 4 && ldc >= N2 &&
                      lda % 4 == 0 && ldb % 4 == 0 && stride_a % 4 == 0 && stride_b % 4 == 0 && ispk_aligned(A, 16) &&
                      ispk_aligned(B, 16), -2,
                  "%s: bad shape batch=%d M=%d N1=%d N2=%d (N1, N2, leading dimensions and batch strides multiples of 4, 16-byte "

@@ -72,6 +72,9 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_train_f32": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
     "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
     "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
+    "ispk_aligner_scores_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _F32, _P],
+    "ispk_masked_instnorm_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
+    "ispk_soft_average_bwd_f32": [_P, _P, _P, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_flow_loss_bwd_f32": [_P, _P, _P, _F32, _P, _I32, _I32, _I32, _P],
     "ispk_adaln_bwd_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
     "ispk_time_embedding_bwd_f32": [_P, _I32, _P, _P, _I32, _P, _P, _P, _I32, _P, _P, _P, _P, _P, _P],
@@ -857,19 +860,68 @@ def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Option
     return out
 
 
-def gemm_tn_batched(a: Tensor, b: Tensor) -> Tensor:
-    """ispk_gemm_tn_batched_f32: C[i] = a[i]^T b[i] for a [batch, M, N1], b [batch, M, N2] (fp32, contiguous) -> [batch, N1, N2]."""
-    _dev(a, b)
+def gemm_tn_batched(a: Tensor, b: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """ispk_gemm_tn_batched_f32: C[i] = a[i]^T b[i] for a [batch, M, N1], b [batch, M, N2] (fp32; any batch / row strides,
+    unit column stride) -> [batch, N1, N2] (`out`: a view with the same freedom)."""
+    _dev(a, b, out)
     assert a.dtype == torch.float32 and b.dtype == torch.float32 and a.ndim == 3 and b.ndim == 3 and a.shape[:2] == b.shape[:2]
-    a, b = a.contiguous(), b.contiguous()
+    if a.stride(2) != 1:
+        a = a.contiguous()
+    if b.stride(2) != 1:
+        b = b.contiguous()
     batch, M, N1 = a.shape
     N2 = b.shape[2]
-    out = torch.empty((batch, N1, N2), dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((batch, N1, N2), dtype=torch.float32, device=a.device)
+    assert out.shape == (batch, N1, N2) and out.stride(2) == 1 and out.dtype == torch.float32
     ws = workspace(a.device, batch * N1 * N2)
     _launch("gemm_tn_kernel<batched>", 2.0 * batch * M * N1 * N2, 4.0 * (a.numel() + b.numel() + out.numel()),
-            lib().ispk_gemm_tn_batched_f32, a.data_ptr(), N1, M * N1, b.data_ptr(), N2, M * N2, out.data_ptr(), N2, N1 * N2, batch,
-            M, N1, N2, None, 0, ws.data_ptr(), ws.numel(), _stream())
+            lib().ispk_gemm_tn_batched_f32, a.data_ptr(), a.stride(1), a.stride(0), b.data_ptr(), b.stride(1), b.stride(0),
+            out.data_ptr(), out.stride(1), out.stride(0), batch, M, N1, N2, None, 0, ws.data_ptr(), ws.numel(), _stream())
     return out
+
+
+def aligner_scores_bwd(attn_logits: Tensor, attn_soft: Tensor, d_soft: Optional[Tensor], d_logits: Optional[Tensor],
+                       text_len: Tensor, mel_len: Tensor, scale: float):
+    """ispk_aligner_scores_bwd_f32 -> (dS [B, M, L4], dSt [B, L, M4]) zero-padded to multiples of 4 columns."""
+    _dev(attn_logits, attn_soft, d_soft, d_logits, text_len, mel_len)
+    B, M, L = attn_logits.shape
+    L4, M4 = (L + 3) // 4 * 4, (M + 3) // 4 * 4
+    dS = torch.zeros((B, M, L4), dtype=torch.float32, device=attn_logits.device)
+    dSt = torch.zeros((B, L, M4), dtype=torch.float32, device=attn_logits.device)
+    cg = lambda t: None if t is None else t.float().contiguous()       # noqa: E731
+    d_soft, d_logits = cg(d_soft), cg(d_logits)
+    _launch("aligner_scores_bwd_kernel", 0.0, 4.0 * B * M * L * 6, lib().ispk_aligner_scores_bwd_f32, attn_logits.contiguous().data_ptr(),
+            attn_soft.contiguous().data_ptr(), _ptr(d_soft), _ptr(d_logits), text_len.to(torch.int64).contiguous().data_ptr(),
+            mel_len.to(torch.int64).contiguous().data_ptr(), dS.data_ptr(), L4, dSt.data_ptr(), M4, B, M, L, scale, _stream())
+    return dS, dSt
+
+
+def masked_instnorm_bwd(y: Tensor, d_out: Tensor, weight: Tensor, lengths: Tensor, eps: float = 1e-5):
+    """ispk_masked_instnorm_bwd_f32: y, d_out [B, T+4, C] (row t = frame t) -> (d_y like y, d_weight [C], d_bias [C])."""
+    _dev(y, d_out, weight, lengths)
+    B, TP, C = y.shape
+    assert y.is_contiguous() and d_out.is_contiguous() and d_out.shape == y.shape and y.dtype == torch.float32
+    d_y = torch.empty_like(y)
+    dw, db = torch.empty((C,), dtype=torch.float32, device=y.device), torch.empty((C,), dtype=torch.float32, device=y.device)
+    ws = workspace(y.device, 2 * B * C)
+    _launch("masked_instnorm_bwd_kernel", 0.0, 4.0 * y.numel() * 5, lib().ispk_masked_instnorm_bwd_f32, y.data_ptr(), d_out.data_ptr(),
+            weight.data_ptr(), lengths.to(torch.int64).contiguous().data_ptr(), d_y.data_ptr(), dw.data_ptr(), db.data_ptr(),
+            ws.data_ptr(), ws.numel(), B, TP - 4, C, eps, _stream())
+    return d_y, dw, db
+
+
+def soft_average_bwd(attn_soft: Tensor, pitch: Tensor, energy: Tensor, d_feats: Tensor, text_len: Tensor) -> Tensor:
+    """ispk_soft_average_bwd_f32 -> d attn_soft [B, M, L]."""
+    _dev(attn_soft, pitch, energy, d_feats, text_len)
+    B, M, L = attn_soft.shape
+    d = torch.empty_like(attn_soft)
+    ws = workspace(attn_soft.device, 3 * B * L)
+    _launch("soft_average_bwd_kernels", 0.0, 4.0 * attn_soft.numel() * 3, lib().ispk_soft_average_bwd_f32,
+            attn_soft.contiguous().data_ptr(), pitch.float().contiguous().data_ptr(), energy.float().contiguous().data_ptr(),
+            d_feats.float().contiguous().data_ptr(), text_len.to(torch.int64).contiguous().data_ptr(), ws.data_ptr(), ws.numel(),
+            d.data_ptr(), 0, B, M, L, _stream())
+    return d
 
 
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], row_mask: Optional[Tensor] = None,

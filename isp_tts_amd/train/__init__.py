@@ -10,6 +10,7 @@
   predictor.py  the flow predictor (time embedding, AdaptiveLayerNorm projections, split input projection, adaptive-norm stack,
              output Linear, flow loss) as autograd nodes: `flow_predictor_loss`.
   model.py   `acoustic_train_forward`: the whole teacher-forced forward with the mel and flow losses differentiable (aligner frozen).
+  aligner.py  the aligner front-end (conv blocks, masked instance norms, scores) and the soft averages as autograd nodes.
   loss.py    MelLoss (models/acoustic/loss.py:22-35), AttentionCTCLoss (:39-77) and AttentionBinarizationLoss (:80-107), value
              and gradient by kernels.
 

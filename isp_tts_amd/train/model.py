@@ -3,9 +3,9 @@
 `acoustic_train_forward` returns the mel output and the reference's dict of losses (`AcousticModelLoss`, loss.py:140-182):
   * "model/mel_loss" and "adaptor/flow_loss" are differentiable - their gradients reach every parameter outside the aligner:
     text embedding, TextEncoder, the adaptor's embedding module and flow predictor, MelDecoder, to_mel;
-  * "aligner/attention_loss" (CTC) and "aligner/kl_loss" (binarisation) are VALUES only: the aligner's own backward (conv
-    stacks, instance norms, the scores kernel) and the two paths by which the mel loss reaches it through attn_soft are not
-    built, so the aligner is frozen in this cut.
+  * "aligner/attention_loss" (CTC) and "aligner/kl_loss" (binarisation) train the aligner front-end (train/aligner.py), which
+    the mel loss also reaches through attn_soft (length regulator, soft averages); with `train_aligner=False` the aligner is
+    frozen and the two terms are values.
 """
 from __future__ import annotations
 
@@ -16,35 +16,49 @@ from torch import Tensor
 
 from .. import runtime
 from .loss import AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
+from .aligner import SoftAverageFunction, conv_attention_train
 from .predictor import flow_predictor_loss
 from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction,
                     transformer_train_forward)
 
 
 def acoustic_train_forward(model, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor, energy: Tensor,
-                           flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None, amp: bool = False):
-    """-> (mel_out [B, 80, M], loss, losses) with loss = mel + flow (the differentiable terms)."""
+                           flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None, amp: bool = False,
+                           train_aligner: bool = True):
+    """-> (mel_out [B, 80, M], loss, losses).  `train_aligner`: the aligner front-end is a differentiable node too
+    (train/aligner.py) and loss = mel + flow + CTC + binarisation, the reference's total (loss.py:140-182); otherwise the
+    aligner is frozen, loss = mel + flow and the two attention terms are values."""
     ad = model.temporal_adaptor
     emb, enc_mask = EmbedTokensFunction.apply(text, model.text_embedding.weight, text_len)
     enc_out = transformer_train_forward(model.encoder, emb, enc_mask, amp)
-    with torch.no_grad():      # the aligner, frozen: soft / hard alignment, durations, the dense targets' averages
-        attn_soft, attn_logits = model.aligner.attention(mel, enc_out.detach().transpose(1, 2), mel_len, text_len)
-        attn_hard, dur = model.aligner.binarize_attention_parallel(attn_logits, text_len, mel_len, return_duration=True)
-        targets = runtime.soft_average(attn_soft, pitch, energy, dur, text_len)       # [log1p duration, pitch, energy]
+    keys_t = enc_out.detach().transpose(1, 2)          # model.py:139: the aligner sees the DETACHED encoder output
+    if train_aligner:
+        attn_soft, attn_logits = conv_attention_train(model.aligner.attention, mel, keys_t, mel_len, text_len)
+        feats = SoftAverageFunction.apply(attn_soft, pitch, energy, text_len)          # pitch / energy targets, differentiable
+    with torch.no_grad():
+        if not train_aligner:
+            attn_soft, attn_logits = model.aligner.attention(mel, keys_t, mel_len, text_len)
+        attn_hard, dur = model.aligner.binarize_attention_parallel(attn_logits.detach(), text_len, mel_len, return_duration=True)
+        targets = runtime.soft_average(attn_soft.detach(), pitch, energy, dur, text_len)       # [log1p duration, pitch, energy]
+    if not train_aligner:
+        feats = targets
     b, l = text.shape
     x0 = flow_noise if flow_noise is not None else torch.randn(b, l, 3, device=text.device)
     t = flow_time if flow_time is not None else torch.rand(b, device=text.device)
     cond = enc_out.detach() if ad.predictor.detach_inputs else enc_out
     flow_loss = flow_predictor_loss(ad.predictor, cond, targets, enc_mask, x0, t, amp)
     emod = ad.embedding
-    h = transformer_train_forward(emod.transformer, targets[..., 1:3], enc_mask, amp)
+    h = transformer_train_forward(emod.transformer, feats[..., 1:3], enc_mask, amp)
     x = MaskedLinearResidualFunction.apply(h, emod.linear_layer.weight, emod.linear_layer.bias, enc_mask, enc_out)
     dec_in, dec_len, dec_mask = LengthRegulateFunction.apply(x, attn_soft, mel_len.view(-1, 1), mel.shape[2])
     dec = transformer_train_forward(model.decoder, dec_in, dec_mask, amp)
     mel_out = ToMelFunction.apply(dec, model.to_mel.weight, model.to_mel.bias, dec_mask)
     mel_loss = MelLoss()(mel_out, mel, mel_len)
-    with torch.no_grad():
+    with torch.set_grad_enabled(train_aligner):
         ctc = AttentionCTCLoss()(attn_logits, text_len, mel_len)
         kl = AttentionBinarizationLoss()(attn_soft, attn_hard)
     losses = {"model/mel_loss": mel_loss, "adaptor/flow_loss": flow_loss, "aligner/attention_loss": ctc, "aligner/kl_loss": kl}
-    return mel_out, mel_loss + flow_loss, losses
+    total = mel_loss + flow_loss
+    if train_aligner:
+        total = total + ctc + kl
+    return mel_out, total, losses

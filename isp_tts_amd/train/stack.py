@@ -69,6 +69,7 @@ class TransformerStackFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tr: Transformer, x: Tensor, mask: Optional[Tensor], amp: bool, *params: Tensor):
         _check(tr)
+        ctx.want_dx = x.requires_grad          # (asked before the copy below: a tensor made inside forward never requires grad)
         x = x.float().contiguous()
         key_len = mask.sum(dim=1) if mask is not None else None
         proj = not isinstance(tr.project_emb, torch.nn.Identity)
@@ -148,7 +149,8 @@ class TransformerStackFunction(torch.autograd.Function):
             # dy is the gradient of the projected input: d W = dy^T x over a handful of input features, d b = column sums;
             # the raw features are targets (no gradient wanted)
             grads = [runtime.smallk_wgrad(dy, ctx.proj_in), runtime.colsum(dy)] + grads
-            dy = None
+            # d x = dy W (a handful of outputs): only when the features themselves carry a gradient (the soft averages do)
+            dy = runtime.linear_small(dy, runtime.transpose(tr.project_emb.weight.detach()), None) if ctx.want_dx else None
         return (None, dy, None, None, *grads, dgf, dbf)
 
 
@@ -186,20 +188,27 @@ def mel_decoder_train_forward(model, dec_in: Tensor, dec_mask: Optional[Tensor],
 
 class LengthRegulateFunction(torch.autograd.Function):
     """out[b] = A[b] x[b] (LengthRegulator, soft branch: temporal_adaptor.py:411-436; forward = `runtime.length_regulate`).
-    Backward for x: d x[b] = A[b]^T d out[b], one batched product.  The alignment is treated as a constant here (its
-    gradient - d A[b] = d out[b] x[b]^T, the path by which the mel loss reaches the aligner - is not built yet)."""
+    Backward: d x[b] = A[b]^T d out[b] (one batched transposed product) and, when the alignment carries a gradient (the
+    path by which the mel loss reaches the aligner), d A[b] = d out[b] x[b]^T - one NT GEMM per utterance in this cut."""
 
     @staticmethod
     def forward(ctx, x: Tensor, alignment: Tensor, durations: Tensor, frames: int):
         out, dec_len, dec_mask = runtime.length_regulate(x, durations, alignment, frames, max_len=frames)
-        ctx.save_for_backward(alignment)
+        ctx.save_for_backward(alignment, x)
+        ctx.want_da = alignment.requires_grad
         ctx.mark_non_differentiable(dec_len, dec_mask)
         return out, dec_len, dec_mask
 
     @staticmethod
     def backward(ctx, d_out: Tensor, _dl, _dm):
-        (alignment,) = ctx.saved_tensors
-        return runtime.gemm_tn_batched(alignment, d_out.float().contiguous()), None, None, None
+        alignment, x = ctx.saved_tensors
+        d_out = d_out.float().contiguous()
+        d_a = None
+        if ctx.want_da:
+            d_a = torch.empty_like(alignment)
+            for b in range(alignment.shape[0]):
+                runtime.gemm(d_out[b], x[b].contiguous(), out=d_a[b])
+        return runtime.gemm_tn_batched(alignment, d_out), d_a, None, None
 
 
 class MaskedLinearResidualFunction(torch.autograd.Function):

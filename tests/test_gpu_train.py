@@ -634,7 +634,8 @@ def test_mel_plus_flow_loss_gradients_of_the_model_match_autograd(state_dict):
     model = model.to(DEV).eval()
     d = {k: v.to(DEV) for k, v in inp.items()}
     mel_out, total, losses = train.acoustic_train_forward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"],
-                                                          d["energy"], flow_noise=d["flow_x0"], flow_time=d["flow_t"])
+                                                          d["energy"], flow_noise=d["flow_x0"], flow_time=d["flow_t"],
+                                                          train_aligner=False)
     _close(total, total_ref, 2e-5, "mel + flow loss")
     _close(losses["adaptor/flow_loss"], ad.flow_loss, 2e-5, "flow loss")
     _close(losses["aligner/attention_loss"], torc.attention_ctc_loss(al.attn_logits.reshape(2, 150, 40), text_len, mel_len), 1e-4, "CTC value")
@@ -648,3 +649,136 @@ def test_mel_plus_flow_loss_gradients_of_the_model_match_autograd(state_dict):
         _close(p.grad, sd[name].grad, 1e-3, f"d {name}")
         checked += 1
     assert checked == 195, checked
+
+
+def test_full_training_loss_gradients_match_autograd(state_dict):
+    """`train.acoustic_train_forward(train_aligner=True)`: the reference's TOTAL loss (mel + flow + CTC + binarisation,
+    loss.py:140-182) and its gradient for EVERY parameter of the model (206 tensors, the aligner's 11 included) against torch
+    autograd over the oracle's forward composed as the reference composes it (aligner on the detached encoder output,
+    model.py:139; flow targets detached, temporal_adaptor.py:112)."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    from oracle import mas_oracle
+    inp = synth.make_inputs(2, 40, 150, variable=True, seed=35)
+    text, text_len, mel, mel_len, pitch, energy = (inp[k] for k in ("text", "text_len", "mel", "mel_len", "pitch", "energy"))
+    sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith("freq_scale") else v.clone())
+          for k, v in state_dict.items()}
+    emb = F.embedding(text, sd["text_embedding.weight"], padding_idx=0)
+    enc_mask = torch.arange(text.shape[1])[None, :] < text_len[:, None]
+    m3 = enc_mask[..., None]
+    enc_out = orc.transformer(sd, "encoder", emb, enc_mask)
+    soft, logits = orc.conv_attention(sd, mel, enc_out.detach().transpose(1, 2), mel_len, text_len)
+    hard = torch.from_numpy(mas_oracle.b_mas(logits.detach().numpy(), text_len.numpy(), mel_len.numpy()))
+    dur = hard.sum(dim=1)
+    pt = orc.soft_average(pitch[:, None], soft).transpose(1, 2) * m3
+    et = orc.soft_average(energy[:, None], soft).transpose(1, 2) * m3
+    targets = torch.cat([torch.log1p(dur.float())[..., None], pt, et], dim=-1)
+    _, flow_loss = orc.predictor_forward(sd, enc_out, targets.detach(), enc_mask, inp["flow_x0"], inp["flow_t"])
+    x = enc_out + orc.embedding_module(sd, torch.cat([pt, et], dim=-1), enc_mask)
+    dec_in = soft @ x
+    dec_mask = torch.arange(mel.shape[2])[None, :] < mel_len[:, None]
+    dec = orc.transformer(sd, "decoder", dec_in, dec_mask)
+    mel_ref = F.linear(dec, sd["to_mel.weight"], sd["to_mel.bias"]).transpose(1, 2) * dec_mask[:, None]
+    terms = {"model/mel_loss": torc.mel_loss(mel_ref, mel, mel_len), "adaptor/flow_loss": flow_loss,
+             "aligner/attention_loss": torc.attention_ctc_loss(logits, text_len, mel_len),
+             "aligner/kl_loss": torc.attention_binarization_loss(soft, hard)}
+    total_ref = sum(terms.values())
+    total_ref.backward()
+
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model = model.to(DEV).eval()
+    d = {k: v.to(DEV) for k, v in inp.items()}
+    mel_out, total, losses = train.acoustic_train_forward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"],
+                                                          d["energy"], flow_noise=d["flow_x0"], flow_time=d["flow_t"],
+                                                          train_aligner=True)
+    for k, v in terms.items():
+        _close(losses[k], v, 1e-4, k)
+    _close(total, total_ref, 1e-4, "total loss")
+    total.backward()
+    checked = 0
+    for name, p in model.named_parameters():
+        assert p.grad is not None, name
+        _close(p.grad, sd[name].grad, 2e-3, f"d {name}")
+        checked += 1
+    assert checked == 206, checked
+
+
+def test_conv_attention_backward_matches_autograd(state_dict):
+    """`train.aligner.ConvAttentionFunction`: (attn_soft, attn_logits) and the gradients of the aligner's 11 parameters under
+    random cotangents for BOTH outputs, against torch autograd over the oracle's ConvAttention (alignment.py:159-208).
+    Ragged lengths; M, L not multiples of 4 (the padded columns of d S)."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    from isp_tts_amd.train import aligner as tal
+    B, L, M = 3, 37, 141
+    mel_len, text_len = torch.tensor([141, 77, 120]), torch.tensor([37, 21, 33])
+    mel, keys = _rand((B, 80, M), 41), _rand((B, 384, L), 42)
+    g_soft, g_logits = _rand((B, M, L), 43), _rand((B, M, L), 44)
+    sd = {k: (v.clone().requires_grad_() if k.startswith("aligner.") and v.is_floating_point() else v) for k, v in state_dict.items()}
+    soft, logits = orc.conv_attention(sd, mel, keys, mel_len, text_len)
+    ((soft * g_soft).sum() + (logits * g_logits).sum()).backward()
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model = model.to(DEV).eval()
+    s, lg = tal.conv_attention_train(model.aligner.attention, mel.to(DEV), keys.to(DEV), mel_len.to(DEV), text_len.to(DEV))
+    _close(s, soft, 1e-4, "attn_soft")
+    _close(lg, logits, 1e-4, "attn_logits")
+    ((s * g_soft.to(DEV)).sum() + (lg * g_logits.to(DEV)).sum()).backward()
+    checked = 0
+    for name, p in model.aligner.attention.named_parameters():
+        _close(p.grad, sd["aligner.attention." + name].grad, 1e-3, f"d {name}")
+        checked += 1
+    assert checked == 11, checked
+
+
+def test_soft_average_and_length_regulator_alignment_gradients():
+    """The two adaptor steps through which the mel loss reaches attn_soft: `SoftAverageFunction` (TemporalAverager,
+    temporal_adaptor.py:446-449) and the alignment operand of `LengthRegulateFunction` (:419-421), against float64 autograd."""
+    from isp_tts_amd.train import aligner as tal
+    B, M, L, D = 3, 150, 40, 384
+    mel_len, text_len = torch.tensor([150, 77, 120]), torch.tensor([40, 21, 33])
+    mm, tm = torch.arange(M)[None, :] < mel_len[:, None], torch.arange(L)[None, :] < text_len[:, None]
+    A = torch.softmax(_rand((B, M, L), 51, 2.0), -1) * mm[..., None] * tm[:, None, :]
+    pitch, energy, gf = _rand((B, M), 52), _rand((B, M), 53), _rand((B, L, 3), 54)
+    A64 = A.double().requires_grad_()
+    avg = lambda v: (orc.soft_average(v.double()[:, None], A64)).transpose(1, 2) * tm[..., None]   # noqa: E731
+    pt, et = avg(pitch), avg(energy)
+    (torch.cat([torch.zeros_like(pt), pt, et], -1) * gf.double()).sum().backward()
+    Ag = A.to(DEV).requires_grad_()
+    f = tal.SoftAverageFunction.apply(Ag, pitch.to(DEV), energy.to(DEV), text_len.to(DEV))
+    _close(f[..., 1:], torch.cat([pt, et], -1), 1e-5, "soft averages")
+    (f * gf.to(DEV)).sum().backward()
+    _close(Ag.grad, A64.grad, 1e-5, "d attn_soft (soft averages)")
+    x, dout = _rand((B, L, D), 55), _rand((B, M, D), 56) * mm[..., None]
+    A64, x64 = A.double().requires_grad_(), x.double().requires_grad_()
+    (torch.bmm(A64, x64) * dout.double()).sum().backward()
+    Ag, xg = A.to(DEV).requires_grad_(), x.to(DEV).requires_grad_()
+    out, _, _ = train.LengthRegulateFunction.apply(xg, Ag, mel_len.view(-1, 1).to(DEV), M)
+    (out * dout.to(DEV)).sum().backward()
+    _close(Ag.grad, A64.grad, 1e-5, "d attn_soft (length regulator)")
+    _close(xg.grad, x64.grad, 1e-5, "d x (length regulator)")
+
+
+def test_projected_stack_passes_a_gradient_to_its_input(state_dict):
+    """The adaptor's embedding stack (2 -> 256 projection in front, transformer.py:170) as a differentiable node of a
+    NON-contiguous input slice (how the soft averages enter it): d input against autograd over the oracle."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    B, L = 2, 40
+    text_len = torch.tensor([40, 23])
+    mask = torch.arange(L)[None, :] < text_len[:, None]
+    feats = _rand((B, L, 3), 61).requires_grad_()
+    sd = {k[len("temporal_adaptor.embedding."):]: v for k, v in state_dict.items() if k.startswith("temporal_adaptor.embedding.")}
+    want = orc.transformer(sd, "transformer", feats[..., 1:3], mask)
+    gy = _rand(tuple(want.shape), 62)
+    (want * gy).sum().backward()
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model = model.to(DEV).eval()
+    fg = feats.detach().to(DEV).requires_grad_()
+    got = train.transformer_train_forward(model.temporal_adaptor.embedding.transformer, fg[..., 1:3], mask.to(DEV))
+    _close(got, want, 1e-4, "projected stack forward")
+    (got * gy.to(DEV)).sum().backward()
+    _close(fg.grad, feats.grad, 1e-3, "d features")
+    assert float(fg.grad[..., 0].abs().max()) == 0.0

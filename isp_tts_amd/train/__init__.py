@@ -1,4 +1,4 @@
-"""Training step for the forward path (BASELINE config 5) - first cut.
+"""Training step for the forward path (BASELINE config 5).
 
   optim.py   FlatParameters (one fp32 arena for parameters / gradients, weight-decay group first) and FlatAdamW: the
              reference's Optimizer.step (experiments/optimizers.py:230-244) as three launches - squared norm of the decay
@@ -9,13 +9,14 @@
   stack.py   also ToMelFunction (to_mel's Linear + transpose + mask, model.py:167-168) and `mel_decoder_train_forward`.
   predictor.py  the flow predictor (time embedding, AdaptiveLayerNorm projections, split input projection, adaptive-norm stack,
              output Linear, flow loss) as autograd nodes: `flow_predictor_loss`.
-  model.py   `acoustic_train_forward`: the whole teacher-forced forward with the mel and flow losses differentiable (aligner frozen).
-  aligner.py  the aligner front-end (conv blocks, masked instance norms, scores) and the soft averages as autograd nodes.
+  model.py   `acoustic_train_forward`: the whole teacher-forced forward under the reference's total loss (mel + flow + CTC +
+             binarisation, loss.py:140-182); gradients for every parameter tensor of the model.
+  aligner.py the aligner front-end (conv blocks, masked instance norms, scores) and the soft averages as autograd nodes
+             (csrc/aligner_bwd.hip).
   loss.py    MelLoss (models/acoustic/loss.py:22-35), AttentionCTCLoss (:39-77) and AttentionBinarizationLoss (:80-107), value
              and gradient by kernels.
 
-Not built yet: backward of the aligner front-end, the adaptor (AdaLN stacks, flow matching, length
-regulation), bf16 attention / weight-gradient kernels.
+Not tuned yet: the attention backward and the weight-gradient GEMMs run in fp32, launches are eager.
 """
 from .loss import AcousticModelLoss, AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
 from .model import acoustic_train_forward

@@ -21,7 +21,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # per-file extras.  ffn2.hip: keep the GELU's fp32 arithmetic scalar - the SLP vectoriser would pack adjacent values into
 # v_pk_*_f32, which issue slowly beside MFMAs (MI355X_MICROARCH.md, "price of one filler beside MFMAs")
-EXTRA_FLAGS = {"ffn2.hip": ["-fno-slp-vectorize"]}
+EXTRA_FLAGS = {"ffn2.hip": ["-fno-slp-vectorize"], "attention.hip": ["-fno-slp-vectorize"]}
 
 
 def _sources() -> list[str]:

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const flo
     float* Ks = reinterpret_cast<float*>(smem_raw);                        // [NB*32][128], swizzled (ks_off)
     char* stage = smem_raw + (threadIdx.x >> 6) * (32 * 144);  // per-wave transpose patch: aliases Ks once S is done
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
     const int m0 = blockIdx.x * (32 * kAsWaves) + wave * 32;

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(MAXT) void attn_f32_kernel(const float* __restrict_
     float* Vs = Ks + 2 * kTileKeys * kLdk;           // [2][64][kLdk]
 
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = wave % H, qhalf = wave / H;
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
     char* const Vl = smem_raw + kSlots * kSlotBytes;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar branches and addresses)
     const int head = wave % H, qhalf = wave / H;
     const int l31 = lane & 31, h = lane >> 5;
     const int b = blockIdx.y;
@@ -333,24 +333,35 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
         for (int c = 0; c < nchunks && c < ahead; ++c) issue_chunk(c);
     }
 
-    // Softmax bookkeeping, built to keep the per-block VALU work small:
-    //   * the ALiBi bias and the running reference maximum enter the score MFMA as its accumulator INIT,
-    //         acc = q·k + init,   init = (-slope2*|key - query| - m_ref) / scale2 = nsl*|key - query| + mref_s,
-    //     so p = exp2(acc * scale2) needs one packed multiply and one v_exp_f32 per score;
-    //   * away from the diagonal block the distance has a fixed sign and init is "wave base -/+ a per-register
-    //     constant" (8 packed adds); only the key0 == q0 block pays for the |.|;
+    // Softmax bookkeeping, built to keep the per-block VALU work small (the kernel is VALU-issue-bound):
+    //   * the ALiBi bias enters the score MFMA as its C operand.  Away from the diagonal block the distance key - query
+    //     has a fixed sign, so the bias is "a per-lane base -/+ a per-register constant": the constants are two loop-
+    //     invariant register vectors handed to the first MFMA as C (no instruction at all), and the base - together
+    //     with the running reference maximum - rides in the one FMA that scales a score into the exp2 argument,
+    //         p = exp2(fma(acc, scale2, base2)),   base2 = -m_ref -/+ slope2 * (key0 - query)   [exp2 units];
+    //     only the key0 == q0 block pays for the |.|;
     //   * m_ref is a LAZY reference: it is raised (and O, l rescaled) only when a block's scores exceed it by more than
     //     2^kLazy, so most blocks skip the 32-register rescale of O; exp2 arguments stay <= kLazy and the row's true
     //     maximum contributes p >= 1, so nothing overflows or underflows (m_ref starts as block 0's exact maximum);
-    //   * the row sum accumulates as packed pairs.
+    //   * plain fp32 instructions throughout (packed fp32 issues slowly beside MFMAs; -fno-slp-vectorize for this file).
     constexpr float kLazy = 16.0f;
     const float nsl = -8.0f * slopes[head];              // = -slope2 / scale2, exact
-    f32x2 cn[8];                                          // nsl * (key offset of accumulator registers 2j, 2j+1)
+    const float nsl2 = nsl * scale2;                      // = -slope2
+    // +/- nsl * (key offset of accumulator register r): MFMA C operands.  Resident (opaque, or hipcc rebuilds them from
+    // literals in front of every block) where the register budget allows: 168 VGPRs at 768 threads; the 1024-thread
+    // instances (128 VGPRs) recompute the vector per block instead.
+    constexpr bool kResidentC = MAXT <= 768;
+    f32x16 cpos, cneg;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        cn[j].x = nsl * (float)(((2 * j) & 3) + 8 * ((2 * j) >> 2));
-        cn[j].y = nsl * (float)(((2 * j + 1) & 3) + 8 * ((2 * j + 1) >> 2));
+    for (int r = 0; r < 16; ++r) {
+        cpos[r] = nsl * (float)((r & 3) + 8 * (r >> 2));
+        cneg[r] = -cpos[r];
     }
+    if constexpr (kResidentC) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(cpos[r]), "+v"(cneg[r]));
+    }
+    const float scale2s = [&] { float c = scale2; asm volatile("" : "+s"(c)); return c; }();   // in an SGPR: no literal dwords
 
     // per-lane LDS byte offsets inside a slot.  K fragment of k-step ks: row l31 (+ 32 per block), logical chunk 2ks + h.
     const uint32_t kl_base = lds_addr(Kl), vl_base = lds_addr(Vl);
@@ -377,8 +388,8 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float mref_s = 0.f;                                    // = -m_ref / scale2
-    f32x2 l2 = {0.f, 0.f};
+    float mref2 = 0.f;                                     // = -m_ref, exp2 units
+    float l2a = 0.f, l2b = 0.f;                            // row sum, two chains
     for (int c = 0; c < nchunks; ++c) {
         if constexpr (ST) ta = __builtin_readcyclecounter();
         if (it == 0) {
@@ -412,29 +423,44 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) lds_read_b128_asm<0>(kf[ks], koff[ks] + blk);
             f32x16 s;
+            float base2;                                   // exp2 argument = fma(s, scale2, base2)
             const float d0 = (float)(key0 + 4 * h - qi);   // key - query of accumulator register 0
-            if (key0 == q0w) {                              // wave-uniform: the one block that straddles the diagonal
+            if constexpr (kResidentC) {
+                lds_wait<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                if (key0 == q0w) {                          // wave-uniform: the one block that straddles the diagonal
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] = fmaf(fabsf(d0 + (float)((r & 3) + 8 * (r >> 2))), nsl, mref_s);
-            } else if (key0 < q0w) {                        // keys before the queries: |d| = -(d0 + c_r)
-                const float base = mref_s - nsl * d0;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const f32x2 t = base - cn[j];
-                    s[2 * j] = t.x; s[2 * j + 1] = t.y;
+                    for (int r = 0; r < 16; ++r) s[r] = fabsf(d0 + (float)((r & 3) + 8 * (r >> 2))) * nsl;
+                    base2 = mref2;
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], s, 0, 0, 0);
+                } else if (key0 < q0w) {                    // keys before the queries: |d| = -(d0 + c_r)
+                    base2 = fmaf(-nsl2, d0, mref2);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], cneg, 0, 0, 0);
+                } else {
+                    base2 = fmaf(nsl2, d0, mref2);
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], cpos, 0, 0, 0);
                 }
+#pragma unroll
+                for (int ks = 1; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
             } else {
-                const float base = mref_s + nsl * d0;
+                if (key0 == q0w) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const f32x2 t = base + cn[j];
-                    s[2 * j] = t.x; s[2 * j + 1] = t.y;
+                    for (int r = 0; r < 16; ++r) s[r] = fabsf(d0 + (float)((r & 3) + 8 * (r >> 2))) * nsl;
+                    base2 = mref2;
+                } else if (key0 < q0w) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = cneg[r];
+                    base2 = fmaf(-nsl2, d0, mref2);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[r] = cpos[r];
+                    base2 = fmaf(nsl2, d0, mref2);
                 }
-            }
-            lds_wait<0>();
-            __builtin_amdgcn_sched_barrier(0);
+                lds_wait<0>();
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s, 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
             u32x2 vr[2][2][2];   // [st][dim tile][run]: keys key0 + 16st + 4h + 0..3 (run 0) and + 8 (run 1) of this lane's dim
             static_for<0, 8>([&](auto ic) {
@@ -457,31 +483,29 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
             float bmax = max3_raw(s[0], s[1], s[2]);
 #pragma unroll
             for (int r = 3; r < 15; r += 2) bmax = max3_raw(bmax, s[r], s[r + 1]);
-            bmax = xhalf_max_swap(fmaxf(bmax, s[15]));
+            // this lane half's block maximum in exp2 units relative to m_ref (the base differs between the halves), then the row's
+            bmax = xhalf_max_swap(fmaf(fmaxf(bmax, s[15]), scale2s, base2));
             const bool first = key0 == 0;
-            if (first || __builtin_amdgcn_ballot_w64(bmax * scale2 > kLazy) != 0) {   // wave-uniform
+            if (first || __builtin_amdgcn_ballot_w64(bmax > kLazy) != 0) {   // wave-uniform
                 // raise the reference to this block's row maximum (block 0: set it), rescale what was accumulated
                 const float delta = first ? bmax : fmaxf(bmax, 0.f);
-                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta * scale2);
-                mref_s -= delta;
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                mref2 -= delta;
+                base2 -= delta;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    s[r] -= delta;
                     o0[r] *= alpha;
                     o1[r] *= alpha;
                 }
-                l2 *= alpha;
+                l2a *= alpha;
+                l2b *= alpha;
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                f32x2 z;
-                z.x = s[2 * j]; z.y = s[2 * j + 1];
-                z = z * scale2;
-                f32x2 pe;
-                pe.x = __builtin_amdgcn_exp2f(z.x);
-                pe.y = __builtin_amdgcn_exp2f(z.y);
-                s[2 * j] = pe.x; s[2 * j + 1] = pe.y;
-                l2 += pe;
+                s[2 * j] = __builtin_amdgcn_exp2f(fmaf(s[2 * j], scale2s, base2));
+                s[2 * j + 1] = __builtin_amdgcn_exp2f(fmaf(s[2 * j + 1], scale2s, base2));
+                l2a += s[2 * j];
+                l2b += s[2 * j + 1];
             }
             // P -> bf16 B-operand fragments (k-step st = registers 8st .. 8st+7)
             union { uint32_t u[4]; bf16x8 f; } pf[2];
@@ -503,7 +527,7 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
             if constexpr (ST) { __builtin_amdgcn_sched_barrier(0); td = __builtin_readcyclecounter(); ts[4] += td - tc; }
         }
     }
-    const float inv = 1.0f / xhalf_sum(l2.x + l2.y);
+    const float inv = 1.0f / xhalf_sum(l2a + l2b);
     if (qi < N) {
         uint16_t* op = out + ((int64_t)b * N + qi) * ldo + head * 64 + 4 * h;
 #pragma unroll

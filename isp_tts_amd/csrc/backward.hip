@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
     // Staging: thread (r = tid / 32, q = tid % 32) fetches float4 q of rows r, r + 8, r + 16, r + 24 of the A chunk and of the
     // B chunk (512 contiguous bytes per row and wave half), one chunk ahead of the MFMAs, double-buffered in LDS.
     extern __shared__ float lds[];
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, c = l & 31, hf = l >> 5;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, c = l & 31, hf = l >> 5;
     const int n1 = blockIdx.x * 128, n2 = blockIdx.y * 128, wa = (wave >> 1) * 64, wb = (wave & 1) * 64;
     // blockIdx.z = batch item * splits + row range (batched form: independent products A_b^T B_b, e.g. one per utterance)
     const int bz = blockIdx.z / splits, split = blockIdx.z - bz * splits;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                             int64_t lddx, int add_to_dx, float* __restrict__ part, int rows,
                                                             float eps) {
     constexpr int D = NPL * 64;
-    const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;
     float gm[NPL], dg[NPL], db[NPL];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                                                             const float* __restrict__ delta, float* __restrict__ dqkv, int N,
                                                             int H, float scale, uint32_t thresh, float inv_keep, uint64_t seed) {
     __shared__ float red[2][2][16][64];     // [dk | dv][M tile][register][lane]
-    const int kt = blockIdx.x, b = blockIdx.y, h = threadIdx.x >> 6, l = threadIdx.x & 63, c = l & 31, hf = l >> 5;
+    const int kt = blockIdx.x, b = blockIdx.y, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, c = l & 31, hf = l >> 5;
     const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
     const int j = kt * 32 + c;
     const float* qb = qkv + (int64_t)b * N * ld;
@@ -616,7 +616,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 // slope = exp(learned_logslopes), embeddings.py:59-82)
 __global__ __launch_bounds__(512) void slope_reduce_kernel(const float* __restrict__ part, int per_head, const float* __restrict__ slopes,
                                                            float* __restrict__ dlogslopes, int H) {
-    const int h = threadIdx.x >> 6, l = threadIdx.x & 63;      // one wave per head; lane l adds partials l, l + 64, ... in order
+    const int h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63;      // one wave per head; lane l adds partials l, l + 64, ... in order
     if (h >= H) return;
     float s = 0.f;
     for (int k = l; k < per_head; k += 64) s += part[(int64_t)h * per_head + k];

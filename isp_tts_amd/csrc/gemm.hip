@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
     float* As = reinterpret_cast<float*>(smem_raw);  // [2][BM][kLdt]
     float* Bs = As + 2 * BM * kLdt;                  // [2][BN][kLdt]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p) {
     uint16_t* As = reinterpret_cast<uint16_t*>(smem_raw);  // [2][BM][kLdtH]
     uint16_t* Bs = As + 2 * BM * kLdtH;                    // [2][BN][kLdtH]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) 
     static_assert((BM + BN) / 8 % NWV == 0 && (S - 1) * IPL <= 63, "DMA split / vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM;
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_panel_kernel(GemmParams p, i
     const int ns = jj % nsplit, mb = (jj / nsplit) * 8 + xcd;
     if (mb >= mblocks) return;  // whole workgroup, before any barrier
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int m = mb * 128 + wave * 32 + l31;
     const int ntiles = (p.N + 63) / 64;
@@ -1384,7 +1384,7 @@ __global__ __launch_bounds__(256, 1) void ffn_bf16_kernel(GemmParams p, const ui
     uint16_t* W2s = W1s + 2 * HC * LD1;                      // [2][D][LD2]
     char* stage = smem_raw + (size_t)(2 * HC * LD1 + 2 * D * LD2) * 2 + (threadIdx.x >> 6) * kStageBytes;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, h = lane >> 5;
     const int mw0 = blockIdx.x * 128 + wave * 32;
     const int m = mw0 + l31;

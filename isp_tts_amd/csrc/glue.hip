@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
     float* As = reinterpret_cast<float*>(smem + 16);                         //  object would shift its 16-byte alignment)
     float* Xs = As + kLrRows * kLrAld;                                       // [16][D]   (As: [64][17] = 4352 B)
     float* cum = Xs + kLrChunk * D;                                          // [L + 1]   (soft path only): cum[t] = sum_{u<t}
-    const int b = blockIdx.y, y0 = blockIdx.x * kLrRows, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, y0 = blockIdx.x * kLrRows, tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool soft = align == nullptr;
 
     // ---- decoder length of this utterance (every workgroup of the utterance computes the same value; tile 0 stores it)

@@ -3,6 +3,8 @@
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from isp_tts_amd import runtime, synth
+if os.environ.get("BENCH_LIB"):      # A/B: time another build of the library (path relative to the package)
+    runtime.LIB_PATH = os.path.join(os.path.dirname(runtime.__file__), os.environ["BENCH_LIB"])
 R, dev, dt = 32768, "cuda", torch.bfloat16
 x = synth._normal("b/x", (R, 384)).to(dev).to(dt)
 x1536 = synth._normal("b/x2", (R, 1536)).to(dev).to(dt)

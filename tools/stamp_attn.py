@@ -2,7 +2,8 @@
 """In-kernel phase stamps of the bf16 attention kernel (ISPK_ATTN_STAMP)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from isp_tts_amd import runtime, synth
+from isp_tts_amd import build, runtime, synth
+runtime.LIB_PATH = build.LIB_EXP      # stamps exist in the experiments build only
 B, T, H, dev = 64, int(sys.argv[1]) if len(sys.argv) > 1 else 512, 6, "cuda"
 qkv = (synth._normal("b/qkv", (B, T, 512)) * 2.0).to(dev).to(torch.bfloat16)
 slopes = torch.tensor(synth.alibi_default_slopes(H), device=dev)

@@ -312,13 +312,14 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     const uint32_t w2a1 = lds0 + kW1Bytes + (192 * half + l31) * 64 + 16 * ((2 + h) ^ psw);  //                        (k-step 1)
     const uint32_t pa0 = lds0 + kPOff + rg * 2048 + l31 * 64 + 16 * ((0 + h) ^ psw);         // + 8192 parity
     const uint32_t pa1 = lds0 + kPOff + rg * 2048 + l31 * 64 + 16 * ((2 + h) ^ psw);
-    bf16x8 r1[4];          // product 1 ring: W1 fragments
-    bf16x8 r2[4], pb[2];   // product 2 ring: W2 fragments; the two P fragments
+    constexpr int kRing = 4;   // operand fragments in flight per matrix stage (6: 246 VGPRs, measured 2 % slower)
+    bf16x8 r1[kRing];          // product 1 ring: W1 fragments
+    bf16x8 r2[kRing], pb[2];   // product 2 ring: W2 fragments; the two P fragments
 
     auto prefetch1 = [&](int it) __attribute__((always_inline)) {     // first 4 W1 fragments of chunk `it`
         const uint32_t a = w1a + (it & 1) * kWbuf;
         if constexpr (ABL != 11)
-            static_for<0, 4>([&](auto kc) { lds_read_b128_asm<32 * decltype(kc)::value>(r1[decltype(kc)::value], a); });
+            static_for<0, kRing>([&](auto kc) { lds_read_b128_asm<32 * decltype(kc)::value>(r1[decltype(kc)::value], a); });
     };
     auto product1 = [&](int it, bool dma) __attribute__((always_inline)) {   // S = W1[chunk it][:, this half of K] · xfᵀ ; send 8, keep 8
         const uint32_t a = w1a + (it & 1) * kWbuf;
@@ -328,11 +329,11 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
         if constexpr (kPrio) __builtin_amdgcn_s_setprio(1);
         static_for<0, 12>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
-            if constexpr (ABL != 11) lds_wait<(11 - ks) < 3 ? (11 - ks) : 3>();   // fragment ks is in; up to 3 younger reads may be in flight
+            if constexpr (ABL != 11) lds_wait<(11 - ks) < kRing - 1 ? (11 - ks) : kRing - 1>();   // fragment ks is in; younger reads may be in flight
             __builtin_amdgcn_sched_barrier(0);
-            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1[ks & 3], xf[ks], S, 0, 0, 0);
+            S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r1[ks % kRing], xf[ks], S, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ks + 4 < 12 && ABL != 11) lds_read_b128_asm<32 * (ks + 4)>(r1[ks & 3], a);
+            if constexpr (ks + kRing < 12 && ABL != 11) lds_read_b128_asm<32 * (ks + kRing)>(r1[ks % kRing], a);
             if constexpr ((ks & 3) == 1) {
                 if (dma) dma_one(std::integral_constant<int, ks / 4>{});           // DMA instructions 0, 1, 2
             }
@@ -377,15 +378,15 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     // product 2 reads, in order: P k-step 0, P k-step 1, then W2 fragment j = 2 nt + ks for j = 0 .. 11
     auto w2read = [&](auto jc, uint32_t b0, uint32_t b1) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        if constexpr (j & 1) lds_read_b128_asm<2048 * (j >> 1)>(r2[j & 3], b1);
-        else lds_read_b128_asm<2048 * (j >> 1)>(r2[j & 3], b0);
+        if constexpr (j & 1) lds_read_b128_asm<2048 * (j >> 1)>(r2[j % kRing], b1);
+        else lds_read_b128_asm<2048 * (j >> 1)>(r2[j % kRing], b0);
     };
     auto prefetch2 = [&](int it) __attribute__((always_inline)) {     // the P fragments and the first 4 W2 fragments
         const uint32_t b0 = w2a0 + (it & 1) * kWbuf, b1 = w2a1 + (it & 1) * kWbuf;
         if constexpr (ABL != 11) {
             lds_read_b128_asm<0>(pb[0], pa0 + (it & 1) * 8192);
             lds_read_b128_asm<0>(pb[1], pa1 + (it & 1) * 8192);
-            static_for<0, 4>([&](auto jc) { w2read(jc, b0, b1); });
+            static_for<0, kRing>([&](auto jc) { w2read(jc, b0, b1); });
         }
     };
     auto product2 = [&](int it, bool dma) __attribute__((always_inline)) {   // acc2 += W2[this half's 192 features][chunk it - 2] · Pᵀ
@@ -393,11 +394,11 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
         if constexpr (kPrio) __builtin_amdgcn_s_setprio(1);
         static_for<0, 12>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
-            if constexpr (ABL != 11) lds_wait<(11 - j) < 3 ? (11 - j) : 3>();
+            if constexpr (ABL != 11) lds_wait<(11 - j) < kRing - 1 ? (11 - j) : kRing - 1>();
             __builtin_amdgcn_sched_barrier(0);
-            acc2[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2[j & 3], pb[j & 1], acc2[j >> 1], 0, 0, 0);
+            acc2[j >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2[j % kRing], pb[j & 1], acc2[j >> 1], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j + 4 < 12 && ABL != 11) w2read(std::integral_constant<int, j + 4>{}, b0, b1);
+            if constexpr (j + kRing < 12 && ABL != 11) w2read(std::integral_constant<int, j + kRing>{}, b0, b1);
             if constexpr ((j & 3) == 1) {
                 if (dma) dma_one(std::integral_constant<int, 3 + j / 4>{});        // DMA instructions 3, 4, 5
             }

@@ -192,18 +192,49 @@ __global__ __launch_bounds__(256) void smallk_wgrad_stage1_kernel(const float* _
 }
 
 // d table[v][:] = sum over the token positions r with ids[r] == v of d_emb[r][:], rows visited in index order (nn.Embedding's
-// backward, model.py:131; the padding row gets no gradient).  One workgroup per vocabulary row.
+// backward, model.py:131; the padding row gets no gradient).  One workgroup per vocabulary row, the token ids walked in
+// segments of kEmbSeg: every thread tests its ids of the segment (independent loads), wave 0 compacts the hits into an
+// ordered row list (ballot + prefix popcount), then thread c adds d_emb[row][c] over the list - the same order as a serial
+// scan, without its 'rows' dependent loads per thread.
+constexpr int kEmbSeg = 4096;
 __global__ __launch_bounds__(128) void embedding_bwd_kernel(const int64_t* __restrict__ ids, const float* __restrict__ d_emb,
                                                             int64_t rows, int D, int padding_idx, float* __restrict__ d_table,
                                                             int64_t ld_table) {
-    const int v = blockIdx.x;
-    for (int c = threadIdx.x; c < D; c += 128) {
-        float s = 0.f;
-        if (v != padding_idx)
-            for (int64_t r = 0; r < rows; ++r)
-                if (ids[r] == v) s += d_emb[r * D + c];
-        d_table[(int64_t)v * ld_table + c] = s;
+    __shared__ uint8_t hit[kEmbSeg];
+    __shared__ int list[kEmbSeg];
+    __shared__ int count_s;
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};                      // columns tid, tid + 128, ... (D <= 512)
+    if (v != padding_idx) {
+        for (int64_t seg = 0; seg < rows; seg += kEmbSeg) {
+            const int n = (int)(rows - seg < kEmbSeg ? rows - seg : kEmbSeg);
+            for (int i = tid; i < kEmbSeg; i += 128) hit[i] = (i < n && ids[seg + i] == v) ? 1 : 0;
+            __syncthreads();
+            if (tid < 64) {
+                int count = 0;
+                for (int base = 0; base < n; base += 64) {
+                    const bool mine = hit[base + lane] != 0;
+                    const unsigned long long m = __ballot(mine);
+                    if (mine) list[count + __popcll(m & ((1ull << lane) - 1ull))] = base + lane;
+                    count += __popcll(m);
+                }
+                if (lane == 0) count_s = count;
+            }
+            __syncthreads();
+            const int count = count_s;
+#pragma unroll 4
+            for (int k = 0; k < count; ++k) {
+                const float* g = d_emb + (seg + list[k]) * D;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (tid + 128 * j < D) s[j] += g[tid + 128 * j];
+            }
+            __syncthreads();
+        }
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (tid + 128 * j < D) d_table[(int64_t)v * ld_table + tid + 128 * j] = s[j];
 }
 
 __global__ __launch_bounds__(256) void colsum_stage2_kernel(const float* __restrict__ part, int cols, float* __restrict__ out) {
@@ -664,7 +695,7 @@ extern "C" int32_t ispk_smallk_wgrad_f32(const float* g, int64_t ldg, const floa
 extern "C" int32_t ispk_embedding_bwd_f32(const int64_t* ids, const float* d_emb, int64_t rows, int32_t dim, int32_t vocab,
                                           int32_t padding_idx, float* d_table, int64_t ld_table, ispk_stream_t stream) {
     ISPK_REQUIRE(ids && d_emb && d_table, -1, "ispk_embedding_bwd_f32: null pointer");
-    ISPK_REQUIRE(rows >= 0 && dim >= 1 && vocab >= 1 && ld_table >= dim, -2, "ispk_embedding_bwd_f32: bad shape rows=%lld dim=%d vocab=%d",
+    ISPK_REQUIRE(rows >= 0 && dim >= 1 && dim <= 512 && vocab >= 1 && ld_table >= dim, -2, "ispk_embedding_bwd_f32: bad shape rows=%lld dim=%d (<= 512) vocab=%d",
                  (long long)rows, dim, vocab);
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3(vocab), dim3(128), 0, reinterpret_cast<hipStream_t>(stream), ids, d_emb, rows, dim,
                        padding_idx, d_table, ld_table);

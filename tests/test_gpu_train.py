@@ -782,3 +782,18 @@ def test_projected_stack_passes_a_gradient_to_its_input(state_dict):
     (got * gy.to(DEV)).sum().backward()
     _close(fg.grad, feats.grad, 1e-3, "d features")
     assert float(fg.grad[..., 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,dim,vocab", [(9001, 384, 50), (6400, 384, 149), (70, 256, 10)])
+def test_embedding_backward_over_segments(rows, dim, vocab):
+    """d table = index_add of the token gradients (nn.Embedding backward, model.py:131) with more tokens than one segment of
+    the kernel's id scan, a ragged tail, an unused vocabulary row and the padding row; fixed order -> identical bits twice."""
+    g = torch.Generator().manual_seed(71)
+    ids = torch.randint(0, vocab - 1, (rows,), generator=g)          # row vocab - 1 never occurs
+    d_emb = _rand((rows, dim), 72)
+    want = torch.zeros(vocab, dim, dtype=torch.float64).index_add_(0, ids, d_emb.double())
+    want[0] = 0.0
+    got = runtime.embedding_bwd(ids.to(DEV), d_emb.to(DEV), vocab, padding_idx=0)
+    _close(got, want, 2e-6, "d table")
+    assert float(got[0].abs().max()) == 0.0 and float(got[vocab - 1].abs().max()) == 0.0
+    assert torch.equal(got, runtime.embedding_bwd(ids.to(DEV), d_emb.to(DEV), vocab, padding_idx=0))

@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from isp_tts_amd import build, runtime, synth
 if os.environ.get("ISPK_FFN2_ABLATE") or os.environ.get("EXP"):   # ablations live in the experiments build only
     runtime.LIB_PATH = build.LIB_EXP
+if os.environ.get("BENCH_LIB"):      # A/B: time another build of the library (path relative to the package)
+    runtime.LIB_PATH = os.path.join(os.path.dirname(runtime.__file__), os.environ["BENCH_LIB"])
 R, D, Fi = int(os.environ.get("R", 32768)), 384, 1536
 dev = "cuda"
 x = synth._normal("b/ffn/x", (R, D), 1.5, 0.4).to(dev)

@@ -450,6 +450,11 @@ int32_t ispk_transpose_f32(const float* x, int64_t ldx, float* y, int64_t ldy, i
 int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
                          int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
                          int64_t workspace_floats, ispk_stream_t stream);
+/* The same product with the fp32 operands rounded to bf16 on their way to the MFMAs, fp32 accumulation: the weight gradient of a
+ * Linear under autocast (recipes/default.yaml:56; torch's Linear backward multiplies bf16 copies of dY and X). */
+int32_t ispk_gemm_tn_bf16(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
+                          int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
+                          int64_t workspace_floats, ispk_stream_t stream);
 /* The same product for `batch` independent pairs (A_b, B_b) at element strides stride_a / stride_b, C_b at stride_c - e.g. the
  * backward of the length regulator (temporal_adaptor.py:419-421: out_b = A_b x_b): d x_b = A_b^T d out_b per utterance.
  * row_mask (or NULL) is [batch][M]; workspace >= batch * N1 * N2 floats. */

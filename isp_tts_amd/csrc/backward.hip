@@ -145,6 +145,147 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
         }
 }
 
+// The same product with bf16 operands (the weight gradients of a step under autocast, recipes/default.yaml:56: the reference's
+// Linear backward multiplies bf16 copies of dY and X): fp32 rows are rounded to bf16 on their way into LDS, the 32-row chunk of
+// each operand is a [32][128] bf16 image with 256-byte rows, 16-byte chunk ch of row r at 256 r + 16 (ch ^ (((r & 3) << 2) |
+// ((r >> 2) & 3))), and ds_read_b64_tr_b16 hands every lane 4 consecutive ROWS of its column - the k-major operand fragment
+// of v_mfma_f32_32x32x16_bf16 without a transposing pass (both operands take rows 8g .. 8g+3 | 8g+4 .. 8g+7 of a 16-row
+// step for lane half g: any k order is fine as long as A and B agree).  fp32 accumulation, the same workspace / ordered sum.
+typedef uint32_t tn_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t tn_img_off(int row, int ch) { return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+template <int OFF>
+__device__ __forceinline__ void tn_read_tr(tn_u32x2& dst, uint32_t addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory");
+}
+constexpr int kTnImg = kTnRows * 256;            // bytes of one operand's chunk image
+
+template <bool kMask>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                           int64_t ldb, float* __restrict__ part, int M, int N1, int N2,
+                                                           int rows_per_split, const uint8_t* __restrict__ mask, int splits,
+                                                           int64_t stride_a, int64_t stride_b) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];      // [2 buffers][A image | B image]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, c = l & 31, hf = l >> 5;
+    const int n1 = blockIdx.x * 128, n2 = blockIdx.y * 128, wa = (wave >> 1) * 64, wb = (wave & 1) * 64;
+    const int bz = blockIdx.z / splits, split = blockIdx.z - bz * splits;
+    A += (int64_t)bz * stride_a;
+    B += (int64_t)bz * stride_b;
+    if (kMask) mask += (int64_t)bz * M;
+    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    const int sr = tid >> 5, sq = (tid & 31) * 4;
+    const bool a_ok = n1 + sq < N1, b_ok = n2 + sq < N2;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 ra[4], rb[4];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + sr + 8 * j;
+            const bool ok = m < m_end;
+            float sc = 1.f;
+            if (kMask) sc = (ok && mask[m]) ? 1.f : 0.f;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            ra[j] = (ok && a_ok) ? *reinterpret_cast<const f32x4*>(A + (int64_t)m * lda + n1 + sq) : z;
+            rb[j] = (ok && b_ok) ? *reinterpret_cast<const f32x4*>(B + (int64_t)m * ldb + n2 + sq) : z;
+            if (kMask) ra[j] *= sc;
+        }
+    };
+    auto pack2 = [](float lo, float hi) {
+        typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 v;
+        v.x = lo; v.y = hi;
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+    };
+    auto stash = [&](int buf) {       // float4 (columns sq .. sq+3) -> 8 bytes at chunk sq / 8, half (sq / 4) & 1
+        char* sa = ldsb + buf * 2 * kTnImg;
+        char* sb = sa + kTnImg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = sr + 8 * j;
+            const uint32_t off = tn_img_off(row, sq >> 3) + 8 * ((sq >> 2) & 1);
+            uint2 pa, pb;
+            pa.x = pack2(ra[j][0], ra[j][1]); pa.y = pack2(ra[j][2], ra[j][3]);
+            pb.x = pack2(rb[j][0], rb[j][1]); pb.y = pack2(rb[j][2], rb[j][3]);
+            *reinterpret_cast<uint2*>(sa + off) = pa;
+            *reinterpret_cast<uint2*>(sb + off) = pb;
+        }
+    };
+    // transposing reads: 16-lane group (half hf, 16-column block sub) takes the block of 4 rows x 16 columns whose lane
+    // 4q + p addresses row r0 + q, columns 4p .. 4p+3, i.e. chunk c0 + (p >> 1), byte 8 (p & 1); lane i receives column i
+    const int sub = (l >> 4) & 1, q = (l & 15) >> 2, pp = l & 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)ldsb;
+    // address of (16-row step ks, rows 8 hf + 4 run + q, 32-column tile at column cb): all tiles / steps / runs differ from
+    // tile 0, step 0, run 0 by a row offset that changes the swizzle, so each gets its own address register (16)
+    uint32_t aoff[2][2][2], boff[2][2][2];      // [step][run][tile]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int run = 0; run < 2; ++run)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = 16 * ks + 8 * hf + 4 * run + q;
+                aoff[ks][run][t] = tn_img_off(row, ((wa + 32 * t) >> 3) + 2 * sub + (pp >> 1)) + 8 * (pp & 1);
+                boff[ks][run][t] = kTnImg + tn_img_off(row, ((wb + 32 * t) >> 3) + 2 * sub + (pp >> 1)) + 8 * (pp & 1);
+            }
+    fetch(m_begin);
+    stash(0);
+    __syncthreads();
+    int buf = 0;
+    for (int m0 = m_begin; m0 < m_end; m0 += kTnRows) {
+        const bool more = m0 + kTnRows < m_end;
+        if (more) fetch(m0 + kTnRows);
+        const uint32_t base = lds0 + buf * 2 * kTnImg;
+        tn_u32x2 fa[2][2][2], fb[2][2][2];     // [step][tile][run]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int run = 0; run < 2; ++run) {
+                    tn_read_tr<0>(fa[ks][t][run], base + aoff[ks][run][t]);
+                    tn_read_tr<0>(fb[ks][t][run], base + boff[ks][run][t]);
+                }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            union { uint32_t u[4]; bf16x8 f; } a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t].u[0] = fa[ks][t][0][0]; a[t].u[1] = fa[ks][t][0][1]; a[t].u[2] = fa[ks][t][1][0]; a[t].u[3] = fa[ks][t][1][1];
+                b[t].u[0] = fb[ks][t][0][0]; b[t].u[1] = fb[ks][t][0][1]; b[t].u[2] = fb[ks][t][1][0]; b[t].u[3] = fb[ks][t][1][1];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].f, b[0].f, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].f, b[1].f, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].f, b[0].f, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].f, b[1].f, acc[1][1], 0, 0, 0);
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    float* out = part + (int64_t)blockIdx.z * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n2 + wb + 32 * j + c;
+            if (col >= N2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n1 + wa + 32 * i + acc_row(r, hf);
+                if (row < N1) out[(int64_t)row * N2 + col] = acc[i][j][r];
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int splits, int64_t n, int cols,
                                                            float* __restrict__ C, int64_t ldc, int accumulate, int64_t stride_c) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -637,7 +778,8 @@ extern "C" int32_t ispk_transpose_f32(const float* x, int64_t ldx, float* y, int
 
 static int32_t gemm_tn_launch(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b, float* C,
                               int64_t ldc, int64_t stride_c, int batch, int M, int N1, int N2, const uint8_t* row_mask,
-                              int accumulate, float* workspace, int64_t workspace_floats, hipStream_t s, const char* who) {
+                              int accumulate, float* workspace, int64_t workspace_floats, hipStream_t s, const char* who,
+                              bool bf16_operands = false) {
     ISPK_REQUIRE(A && B && C && workspace, -1, "%s: null pointer", who);
     // (ldb < N2 is allowed: overlapping rows, i.e. the 5-tap windows of a padded convolution input)
     ISPK_REQUIRE(batch >= 1 && M >= 1 && N1 >= 4 && N2 >= 4 && N1 % 4 == 0 && N2 % 4 == 0 && lda >= N1 && ldb >= 4 && ldc >= N2 &&
@@ -659,6 +801,18 @@ static int32_t gemm_tn_launch(const float* A, int64_t lda, int64_t stride_a, con
     splits = (M + rows_per - 1) / rows_per;
     ISPK_REQUIRE(splits * batch <= 65535, -4, "%s: batch %d x %lld row ranges exceed the grid limit", who, batch, (long long)splits);
     const dim3 grid((N1 + 127) / 128, (N2 + 127) / 128, (unsigned)(splits * batch));
+    if (bf16_operands) {
+        constexpr size_t lds16 = 2 * 2 * kTnImg;                  // 32 KB
+        if (row_mask)
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
+                               row_mask, (int)splits, stride_a, stride_b);
+        else
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
+                               row_mask, (int)splits, stride_a, stride_b);
+        hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((tile + 255) / 256), batch), dim3(256), 0, s, workspace, (int)splits,
+                           tile, N2, C, ldc, accumulate, stride_c);
+        return ispk_launch_status();
+    }
     constexpr size_t lds_bytes = 2 * kTnStage * sizeof(float);   // 80 KB: two workgroups per CU
     if (row_mask) {
         ISPK_RESERVE_LDS(gemm_tn_kernel<true>, lds_bytes, "ispk_gemm_tn_f32");
@@ -679,6 +833,13 @@ extern "C" int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B,
                                     int64_t workspace_floats, ispk_stream_t stream) {
     return gemm_tn_launch(A, lda, 0, B, ldb, 0, C, ldc, 0, 1, M, N1, N2, row_mask, accumulate, workspace, workspace_floats,
                           reinterpret_cast<hipStream_t>(stream), "ispk_gemm_tn_f32");
+}
+
+extern "C" int32_t ispk_gemm_tn_bf16(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
+                                     int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
+                                     int64_t workspace_floats, ispk_stream_t stream) {
+    return gemm_tn_launch(A, lda, 0, B, ldb, 0, C, ldc, 0, 1, M, N1, N2, row_mask, accumulate, workspace, workspace_floats,
+                          reinterpret_cast<hipStream_t>(stream), "ispk_gemm_tn_bf16", true);
 }
 
 extern "C" int32_t ispk_gemm_tn_batched_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb,

@@ -64,6 +64,7 @@ SIGNATURES = {
     "ispk_soft_average_f32": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_transpose_f32": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ispk_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
+    "ispk_gemm_tn_bf16": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_gemm_tn_batched_f32": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_layernorm_bwd_f32": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _I64, _I32, _F32, _P],
     "ispk_gelu_f32": [_P, _P, _I64, _F32, _U64, _P],
@@ -839,8 +840,9 @@ def workspace(device, floats: int) -> Tensor:
 
 
 def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Optional[Tensor] = None,
-            accumulate: bool = False) -> Tensor:
-    """ispk_gemm_tn_f32: C[N1, N2] (+)= sum_m mask[m] a[m, N1] b[m, N2] - the weight gradient dY^T . X of a Linear."""
+            accumulate: bool = False, bf16: bool = False) -> Tensor:
+    """ispk_gemm_tn_f32: C[N1, N2] (+)= sum_m mask[m] a[m, N1] b[m, N2] - the weight gradient dY^T . X of a Linear.
+    `bf16`: ispk_gemm_tn_bf16, the operands rounded to bf16 in flight (autocast's weight gradient), fp32 accumulation."""
     _dev(a, b, row_mask, out)
     a2, b2 = _rows2d(a), _rows2d(b)
     assert a2.dtype == torch.float32 and b2.dtype == torch.float32 and a2.shape[0] == b2.shape[0]
@@ -854,8 +856,8 @@ def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Option
         row_mask = row_mask.reshape(-1).contiguous()
         assert row_mask.dtype == torch.bool and row_mask.numel() == M
     ws = workspace(a.device, N1 * N2)
-    _launch(f"gemm_tn_kernel<{N1}x{N2}>", 2.0 * M * N1 * N2, 4.0 * (a2.numel() + b2.numel() + out.numel()),
-            lib().ispk_gemm_tn_f32, a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), out.data_ptr(), out.stride(0), M,
+    _launch(f"gemm_tn_{'bf16_' if bf16 else ''}kernel<{N1}x{N2}>", 2.0 * M * N1 * N2, 4.0 * (a2.numel() + b2.numel() + out.numel()),
+            lib().ispk_gemm_tn_bf16 if bf16 else lib().ispk_gemm_tn_f32, a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), out.data_ptr(), out.stride(0), M,
             N1, N2, _ptr(row_mask), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
     return out
 

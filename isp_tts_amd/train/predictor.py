@@ -206,18 +206,18 @@ class AdaptiveStackFunction(torch.autograd.Function):
             w1_t16, w2_t16 = ff._cache.get("t16", (ff.net[0].weight, ff.net[3].weight),
                                            lambda: t16(w1_t, w2_t)) if amp else (None, None)
             c = 4 * li * D
-            dw2 = runtime.gemm_tn(dy, a, row_mask=mask)
+            dw2 = runtime.gemm_tn(dy, a, row_mask=mask, bf16=amp)
             da = _mm(dy, w2_t, w2_t16, mask=mask, flags=mflag)
             du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
-            dw1 = runtime.gemm_tn(du, h2)
+            dw1 = runtime.gemm_tn(du, h2, bf16=amp)
             dh2 = _mm(du, w1_t, w1_t16)
             dx1 = runtime.adaln_bwd(x1, dh2, ss[:, c + 2 * D:c + 3 * D], mask, dy, True, d_ss[:, c + 2 * D:c + 3 * D],
                                     d_ss[:, c + 3 * D:c + 4 * D], layer.feed_forward_norm.eps)
-            dwo = runtime.gemm_tn(dx1, o, row_mask=mask)
+            dwo = runtime.gemm_tn(dx1, o, row_mask=mask, bf16=amp)
             d_o = _mm(dx1, wo_t, wo_t16, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
                                                         seed=seed_att)
-            dwqkv = runtime.gemm_tn(dqkv, h)
+            dwqkv = runtime.gemm_tn(dqkv, h, bf16=amp)
             dh = _mm(dqkv, wqkv_t, wqkv_t16)
             dy = runtime.adaln_bwd(xin, dh, ss[:, c:c + D], None, dx1, True, d_ss[:, c:c + D], d_ss[:, c + D:c + 2 * D],
                                    layer.attention_norm.eps)

@@ -127,18 +127,18 @@ class TransformerStackFunction(torch.autograd.Function):
             w1_t16, w2_t16 = ff._cache.get("t16", (ff.net[0].weight, ff.net[3].weight),
                                            lambda: t16(w1_t, w2_t)) if amp else (None, None)
             # feed-forward block
-            dw2 = runtime.gemm_tn(dy, a, row_mask=mask)                         # [dim, inner]
+            dw2 = runtime.gemm_tn(dy, a, row_mask=mask, bf16=amp)                         # [dim, inner]
             da = _mm(dy, w2_t, w2_t16, mask=mask, flags=mflag)                   # (m dy) W2
             du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
-            dw1 = runtime.gemm_tn(du, h2)                                        # [inner, dim]
+            dw1 = runtime.gemm_tn(du, h2, bf16=amp)                                        # [inner, dim]
             dh2 = _mm(du, w1_t, w1_t16)
             dx1, dg2, db2 = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps)
             # attention block
-            dwo = runtime.gemm_tn(dx1, o, row_mask=mask)                         # [dim, heads*64]
+            dwo = runtime.gemm_tn(dx1, o, row_mask=mask, bf16=amp)                         # [dim, heads*64]
             d_o = _mm(dx1, wo_t, wo_t16, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
                                                         seed=seed_att)
-            dwqkv = runtime.gemm_tn(dqkv, h)                                     # [heads*64 + 128, dim]
+            dwqkv = runtime.gemm_tn(dqkv, h, bf16=amp)                                     # [heads*64 + 128, dim]
             dh = _mm(dqkv, wqkv_t, wqkv_t16)
             dy, dg1, db1 = runtime.layernorm_bwd(xin, dh, an.weight, dx=dx1, add_to_dx=True, eps=an.eps)
             hq = att.heads * 64

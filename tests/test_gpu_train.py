@@ -797,3 +797,23 @@ def test_embedding_backward_over_segments(rows, dim, vocab):
     _close(got, want, 2e-6, "d table")
     assert float(got[0].abs().max()) == 0.0 and float(got[vocab - 1].abs().max()) == 0.0
     assert torch.equal(got, runtime.embedding_bwd(ids.to(DEV), d_emb.to(DEV), vocab, padding_idx=0))
+
+
+@pytest.mark.parametrize("M,N1,N2,masked", [(1000, 80, 384, False), (4099, 384, 1536, True), (64, 512, 384, True),
+                                             (32768, 1536, 384, False)])
+def test_gemm_tn_bf16_operands(M, N1, N2, masked):
+    """ispk_gemm_tn_bf16 (autocast's weight gradient): the fp32 operands rounded to bf16 in flight, fp32 accumulation -
+    against float64 over the SAME bf16-rounded operands (2e-5 of the result's scale: accumulation order only), and within
+    bf16 rounding of the fp32 product.  Row tails, column tails, row mask, accumulation; identical bits run to run."""
+    a, b = _rand((M, N1), 81), _rand((M, N2), 82)
+    mask = (torch.arange(M) % 7 != 3) if masked else None
+    a16, b16 = a.bfloat16().double(), b.bfloat16().double()
+    want = ((a16 * mask[:, None]) if masked else a16).T @ b16
+    ad, bd, md = a.to(DEV), b.to(DEV), (mask.to(DEV) if masked else None)
+    got = runtime.gemm_tn(ad, bd, row_mask=md, bf16=True)
+    _close(got, want, 2e-5, "gemm_tn bf16")
+    _close(got, ((a.double() * mask[:, None]) if masked else a.double()).T @ b.double(), 1e-2, "gemm_tn bf16 vs the fp32 product")
+    assert torch.equal(got, runtime.gemm_tn(ad, bd, row_mask=md, bf16=True))
+    acc = got.clone()
+    runtime.gemm_tn(ad, bd, row_mask=md, out=acc, accumulate=True, bf16=True)
+    _close(acc, 2 * want, 2e-5, "gemm_tn bf16 accumulate")

@@ -685,8 +685,9 @@ def worker(args) -> int:
                 kern = None
                 if prof is not None:
                     runtime.set_profiler(prof)
-                    st()
-                    torch.cuda.synchronize()
+                st()                       # EVERY rank takes this step (its collectives must match); rank 0 records it
+                torch.cuda.synchronize()
+                if prof is not None:
                     runtime.set_profiler(None)
                     summ = prof.summary()
                     kern = {k: {"ms": round(v["total_ms"], 3), "launches": v["launches"]} for k, v in

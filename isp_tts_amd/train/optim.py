@@ -108,6 +108,7 @@ class FlatAdamW:
         self.exp_avg = torch.zeros(self.shard, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(self.shard, dtype=torch.float32, device=dev)
         self.grad_shard = torch.zeros(self.shard, dtype=torch.float32, device=dev) if self.world > 1 else None
+        self.param_shard = torch.zeros(self.shard, dtype=torch.float32, device=dev) if self.world > 1 else None
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._update = update or runtime.adamw          # (hooks: the CPU gloo test drives the exchange with the oracle's math)
         self._sqnorm = sqnorm or runtime.grad_sqnorm
@@ -144,7 +145,9 @@ class FlatAdamW:
                      self.eps, self.weight_decay, self.step_count, self.sq if clip else None,
                      self.grad_clip if clip else 1.0, 1.0 / self.world)
         if self.world > 1:
-            dist.all_gather_into_tensor(flat.data, flat.data[self.lo:self.lo + self.shard], group=self.group)
+            # (from a copy of the slice: input and output of the collective do not alias)
+            self.param_shard.copy_(flat.data[self.lo:self.lo + self.shard])
+            dist.all_gather_into_tensor(flat.data, self.param_shard, group=self.group)
         flat.mark_updated()
         flat.zero_grad()
         if not clip:

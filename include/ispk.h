@@ -364,8 +364,9 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
                                  int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
- * Training step (BASELINE config 5) - first cut: fp32, dropout 0.  The reference has no backward code of its
- * own (autograd of the modules above); what these replace is cited per entry.
+ * Training step (BASELINE config 5): fp32 kernels with the recipes' dropout; under AMP the Linear GEMMs and
+ * their weight gradients take bf16 operands.  The reference has no backward code of its own (autograd of the modules above);
+ * what these replace is cited per entry.
  *
  * ispk_transpose_f32           y[c][r] = x[r][c]: weights for dX = dY . W through the NT GEMM (ispk_gemm_f32 wants W^T rows).
  * ispk_gemm_tn_f32             C[N1][N2] (+)= sum_m mask[m] A[m][N1-slice] B[m][N2-slice]: dW = dY^T . X of every nn.Linear
@@ -374,6 +375,7 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              row_mask uint8 [M] or NULL; accumulate != 0 adds to C.  N1, N2, lda, ldb multiples of 4,
  *                              A and B 16-byte aligned; ldb < N2 is allowed (overlapping rows: the windows of a padded
  *                              convolution input, for the convolution's weight gradient).
+ * ispk_gemm_tn_bf16            the same product, operands rounded to bf16 in flight (autocast's weight gradient), fp32 sums.
  * ispk_layernorm_bwd_f32       backward of modules/transformer/normalization.py:20-31 followed by `* mask` (transformer.py:102):
  *                              dx (=) or (+=, add_to_dx) rstd (g - mean(g) - xhat mean(g xhat)), g = dy mask gamma;
  *                              dgamma = sum_rows dy mask xhat, dbeta = sum_rows dy mask (either may be NULL; both NULL needs no

@@ -2,7 +2,8 @@
 """In-kernel phase stamps of the panel GEMM (ISPK_PANEL_STAMP): per-wave cycle sums per phase."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from isp_tts_amd import runtime, synth
+from isp_tts_amd import build, runtime, synth
+runtime.LIB_PATH = build.LIB_EXP      # stamps exist in the experiments build only
 R, dev, dt = 32768, "cuda", torch.bfloat16
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
 flags = runtime.EP_GELU if N == 1536 else 0

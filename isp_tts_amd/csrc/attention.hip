@@ -282,7 +282,18 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: scalar branches and addresses)
     const int head = wave % H, qhalf = wave / H;
     const int l31 = lane & 31, h = lane >> 5;
-    const int b = blockIdx.y;
+    // XCD-aware (batch item, tile group) mapping: workgroups are dealt to the 8 XCDs round-robin in linear order, so the
+    // gridDim.x workgroups of one batch item - which fetch the same K/V - would land on different L2s.  Within each run of
+    // 8 * gridDim.x workgroups, item = 8 * run + (linear % 8), group = (linear / 8) % gridDim.x: one item, one XCD.
+    int b = blockIdx.y, bx = blockIdx.x;
+    {
+        const int gx = gridDim.x, lin = blockIdx.y * gx + blockIdx.x, run = lin / (8 * gx);
+        if ((run + 1) * 8 <= (int)gridDim.y) {            // (a ragged last run keeps the plain mapping)
+            const int r = lin - run * 8 * gx;
+            b = run * 8 + (r & 7);
+            bx = r >> 3;
+        }
+    }
     int klen = key_len ? (int)key_len[b] : N;
     klen = klen < 1 ? 1 : (klen > N ? N : klen);
     constexpr float kLog2e = 1.4426950408889634f;
@@ -327,7 +338,7 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(qf[ks]) : "v"(qp + ks * 16) : "memory");
     };
     bf16x8 qf[4];
-    load_q(qf, (blockIdx.x * qpw) * 64 + qhalf * 32);
+    load_q(qf, (bx * qpw) * 64 + qhalf * 32);
     if (loader) {
 #pragma unroll 1
         for (int c = 0; c < nchunks && c < ahead; ++c) issue_chunk(c);
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
     const int nqt = (N + 63) / 64;
 #pragma unroll 1
     for (int it = 0; it < qpw; ++it) {
-    const int qt = blockIdx.x * qpw + it;
+    const int qt = bx * qpw + it;
     if (qt >= nqt) break;                                  // workgroup-uniform
     const int q0 = qt * 64 + qhalf * 32, qi = q0 + l31;
     const int q0w = q0;                                    // the wave's first query: the diagonal block has key0 == q0w

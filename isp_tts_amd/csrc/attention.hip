@@ -244,6 +244,10 @@ __device__ __forceinline__ float max3_raw(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// exchange the upper half (lanes 32-63) of x with the lower half (lanes 0-31) of y
+__device__ __forceinline__ void half_swap(uint32_t& x, uint32_t& y) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(x), "+v"(y));
+}
 __device__ __forceinline__ float xhalf_max_swap(float v) {
     float a = v, b = v;
     asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
@@ -325,6 +329,7 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
     // A workgroup serves qpw consecutive 64-query tiles of its batch element.  When the whole key range fits the ring
     // (resident: nchunks <= kSlots) K/V are fetched ONCE, all chunks requested up front, and every tile after the first
     // runs without a single wait or barrier; the launcher picks qpw > 1 only then.
+    const bool wide_store = (ldo & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0;   // 16-byte row pieces
     const bool resident = nchunks <= kSlots;
     const int ahead = resident ? kSlots : kSlots - 1;      // chunks in flight
     // Q fragments are loaded by opaque asm (hipcc would drain every DMA with vmcnt(0) at their first use): they are
@@ -539,17 +544,43 @@ __global__ __launch_bounds__(MAXT) void attn_bf16_kernel(const uint16_t* __restr
         }
     }
     const float inv = 1.0f / xhalf_sum(l2a + l2b);
-    if (qi < N) {
+    // A lane holds four 4-dim groups of each 32-dim tile (dims 8g + 4h ..): as they are, 8-byte stores - 16 per row and
+    // store-issue-bound.  The two halves of a query trade groups (v_permlane32_swap: half 0 ends up with dims 8g .. 8g+7 of
+    // g = 0 and 2, half 1 with those of g = 1 and 3), so a row leaves in 16-byte pieces, half as many instructions.
+    uint2 pk[2][4];   // [tile][g]
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        pk[0][g].x = pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+        pk[0][g].y = pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+        pk[1][g].x = pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+        pk[1][g].y = pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+    }
+    if (wide_store) {      // kernel-uniform
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                // x = group 2gp, y = group 2gp+1: afterwards half 0 holds (its x, the partner's x), half 1 (the partner's y, its y)
+                half_swap(pk[t][2 * gp].x, pk[t][2 * gp + 1].x);
+                half_swap(pk[t][2 * gp].y, pk[t][2 * gp + 1].y);
+            }
+        if (qi < N) {
+            uint16_t* op = out + ((int64_t)b * N + qi) * ldo + head * 64 + 8 * h;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint4 v;
+                    v.x = pk[t][2 * gp].x; v.y = pk[t][2 * gp].y; v.z = pk[t][2 * gp + 1].x; v.w = pk[t][2 * gp + 1].y;
+                    *reinterpret_cast<uint4*>(op + 32 * t + 16 * gp) = v;
+                }
+        }
+    } else if (qi < N) {
         uint16_t* op = out + ((int64_t)b * N + qi) * ldo + head * 64 + 4 * h;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            uint2 a, c;
-            a.x = pack_bf16(o0[4 * g] * inv, o0[4 * g + 1] * inv);
-            a.y = pack_bf16(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
-            c.x = pack_bf16(o1[4 * g] * inv, o1[4 * g + 1] * inv);
-            c.y = pack_bf16(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
-            *reinterpret_cast<uint2*>(op + 8 * g) = a;
-            *reinterpret_cast<uint2*>(op + 32 + 8 * g) = c;
+            *reinterpret_cast<uint2*>(op + 8 * g) = pk[0][g];
+            *reinterpret_cast<uint2*>(op + 32 + 8 * g) = pk[1][g];
         }
     }
     }   // query tiles

@@ -75,7 +75,10 @@ class BatchIngest:
         assert self.pending < self.slots, "every slot holds a batch that has not been taken with get() yet"
         k = self.head
         if self.on_gpu:
-            self.consumed[k].synchronize()     # the compute that read this slot's device buffers has finished (no-op at first)
+            # the HOST only waits for this pinned slot's own previous upload (long finished); the slot's DEVICE buffers are
+            # protected on the copy stream below - waiting here for `consumed` would hold the host until the forward that is
+            # running has finished, and the next batch's staging + launch would then start on an idle GPU
+            self.copied[k].synchronize()
         shapes = {}
         for name, dt in FIELDS:
             t = batch[name]
@@ -87,6 +90,7 @@ class BatchIngest:
         self.shapes[k] = shapes
         if self.on_gpu:
             with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(self.consumed[k])      # the compute that read this slot's device buffers (no-op at first)
                 for name, _ in FIELDS:
                     n = _numel(shapes[name])
                     self.dev[k][name][:n].copy_(self.host[k][name][:n], non_blocking=True)

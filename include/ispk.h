@@ -479,6 +479,16 @@ int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const floa
                                     const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
                                     float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
                                     const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
+/* The same two entries with every product on bf16 MFMAs (operands rounded to bf16 in registers, fp32 accumulation and
+ * statistics): the attention of a step under autocast (recipes/default.yaml:56; SDPA and its backward then see bf16 q / k / v).
+ * Forward and backward must be used as a pair (the row statistics of one are the other's). */
+int32_t ispk_alibi_mqa_attn_train_amp(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len, float* o,
+                                      int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H, float dropout_p, uint64_t seed,
+                                      ispk_stream_t stream);
+int32_t ispk_alibi_mqa_attn_bwd_amp(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
+                                    const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
+                                    float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
+                                    const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
                           float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
 int32_t ispk_aligner_scores_bwd_f32(const float* attn_logits, const float* attn_soft, const float* d_soft, const float* d_logits,

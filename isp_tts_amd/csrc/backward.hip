@@ -481,10 +481,81 @@ __device__ __forceinline__ f32x16 dot_frags(const Frag& a, const Frag& b) {
     return acc;
 }
 
+// bf16-operand mode (kB16: the step under autocast, recipes/default.yaml:56 - SDPA and its backward take bf16 q / k / v / dO):
+// the same kernels with every product on v_mfma_f32_32x32x16_bf16, 16 x the fp32 MFMA rate.  A 32-float Frag becomes four
+// 8-element operands: k-slot e of step s of lane half hf is the Frag's element 8 s + e - ANY assignment of the head
+// dimensions to k-slots is right as long as both operands of a product use the same one, and both come from load_frag.
+// Where an accumulator tile (P, dS) is the B operand, step u takes its registers 8u .. 8u+7 (reduction rows
+// acc_row(8u + e, hf)) and the A operand gathers the same rows.  Values are rounded to bf16 (RNE) in registers.
+struct Frag16 { bf16x8 s[4]; };
+__device__ __forceinline__ uint32_t bw_pack2(float lo, float hi) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 v;
+    v.x = lo; v.y = hi;
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
+}
+__device__ __forceinline__ bf16x8 bw_pack8(const float* v) {
+    union { uint32_t u[4]; bf16x8 f; } r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) r.u[e] = bw_pack2(v[2 * e], v[2 * e + 1]);
+    return r.f;
+}
+__device__ __forceinline__ Frag16 to_frag16(const Frag& f) {
+    Frag16 r;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) r.s[st] = bw_pack8(f.v + 8 * st);
+    return r;
+}
+__device__ __forceinline__ f32x16 dot_frags16(const Frag16& a, const Frag16& b) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s[st], b.s[st], acc, 0, 0, 0);
+    return acc;
+}
+// acc[mt] += sum over the 32 reduction rows of rowsrc[row][c + 32 mt] * w[t]   (w: an accumulator tile, t <-> acc_row(t, hf))
+template <bool kB16>
+__device__ __forceinline__ void acc_operand_update(f32x16 (&acc)[2], const float* __restrict__ rowsrc, int64_t ld, int row0, int nrows,
+                                                   int c, int hf, const float (&w)[16]) {
+    if constexpr (kB16) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float a0[8], a1[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int row = row0 + acc_row(8 * u + e, hf);
+                const bool ok = row < nrows;
+                const float* r = rowsrc + (int64_t)(ok ? row : 0) * ld;
+                a0[e] = ok ? r[c] : 0.f;
+                a1[e] = ok ? r[32 + c] : 0.f;
+            }
+            const bf16x8 b = bw_pack8(w + 8 * u);
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_pack8(a0), b, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_pack8(a1), b, acc[1], 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const int row = row0 + acc_row(t, hf);
+            const bool ok = row < nrows;
+            const float* r = rowsrc + (int64_t)(ok ? row : 0) * ld;
+            const float a0 = ok ? r[c] : 0.f, a1 = ok ? r[32 + c] : 0.f;
+            acc[0] = mfma2(a0, w[t], acc[0]);
+            acc[1] = mfma2(a1, w[t], acc[1]);
+        }
+    }
+}
+// S or dP of one 32 x 32 tile: fp32 MFMAs over the Frags, or bf16 MFMAs over their rounded copies
+template <bool kB16>
+__device__ __forceinline__ f32x16 tile_dot(const Frag& a, const Frag& b, const Frag16& b16) {
+    if constexpr (kB16) return dot_frags16(to_frag16(a), b16);
+    else return dot_frags(a, b);
+}
+
 // dQ kernel: one wave per (query tile of 32, head, batch item), transposed orientation S^T[key][query] (query on the lane).
 // Pass 1: row maxima / sums -> LSE (kept, and written for the dK/dV kernel together with delta).  Pass 2: P, dP, dS,
 // dQ^T += K^T dS^T, slope partial.
-template <bool kDrop>
+template <bool kDrop, bool kB16>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ o,
                                                          const float* __restrict__ dout, int64_t ldo,
                                                          const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
@@ -504,6 +575,8 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
     const float slope = slopes[h];
     const Frag qf = load_frag(qb + h * 64, ld, i, N, hf);
     const Frag dof = load_frag(dob, ldo, i, N, hf);
+    Frag16 qf16, dof16;
+    if constexpr (kB16) { qf16 = to_frag16(qf); dof16 = to_frag16(dof); }
     float dl = 0.f;
     {
         const Frag of = load_frag(ob, ldo, i, N, hf);
@@ -517,7 +590,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
     float mx = -INFINITY, sum = 0.f;
     for (int kt = 0; kt < (lse_in ? 0 : kt_end); ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
-        const f32x16 s = dot_frags(kf, qf);
+        const f32x16 s = tile_dot<kB16>(kf, qf, qf16);
         float sv[16], tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -551,9 +624,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
     float gs = 0.f;
     for (int kt = 0; kt < kt_end; ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
-        const f32x16 s = dot_frags(kf, qf);
+        const f32x16 s = tile_dot<kB16>(kf, qf, qf16);
         const Frag vf = load_frag(vb, ld, kt * 32 + c, N, hf);
-        const f32x16 dp = dot_frags(vf, dof);
+        const f32x16 dp = tile_dot<kB16>(vf, dof, dof16);
         float ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -566,14 +639,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
             gs -= ds[r] * dist;
         }
         // dQ^T[d][i] += sum_j K[j][d] dS^T[j][i]: A = K^T, its reduction index j walked in accumulator-row order
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int j = kt * 32 + acc_row(t, hf);
-            const float* kr = kb + (int64_t)(j < N ? j : 0) * ld;
-            const float k0 = j < N ? kr[c] : 0.f, k1 = j < N ? kr[32 + c] : 0.f;
-            dq[0] = mfma2(k0, ds[t], dq[0]);
-            dq[1] = mfma2(k1, ds[t], dq[1]);
-        }
+        acc_operand_update<kB16>(dq, kb, ld, kt * 32, N, c, hf, ds);
     }
     if (i < N) {
         float* dst = dqkv + ((int64_t)b * N + i) * ld + h * 64;
@@ -592,6 +658,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
 // Training forward (attention dropout, attend.py:118 / SDPA dropout_p): the dQ kernel's skeleton - pass 1 row statistics
 // (kept for the backward), pass 2 P, dropout, O^T[d][i] += sum_j V[j][d] Pdrop^T[j][i] with the accumulator fed back as the
 // operand.  fp32, one wave per (32 queries, head, batch item).
+template <bool kB16>
 __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restrict__ qkv, int64_t ld,
                                                             const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
                                                             float* __restrict__ o, int64_t ldo, float* __restrict__ lse, int N, int H,
@@ -604,12 +671,14 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
     const float* vb = kb + 64;
     const float slope = slopes[h];
     const Frag qf = load_frag(qb + h * 64, ld, i, N, hf);
+    Frag16 qf16;
+    if constexpr (kB16) qf16 = to_frag16(qf);
     const int kt_end = (klen + 31) / 32;
     const uint32_t row_idx = (((uint32_t)b * H + h) * N + (uint32_t)(i < N ? i : 0)) * (uint32_t)N;
     float mx = -INFINITY, sum = 0.f;
     for (int kt = 0; kt < kt_end; ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
-        const f32x16 s = dot_frags(kf, qf);
+        const f32x16 s = tile_dot<kB16>(kf, qf, qf16);
         float sv[16], tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -636,7 +705,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
     f32x16 ot[2] = {zero16(), zero16()};
     for (int kt = 0; kt < kt_end; ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
-        const f32x16 s = dot_frags(kf, qf);
+        const f32x16 s = tile_dot<kB16>(kf, qf, qf16);
         float pd[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -645,14 +714,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
             if (thresh) p = drop_keep(seed, row_idx + (uint32_t)j, thresh) ? p * inv_keep : 0.f;
             pd[r] = p;
         }
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int j = kt * 32 + acc_row(t, hf);
-            const float* vr = vb + (int64_t)(j < N ? j : 0) * ld;
-            const float v0 = j < N ? vr[c] : 0.f, v1 = j < N ? vr[32 + c] : 0.f;
-            ot[0] = mfma2(v0, pd[t], ot[0]);
-            ot[1] = mfma2(v1, pd[t], ot[1]);
-        }
+        acc_operand_update<kB16>(ot, vb, ld, kt * 32, N, c, hf, pd);
     }
     if (i < N) {
         float* dst = o + ((int64_t)b * N + i) * ldo + h * 64;
@@ -668,7 +730,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
 // dK / dV kernel: one workgroup per (key tile of 32, batch item), one wave per head; a wave loops over the query tiles
 // (S[query][key], key on the lane) with its head's sums in registers, then the H waves add their tiles into one LDS tile in
 // head order (barrier between heads): no atomics, a fixed summation order, one write per element.
-template <bool kDrop>
+template <bool kDrop, bool kB16>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ dout,
                                                             int64_t ldo, const float* __restrict__ slopes,
                                                             const int64_t* __restrict__ key_len, const float* __restrict__ lse,
@@ -685,6 +747,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
     if (kt * 32 < klen) {
         const Frag kf = load_frag(kb, ld, j, N, hf);
         const Frag vf = load_frag(vb, ld, j, N, hf);
+        Frag16 kf16, vf16;
+        if constexpr (kB16) { kf16 = to_frag16(kf); vf16 = to_frag16(vf); }
         const int qt_end = (N + 31) / 32;
         const float slope = slopes[h];
         const float* qh = qb + h * 64;
@@ -693,9 +757,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
         const float* dh = delta + ((int64_t)b * H + h) * N;
         for (int qt = 0; qt < qt_end; ++qt) {
             const Frag qf = load_frag(qh, ld, qt * 32 + c, N, hf);
-            const f32x16 s = dot_frags(qf, kf);
+            const f32x16 s = tile_dot<kB16>(qf, kf, kf16);
             const Frag dof = load_frag(doh, ldo, qt * 32 + c, N, hf);
-            const f32x16 dp = dot_frags(dof, vf);
+            const f32x16 dp = tile_dot<kB16>(dof, vf, vf16);
             float p[16], ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -711,19 +775,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                     ds[r] = p[r] * (dp[r] - dl);
                 }
             }
-#pragma unroll
-            for (int t = 0; t < 16; ++t) {
-                const int i = qt * 32 + acc_row(t, hf);
-                const bool ok = i < N;
-                const float* dor = doh + (int64_t)(ok ? i : 0) * ldo;
-                const float* qr = qh + (int64_t)(ok ? i : 0) * ld;
-                const float d0 = ok ? dor[c] : 0.f, d1 = ok ? dor[32 + c] : 0.f;
-                const float q0 = ok ? qr[c] : 0.f, q1 = ok ? qr[32 + c] : 0.f;
-                dv[0] = mfma2(d0, p[t], dv[0]);
-                dv[1] = mfma2(d1, p[t], dv[1]);
-                dk[0] = mfma2(q0, ds[t], dk[0]);
-                dk[1] = mfma2(q1, ds[t], dk[1]);
-            }
+            acc_operand_update<kB16>(dv, doh, ldo, qt * 32, N, c, hf, p);
+            acc_operand_update<kB16>(dk, qh, ld, qt * 32, N, c, hf, ds);
         }
     }
     for (int hh = 0; hh < H; ++hh) {          // heads add in index order
@@ -912,16 +965,72 @@ extern "C" int32_t ispk_dropout_mask_u8(uint8_t* out, int64_t n, float dropout_p
     return ispk_launch_status();
 }
 
+static int32_t attn_train_launch(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len, float* o, int64_t ld_o,
+                                 float* lse, int32_t B, int32_t N, int32_t H, float dropout_p, uint64_t seed, hipStream_t s,
+                                 bool bf16_operands, const char* who) {
+    ISPK_REQUIRE(qkv && slopes && o && lse, -1, "%s: null pointer", who);
+    ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 8 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
+                     ld_o % 4 == 0 && B <= 65535, -2, "%s: bad shape B=%d N=%d H=%d", who, B, N, H);
+    ISPK_REQUIRE(ispk_aligned(qkv, 16) && ispk_aligned(o, 16), -3, "%s: arrays must be 16-byte aligned", who);
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -4, "%s: dropout_p must be in [0, 1)", who);
+    const dim3 grid((N + 31) / 32, H, B);
+    if (bf16_operands)
+        hipLaunchKernelGGL(attn_train_fwd_kernel<true>, grid, dim3(64), 0, s, qkv, ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f,
+                           drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
+    else
+        hipLaunchKernelGGL(attn_train_fwd_kernel<false>, grid, dim3(64), 0, s, qkv, ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f,
+                           drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
+    return ispk_launch_status();
+}
+
 extern "C" int32_t ispk_alibi_mqa_attn_train_f32(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len,
                                                  float* o, int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H,
                                                  float dropout_p, uint64_t seed, ispk_stream_t stream) {
-    ISPK_REQUIRE(qkv && slopes && o && lse, -1, "ispk_alibi_mqa_attn_train_f32: null pointer");
+    return attn_train_launch(qkv, ld_qkv, slopes, key_len, o, ld_o, lse, B, N, H, dropout_p, seed,
+                             reinterpret_cast<hipStream_t>(stream), false, "ispk_alibi_mqa_attn_train_f32");
+}
+
+extern "C" int32_t ispk_alibi_mqa_attn_train_amp(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len,
+                                                 float* o, int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H,
+                                                 float dropout_p, uint64_t seed, ispk_stream_t stream) {
+    return attn_train_launch(qkv, ld_qkv, slopes, key_len, o, ld_o, lse, B, N, H, dropout_p, seed,
+                             reinterpret_cast<hipStream_t>(stream), true, "ispk_alibi_mqa_attn_train_amp");
+}
+
+template <bool kDrop, bool kB16>
+static void attn_bwd_kernels(hipStream_t s, int tiles, const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
+                             const float* slopes, const int64_t* key_len, float* dqkv, float* lse, float* delta, float* spart, int B,
+                             int N, int H, const float* lse_in, uint32_t thresh, float inv_keep, uint64_t seed) {
+    const float scale = 0.125f;
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<kDrop, kB16>), dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len,
+                       dqkv, lse, delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<kDrop, kB16>), dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len,
+                       lse, delta, dqkv, N, H, scale, thresh, inv_keep, seed);
+}
+
+static int32_t attn_bwd_launch(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o, const float* slopes,
+                               const int64_t* key_len, float* dqkv, float* dlogslopes, float* workspace, int64_t workspace_floats,
+                               int32_t B, int32_t N, int32_t H, const float* lse_in, float dropout_p, uint64_t seed, hipStream_t s,
+                               bool bf16_operands, const char* who) {
+    ISPK_REQUIRE(qkv && o && d_o && slopes && dqkv && workspace, -1, "%s: null pointer", who);
     ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 8 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
-                     ld_o % 4 == 0 && B <= 65535, -2, "ispk_alibi_mqa_attn_train_f32: bad shape B=%d N=%d H=%d", B, N, H);
-    ISPK_REQUIRE(ispk_aligned(qkv, 16) && ispk_aligned(o, 16), -3, "ispk_alibi_mqa_attn_train_f32: arrays must be 16-byte aligned");
-    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -4, "ispk_alibi_mqa_attn_train_f32: dropout_p must be in [0, 1)");
-    hipLaunchKernelGGL(attn_train_fwd_kernel, dim3((N + 31) / 32, H, B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), qkv,
-                       ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
+                     ld_o % 4 == 0, -2, "%s: bad shape B=%d N=%d H=%d", who, B, N, H);
+    ISPK_REQUIRE(ispk_aligned(qkv, 16) && ispk_aligned(o, 16) && ispk_aligned(d_o, 16) && ispk_aligned(dqkv, 16), -3,
+                 "%s: arrays must be 16-byte aligned", who);
+    const int tiles = (N + 31) / 32;
+    const int64_t stat = (int64_t)B * H * N, need = 2 * stat + (int64_t)H * B * tiles;
+    ISPK_REQUIRE(workspace_floats >= need, -4, "%s: workspace needs %lld floats", who, (long long)need);
+    float *lse = workspace, *delta = workspace + stat, *spart = workspace + 2 * stat;
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -5, "%s: dropout_p must be in [0, 1)", who);
+    const uint32_t thresh = drop_thresh(dropout_p);
+    const float inv_keep = 1.0f / (1.0f - dropout_p);
+#define ISPK_BWD(D_, B16_) attn_bwd_kernels<D_, B16_>(s, tiles, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse, delta, spart, B, N, \
+                                                     H, lse_in, thresh, inv_keep, seed)
+    if (thresh) { if (bf16_operands) ISPK_BWD(true, true); else ISPK_BWD(true, false); }
+    else { if (bf16_operands) ISPK_BWD(false, true); else ISPK_BWD(false, false); }
+#undef ISPK_BWD
+    if (dlogslopes)
+        hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64 * H), 0, s, spart, B * tiles, slopes, dlogslopes, H);
     return ispk_launch_status();
 }
 
@@ -929,32 +1038,14 @@ extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv,
                                                const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
                                                float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
                                                const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream) {
-    ISPK_REQUIRE(qkv && o && d_o && slopes && dqkv && workspace, -1, "ispk_alibi_mqa_attn_bwd_f32: null pointer");
-    ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 8 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
-                     ld_o % 4 == 0, -2, "ispk_alibi_mqa_attn_bwd_f32: bad shape B=%d N=%d H=%d", B, N, H);
-    ISPK_REQUIRE(ispk_aligned(qkv, 16) && ispk_aligned(o, 16) && ispk_aligned(d_o, 16) && ispk_aligned(dqkv, 16), -3,
-                 "ispk_alibi_mqa_attn_bwd_f32: arrays must be 16-byte aligned");
-    const int tiles = (N + 31) / 32;
-    const int64_t stat = (int64_t)B * H * N, need = 2 * stat + (int64_t)H * B * tiles;
-    ISPK_REQUIRE(workspace_floats >= need, -4, "ispk_alibi_mqa_attn_bwd_f32: workspace needs %lld floats", (long long)need);
-    float *lse = workspace, *delta = workspace + stat, *spart = workspace + 2 * stat;
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const float scale = 0.125f;
-    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -5, "ispk_alibi_mqa_attn_bwd_f32: dropout_p must be in [0, 1)");
-    const uint32_t thresh = drop_thresh(dropout_p);
-    const float inv_keep = 1.0f / (1.0f - dropout_p);
-    if (thresh) {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len,
-                           dqkv, lse, delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len,
-                           lse, delta, dqkv, N, H, scale, thresh, inv_keep, seed);
-    } else {
-        hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len,
-                           dqkv, lse, delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
-        hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len,
-                           lse, delta, dqkv, N, H, scale, thresh, inv_keep, seed);
-    }
-    if (dlogslopes)
-        hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64 * H), 0, s, spart, B * tiles, slopes, dlogslopes, H);
-    return ispk_launch_status();
+    return attn_bwd_launch(qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, dlogslopes, workspace, workspace_floats, B, N, H, lse_in,
+                           dropout_p, seed, reinterpret_cast<hipStream_t>(stream), false, "ispk_alibi_mqa_attn_bwd_f32");
+}
+
+extern "C" int32_t ispk_alibi_mqa_attn_bwd_amp(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
+                                               const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
+                                               float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
+                                               const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream) {
+    return attn_bwd_launch(qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, dlogslopes, workspace, workspace_floats, B, N, H, lse_in,
+                           dropout_p, seed, reinterpret_cast<hipStream_t>(stream), true, "ispk_alibi_mqa_attn_bwd_amp");
 }

@@ -72,6 +72,8 @@ SIGNATURES = {
     "ispk_dropout_mask_u8": [_P, _I64, _F32, _U64, _P],
     "ispk_alibi_mqa_attn_train_f32": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
     "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
+    "ispk_alibi_mqa_attn_train_amp": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
+    "ispk_alibi_mqa_attn_bwd_amp": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
     "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_aligner_scores_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _F32, _P],
     "ispk_masked_instnorm_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
@@ -972,9 +974,10 @@ def dropout_mask(n: int, dropout_p: float, seed: int, device) -> Tensor:
     return out
 
 
-def alibi_mqa_attention_train(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor], dropout_p: float, seed: int):
+def alibi_mqa_attention_train(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor], dropout_p: float, seed: int,
+                              bf16: bool = False):
     """ispk_alibi_mqa_attn_train_f32 -> (o fp32 [B, N, heads*64], lse fp32 [B, heads, N]): attention with dropped
-    probabilities, row statistics kept for the backward."""
+    probabilities, row statistics kept for the backward.  `bf16`: ispk_alibi_mqa_attn_train_amp (bf16 MFMA operands)."""
     _dev(qkv, slopes, key_len)
     B, N, W = qkv.shape
     assert W == heads * 64 + 128 and qkv.dtype == torch.float32 and qkv.is_contiguous()
@@ -983,8 +986,8 @@ def alibi_mqa_attention_train(qkv: Tensor, heads: int, slopes: Tensor, key_len: 
         key_len = key_len.to(torch.int64).contiguous()
     o = torch.empty((B, N, heads * 64), dtype=torch.float32, device=qkv.device)
     lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
-    _launch("attn_train_fwd_kernel", 6.0 * B * heads * N * N * 64, 4.0 * (qkv.numel() + o.numel()),
-            lib().ispk_alibi_mqa_attn_train_f32, qkv.data_ptr(), W, slopes.data_ptr(), _ptr(key_len), o.data_ptr(), heads * 64,
+    _launch("attn_train_fwd_kernel<bf16>" if bf16 else "attn_train_fwd_kernel", 6.0 * B * heads * N * N * 64, 4.0 * (qkv.numel() + o.numel()),
+            lib().ispk_alibi_mqa_attn_train_amp if bf16 else lib().ispk_alibi_mqa_attn_train_f32, qkv.data_ptr(), W, slopes.data_ptr(), _ptr(key_len), o.data_ptr(), heads * 64,
             lse.data_ptr(), B, N, heads, dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return o, lse
 
@@ -1002,9 +1005,10 @@ def gelu_bwd(da: Tensor, u: Tensor, out: Optional[Tensor] = None, dropout_p: flo
 
 
 def alibi_mqa_attention_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor],
-                            lse: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0):
+                            lse: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0, bf16: bool = False):
     """ispk_alibi_mqa_attn_bwd_f32 -> (dqkv fp32 like qkv, dlogslopes fp32 [heads]).  `lse` (from the training forward)
-    saves the statistics pass; dropout_p / seed must be the forward's."""
+    saves the statistics pass; dropout_p / seed must be the forward's.  `bf16`: ispk_alibi_mqa_attn_bwd_amp (bf16 MFMA
+    operands; pairs with the bf16 training forward)."""
     _dev(qkv, o, d_o, slopes, key_len, lse)
     B, N, W = qkv.shape
     assert W == heads * 64 + 128 and qkv.dtype == torch.float32 and qkv.is_contiguous()
@@ -1017,8 +1021,8 @@ def alibi_mqa_attention_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, heads: int, slo
     dls = torch.empty((heads,), dtype=torch.float32, device=qkv.device)
     tiles = (N + 31) // 32
     ws = workspace(qkv.device, 2 * B * heads * N + heads * B * tiles)
-    _launch("attn_bwd_kernels", 10.0 * B * heads * N * N * 64, 4.0 * (2 * qkv.numel() + 2 * o.numel()),
-            lib().ispk_alibi_mqa_attn_bwd_f32, qkv.data_ptr(), W, o.data_ptr(), d_o.data_ptr(), heads * 64, slopes.data_ptr(),
+    _launch("attn_bwd_kernels<bf16>" if bf16 else "attn_bwd_kernels", 10.0 * B * heads * N * N * 64, 4.0 * (2 * qkv.numel() + 2 * o.numel()),
+            lib().ispk_alibi_mqa_attn_bwd_amp if bf16 else lib().ispk_alibi_mqa_attn_bwd_f32, qkv.data_ptr(), W, o.data_ptr(), d_o.data_ptr(), heads * 64, slopes.data_ptr(),
             _ptr(key_len), dqkv.data_ptr(), dls.data_ptr(), ws.data_ptr(), ws.numel(), B, N, heads, _ptr(lse), dropout_p,
             seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return dqkv, dls

@@ -167,8 +167,8 @@ class AdaptiveStackFunction(torch.autograd.Function):
             p_ff = float(ff.dropout_p) if layer.training else 0.0
             seed_att, seed_ff = base_seed + 2 * li, base_seed + 2 * li + 1
             lse = None
-            if p_att > 0:
-                o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att)
+            if p_att > 0 or amp:
+                o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att, bf16=amp)
             else:
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
             x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
@@ -216,7 +216,7 @@ class AdaptiveStackFunction(torch.autograd.Function):
             dwo = runtime.gemm_tn(dx1, o, row_mask=mask, bf16=amp)
             d_o = _mm(dx1, wo_t, wo_t16, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
-                                                        seed=seed_att)
+                                                        seed=seed_att, bf16=amp)
             dwqkv = runtime.gemm_tn(dqkv, h, bf16=amp)
             dh = _mm(dqkv, wqkv_t, wqkv_t16)
             dy = runtime.adaln_bwd(xin, dh, ss[:, c:c + D], None, dx1, True, d_ss[:, c:c + D], d_ss[:, c + D:c + 2 * D],

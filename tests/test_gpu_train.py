@@ -817,3 +817,29 @@ def test_gemm_tn_bf16_operands(M, N1, N2, masked):
     acc = got.clone()
     runtime.gemm_tn(ad, bd, row_mask=md, out=acc, accumulate=True, bf16=True)
     _close(acc, 2 * want, 2e-5, "gemm_tn bf16 accumulate")
+
+
+@pytest.mark.parametrize("B,N,H,lens,p", [(2, 100, 6, [100, 73], 0.1), (2, 140, 4, None, 0.0), (1, 37, 8, [20], 0.1)])
+def test_attention_training_pair_with_bf16_operands(B, N, H, lens, p):
+    """ispk_alibi_mqa_attn_train_amp / _bwd_amp (the step under autocast): the same kernels with every product on bf16 MFMAs.
+    Checked against the fp32 pair run on the SAME bf16-rounded q / k / v / dO (what remains is the rounding of P and dS to
+    bf16 and the accumulation order: 1e-2 of each tensor's scale), with the same dropout mask (same seed)."""
+    qkv = _rand((B, N, H * 64 + 128), 91).bfloat16().float().to(DEV)
+    d_o = _rand((B, N, H * 64), 92).bfloat16().float().to(DEV)
+    slopes = (torch.tensor(synth.alibi_default_slopes(H)) * 1.1).to(DEV)
+    key_len = None if lens is None else torch.tensor(lens, device=DEV)
+    o32, lse32 = runtime.alibi_mqa_attention_train(qkv, H, slopes, key_len, p, 1234)
+    o16, lse16 = runtime.alibi_mqa_attention_train(qkv, H, slopes, key_len, p, 1234, bf16=True)
+    _close(o16, o32, 1e-2, "o")
+    valid = torch.isfinite(lse32)
+    assert torch.equal(valid, torch.isfinite(lse16))
+    _close(lse16[valid], lse32[valid], 1e-5, "lse")
+    dq32, ds32 = runtime.alibi_mqa_attention_bwd(qkv, o32, d_o, H, slopes, key_len, lse=lse32, dropout_p=p, seed=1234)
+    dq16, ds16 = runtime.alibi_mqa_attention_bwd(qkv, o16, d_o, H, slopes, key_len, lse=lse16, dropout_p=p, seed=1234, bf16=True)
+    hq = H * 64
+    _close(dq16[..., :hq], dq32[..., :hq], 1e-2, "dq")
+    _close(dq16[..., hq:hq + 64], dq32[..., hq:hq + 64], 1e-2, "dk")
+    _close(dq16[..., hq + 64:], dq32[..., hq + 64:], 1e-2, "dv")
+    _close(ds16, ds32, 2e-2, "d log-slope")
+    again, _ = runtime.alibi_mqa_attention_bwd(qkv, o16, d_o, H, slopes, key_len, lse=lse16, dropout_p=p, seed=1234, bf16=True)
+    assert torch.equal(again, dq16)

@@ -376,6 +376,7 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
  *                              A and B 16-byte aligned; ldb < N2 is allowed (overlapping rows: the windows of a padded
  *                              convolution input, for the convolution's weight gradient).
  * ispk_gemm_tn_bf16            the same product, operands rounded to bf16 in flight (autocast's weight gradient), fp32 sums.
+ * ispk_alibi_mqa_attn_train_amp / ispk_alibi_mqa_attn_bwd_amp   the attention pair below on bf16 MFMAs (the step under autocast).
  * ispk_layernorm_bwd_f32       backward of modules/transformer/normalization.py:20-31 followed by `* mask` (transformer.py:102):
  *                              dx (=) or (+=, add_to_dx) rstd (g - mean(g) - xhat mean(g xhat)), g = dy mask gamma;
  *                              dgamma = sum_rows dy mask xhat, dbeta = sum_rows dy mask (either may be NULL; both NULL needs no

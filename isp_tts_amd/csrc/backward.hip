@@ -545,6 +545,12 @@ __device__ __forceinline__ void acc_operand_update(f32x16 (&acc)[2], const float
         }
     }
 }
+// exp for the probabilities: libm in the fp32 kernels; v_exp_f32 (1 ulp) where P is rounded to bf16 right after
+template <bool kB16>
+__device__ __forceinline__ float prob_exp(float x) {
+    if constexpr (kB16) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    else return expf(x);
+}
 // S or dP of one 32 x 32 tile: fp32 MFMAs over the Frags, or bf16 MFMAs over their rounded copies
 template <bool kB16>
 __device__ __forceinline__ f32x16 tile_dot(const Frag& a, const Frag& b, const Frag16& b16) {
@@ -601,7 +607,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
         const float nm = fmaxf(mx, tmax);
         float part = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : expf(sv[r] - nm);
+        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : prob_exp<kB16>(sv[r] - nm);
         sum = (mx == -INFINITY ? 0.f : sum * expf(mx - nm)) + part;
         mx = nm;
     }
@@ -632,7 +638,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
         for (int r = 0; r < 16; ++r) {
             const int j = kt * 32 + acc_row(r, hf);
             const float dist = fabsf((float)(i - j));
-            const float p = (j < klen && i < N) ? expf(s[r] * scale - slope * dist - L) : 0.f;
+            const float p = (j < klen && i < N) ? prob_exp<kB16>(s[r] * scale - slope * dist - L) : 0.f;
             float dpr = dp[r];
             if constexpr (kDrop) dpr = drop_keep(seed, row_idx + (uint32_t)j, thresh) ? dpr * inv_keep : 0.f;   // through the dropout
             ds[r] = p * (dpr - dl);
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
         const float nm = fmaxf(mx, tmax);
         float part = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : expf(sv[r] - nm);
+        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : prob_exp<kB16>(sv[r] - nm);
         sum = (mx == -INFINITY ? 0.f : sum * expf(mx - nm)) + part;
         mx = nm;
     }
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = kt * 32 + acc_row(r, hf);
-            float p = (j < klen && i < N) ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
+            float p = (j < klen && i < N) ? prob_exp<kB16>(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
             if (thresh) p = drop_keep(seed, row_idx + (uint32_t)j, thresh) ? p * inv_keep : 0.f;
             pd[r] = p;
         }
@@ -766,7 +772,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                 const int i = qt * 32 + acc_row(r, hf);
                 const bool ok = i < N && j < klen;
                 const float L = i < N ? lh[i] : 0.f, dl = i < N ? dh[i] : 0.f;
-                p[r] = ok ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
+                p[r] = ok ? prob_exp<kB16>(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
                 if constexpr (kDrop) {
                     const bool keep = drop_keep(seed, (((uint32_t)b * H + h) * N + (uint32_t)(i < N ? i : 0)) * (uint32_t)N + (uint32_t)j, thresh);
                     ds[r] = p[r] * ((keep ? dp[r] * inv_keep : 0.f) - dl);

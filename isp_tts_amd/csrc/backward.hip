@@ -32,8 +32,11 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32": two mu
     return x;
 }
 __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t idx) {
-    // (a 64-bit finaliser costs ~30 VALU instructions per element; this is 14.  The element index enters modulo 2^32.)
-    return mix32(mix32(idx ^ (uint32_t)seed) + (uint32_t)(seed >> 32));
+    // ONE round over (index ^ low seed word), the high word folded in after it: 7 VALU instructions per element (a second
+    // round: 14; a 64-bit finaliser: ~30).  `seed` here is the launcher's splitmix64 of the caller's seed (mix_seed below),
+    // so consecutive caller seeds - one per layer - give unrelated words: two layers' masks are the same hash values at
+    // indices a random 32-bit XOR apart, not shifted copies of each other.  The element index enters modulo 2^32.
+    return mix32(idx ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32);
 }
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t idx, uint32_t thresh) { return drop_hash(seed, idx) >= thresh; }
 
@@ -934,6 +937,12 @@ extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const flo
     return ispk_launch_status();
 }
 
+static inline uint64_t mix_seed(uint64_t z) {   // splitmix64 finaliser: the kernels' two seed words from the caller's seed
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
 static inline uint32_t drop_thresh(float p) {   // keep when hash >= thresh; 0 = dropout off
     if (!(p > 0.f)) return 0u;
     const double t = (double)p * 4294967296.0;
@@ -948,7 +957,7 @@ extern "C" int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du,
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_bwd_f32: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
+                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
     return ispk_launch_status();
 }
 
@@ -959,7 +968,7 @@ extern "C" int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, float drop
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_f32: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
+                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
     return ispk_launch_status();
 }
 
@@ -967,7 +976,7 @@ extern "C" int32_t ispk_dropout_mask_u8(uint8_t* out, int64_t n, float dropout_p
     ISPK_REQUIRE(out && n >= 0 && dropout_p >= 0.f && dropout_p < 1.f, -1, "ispk_dropout_mask_u8: bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       out, n, drop_thresh(dropout_p), seed);
+                       out, n, drop_thresh(dropout_p), mix_seed(seed));
     return ispk_launch_status();
 }
 
@@ -982,10 +991,10 @@ static int32_t attn_train_launch(const float* qkv, int64_t ld_qkv, const float* 
     const dim3 grid((N + 31) / 32, H, B);
     if (bf16_operands)
         hipLaunchKernelGGL(attn_train_fwd_kernel<true>, grid, dim3(64), 0, s, qkv, ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f,
-                           drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
+                           drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
     else
         hipLaunchKernelGGL(attn_train_fwd_kernel<false>, grid, dim3(64), 0, s, qkv, ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f,
-                           drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), seed);
+                           drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
     return ispk_launch_status();
 }
 
@@ -1031,7 +1040,7 @@ static int32_t attn_bwd_launch(const float* qkv, int64_t ld_qkv, const float* o,
     const uint32_t thresh = drop_thresh(dropout_p);
     const float inv_keep = 1.0f / (1.0f - dropout_p);
 #define ISPK_BWD(D_, B16_) attn_bwd_kernels<D_, B16_>(s, tiles, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse, delta, spart, B, N, \
-                                                     H, lse_in, thresh, inv_keep, seed)
+                                                     H, lse_in, thresh, inv_keep, mix_seed(seed))
     if (thresh) { if (bf16_operands) ISPK_BWD(true, true); else ISPK_BWD(true, false); }
     else { if (bf16_operands) ISPK_BWD(false, true); else ISPK_BWD(false, false); }
 #undef ISPK_BWD

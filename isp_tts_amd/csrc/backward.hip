@@ -20,7 +20,7 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __b
 __device__ __forceinline__ int acc_row(int r, int hf) { return 8 * (r >> 2) + 4 * hf + (r & 3); }
 
 // Dropout masks are a pure function of (seed, element index): forward and backward evaluate the same function instead of
-// storing a mask.  Two rounds of a 32-bit multiply-xorshift mix over (seed, index); an element is KEPT when the hash is
+// storing a mask.  One 32-bit multiply-xorshift round over (index ^ seed word), see drop_hash; an element is KEPT when the hash is
 // >= p * 2^32.  (The reference draws torch's Philox stream: same distribution, another sequence - masks are tested for
 // their rate and forward / backward consistency, gradients against autograd with the exported mask.)
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32": two multiply-xorshift rounds, 32-bit arithmetic only

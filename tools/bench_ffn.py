@@ -33,10 +33,11 @@ if runtime.LIB_PATH == build.LIB_EXP:
     variants["eight-wave, no weight DMA after group 1 (compute only)"] = ablated("1")
     variants["eight-wave, DMA + barriers only (no products)"] = ablated("2")
     variants["eight-wave, DMA issued one by one inside the matrix stages"] = ablated("5")
-    variants["eight-wave + setprio on matrix stages"] = ablated("6")
+    variants["eight-wave without setprio on the matrix stages"] = ablated("6")
     variants["eight-wave + tanh-form GELU"] = ablated("7")
     variants["eight-wave + DMA issued by half 0 only"] = ablated("8")
     variants["eight-wave + all three"] = ablated("9")
+    variants["eight-wave + DMA by half 0 (12)"] = ablated("12")
     variants["eight-wave without the finish stage (no GELU / exchange)"] = ablated("10")
     variants["eight-wave, matrix stages without operand reads"] = ablated("11")
 for f in variants.values():

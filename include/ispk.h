@@ -362,6 +362,11 @@ int32_t ispk_time_embedding_f32(const float* t, int32_t n, const float* inv_freq
 int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, const int64_t* dur_i64, const int64_t* enc_len,
                                  const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
                                  int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream);
+/* The same operator for the bf16 compute path: each fp32 operand value is split into two bf16 terms in registers and a product
+ * is three bf16 MFMAs (hi hi + hi lo + lo hi, ~2^-16 relative error) instead of eight exact fp32 ones. */
+int32_t ispk_length_regulate_split_bf16(const float* alignment, const float* dur_f32, const int64_t* dur_i64, const int64_t* enc_len,
+                                 const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
+                                 int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Training step (BASELINE config 5): fp32 kernels with the recipes' dropout; under AMP the Linear GEMMs and

@@ -80,6 +80,7 @@ class AcousticModel(nn.Module, Constructor):
         self.temporal_adaptor.predictor.transformer.set_compute_dtype(dtype)
         self.temporal_adaptor.embedding.transformer.set_compute_dtype(dtype)
         self.aligner.attention.compute_dtype = chain
+        self.temporal_adaptor.length_regulator.split_bf16 = dtype == torch.bfloat16    # three bf16 MFMAs per product (2^-16)
         self.compute_dtype = dtype
         return self
 

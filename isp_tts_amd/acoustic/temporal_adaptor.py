@@ -153,7 +153,9 @@ class LengthRegulator(nn.Module):
     dec_lens = (sum(dur) + .5).long(), both cut to max_len.  One kernel (`ispk_length_regulate_f32`: exact-fp32 MFMA
     products, decoder lengths and the decoder mask from the same launch; the mask of the last call is kept in
     `self.dec_mask` for the caller that needs it next).  `alignment=None` with fp32 durations: the soft path of
-    `generate_soft_path` is generated inside the kernel (`infer`)."""
+    `generate_soft_path` is generated inside the kernel (`infer`).  `split_bf16` (set by `AcousticModel.set_compute_dtype` on the
+    bf16 path): `ispk_length_regulate_split_bf16`, each product as three bf16 MFMAs on hi / lo splits of the fp32 operands."""
+    split_bf16 = False
 
     def forward(self, x: Tensor, durations: Tensor, max_len: Optional[int] = None, alignment: Optional[Tensor] = None, *,
                 enc_len: Optional[Tensor] = None, frames: Optional[int] = None):
@@ -164,7 +166,8 @@ class LengthRegulator(nn.Module):
             rows = min(rows, max_len)
             alignment = alignment[:, :rows]
         out, dec_lens, self.dec_mask = runtime.length_regulate(x.float(), durations, alignment, rows,
-                                                               max_len=-1 if max_len is None else max_len, enc_len=enc_len)
+                                                               max_len=-1 if max_len is None else max_len, enc_len=enc_len,
+                                                               split_bf16=self.split_bf16)
         return out, dec_lens
 
 

@@ -75,7 +75,32 @@ __global__ __launch_bounds__(64) void time_embedding_kernel(const float* __restr
 // of 16; the next chunk is fetched into registers while the current one multiplies.
 constexpr int kLrRows = 64, kLrChunk = 16, kLrAld = kLrChunk + 1;
 
-template <int NT>   // D = 128 * NT: a wave owns NT 32-feature tiles
+// kSplit (ispk_length_regulate_split_bf16, the bf16 compute path): every fp32 operand value v is split in registers into
+// hi = bf16(v) and lo = bf16(v - hi), and a product is three v_mfma_f32_32x32x16_bf16 (hi hi + hi lo + lo hi; the lo lo term
+// is below 2^-16 of the product) instead of eight v_mfma_f32_32x32x2_f32: 18 MFMAs of 32 cycles per 16-token chunk and wave
+// against 48 of 64 cycles, at ~2^-16 relative error per product - three decimal digits finer than the bf16 GEMMs the result
+// feeds.  The fp32 parity path keeps the exact fp32 MFMAs.
+typedef uint32_t lr_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void lr_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    union { lr_u32x4 u; bf16x8 f; } h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f2 a;
+        a.x = v[2 * e]; a.y = v[2 * e + 1];
+        const uint32_t ph = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2));
+        f2 r;
+        r.x = a.x - __builtin_bit_cast(float, ph << 16);
+        r.y = a.y - __builtin_bit_cast(float, ph & 0xffff0000u);
+        h.u[e] = ph;
+        l.u[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf2));
+    }
+    hi = h.f;
+    lo = l.f;
+}
+
+template <int NT, bool kSplit = false>   // D = 128 * NT: a wave owns NT 32-feature tiles
 __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ align, const float* __restrict__ dur_f,
                                                               const int64_t* __restrict__ dur_i,
                                                               const int64_t* __restrict__ enc_len,
@@ -181,6 +206,32 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
         __syncthreads();
         if (t0 + kLrChunk < L) fetch(t0 + kLrChunk);
         const int r = lane & 31, kh = lane >> 5;
+        if constexpr (kSplit) {
+            // lane half kh takes tokens 8 kh .. 8 kh + 7 of the chunk in both operands
+            bf16x8 ah[2], al[2];
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                float av[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) av[e] = As[(32 * rt + r) * kLrAld + 8 * kh + e];
+                lr_split8(av, ah[rt], al[rt]);
+            }
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                float bv[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bv[e] = Xs[(8 * kh + e) * D + wave * (32 * NT) + ct * 32 + r];
+                bf16x8 bh, bl;
+                lr_split8(bv, bh, bl);
+#pragma unroll
+                for (int rt = 0; rt < 2; ++rt) {
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][ct], 0, 0, 0);
+                }
+            }
+            continue;
+        }
 #pragma unroll
         for (int kk = 0; kk < kLrChunk; kk += 2) {
             const float a0 = As[r * kLrAld + kk + kh], a1 = As[(32 + r) * kLrAld + kk + kh];
@@ -234,10 +285,10 @@ extern "C" int32_t ispk_time_embedding_f32(const float* t, int32_t n, const floa
     return ispk_launch_status();
 }
 
-extern "C" int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, const int64_t* dur_i64,
-                                            const int64_t* enc_len, const float* x, int64_t ldx, float* out,
-                                            int64_t* dec_len, uint8_t* dec_mask, int32_t B, int32_t M, int32_t L, int32_t D,
-                                            int32_t max_len, int32_t dur_cols, ispk_stream_t stream) {
+static int32_t length_regulate_launch(const float* alignment, const float* dur_f32, const int64_t* dur_i64, const int64_t* enc_len,
+                                      const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
+                                      int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream,
+                                      bool split) {
     ISPK_REQUIRE(x && out && dec_len, ISPK_E_NULL, "length_regulate: null pointer");
     ISPK_REQUIRE((dur_f32 != nullptr) != (dur_i64 != nullptr), ISPK_E_NULL,
                  "length_regulate: exactly one of dur_f32 / dur_i64 must be given");
@@ -253,14 +304,30 @@ extern "C" int32_t ispk_length_regulate_f32(const float* alignment, const float*
     const size_t lds = 16 + (size_t)(kLrRows * kLrAld + kLrChunk * D + L + 1) * sizeof(float);
     const dim3 grid((M + kLrRows - 1) / kLrRows, B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (D == 384) {
-        ISPK_RESERVE_LDS((&length_regulate_kernel<3>), lds, "length_regulate");
-        hipLaunchKernelGGL(length_regulate_kernel<3>, grid, dim3(256), lds, s, alignment, dur_f32, dur_i64, enc_len, x, ldx,
-                           out, dec_len, dec_mask, M, L, max_len, dur_cols);
-    } else {
-        ISPK_RESERVE_LDS((&length_regulate_kernel<2>), lds, "length_regulate");
-        hipLaunchKernelGGL(length_regulate_kernel<2>, grid, dim3(256), lds, s, alignment, dur_f32, dur_i64, enc_len, x, ldx,
-                           out, dec_len, dec_mask, M, L, max_len, dur_cols);
-    }
+#define ISPK_LR(NT_, SP_)                                                                                              \
+    do {                                                                                                               \
+        ISPK_RESERVE_LDS((&length_regulate_kernel<NT_, SP_>), lds, "length_regulate");                                 \
+        hipLaunchKernelGGL((length_regulate_kernel<NT_, SP_>), grid, dim3(256), lds, s, alignment, dur_f32, dur_i64, enc_len, x, \
+                           ldx, out, dec_len, dec_mask, M, L, max_len, dur_cols);                                      \
+    } while (0)
+    if (D == 384) { if (split) ISPK_LR(3, true); else ISPK_LR(3, false); }
+    else { if (split) ISPK_LR(2, true); else ISPK_LR(2, false); }
+#undef ISPK_LR
     return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, const int64_t* dur_i64,
+                                            const int64_t* enc_len, const float* x, int64_t ldx, float* out,
+                                            int64_t* dec_len, uint8_t* dec_mask, int32_t B, int32_t M, int32_t L, int32_t D,
+                                            int32_t max_len, int32_t dur_cols, ispk_stream_t stream) {
+    return length_regulate_launch(alignment, dur_f32, dur_i64, enc_len, x, ldx, out, dec_len, dec_mask, B, M, L, D, max_len, dur_cols,
+                                  stream, false);
+}
+
+extern "C" int32_t ispk_length_regulate_split_bf16(const float* alignment, const float* dur_f32, const int64_t* dur_i64,
+                                                   const int64_t* enc_len, const float* x, int64_t ldx, float* out,
+                                                   int64_t* dec_len, uint8_t* dec_mask, int32_t B, int32_t M, int32_t L,
+                                                   int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream) {
+    return length_regulate_launch(alignment, dur_f32, dur_i64, enc_len, x, ldx, out, dec_len, dec_mask, B, M, L, D, max_len, dur_cols,
+                                  stream, true);
 }

@@ -58,6 +58,7 @@ SIGNATURES = {
     "ispk_embed_tokens_f32": [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_time_embedding_f32": [_P, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P],
     "ispk_length_regulate_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "ispk_length_regulate_split_bf16": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F32, _P],
     "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
@@ -776,9 +777,10 @@ def time_embedding(t: Tensor, inv_freq: Tensor, freq_scale: Tensor, w0: Tensor, 
 
 
 def length_regulate(x: Tensor, durations: Tensor, alignment: Optional[Tensor], frames: int, max_len: int = -1,
-                    enc_len: Optional[Tensor] = None, want_mask: bool = True):
+                    enc_len: Optional[Tensor] = None, want_mask: bool = True, split_bf16: bool = False):
     """ispk_length_regulate_f32 -> (out fp32 [B, frames, D], dec_len int64 [B], dec_mask bool [B, frames] | None).
-    alignment fp32 [B, frames, L] (forward), or None: the soft path generated from the fp32 `durations` (infer)."""
+    alignment fp32 [B, frames, L] (forward), or None: the soft path generated from the fp32 `durations` (infer).
+    `split_bf16`: ispk_length_regulate_split_bf16 (the bf16 compute path: three bf16 MFMAs per product, ~2^-16 relative)."""
     _dev(x, durations, alignment, enc_len)
     assert x.dtype == torch.float32 and x.ndim == 3
     if x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
@@ -802,7 +804,8 @@ def length_regulate(x: Tensor, durations: Tensor, alignment: Optional[Tensor], f
     dec_len = torch.empty((B,), dtype=torch.int64, device=x.device)
     mask = torch.empty((B, frames), dtype=torch.bool, device=x.device) if want_mask else None
     nb = 4.0 * B * (frames * D + L * D + (frames * L if alignment is not None else 0))
-    _launch("length_regulate_kernel", 2.0 * B * frames * L * D, nb, lib().ispk_length_regulate_f32, _ptr(alignment),
+    _launch("length_regulate_kernel<split>" if split_bf16 else "length_regulate_kernel", 2.0 * B * frames * L * D, nb,
+            lib().ispk_length_regulate_split_bf16 if split_bf16 else lib().ispk_length_regulate_f32, _ptr(alignment),
             _ptr(dur_f), _ptr(dur_i), _ptr(enc_len), x.data_ptr(), x.stride(1), out.data_ptr(), dec_len.data_ptr(),
             _ptr(mask), B, frames, L, D, max_len, dur_cols, _stream())
     return out, dec_len, mask

@@ -312,6 +312,11 @@ int32_t ispk_masked_instnorm_f32(const float* y, const float* weight, const floa
 int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_b, const float* k_enc, int64_t k_stride_b,
                                 const int64_t* text_len, const int64_t* mel_len, float* attn_logits, float* attn_soft,
                                 int32_t B, int32_t M, int32_t L, int32_t D, ispk_stream_t stream);
+/* The same operator for the bf16 compute path (its q_enc / k_enc carry the convolutions' bf16 rounding): score products as
+ * three bf16 MFMAs over hi / lo splits of the fp32 operands (~2^-16 relative), v_exp_f32 / v_log_f32 instead of libm. */
+int32_t ispk_aligner_scores_fast_f32(const float* q_enc, int64_t q_stride_b, const float* k_enc, int64_t k_stride_b,
+                                const int64_t* text_len, const int64_t* mel_len, float* attn_logits, float* attn_soft,
+                                int32_t B, int32_t M, int32_t L, int32_t D, ispk_stream_t stream);
 int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const float* energy, const int64_t* duration,
                               const int64_t* text_len, float* feats, int32_t B, int32_t M, int32_t L,
                               ispk_stream_t stream);

@@ -120,7 +120,7 @@ class ConvAttention(nn.Module, Constructor):
         k = runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len, out_dtype=dt)
         k = runtime.conv5_padded(k, wk[1])
         q = q_proj if q_proj is not None else self.project_queries(queries, query_len)
-        return runtime.aligner_scores(q, k, key_len, query_len, max_q, max_k)
+        return runtime.aligner_scores(q, k, key_len, query_len, max_q, max_k, fast=dt == torch.bfloat16)
 
 
 class AlignerOutput(NamedTuple):

@@ -153,7 +153,40 @@ __device__ __forceinline__ int ks_off(int row, int chunk) { return row * kAD + (
 // overlap the other's (one 4-wave workgroup per CU ran them strictly one after the other: 56 us at B=64 x 512 x 100).
 // NB = ceil(L_max / 32) 32-key blocks held in registers (NB <= 10: L_max <= 320).
 constexpr int kAsWaves = 2;
-template <int NB>
+// kFast (ispk_aligner_scores_fast_f32, the bf16 compute path - its q / k already carry the convolutions' bf16 rounding): the
+// score products as three bf16 MFMAs over hi / lo splits of the fp32 operands (~2^-16 relative; 24 MFMAs of 32 cycles per
+// 32-key block instead of 64 of 64 cycles) and v_exp_f32 / v_log_f32 instead of libm's expf / logf.
+typedef uint32_t as_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void as_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    union { as_u32x4 u; bf16x8 f; } h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        f2 a;
+        a.x = v[2 * e]; a.y = v[2 * e + 1];
+        const uint32_t ph = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2));
+        f2 r;
+        r.x = a.x - __builtin_bit_cast(float, ph << 16);
+        r.y = a.y - __builtin_bit_cast(float, ph & 0xffff0000u);
+        h.u[e] = ph;
+        l.u[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf2));
+    }
+    hi = h.f;
+    lo = l.f;
+}
+template <bool kFast>
+__device__ __forceinline__ float as_exp(float x) {
+    if constexpr (kFast) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
+    else return expf(x);
+}
+template <bool kFast>
+__device__ __forceinline__ float as_log(float x) {
+    if constexpr (kFast) return __builtin_amdgcn_logf(x) * 0.6931471805599453f;
+    else return logf(x);
+}
+
+template <int NB, bool kFast = false>
 __global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const float* __restrict__ qe, int64_t q_stride_b,
                                                              const float* __restrict__ ke, int64_t k_stride_b,
                                                              const int64_t* __restrict__ text_len,
@@ -208,6 +241,35 @@ __global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const flo
 
     // S^T[key][mel]: register r of block kb_ is key 32*kb_ + (r&3) + 8(r>>2) + 4h
     f32x16 s[NB];
+    if constexpr (kFast) {
+        // step st of lane half h covers dims 64 h + 8 st .. + 7 (chunks 2 st, 2 st + 1 of the half) in both operands
+        bf16x8 qh[8], ql[8];
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] = qf[2 * st][e]; v[4 + e] = qf[2 * st + 1][e]; }
+            as_split8(v, qh[st], ql[st]);
+        }
+#pragma unroll
+        for (int kb_ = 0; kb_ < NB; ++kb_) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kb_][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const f32x4 k0 = *reinterpret_cast<const f32x4*>(Ks + ks_off(kb_ * 32 + l31, h * 16 + 2 * st));
+                const f32x4 k1 = *reinterpret_cast<const f32x4*>(Ks + ks_off(kb_ * 32 + l31, h * 16 + 2 * st + 1));
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = k0[e]; v[4 + e] = k1[e]; }
+                bf16x8 kh, kl;
+                as_split8(v, kh, kl);
+                s[kb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[st], s[kb_], 0, 0, 0);
+                s[kb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[st], s[kb_], 0, 0, 0);
+                s[kb_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[st], s[kb_], 0, 0, 0);
+            }
+        }
+    } else {
 #pragma unroll
     for (int kb_ = 0; kb_ < NB; ++kb_) {
 #pragma unroll
@@ -218,6 +280,7 @@ __global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const flo
 #pragma unroll
             for (int e = 0; e < 4; ++e) s[kb_] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[c][e], s[kb_], 0, 0, 0);
         }
+    }
     }
 
     __syncthreads();  // every wave has its scores in registers: the key tile is dead, its space becomes the patches
@@ -243,18 +306,18 @@ __global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const flo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kb_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            rsum += expf(s[kb_][r] - rmax);  // exp(-inf) = 0 for key >= L
+            rsum += as_exp<kFast>(s[kb_][r] - rmax);  // exp(-inf) = 0 for key >= L
             // un-normalised diagonal prior (alignment.py:22-32): exp(-(t/T - m/M)^2 / (2 * 0.1^2)), 0 outside the lengths
             pe[kb_][r] = 0.f;
             if (key < tl && m < ml) {
                 const float g = (float)key / (float)tl - mq;
-                pe[kb_][r] = expf(-(g * g) / (2.0f * 0.1f * 0.1f));
+                pe[kb_][r] = as_exp<kFast>(-(g * g) / (2.0f * 0.1f * 0.1f));
                 psum += pe[kb_][r];
             }
         }
     rsum += __shfl_xor(rsum, 32, 64);
     psum += __shfl_xor(psum, 32, 64);
-    const float lse = rmax + logf(rsum);
+    const float lse = rmax + as_log<kFast>(rsum);
     const float pinv = 1.0f / (psum + 1e-5f);
 
     // ---- logits = log_softmax + log(prior + 1e-6); soft = mask * softmax(logits with masked keys)
@@ -269,7 +332,7 @@ __global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const flo
                 pr = pe[kb_][r] * pinv;
                 pr = pr < 1e-4f ? 0.f : pr;
             }
-            const float lg = (s[kb_][r] - lse) + logf(pr + 1e-6f);
+            const float lg = (s[kb_][r] - lse) + as_log<kFast>(pr + 1e-6f);
             s[kb_][r] = lg;  // keys >= L: -inf (never stored)
             if (key < tl) smax = fmaxf(smax, lg);
         }
@@ -280,7 +343,7 @@ __global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const flo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int key = kb_ * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (key < tl) esum += expf(s[kb_][r] - smax);
+            if (key < tl) esum += as_exp<kFast>(s[kb_][r] - smax);
         }
     esum += __shfl_xor(esum, 32, 64);
     const float einv = (m < ml) ? 1.0f / esum : 0.f;
@@ -302,7 +365,7 @@ __global__ __launch_bounds__(64 * kAsWaves) void aligner_scores_kernel(const flo
                 for (int e = 0; e < 4; ++e) {
                     const int key = kb_ * 32 + 8 * g + 4 * h + e;
                     const float lg = s[kb_][4 * g + e];
-                    pv[e] = pass == 0 ? lg : (key < tl ? expf(lg - smax) * einv : 0.f);
+                    pv[e] = pass == 0 ? lg : (key < tl ? as_exp<kFast>(lg - smax) * einv : 0.f);
                 }
                 *reinterpret_cast<float4*>(stage + l31 * 144 + (8 * g + 4 * h) * 4) = v;
             }
@@ -517,10 +580,9 @@ extern "C" int32_t ispk_masked_instnorm_f32(const float* y, const float* weight,
     return ispk_launch_status();
 }
 
-extern "C" int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_b, const float* k_enc,
-                                           int64_t k_stride_b, const int64_t* text_len, const int64_t* mel_len,
-                                           float* attn_logits, float* attn_soft, int32_t B, int32_t M, int32_t L,
-                                           int32_t D, ispk_stream_t stream) {
+static int32_t aligner_scores_launch(const float* q_enc, int64_t q_stride_b, const float* k_enc, int64_t k_stride_b,
+                                     const int64_t* text_len, const int64_t* mel_len, float* attn_logits, float* attn_soft,
+                                     int32_t B, int32_t M, int32_t L, int32_t D, ispk_stream_t stream, bool fast) {
     ISPK_REQUIRE(q_enc && k_enc && text_len && mel_len && attn_logits && attn_soft, ISPK_E_NULL,
                  "aligner_scores: null pointer");
     ISPK_REQUIRE(D == kAD, ISPK_E_UNSUPPORTED, "aligner_scores: attention_dim %d (built for 128)", D);
@@ -539,9 +601,15 @@ extern "C" int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define ISPK_AL_CASE(NB)                                                                                              \
     case NB:                                                                                                          \
-        ISPK_RESERVE_LDS((&aligner_scores_kernel<NB>), lds, "aligner_scores");                                        \
-        hipLaunchKernelGGL((aligner_scores_kernel<NB>), grid, block, lds, s, q_enc, q_stride_b, k_enc, k_stride_b,     \
-                           text_len, mel_len, attn_logits, attn_soft, M, L, scale);                                   \
+        if (fast) {                                                                                                   \
+            ISPK_RESERVE_LDS((&aligner_scores_kernel<NB, true>), lds, "aligner_scores");                              \
+            hipLaunchKernelGGL((aligner_scores_kernel<NB, true>), grid, block, lds, s, q_enc, q_stride_b, k_enc,      \
+                               k_stride_b, text_len, mel_len, attn_logits, attn_soft, M, L, scale);                   \
+        } else {                                                                                                      \
+            ISPK_RESERVE_LDS((&aligner_scores_kernel<NB, false>), lds, "aligner_scores");                             \
+            hipLaunchKernelGGL((aligner_scores_kernel<NB, false>), grid, block, lds, s, q_enc, q_stride_b, k_enc,     \
+                               k_stride_b, text_len, mel_len, attn_logits, attn_soft, M, L, scale);                   \
+        }                                                                                                             \
         break;
     switch (nb) {
         ISPK_AL_CASE(1) ISPK_AL_CASE(2) ISPK_AL_CASE(3) ISPK_AL_CASE(4) ISPK_AL_CASE(5) ISPK_AL_CASE(6) ISPK_AL_CASE(7)
@@ -550,6 +618,22 @@ extern "C" int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_
     }
 #undef ISPK_AL_CASE
     return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_aligner_scores_f32(const float* q_enc, int64_t q_stride_b, const float* k_enc,
+                                           int64_t k_stride_b, const int64_t* text_len, const int64_t* mel_len,
+                                           float* attn_logits, float* attn_soft, int32_t B, int32_t M, int32_t L,
+                                           int32_t D, ispk_stream_t stream) {
+    return aligner_scores_launch(q_enc, q_stride_b, k_enc, k_stride_b, text_len, mel_len, attn_logits, attn_soft, B, M, L, D, stream,
+                                 false);
+}
+
+extern "C" int32_t ispk_aligner_scores_fast_f32(const float* q_enc, int64_t q_stride_b, const float* k_enc,
+                                                int64_t k_stride_b, const int64_t* text_len, const int64_t* mel_len,
+                                                float* attn_logits, float* attn_soft, int32_t B, int32_t M, int32_t L,
+                                                int32_t D, ispk_stream_t stream) {
+    return aligner_scores_launch(q_enc, q_stride_b, k_enc, k_stride_b, text_len, mel_len, attn_logits, attn_soft, B, M, L, D, stream,
+                                 true);
 }
 
 extern "C" int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const float* energy,

@@ -62,6 +62,7 @@ SIGNATURES = {
     "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F32, _P],
     "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
+    "ispk_aligner_scores_fast_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_soft_average_f32": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_transpose_f32": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ispk_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
@@ -692,17 +693,18 @@ def masked_instnorm(y: Tensor, weight: Tensor, bias: Tensor, lengths: Tensor, ep
     return out
 
 
-def aligner_scores(q_enc: Tensor, k_enc: Tensor, text_len: Tensor, mel_len: Tensor, M: int, L: int):
+def aligner_scores(q_enc: Tensor, k_enc: Tensor, text_len: Tensor, mel_len: Tensor, M: int, L: int, fast: bool = False):
     """ispk_aligner_scores_f32: q_enc [B, M+4, 128], k_enc [B, L+4, 128] (row t = frame/token t) ->
-    (attn_soft, attn_logits), both [B, M, L]."""
+    (attn_soft, attn_logits), both [B, M, L].  `fast`: ispk_aligner_scores_fast_f32 (bf16 compute path: split-bf16 score
+    products, hardware exp / log)."""
     _dev(q_enc, k_enc, text_len, mel_len)
     B, D = q_enc.shape[0], q_enc.shape[2]
     logits = torch.empty((B, M, L), dtype=torch.float32, device=q_enc.device)
     soft = torch.empty((B, M, L), dtype=torch.float32, device=q_enc.device)
     text_len = text_len.to(torch.int64).contiguous()
     mel_len = mel_len.to(torch.int64).contiguous()
-    _launch("aligner_scores_kernel", 2.0 * B * M * L * D, 4.0 * B * (M * D + L * D + 2 * M * L),
-            lib().ispk_aligner_scores_f32, q_enc.data_ptr(), q_enc.stride(0), k_enc.data_ptr(), k_enc.stride(0),
+    _launch("aligner_scores_kernel<fast>" if fast else "aligner_scores_kernel", 2.0 * B * M * L * D, 4.0 * B * (M * D + L * D + 2 * M * L),
+            lib().ispk_aligner_scores_fast_f32 if fast else lib().ispk_aligner_scores_f32, q_enc.data_ptr(), q_enc.stride(0), k_enc.data_ptr(), k_enc.stride(0),
             text_len.data_ptr(), mel_len.data_ptr(), logits.data_ptr(), soft.data_ptr(), B, M, L, D, _stream())
     return soft, logits
 

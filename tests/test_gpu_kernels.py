@@ -768,6 +768,22 @@ def test_conv_attention_front_end_matches_oracle(state_dict, B, M, L):
     assert (logits.cpu() - logits_ref).abs().max() < 2e-4       # logits reach -35; relative 1e-5
 
 
+@pytest.mark.parametrize("B,M,L", [(2, 512, 100), (3, 203, 37), (1, 300, 290)])
+def test_aligner_scores_fast_mode(B, M, L):
+    """ispk_aligner_scores_fast_f32 (bf16 compute path): split-bf16 score products and hardware exp / log against the exact
+    kernel on the same inputs - logits to 1e-3 absolute (they reach -35: 3e-5 relative), soft attention to 1e-4."""
+    q = synth._normal(f"t/asf/q{M}", (B, M + 4, 128), 2.0).to(DEV)
+    k = synth._normal(f"t/asf/k{L}", (B, L + 4, 128), 2.0).to(DEV)
+    text_len = torch.tensor([L, max(1, L // 2), L - 3][:B], device=DEV)
+    mel_len = torch.tensor([M, max(1, M - 40), M // 2][:B], device=DEV)
+    soft, logits = runtime.aligner_scores(q, k, text_len, mel_len, M, L)
+    soft_f, logits_f = runtime.aligner_scores(q, k, text_len, mel_len, M, L, fast=True)
+    fin = torch.isfinite(logits)
+    assert torch.equal(fin, torch.isfinite(logits_f))
+    assert (logits_f[fin] - logits[fin]).abs().max().item() < 1e-3
+    assert (soft_f - soft).abs().max().item() < 1e-4
+
+
 def test_soft_average_targets():
     B, M, L = 3, 130, 41
     g = synth._rng("t/avg")

@@ -703,7 +703,7 @@ def aligner_scores(q_enc: Tensor, k_enc: Tensor, text_len: Tensor, mel_len: Tens
     soft = torch.empty((B, M, L), dtype=torch.float32, device=q_enc.device)
     text_len = text_len.to(torch.int64).contiguous()
     mel_len = mel_len.to(torch.int64).contiguous()
-    _launch("aligner_scores_kernel<fast>" if fast else "aligner_scores_kernel", 2.0 * B * M * L * D, 4.0 * B * (M * D + L * D + 2 * M * L),
+    _launch("aligner_scores_kernel<bf16x3>" if fast else "aligner_scores_kernel", 2.0 * B * M * L * D, 4.0 * B * (M * D + L * D + 2 * M * L),
             lib().ispk_aligner_scores_fast_f32 if fast else lib().ispk_aligner_scores_f32, q_enc.data_ptr(), q_enc.stride(0), k_enc.data_ptr(), k_enc.stride(0),
             text_len.data_ptr(), mel_len.data_ptr(), logits.data_ptr(), soft.data_ptr(), B, M, L, D, _stream())
     return soft, logits
@@ -806,7 +806,7 @@ def length_regulate(x: Tensor, durations: Tensor, alignment: Optional[Tensor], f
     dec_len = torch.empty((B,), dtype=torch.int64, device=x.device)
     mask = torch.empty((B, frames), dtype=torch.bool, device=x.device) if want_mask else None
     nb = 4.0 * B * (frames * D + L * D + (frames * L if alignment is not None else 0))
-    _launch("length_regulate_kernel<split>" if split_bf16 else "length_regulate_kernel", 2.0 * B * frames * L * D, nb,
+    _launch("length_regulate_kernel<bf16x3>" if split_bf16 else "length_regulate_kernel", 2.0 * B * frames * L * D, nb,
             lib().ispk_length_regulate_split_bf16 if split_bf16 else lib().ispk_length_regulate_f32, _ptr(alignment),
             _ptr(dur_f), _ptr(dur_i), _ptr(enc_len), x.data_ptr(), x.stride(1), out.data_ptr(), dec_len.data_ptr(),
             _ptr(mask), B, frames, L, D, max_len, dur_cols, _stream())

@@ -103,6 +103,7 @@ int32_t ispk_layernorm_f32_bf16(const float* x, int64_t ldx, const float* gamma,
 #define ISPK_EP_MASK_COL 32u
 #define ISPK_EP_OUT_BF16 64u   /* _bf16 entry only: C is bf16 (default fp32) */
 #define ISPK_EP_RESID_BF16 128u /* _bf16 entry only: resid is bf16 (default fp32) */
+#define ISPK_EP_OUT_SPLIT 512u  /* _split_f16 entry only: C is a pair of fp16 planes (hi at C, lo c_plane elements behind) */
 #define ISPK_EP_ROWS_T 256u     /* _bf16 entry, K = 256 / 384, fp32 C, no resid: the M rows are [batch][T] frames with
                                    T = cols_per_batch and C is stored transposed per batch,
                                    C[(i / T) * batch_stride + j * ldc + (i % T)]  (bias by column j, mask by row i): the
@@ -536,6 +537,43 @@ int32_t ispk_grad_sqnorm_f32(const float* g, int64_t n, float* partial, float* o
 int32_t ispk_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay, float lr, float beta1,
                        float beta2, float eps, float weight_decay, int32_t step, const float* grad_sqnorm, float max_norm,
                        float grad_scale, ispk_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * The fp32-grade fast path ("split fp16"): every fp32 operand value v is carried as two fp16 terms, hi = fp16(v) and
+ * lo = fp16(v - hi) (22 significant bits), and a product is three fp16 MFMAs, hi hi + hi lo + lo hi, fp32 accumulation:
+ * 5.3x the rate of the exact-fp32 MFMAs at fp32-grade results (mel L-inf vs the reference stays < 1e-4; csrc/split.hip).
+ * Replaces, on the parity path, the same reference call sites as ispk_gemm_f32 / ispk_alibi_mqa_attn_f32: every nn.Linear
+ * of the stacks (attention.py:105,111,168; feedforward.py:33-36; transformer.py:170; model.py:167-168), the aligner's Conv1d
+ * as a GEMM (alignment.py:69-83) and Attend.efficient_attn (attend.py:49-122).
+ *
+ * "Split planes": a [rows][cols] matrix as two fp16 matrices of the same leading stride, the lo plane `*_plane` ELEMENTS
+ * behind the hi plane.  Domain |v| <= 65504 (values beyond are clamped).
+ * ispk_split_f16            x fp32 [rows][cols] (stride ldx) -> hi / lo planes (stride ldy); cols % 4 == 0.
+ * ispk_gemm_split_f16       C = epilogue(A W^T) as ispk_gemm_f32, A [M][K] and W [N][K] as split planes (lda < K allowed: the
+ *                           sliding-window Conv1d view).  Epilogue: bias by column, GELU (A&S 7.1.28 erf, |err| <= 3e-7) /
+ *                           SILU, MASK_ACC, fp32 residual, MASK_OUT; C fp32 row-major, or ISPK_EP_OUT_SPLIT: C is a pair of
+ *                           planes (c_plane; no residual), or ISPK_EP_ROWS_T (cols_per_batch = T, batch_stride): rows are
+ *                           [batch][T] frames and C[b][n][t] is written (Linear + transpose(1, 2) of model.py:167-168; bias
+ *                           + MASK_OUT only).  K % 8 == 0, N % 4 == 0.
+ * ispk_gemm_split_f16_tile  which tile ispk_gemm_split_f16 uses for (M, N, K): TN * 10 + WM = 64 TN features x 32 WM rows.
+ * ispk_layernorm_f32_split  ispk_layernorm_f32 with the result written as split planes (y_hi, lo y_plane behind).
+ * ispk_alibi_mqa_attn_split_f16   ispk_alibi_mqa_attn_f32 on split terms: q / k / v fp32 as there (K / V are split once per
+ *                           workgroup while staged, Q and the probabilities in registers); out fp32 [B][N][H*64] (o_plane
+ *                           == 0) or split planes (uint16 elements, lo o_plane behind) for the out-projection GEMM. */
+int32_t ispk_split_f16(const float* x, int64_t ldx, uint16_t* hi, uint16_t* lo, int64_t ldy, int32_t rows, int32_t cols,
+                       ispk_stream_t stream);
+int32_t ispk_gemm_split_f16_tile(int32_t M, int32_t N, int32_t K);
+int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a_plane, const uint16_t* W, int64_t ldw, int64_t w_plane,
+                            void* C, int64_t ldc, int64_t c_plane, const float* bias, const float* resid, int64_t ldr,
+                            const uint8_t* mask, int32_t M, int32_t N, int32_t K, uint32_t flags, int32_t cols_per_batch,
+                            int64_t batch_stride, ispk_stream_t stream);
+int32_t ispk_layernorm_f32_split(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* ada_scale,
+                                 const float* ada_shift, int64_t ada_stride, int32_t rows_per_batch, const uint8_t* row_mask,
+                                 uint16_t* y_hi, int64_t ldy, int64_t y_plane, int32_t rows, int32_t D, float eps,
+                                 ispk_stream_t stream);
+int32_t ispk_alibi_mqa_attn_split_f16(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                      const float* slopes, const int64_t* key_len, void* out, int64_t ldo, int64_t o_plane,
+                                      int32_t B, int32_t N, int32_t H, ispk_stream_t stream);
 
 /* fp32 -> bf16 conversion (round-to-nearest-even) of a [rows][cols] matrix; used to stage weights/activations. */
 int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int32_t rows, int32_t cols,

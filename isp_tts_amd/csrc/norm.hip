@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ ada_scale,
                                                         const float* __restrict__ ada_shift, int64_t ada_stride,
                                                         int rows_per_batch, const uint8_t* __restrict__ row_mask,
-                                                        OutT* __restrict__ y, int64_t ldy, int rows, float eps) {
+                                                        OutT* __restrict__ y, int64_t ldy, int rows, float eps,
+                                                        int64_t y_plane) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -65,6 +66,15 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         float o = (v[c] - mean) * rstd;
         if (sc) o *= sc[col];
         if (sh) o += sh[col];
+        if constexpr (sizeof(OutT) == 2) {
+            if (y_plane) {   // split fp16 planes (kernel-uniform)
+                const float val = __builtin_amdgcn_fmed3f(o * mk, -65504.0f, 65504.0f);
+                const _Float16 hh = (_Float16)val;
+                yr[col] = __builtin_bit_cast(uint16_t, hh);
+                yr[col + y_plane] = __builtin_bit_cast(uint16_t, (_Float16)(val - (float)hh));
+                continue;
+            }
+        }
         store_out<OutT>(yr + col, o * mk);
     }
 }
@@ -86,7 +96,8 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
                                                             const float* __restrict__ ada_scale,
                                                             const float* __restrict__ ada_shift, int64_t ada_stride,
                                                             int rows_per_batch, const uint8_t* __restrict__ row_mask,
-                                                            OutT* __restrict__ y, int64_t ldy, int rows, float eps) {
+                                                            OutT* __restrict__ y, int64_t ldy, int rows, float eps,
+                                                            int64_t y_plane) {
     const int lane = threadIdx.x & 63, l = lane & 31;
     const int row_raw = blockIdx.x * 8 + (threadIdx.x >> 6) * 2 + (lane >> 5);
     const int row = row_raw < rows ? row_raw : rows - 1;   // out-of-range halves recompute the last row and store nothing
@@ -134,6 +145,19 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
         o.x *= mk; o.y *= mk; o.z *= mk; o.w *= mk;
         if constexpr (sizeof(OutT) == 4) {
             *reinterpret_cast<float4*>(yr + col) = o;
+        } else if (y_plane) {   // split fp16 planes (kernel-uniform): hi = fp16(v), lo = fp16(v - hi)
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const float vv[4] = {__builtin_amdgcn_fmed3f(o.x, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(o.y, -65504.0f, 65504.0f),
+                                 __builtin_amdgcn_fmed3f(o.z, -65504.0f, 65504.0f), __builtin_amdgcn_fmed3f(o.w, -65504.0f, 65504.0f)};
+            uint2 ph, pl;
+            h2 a, b, c, d;
+            a.x = (_Float16)vv[0]; a.y = (_Float16)vv[1]; b.x = (_Float16)vv[2]; b.y = (_Float16)vv[3];
+            c.x = (_Float16)(vv[0] - (float)a.x); c.y = (_Float16)(vv[1] - (float)a.y);
+            d.x = (_Float16)(vv[2] - (float)b.x); d.y = (_Float16)(vv[3] - (float)b.y);
+            ph.x = __builtin_bit_cast(uint32_t, a); ph.y = __builtin_bit_cast(uint32_t, b);
+            pl.x = __builtin_bit_cast(uint32_t, c); pl.y = __builtin_bit_cast(uint32_t, d);
+            *reinterpret_cast<uint2*>(yr + col) = ph;
+            *reinterpret_cast<uint2*>(yr + y_plane + col) = pl;
         } else {
             uint2 pk;
             pk.x = (uint32_t)f32_to_bf16(o.x) | ((uint32_t)f32_to_bf16(o.y) << 16);
@@ -146,8 +170,10 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(const float* __restr
 template <typename OutT>
 int32_t layernorm_dispatch(const float* x, int64_t ldx, const float* gamma, const float* beta, const float* ada_scale,
                            const float* ada_shift, int64_t ada_stride, int32_t rows_per_batch, const uint8_t* row_mask,
-                           OutT* y, int64_t ldy, int32_t rows, int32_t D, float eps, ispk_stream_t stream) {
+                           OutT* y, int64_t ldy, int32_t rows, int32_t D, float eps, ispk_stream_t stream,
+                           int64_t y_plane = 0) {
     ISPK_REQUIRE(x && y, ISPK_E_NULL, "layernorm: null x/y");
+    ISPK_REQUIRE(y_plane % 4 == 0 && (y_plane == 0 || sizeof(OutT) == 2), ISPK_E_ALIGN, "layernorm: y_plane %% 4 (split output)");
     ISPK_REQUIRE(rows >= 0 && D >= 64 && D <= 1024 && D % 64 == 0, ISPK_E_SHAPE,
                  "layernorm: D=%d must be a multiple of 64 in [64, 1024]", D);
     ISPK_REQUIRE(ldx >= D && ldy >= D, ISPK_E_SHAPE, "layernorm: leading stride < D");
@@ -165,7 +191,7 @@ int32_t layernorm_dispatch(const float* x, int64_t ldx, const float* gamma, cons
 #define ISPK_LNV_CASE(NV4)                                                                                               \
     case NV4:                                                                                                           \
         hipLaunchKernelGGL((layernorm_vec_kernel<NV4, OutT>), grid8, block8, 0, s, x, ldx, gamma, beta, ada_scale,      \
-                           ada_shift, ada_stride, rows_per_batch, row_mask, y, ldy, rows, eps);                         \
+                           ada_shift, ada_stride, rows_per_batch, row_mask, y, ldy, rows, eps, y_plane);                \
         break;
         switch (D / 128) { ISPK_LNV_CASE(1) ISPK_LNV_CASE(2) ISPK_LNV_CASE(3) ISPK_LNV_CASE(4) }
 #undef ISPK_LNV_CASE
@@ -175,7 +201,7 @@ int32_t layernorm_dispatch(const float* x, int64_t ldx, const float* gamma, cons
 #define ISPK_LN_CASE(NV)                                                                                              \
     case NV:                                                                                                          \
         hipLaunchKernelGGL((layernorm_kernel<NV, OutT>), grid, block, 0, s, x, ldx, gamma, beta, ada_scale, ada_shift, \
-                           ada_stride, rows_per_batch, row_mask, y, ldy, rows, eps);                                  \
+                           ada_stride, rows_per_batch, row_mask, y, ldy, rows, eps, y_plane);                         \
         break;
     switch (D / 64) {
         ISPK_LN_CASE(1) ISPK_LN_CASE(2) ISPK_LN_CASE(3) ISPK_LN_CASE(4) ISPK_LN_CASE(5) ISPK_LN_CASE(6)
@@ -256,6 +282,15 @@ extern "C" int32_t ispk_layernorm_f32_bf16(const float* x, int64_t ldx, const fl
                                            int32_t rows, int32_t D, float eps, ispk_stream_t stream) {
     return layernorm_dispatch<uint16_t>(x, ldx, gamma, beta, ada_scale, ada_shift, ada_stride, rows_per_batch, row_mask,
                                         y, ldy, rows, D, eps, stream);
+}
+
+extern "C" int32_t ispk_layernorm_f32_split(const float* x, int64_t ldx, const float* gamma, const float* beta,
+                                            const float* ada_scale, const float* ada_shift, int64_t ada_stride,
+                                            int32_t rows_per_batch, const uint8_t* row_mask, uint16_t* y_hi, int64_t ldy,
+                                            int64_t y_plane, int32_t rows, int32_t D, float eps, ispk_stream_t stream) {
+    ISPK_REQUIRE(y_plane > 0, ISPK_E_SHAPE, "layernorm_split: y_plane must be positive");
+    return layernorm_dispatch<uint16_t>(x, ldx, gamma, beta, ada_scale, ada_shift, ada_stride, rows_per_batch, row_mask,
+                                        y_hi, ldy, rows, D, eps, stream, y_plane);
 }
 
 extern "C" int32_t ispk_linear_small_f32(const float* a, int64_t lda, const float* w, int64_t ldw, const float* bias,

@@ -1,0 +1,614 @@
+// The fp32-grade fast path: every fp32 operand value v travels as TWO fp16 terms, hi = fp16(v) and lo = fp16(v - hi)
+// (22 significant bits together), and a product of two such operands is three v_mfma_f32_32x32x16_f16 instructions,
+//     a * b  ~=  hi_a hi_b + hi_a lo_b + lo_a hi_b          (the lo lo term is below 2^-22 of the product),
+// each fp16 x fp16 product exact in the MFMA's fp32 accumulator.  That is three matrix instructions at the fp16 / bf16
+// rate (2.5 PF dense) where the exact-fp32 path (v_mfma_f32_32x32x2_f32, 157 TF) needs sixteen times the cycles of one:
+// 5.3x the fp32 MFMA rate at fp32-grade results.  (Split into bf16 terms, the same three products keep only 16 bits: mel
+// L-inf 5e-5 against 9e-6 on the oracle's forward, tools/split_numerics.py - fp16's 11-bit terms are what makes two terms
+// enough.)  Domain: |v| <= 65504 (clamped); terms below fp16's normal range keep fp16's subnormal spacing (2^-24
+// absolute), which MFMA inputs do not flush.
+//
+// Operand format in HBM ("split planes"): a [rows][cols] fp32 matrix becomes two fp16 matrices of the same shape and
+// leading stride, the lo plane `plane` elements behind the hi plane - 4 bytes per value, like the fp32 it replaces, so
+// that a producer splits each value ONCE (LayerNorm, GELU epilogue, attention epilogue) and every consumer GEMM streams
+// fp16 tiles by LDS-DMA without touching a VALU.
+//
+// Replaces, on the parity path, the exact-fp32 kernels behind the same reference call sites: nn.Linear (attention.py:105,
+// 111,168; feedforward.py:33-36; transformer.py:170; model.py:167-168; the aligner's Conv1d as a GEMM, alignment.py:69-83)
+// and Attend.efficient_attn (attend.py:49-122).
+#include "gemm_common.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t su32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f16x8 as_f16x8(const bf16x8& v) { return __builtin_bit_cast(f16x8, v); }
+
+// two fp32 values -> packed fp16 hi terms and packed fp16 lo terms (round to nearest even both times; v - hi is exact)
+__device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
+    a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f);
+    b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
+    f16x2 h;
+    h.x = (_Float16)a;
+    h.y = (_Float16)b;
+    f16x2 l;
+    l.x = (_Float16)(a - (float)h.x);
+    l.y = (_Float16)(b - (float)h.y);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+// the same without the range clamp, for values known to lie inside fp16's range (softmax probabilities, scaled queries)
+__device__ __forceinline__ void split_pair_nc(float a, float b, uint32_t& hi, uint32_t& lo) {
+    f16x2 h;
+    h.x = (_Float16)a;
+    h.y = (_Float16)b;
+    f16x2 l;
+    l.x = (_Float16)(a - (float)h.x);
+    l.y = (_Float16)(b - (float)h.y);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// ------------------------------------------------------------------------------------------------ fp32 -> split planes
+// One thread per 4 consecutive values: 16-byte load, two 8-byte stores.
+__global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict__ x, int64_t ldx, uint16_t* __restrict__ hi,
+                                                        uint16_t* __restrict__ lo, int64_t ldy, int rows, int cols4) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)rows * cols4) return;
+    const int r = (int)(idx / cols4), c = (int)(idx - (int64_t)r * cols4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(x + (int64_t)r * ldx + c);
+    uint2 h, l;
+    split_pair(v.x, v.y, h.x, l.x);
+    split_pair(v.z, v.w, h.y, l.y);
+    *reinterpret_cast<uint2*>(hi + (int64_t)r * ldy + c) = h;
+    *reinterpret_cast<uint2*>(lo + (int64_t)r * ldy + c) = l;
+}
+
+// ------------------------------------------------------------------------------------------------ Linear on split planes
+// C = epilogue(A · Wᵀ) with A [M][K] and W [N][K] given as split planes.  Skeleton of gemm_bf16_wide_kernel (gemm.hip): one
+// workgroup = 32 WM activation rows x 64 TN output features, WM x 2 waves, a wave holds 32 rows x TN 32-feature tiles in
+// accumulators, computed transposed (D = W_tile · Xᵀ) so that a lane owns one activation row for the row-coalescing
+// epilogue; operand tiles stream by LDS-DMA (global_load_lds_dwordx4) into a ring of S slots, one raw s_barrier per
+// K chunk.  What is different:
+//   * a K chunk is 32 deep and an LDS row (128 B) holds BOTH terms of it: 16-byte slots 0-3 = hi k 0..31, slots 4-7 = lo.
+//     A DMA lane picks its plane with its slot, so in HBM the planes stay separate matrices (and a leading stride SMALLER
+//     than K - the sliding-window view that turns a padded channel-last Conv1d into a GEMM - keeps working per plane);
+//     the XOR swizzle (physical slot = logical slot ^ ((row >> 1) & 7)) is applied on the source side as before;
+//   * per 16-deep k-step a wave reads X hi / X lo and W hi / W lo fragments (2 + 2 TN ds_read_b128) for 3 TN MFMAs.
+template <int TN, int WM>
+__global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p) {
+    constexpr int BM = 32 * WM, BN = 64 * TN, NT = WM * 128, NWV = NT / 64;
+    constexpr int kSlot = (BM + BN) * 128;                       // bytes per ring slot: X rows then W rows, 128 B each
+    constexpr int S = 4 * kSlot <= 128 * 1024 ? 4 : (3 * kSlot <= 152 * 1024 ? 3 : 2);
+    constexpr int IPL = (BM + BN) / 8 / NWV;
+    static_assert((BM + BN) / 8 % NWV == 0 && (S - 1) * IPL <= 63, "DMA split / vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * BM;
+    const int nb0 = blockIdx.y * BN;
+    const uint16_t* A = static_cast<const uint16_t*>(p.A);
+    const uint16_t* W = static_cast<const uint16_t*>(p.W);
+
+    // this lane's part of DMA instruction j: row (8-row group wave*IPL + j, row lane>>3), physical LDS slot lane&7
+    const uint16_t* src_row[IPL];
+    int src_k[IPL];
+#pragma unroll
+    for (int j = 0; j < IPL; ++j) {
+        const int r = (wave * IPL + j) * 8 + (lane >> 3);       // row of the concatenated [X; W] tile
+        const int rr = r < BM ? r : r - BM;
+        const int ls = (lane & 7) ^ ((rr >> 1) & 7);             // logical slot: plane ls >> 2, k offset 8 (ls & 3)
+        src_k[j] = (ls & 3) * 8;
+        if (r < BM) {
+            const int row = m0 + r < p.M ? m0 + r : p.M - 1;     // rows past the end: a valid row, never stored
+            src_row[j] = A + (int64_t)row * p.lda + (ls >> 2) * p.a_plane;
+        } else {
+            const int n = nb0 + rr < p.N ? nb0 + rr : p.N - 1;
+            src_row[j] = W + (int64_t)n * p.ldw + (ls >> 2) * p.w_plane;
+        }
+    }
+    auto issue = [&](int kt) {
+        char* slot = smem_raw + (kt % S) * kSlot + wave * (IPL * 1024);
+#pragma unroll
+        for (int j = 0; j < IPL; ++j) {
+            const int k = kt * 32 + src_k[j];
+            const uint16_t* src = k < p.K ? src_row[j] + k : g_zero16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(slot + j * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int t = 0; t < TN; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int nk = (p.K + 31) / 32;
+#pragma unroll 1
+    for (int kt = 0; kt < nk && kt < S - 1; ++kt) issue(kt);
+
+    // fragment byte offsets inside a slot: group g = 2 * plane + k-step, logical slot 2g + h of row l31
+    uint32_t xoff[4], woff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint32_t sw = (uint32_t)(((2 * g + h) ^ ((l31 >> 1) & 7)) << 4);
+        xoff[g] = (wm * 32 + l31) * 128 + sw;
+        woff[g] = (BM + wn * 32 * TN + l31) * 128 + sw;
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int after = (nk - 1 - kt) < (S - 2) ? (nk - 1 - kt) : (S - 2);   // younger chunks this wave has in flight
+        if (S >= 4 && after >= 2) vm_wait<2 * IPL>();
+        else if (S >= 3 && after == 1) vm_wait<IPL>();
+        else vm_wait<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();            // publishes chunk kt; every wave is done with chunk kt-1
+        asm volatile("" ::: "memory");
+        const uint32_t sl = lds_addr(smem_raw) + (uint32_t)((kt % S) * kSlot);
+        bf16x8 fr[4][TN + 1];                    // [group][X, W tile 0 .. TN-1]
+        auto rd = [&](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            lds_read_b128_asm<0>(fr[g][0], sl + xoff[g]);
+            static_for<0, TN>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                lds_read_b128_asm<t * 32 * 128>(fr[g][1 + t], sl + woff[g]);
+            });
+        };
+        rd(std::integral_constant<int, 0>{});    // hi, k-step 0
+        rd(std::integral_constant<int, 2>{});    // lo, k-step 0
+        rd(std::integral_constant<int, 1>{});    // hi, k-step 1
+        rd(std::integral_constant<int, 3>{});    // lo, k-step 1
+        if (kt + S - 1 < nk) issue(kt + S - 1);  // into the slot chunk kt-1 just left
+        static_for<0, 2>([&](auto kc) {
+            constexpr int ks = decltype(kc)::value;
+            if constexpr (ks == 0) lds_wait<2 * (TN + 1)>(); else lds_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)         // W lo · X hi
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[2 + ks][1 + t]), as_f16x8(fr[ks][0]), acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)         // W hi · X lo
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[ks][1 + t]), as_f16x8(fr[2 + ks][0]), acc[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)         // W hi · X hi
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[ks][1 + t]), as_f16x8(fr[ks][0]), acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+    __syncthreads();   // the epilogue's transposition patches alias the ring
+
+    const int m = m0 + wm * 32 + l31;
+    const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+    if (p.flags & ISPK_EP_ROWS_T) {
+        // rows are [batch][T] frames, T = cpb; output feature n of frame (b, t) goes to C[b][n][t] (to_mel + transpose)
+        float* cb = nullptr;
+        if (m < p.M) {
+            const int bb = m / p.cpb;
+            cb = static_cast<float*>(p.C) + (int64_t)bb * p.bstride + (m - bb * p.cpb);
+        }
+        const float mo = (p.flags & ISPK_EP_MASK_OUT) ? mk : 1.0f;
+#pragma unroll
+        for (int t = 0; t < TN; ++t) store_rows_t(p, cb, nb0 + (wn * TN + t) * 32, acc[t], mo, h);
+    } else if (p.flags & ISPK_EP_OUT_SPLIT) {
+        // split-plane output: two adjacent 32-feature tiles per pass through a pair of wave-private LDS patches
+        char* stage = smem_raw + wave * (2 * kStageBytes);
+        static_assert(TN % 2 == 0 || TN == 3, "tile pairing");
+        uint16_t* Chi = static_cast<uint16_t*>(p.C);
+#pragma unroll
+        for (int t = 0; t < TN; t += 2) {
+            const bool pair = t + 1 < TN;
+            const int n0 = nb0 + (wn * TN + t) * 32;
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                if (tt == 1 && !pair) break;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[t + tt < TN ? t + tt : t][4 * g + e];
+                    const int n = n0 + tt * 32 + 8 * g + 4 * h;
+                    pre_stage(p, n < p.N ? n : 0, v, mk);
+                    if (p.flags & ISPK_EP_MASK_OUT) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] *= mk;
+                    }
+                    uint2 oh, ol;
+                    split_pair(v[0], v[1], oh.x, ol.x);
+                    split_pair(v[2], v[3], oh.y, ol.y);
+                    *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = oh;
+                    *reinterpret_cast<uint2*>(stage + kStageBytes + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = ol;
+                }
+            }
+            const int c = lane & 7, n = n0 + 8 * c;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + (lane >> 3), mr = m0 + wm * 32 + r;
+                const uint4 vh = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
+                const uint4 vl = *reinterpret_cast<const uint4*>(stage + kStageBytes + r * kStageRow + c * 16);
+                if (mr < p.M && n < p.N && (pair || c < 4)) {
+                    *reinterpret_cast<uint4*>(Chi + (int64_t)mr * p.ldc + n) = vh;
+                    *reinterpret_cast<uint4*>(Chi + p.c_plane + (int64_t)mr * p.ldc + n) = vl;
+                }
+            }
+        }
+    } else {
+        char* stage = smem_raw + wave * kStageBytes;
+        float mo4[4];
+        mask_rows(p, m0 + wm * 32, lane, mo4);
+        float4 rres[TN][4];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) resid_prefetch(p, m0 + wm * 32, nb0 + (wn * TN + t) * 32, lane, rres[t]);
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+            store_rows_f32(p, stage, m0 + wm * 32, nb0 + (wn * TN + t) * 32, acc[t], mk, lane, nullptr, rres[t], mo4);
+    }
+}
+
+template <int TN, int WM>
+int32_t launch_split(const GemmParams& p, hipStream_t s) {
+    constexpr int BM = 32 * WM, BN = 64 * TN;
+    constexpr size_t slot = (size_t)(BM + BN) * 128;
+    constexpr size_t lds_tiles = (4 * slot <= 128 * 1024 ? 4 : (3 * slot <= 152 * 1024 ? 3 : 2)) * slot;
+    constexpr size_t lds_epi = (size_t)WM * 2 * 2 * kStageBytes;
+    constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
+    static_assert(lds <= 160 * 1024, "LDS budget");
+    ISPK_RESERVE_LDS((&gemm_split_f16_kernel<TN, WM>), lds, "gemm_split");
+    hipLaunchKernelGGL((gemm_split_f16_kernel<TN, WM>), dim3((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), dim3(WM * 128),
+                       lds, s, p);
+    return ispk_launch_status();
+}
+
+}  // namespace
+
+extern "C" int32_t ispk_split_f16(const float* x, int64_t ldx, uint16_t* hi, uint16_t* lo, int64_t ldy, int32_t rows,
+                                  int32_t cols, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && hi && lo, ISPK_E_NULL, "split_f16: null pointer");
+    ISPK_REQUIRE(rows >= 0 && cols >= 4 && cols % 4 == 0, ISPK_E_SHAPE, "split_f16: cols=%d must be a positive multiple of 4", cols);
+    ISPK_REQUIRE(ldx % 4 == 0 && ldy % 4 == 0 && ldx >= cols && ldy >= cols, ISPK_E_ALIGN, "split_f16: strides must be multiples of 4");
+    ISPK_REQUIRE(ispk_aligned(x, 16) && ispk_aligned(hi, 8) && ispk_aligned(lo, 8), ISPK_E_ALIGN, "split_f16: alignment");
+    if (rows == 0) return 0;
+    const int64_t n = (int64_t)rows * (cols / 4);
+    hipLaunchKernelGGL(split_f16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       x, ldx, hi, lo, ldy, rows, cols / 4);
+    return ispk_launch_status();
+}
+
+// Tile choice (TN * 10 + WM): the widest feature block that divides N into whole blocks, 128-row blocks while they still
+// give every CU a workgroup, else 64-row blocks.
+extern "C" int32_t ispk_gemm_split_f16_tile(int32_t M, int32_t N, int32_t K) {
+    (void)K;
+    if (const char* e = ispk_knob("ISPK_SPLIT_TILE")) return atoi(e);  // experiments only
+    int tn;
+    if (N % 256 == 0) tn = 4;
+    else if (N % 192 == 0) tn = 3;
+    else if (N > 128 && N % 128 != 0 && N <= 192) tn = 3;
+    else tn = 2;
+    const int64_t blocks128 = (int64_t)((M + 127) / 128) * ((N + 64 * tn - 1) / (64 * tn));
+    return tn * 10 + (blocks128 >= 200 ? 4 : 2);
+}
+
+extern "C" int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a_plane, const uint16_t* W, int64_t ldw,
+                                       int64_t w_plane, void* C, int64_t ldc, int64_t c_plane, const float* bias,
+                                       const float* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N, int32_t K,
+                                       uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream) {
+    GemmParams p{A, lda, W, ldw, C, ldc, bias, resid, ldr, mask, M, N, K, flags, cols_per_batch, batch_stride};
+    p.a_plane = a_plane;
+    p.w_plane = w_plane;
+    p.c_plane = c_plane;
+    ISPK_REQUIRE(A && W && C, ISPK_E_NULL, "gemm_split: null A/W/C");
+    ISPK_REQUIRE(M >= 0 && N >= 1 && K >= 1 && K % 8 == 0, ISPK_E_SHAPE, "gemm_split: bad shape M=%d N=%d K=%d (K %% 8)", M, N, K);
+    ISPK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && a_plane % 8 == 0 && w_plane % 8 == 0 && lda >= 1 && ldw >= K, ISPK_E_ALIGN,
+                 "gemm_split: lda / ldw / plane offsets must be multiples of 8 (ldw >= K)");
+    ISPK_REQUIRE(ispk_aligned(A, 16) && ispk_aligned(W, 16), ISPK_E_ALIGN, "gemm_split: A/W must be 16-byte aligned");
+    ISPK_REQUIRE(!((flags & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT)) && !mask), ISPK_E_NULL, "gemm_split: mask flag without mask");
+    ISPK_REQUIRE(!(flags & (ISPK_EP_OUT_BF16 | ISPK_EP_RESID_BF16 | ISPK_EP_BIAS_ROW | ISPK_EP_MASK_COL)), ISPK_E_UNSUPPORTED,
+                 "gemm_split: bf16 output / residual, row bias and column mask are not built");
+    ISPK_REQUIRE(!((flags & ISPK_EP_GELU) && (flags & ISPK_EP_SILU)), ISPK_E_UNSUPPORTED, "gemm_split: GELU and SILU together");
+    ISPK_REQUIRE(N % 4 == 0 && (!bias || ispk_aligned(bias, 16)), ISPK_E_ALIGN, "gemm_split: N %% 4, 16-byte aligned bias");
+    if (flags & ISPK_EP_ROWS_T) {
+        ISPK_REQUIRE(cols_per_batch > 0 && M % cols_per_batch == 0 && !resid && ldc >= cols_per_batch && ispk_aligned(C, 4) &&
+                         !(flags & (ISPK_EP_OUT_SPLIT | ISPK_EP_GELU | ISPK_EP_SILU | ISPK_EP_MASK_ACC)),
+                     ISPK_E_UNSUPPORTED, "gemm_split: ROWS_T takes bias + MASK_OUT only, fp32 C, M %% cols_per_batch == 0");
+    } else if (flags & ISPK_EP_OUT_SPLIT) {
+        ISPK_REQUIRE(cols_per_batch <= 0 && !resid && N % 8 == 0 && ldc % 8 == 0 && c_plane % 8 == 0 && ispk_aligned(C, 16),
+                     ISPK_E_UNSUPPORTED, "gemm_split: split output needs N, ldc, c_plane %% 8 == 0, no residual");
+    } else {
+        ISPK_REQUIRE(cols_per_batch <= 0 && ldc % 4 == 0 && ispk_aligned(C, 16) &&
+                         (!resid || (ldr % 4 == 0 && ispk_aligned(resid, 16))),
+                     ISPK_E_ALIGN, "gemm_split: fp32 C / resid rows must be 16-byte aligned");
+    }
+    if (M == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    switch (ispk_gemm_split_f16_tile(M, N, K)) {
+        case 44: return launch_split<4, 4>(p, s);
+        case 42: return launch_split<4, 2>(p, s);
+        case 34: return launch_split<3, 4>(p, s);
+        case 32: return launch_split<3, 2>(p, s);
+        case 24: return launch_split<2, 4>(p, s);
+        case 64: return launch_split<6, 4>(p, s);
+    }
+    return launch_split<2, 2>(p, s);
+}
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ attention on split terms
+// ALiBi-biased multi-query attention (attend.py:49-122, embeddings.py:51-82, attention.py:128-152) with fp32-grade
+// products at the fp16 MFMA rate.  q / k / v arrive as fp32 (the fused projection's [Q | K | V] rows); the decomposition is
+// attn_f32_kernel's (attention.hip): a workgroup = one (batch item, 64-query tile) for ALL heads, wave = (head, 32-query
+// half), Sᵀ = K·Qᵀ so that a lane owns one query's softmax row and the P accumulator is already the next product's operand.
+//   * K / V tiles (64 keys) are split ONCE per workgroup while they are staged into LDS (hi and lo planes, row-major
+//     [key][64] fp16, 128-B rows, XOR-swizzled 16-B slots as in attn_bf16_kernel: K by (row >> 1) & 7, V by
+//     ((row >> 1) & 1) << 2) and shared by all 2 H waves;
+//   * Q (pre-scaled by 1/8, exact) is split once per wave into 4 + 4 register fragments;
+//   * Sᵀ = K hi Q hi + K hi Q lo + K lo Q hi: 12 MFMAs per 32 x 32 block; softmax in fp32 with the exact running maximum
+//     (exp through v_exp_f32 on log2-domain differences: relative error ~1e-6 on probabilities that are summed in fp32);
+//   * P is split in registers (p in [0, 1]: no clamp) and Oᵀ += V hi P hi + V hi P lo + V lo P hi with V read through the
+//     transposing ds_read_b64_tr_b16 in the accumulator's key order (guide T10): 12 MFMAs per block.
+// Output: fp32 rows, or split planes for the out-projection GEMM.
+constexpr int kSaKeys = 64;                         // keys per staged tile
+constexpr int kSaPlane = kSaKeys * 128;             // bytes of one fp16 plane of one tile
+constexpr int kSaBuf = 4 * kSaPlane;                // K hi, K lo, V hi, V lo
+
+template <int OFF>
+__device__ __forceinline__ void sa_read_tr16_b64(su32x2& dst, uint32_t lds_byte_addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(lds_byte_addr), "n"(OFF) : "memory");
+}
+
+template <int MAXT, int NS, bool SPLIT_OUT>   // NS = ceil(2048 / threads): staged float4 per thread and tile
+__global__ __launch_bounds__(MAXT) void attn_split_f16_kernel(const float* __restrict__ q, int64_t ldq,
+                                                              const float* __restrict__ k, const float* __restrict__ v,
+                                                              int64_t ldkv, const float* __restrict__ slopes,
+                                                              const int64_t* __restrict__ key_len, void* __restrict__ out,
+                                                              int64_t ldo, int64_t o_plane, int N, int H) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = wave % H, qhalf = wave / H;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + qhalf * 32;
+    int klen = key_len ? (int)key_len[b] : N;
+    klen = klen < 1 ? 1 : (klen > N ? N : klen);
+    const float slope = slopes[head];
+    const float ninf = -__builtin_huge_valf();
+    constexpr float kLog2e = 1.4426950408889634f;
+
+    // ---- Q fragments: lane (query l31, half h) holds head dims 16 ks + 8 h .. + 7 of k-step ks, scaled by 1/8, split
+    const int qi = q0 + l31;
+    const int qrow = qi < N ? qi : N - 1;
+    f16x8 qh[4], ql[4];
+    {
+        const float* qp = q + ((int64_t)b * N + qrow) * ldq + head * 64 + h * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + ks * 16);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(qp + ks * 16 + 4);
+            union { uint32_t u[4]; f16x8 f; } hh, ll;
+            split_pair(a[0] * 0.125f, a[1] * 0.125f, hh.u[0], ll.u[0]);
+            split_pair(a[2] * 0.125f, a[3] * 0.125f, hh.u[1], ll.u[1]);
+            split_pair(c[0] * 0.125f, c[1] * 0.125f, hh.u[2], ll.u[2]);
+            split_pair(c[2] * 0.125f, c[3] * 0.125f, hh.u[3], ll.u[3]);
+            qh[ks] = hh.f;
+            ql[ks] = ll.f;
+        }
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = ninf, l_run = 0.f;
+
+    const float* kb = k + (int64_t)b * N * ldkv;
+    const float* vb = v + (int64_t)b * N * ldkv;
+    const int ntiles = (klen + kSaKeys - 1) / kSaKeys;
+
+    // staging: the fp32 loads of tile t+1 are issued before tile t is computed; split + LDS writes happen after it
+    f32x4 sreg[NS];
+    auto stage_load = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = tid + i * nthreads;
+            const int isv = idx >> 10, rem = idx & 1023;
+            const int row = rem >> 4, c4 = (rem & 15) * 4;
+            const int key = t * kSaKeys + row;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (idx < 2048 && key < N) val = *reinterpret_cast<const f32x4*>((isv ? vb : kb) + (int64_t)key * ldkv + c4);
+            sreg[i] = val;
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int idx = tid + i * nthreads;
+            const int isv = idx >> 10, rem = idx & 1023;
+            const int row = rem >> 4, c4 = (rem & 15) * 4;
+            if (idx < 2048) {
+                const int sw = isv ? ((row >> 1) & 1) << 2 : (row >> 1) & 7;
+                char* dst = smem_raw + buf * kSaBuf + isv * 2 * kSaPlane + row * 128 + (((c4 >> 3) ^ sw) << 4) + (c4 & 4) * 2;
+                uint2 hh, ll;
+                split_pair(sreg[i][0], sreg[i][1], hh.x, ll.x);
+                split_pair(sreg[i][2], sreg[i][3], hh.y, ll.y);
+                *reinterpret_cast<uint2*>(dst) = hh;
+                *reinterpret_cast<uint2*>(dst + kSaPlane) = ll;
+            }
+        }
+    };
+
+    // per-lane LDS byte offsets inside a buffer.  K fragment of k-step ks: row l31 (+ 32 per block), logical slot 2 ks + h
+    const uint32_t lbase = lds_addr(smem_raw);
+    uint32_t koff[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + h) ^ ((l31 >> 1) & 7)) << 4);
+    // V transposing read (as attn_bf16_kernel): 16-lane group = (h, dim half dh); lane 4 qq + pp of the group points at key
+    // row 4 h + qq, dims 4 pp .. 4 pp + 3 of the group's 16-dim block = logical slot 4 dt + 2 dh + (pp >> 1), byte 8 (pp & 1)
+    const int qq = (lane & 15) >> 2, pp = lane & 3, dh = (lane >> 4) & 1;
+    uint32_t voff[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+        voff[dt] = 2 * kSaPlane + (4 * h + qq) * 128 + (((4 * dt + 2 * dh + (pp >> 1)) ^ ((qq >> 1) << 2)) << 4) + 8 * (pp & 1);
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) stage_load(t + 1);
+#pragma unroll 1
+        for (int kblk = 0; kblk < 2; ++kblk) {
+            const int key0 = t * kSaKeys + kblk * 32;
+            if (key0 >= klen) break;  // wave-uniform
+            const uint32_t blk = lbase + (uint32_t)(buf * kSaBuf + kblk * 32 * 128);
+            // ---- Sᵀ[key][query]
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                bf16x8 kh, kl;
+                lds_read_b128_asm<0>(kh, blk + koff[ks]);
+                lds_read_b128_asm<kSaPlane>(kl, blk + koff[ks]);
+                lds_wait<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(kl), qh[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(kh), ql[ks], s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(kh), qh[ks], s, 0, 0, 0);
+            }
+            // V fragments for the second product: requested now, they land during the softmax
+            su32x2 vh[2][2][2], vl[2][2][2];   // [k-step st][dim tile][run]
+            static_for<0, 8>([&](auto ic) {
+                constexpr int i8 = decltype(ic)::value, st = i8 >> 2, dt = (i8 >> 1) & 1, run = i8 & 1;
+                sa_read_tr16_b64<(16 * st + 8 * run) * 128>(vh[st][dt][run], blk + voff[dt]);
+                sa_read_tr16_b64<(16 * st + 8 * run) * 128 + kSaPlane>(vl[st][dt][run], blk + voff[dt]);
+            });
+            // ---- bias, mask, online softmax (per query = per lane pair)
+            float smax = ninf;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int dist = key > qi ? key - qi : qi - key;
+                float val = s[r] - slope * (float)dist;
+                val = key < klen ? val : ninf;
+                s[r] = val;
+                smax = fmaxf(smax, val);
+            }
+            smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
+            const float m_new = fmaxf(m_run, smax);
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);  // first block: exp2(-inf) = 0
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pexp = __builtin_amdgcn_exp2f((s[r] - m_new) * kLog2e);
+                s[r] = pexp;
+                psum += pexp;
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+            // ---- P -> split B-operand fragments (k-step st = registers 8 st .. 8 st + 7)
+            union { uint32_t u[4]; f16x8 f; } ph[2], pl[2];
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split_pair_nc(s[8 * st + 2 * e], s[8 * st + 2 * e + 1], ph[st].u[e], pl[st].u[e]);
+            lds_wait<0>();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                union { uint32_t u[4]; f16x8 f; } ah0, ah1, al0, al1;
+                ah0.u[0] = vh[st][0][0][0]; ah0.u[1] = vh[st][0][0][1]; ah0.u[2] = vh[st][0][1][0]; ah0.u[3] = vh[st][0][1][1];
+                ah1.u[0] = vh[st][1][0][0]; ah1.u[1] = vh[st][1][0][1]; ah1.u[2] = vh[st][1][1][0]; ah1.u[3] = vh[st][1][1][1];
+                al0.u[0] = vl[st][0][0][0]; al0.u[1] = vl[st][0][0][1]; al0.u[2] = vl[st][0][1][0]; al0.u[3] = vl[st][0][1][1];
+                al1.u[0] = vl[st][1][0][0]; al1.u[1] = vl[st][1][0][1]; al1.u[2] = vl[st][1][1][0]; al1.u[3] = vl[st][1][1][1];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0.f, ph[st].f, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1.f, ph[st].f, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0.f, pl[st].f, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1.f, pl[st].f, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0.f, ph[st].f, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1.f, ph[st].f, o1, 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) stage_store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane (query, half) holds d = tile * 32 + (r & 3) + 8 (r >> 2) + 4 h
+    const float lsum = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / lsum;
+    if (qi < N) {
+        if constexpr (SPLIT_OUT) {
+            uint16_t* op = static_cast<uint16_t*>(out) + ((int64_t)b * N + qi) * ldo + head * 64 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 h0, l0, h1, l1;
+                split_pair(o0[4 * g] * inv, o0[4 * g + 1] * inv, h0.x, l0.x);
+                split_pair(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv, h0.y, l0.y);
+                split_pair(o1[4 * g] * inv, o1[4 * g + 1] * inv, h1.x, l1.x);
+                split_pair(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv, h1.y, l1.y);
+                *reinterpret_cast<uint2*>(op + 8 * g) = h0;
+                *reinterpret_cast<uint2*>(op + 32 + 8 * g) = h1;
+                *reinterpret_cast<uint2*>(op + o_plane + 8 * g) = l0;
+                *reinterpret_cast<uint2*>(op + o_plane + 32 + 8 * g) = l1;
+            }
+        } else {
+            float* op = static_cast<float*>(out) + ((int64_t)b * N + qi) * ldo + head * 64 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a, c;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    a[e] = o0[4 * g + e] * inv;
+                    c[e] = o1[4 * g + e] * inv;
+                }
+                *reinterpret_cast<f32x4*>(op + 8 * g) = a;
+                *reinterpret_cast<f32x4*>(op + 32 + 8 * g) = c;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int32_t ispk_alibi_mqa_attn_split_f16(const float* q, int64_t ldq, const float* k, const float* v, int64_t ldkv,
+                                                 const float* slopes, const int64_t* key_len, void* out, int64_t ldo,
+                                                 int64_t o_plane, int32_t B, int32_t N, int32_t H, ispk_stream_t stream) {
+    ISPK_REQUIRE(q && k && v && slopes && out, ISPK_E_NULL, "attn_split: null pointer");
+    ISPK_REQUIRE(B >= 0 && N >= 1 && H >= 1 && H <= 8, ISPK_E_SHAPE, "attn_split: bad shape B=%d N=%d H=%d (H <= 8)", B, N, H);
+    ISPK_REQUIRE(B <= 65535, ISPK_E_SHAPE, "attn_split: B=%d exceeds the grid limit 65535", B);
+    ISPK_REQUIRE(ldq >= H * 64 && ldo >= H * 64 && ldkv >= 64, ISPK_E_SHAPE, "attn_split: leading strides too small");
+    ISPK_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && o_plane % 4 == 0, ISPK_E_ALIGN,
+                 "attn_split: strides must be multiples of 4");
+    ISPK_REQUIRE(ispk_aligned(q, 16) && ispk_aligned(k, 16) && ispk_aligned(v, 16) && ispk_aligned(out, 16), ISPK_E_ALIGN,
+                 "attn_split: pointers must be 16-byte aligned");
+    if (B == 0) return 0;
+    constexpr size_t lds = (size_t)2 * kSaBuf;   // 64 KB
+    dim3 grid((N + 63) / 64, B), block(2 * H * 64);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const bool so = o_plane != 0;
+#define ISPK_SA_GO(MAXT_, NS_)                                                                                           \
+    do {                                                                                                                 \
+        if (so) {                                                                                                        \
+            ISPK_RESERVE_LDS((&attn_split_f16_kernel<MAXT_, NS_, true>), lds, "attn_split");                             \
+            hipLaunchKernelGGL((attn_split_f16_kernel<MAXT_, NS_, true>), grid, block, lds, st, q, ldq, k, v, ldkv,      \
+                               slopes, key_len, out, ldo, o_plane, N, H);                                                \
+        } else {                                                                                                         \
+            ISPK_RESERVE_LDS((&attn_split_f16_kernel<MAXT_, NS_, false>), lds, "attn_split");                            \
+            hipLaunchKernelGGL((attn_split_f16_kernel<MAXT_, NS_, false>), grid, block, lds, st, q, ldq, k, v, ldkv,     \
+                               slopes, key_len, out, ldo, o_plane, N, H);                                                \
+        }                                                                                                                \
+    } while (0)
+    if (H >= 7) ISPK_SA_GO(1024, 3);
+    else if (H >= 4) ISPK_SA_GO(768, 4);
+    else if (H >= 2) ISPK_SA_GO(384, 8);
+    else ISPK_SA_GO(128, 16);
+#undef ISPK_SA_GO
+    return ispk_launch_status();
+}

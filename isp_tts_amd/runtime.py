@@ -16,8 +16,8 @@ from torch import Tensor
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libispk.so")
 
-EP_GELU, EP_SILU, EP_MASK_ACC, EP_MASK_OUT, EP_BIAS_ROW, EP_MASK_COL, EP_OUT_BF16, EP_RESID_BF16, EP_ROWS_T = (
-    1, 2, 4, 8, 16, 32, 64, 128, 256)
+EP_GELU, EP_SILU, EP_MASK_ACC, EP_MASK_OUT, EP_BIAS_ROW, EP_MASK_COL, EP_OUT_BF16, EP_RESID_BF16, EP_ROWS_T, EP_OUT_SPLIT = (
+    1, 2, 4, 8, 16, 32, 64, 128, 256, 512)
 
 _P, _I32, _I64, _U32, _F32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32, ctypes.c_float
 _U64 = ctypes.c_uint64
@@ -53,6 +53,12 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_alibi_mqa_attn_bf16_tiles": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_cast_f32_bf16": [_P, _I64, _P, _I64, _I32, _I32, _P],
+    "ispk_split_f16": [_P, _I64, _P, _P, _I64, _I32, _I32, _P],
+    "ispk_gemm_split_f16_tile": [_I32, _I32, _I32],
+    "ispk_gemm_split_f16": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32,
+                            _I64, _P],
+    "ispk_layernorm_f32_split": [_P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I64, _I32, _I32, _F32, _P],
+    "ispk_alibi_mqa_attn_split_f16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
     "ispk_flow_mix_f32": [_P, _P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
     "ispk_flow_finish_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_embed_tokens_f32": [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _I32, _P],
@@ -640,6 +646,140 @@ def alibi_mqa_attention(qkv: Tensor, heads: int, slopes: Tensor, key_len: Option
     assert W == heads * 64 + 128 and qkv.is_contiguous()
     return alibi_mqa_attention_raw(qkv, W, qkv[..., heads * 64:], qkv[..., heads * 64 + 64:], W, slopes, key_len, B, N,
                                    heads, q_tiles)
+
+
+# ------------------------------------------------------------------------------------------------- split-fp16 (parity-grade fast path)
+# A "split" tensor is a torch.float16 tensor [2, *shape]: plane 0 = hi = fp16(v), plane 1 = lo = fp16(v - hi).
+def split_f16(x: Tensor) -> Tensor:
+    """ispk_split_f16: fp32 [..., C] (unit inner stride) -> split planes fp16 [2, ..., C]."""
+    _dev(x)
+    assert x.dtype == torch.float32
+    x2 = _rows2d(x)
+    rows, cols = x2.shape
+    out = torch.empty((2, *x.shape), dtype=torch.float16, device=x.device)
+    _launch("split_f16_kernel", 0.0, 8.0 * rows * cols, lib().ispk_split_f16, x2.data_ptr(), x2.stride(0), out[0].data_ptr(),
+            out[1].data_ptr(), cols, rows, cols, _stream())
+    return out
+
+
+def layernorm_split(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], ada_scale: Optional[Tensor] = None,
+                    ada_shift: Optional[Tensor] = None, rows_per_batch: int = 1, row_mask: Optional[Tensor] = None,
+                    eps: float = 1e-5) -> Tensor:
+    """ispk_layernorm_f32_split: `layernorm` with the result as split planes fp16 [2, ..., D]."""
+    _dev(x, gamma, beta, ada_scale, ada_shift, row_mask)
+    assert x.dtype == torch.float32
+    x2 = _rows2d(x)
+    rows, D = x2.shape
+    y = torch.empty((2, *x.shape), dtype=torch.float16, device=x.device)
+    ada_stride = 0
+    if ada_scale is not None:
+        ada_scale = ada_scale.reshape(-1, D) if ada_scale.ndim != 2 else ada_scale
+        if ada_scale.stride(1) != 1:
+            ada_scale = ada_scale.contiguous()
+        if ada_shift is not None:
+            ada_shift = ada_shift.reshape(-1, D) if ada_shift.ndim != 2 else ada_shift
+            if ada_shift.stride(1) != 1 or ada_shift.stride(0) != ada_scale.stride(0):
+                ada_scale, ada_shift = ada_scale.contiguous(), ada_shift.contiguous()
+        ada_stride = ada_scale.stride(0) if ada_scale.shape[0] > 1 else 0
+    if row_mask is not None:
+        row_mask = row_mask.reshape(-1).contiguous()
+        assert row_mask.dtype == torch.bool and row_mask.numel() == rows
+    label = f"layernorm_vec_kernel<{D // 128},split>" if D % 128 == 0 and D <= 512 else f"layernorm_kernel<{D // 64},split>"
+    _launch(label, 0.0, float(rows) * D * 8, lib().ispk_layernorm_f32_split, x2.data_ptr(), x2.stride(0), _ptr(gamma),
+            _ptr(beta), _ptr(ada_scale), _ptr(ada_shift), ada_stride, rows_per_batch, _ptr(row_mask), y.data_ptr(), D,
+            y.stride(0), rows, D, eps, _stream())
+    return y
+
+
+def _split_label(M: int, N: int, K: int) -> str:
+    t = lib().ispk_gemm_split_f16_tile(M, N, K)
+    return f"gemm_split_f16_kernel<{t // 10},{t % 10}>"
+
+
+def gemm_split(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,
+               mask: Optional[Tensor] = None, flags: int = 0, out_split: bool = False) -> Tensor:
+    """ispk_gemm_split_f16: epilogue(a @ w^T) with a = split planes [2, ..., K], w = split planes [2, N, K].
+    Returns fp32 [..., N], or split planes [2, ..., N] with `out_split` (no residual)."""
+    _dev(a, w, bias, resid, mask)
+    assert a.dtype == torch.float16 and w.dtype == torch.float16 and a.shape[0] == 2 and w.ndim == 3 and w.shape[0] == 2
+    assert a.is_contiguous() and w.is_contiguous()
+    K, N = a.shape[-1], w.shape[1]
+    assert w.shape[2] == K
+    M = a[0].numel() // K
+    lead = a.shape[1:-1]
+    r2 = None
+    if resid is not None:
+        r2 = _rows2d(resid)
+        assert r2.shape == (M, N) and r2.dtype == torch.float32 and not out_split
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+        assert mask.dtype == torch.bool
+    if out_split:
+        out = torch.empty((2, *lead, N), dtype=torch.float16, device=a.device)
+        flags |= EP_OUT_SPLIT
+        c_plane, nb_out = out.stride(0), 4.0 * M * N
+    else:
+        out = torch.empty((*lead, N), dtype=torch.float32, device=a.device)
+        c_plane, nb_out = 0, 4.0 * M * N
+    nb = 4.0 * M * K + 4.0 * N * K + nb_out + (4.0 * M * N if r2 is not None else 0.0)
+    _launch(_split_label(M, N, K), 2.0 * M * N * K, nb, lib().ispk_gemm_split_f16, a.data_ptr(), K, a.stride(0), w.data_ptr(), K,
+            w.stride(0), out.data_ptr(), N, c_plane, _ptr(bias), _ptr(r2), r2.stride(0) if r2 is not None else 0, _ptr(mask), M, N,
+            K, flags, 0, 0, _stream())
+    return out
+
+
+def to_mel_split(dec: Tensor, w: Tensor, bias: Tensor, mask: Optional[Tensor]) -> Tensor:
+    """mel[B, C, T] = mask * (dec @ w^T + bias) from split planes dec [2, B, T, D], w [2, C, D] (ISPK_EP_ROWS_T)."""
+    _dev(dec, w, bias, mask)
+    _, B, T, D = dec.shape
+    C = w.shape[1]
+    out = torch.empty((B, C, T), dtype=torch.float32, device=dec.device)
+    flags = EP_ROWS_T
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+        flags |= EP_MASK_OUT
+    _launch(_split_label(B * T, C, D), 2.0 * C * B * T * D, 4.0 * (B * T * D + C * D + B * C * T), lib().ispk_gemm_split_f16,
+            dec.data_ptr(), D, dec.stride(0), w.data_ptr(), D, w.stride(0), out.data_ptr(), T, 0, _ptr(bias), None, 0, _ptr(mask),
+            B * T, C, D, flags, T, C * T, _stream())
+    return out
+
+
+def conv5_padded_split(xpad: Tensor, w2d: Tensor, flags: int = 0) -> Tensor:
+    """`conv5_padded` on split planes: xpad [2, B, T+4, C], w2d [2, O, k*C] -> fp32 [B, T+4, O] (row t = frame t)."""
+    _dev(xpad, w2d)
+    _, B, TP, C = xpad.shape
+    _, O, K = w2d.shape
+    taps = K // C
+    assert taps * C == K and taps in (1, 5) and xpad.is_contiguous() and w2d.is_contiguous()
+    out = torch.empty((B, TP, O), dtype=torch.float32, device=xpad.device)
+    a_ptr = xpad.data_ptr() + (0 if taps == 5 else 2 * C * 2)   # k=1: frame t sits at padded row t+2
+    M = B * TP - 4
+    _launch(_split_label(M, O, K), 2.0 * M * O * K, 4.0 * (M * C + O * K + M * O), lib().ispk_gemm_split_f16, a_ptr, C,
+            xpad.stride(0), w2d.data_ptr(), K, w2d.stride(0), out.data_ptr(), O, 0, None, None, 0, None, M, O, K, flags, 0, 0,
+            _stream())
+    return out
+
+
+def alibi_mqa_attention_split(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor], out_split: bool = True) -> Tensor:
+    """ispk_alibi_mqa_attn_split_f16: qkv fp32 [B, N, H*64 + 128] -> merged heads as split planes [2, B, N, H*64] (or fp32)."""
+    _dev(qkv, slopes, key_len)
+    B, N, W = qkv.shape
+    assert W == heads * 64 + 128 and qkv.is_contiguous() and qkv.dtype == torch.float32
+    if key_len is not None:
+        key_len = key_len.to(torch.int64).contiguous()
+    slopes = slopes.to(torch.float32).contiguous()
+    if out_split:
+        out = torch.empty((2, B, N, heads * 64), dtype=torch.float16, device=qkv.device)
+        plane = out.stride(0)
+    else:
+        out = torch.empty((B, N, heads * 64), dtype=torch.float32, device=qkv.device)
+        plane = 0
+    es = qkv.element_size()
+    _launch("attn_split_f16_kernel", 256.0 * B * N * N * heads, float(B) * N * (2 * heads * 64 + 128) * 4,
+            lib().ispk_alibi_mqa_attn_split_f16, qkv.data_ptr(), W, qkv.data_ptr() + heads * 64 * es,
+            qkv.data_ptr() + (heads * 64 + 64) * es, W, slopes.data_ptr(), _ptr(key_len), out.data_ptr(), heads * 64, plane, B, N,
+            heads, _stream())
+    return out
 
 
 # ------------------------------------------------------------------------------------------------- aligner front-end

@@ -53,8 +53,9 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=64, help="utterances per GPU (weak) or in total (strong)")
     ap.add_argument("--text-len", type=int, default=100)
     ap.add_argument("--mel-len", type=int, default=512)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
-                    help="bf16 = BASELINE config 3 (throughput path); f32 = the 1e-4 parity path")
+    ap.add_argument("--dtype", choices=["f32", "bf16", "split"], default="bf16",
+                    help="bf16 = BASELINE config 3 (throughput path); f32 = the 1e-4 parity path on exact-fp32 MFMAs; "
+                         "split = the 1e-4 parity path on split-fp16 products (three fp16 MFMAs per fp32-grade product)")
     ap.add_argument("--alignment", choices=["auto", "f32"], default="auto",
                     help="precision of the chain upstream of MAS (text encoder + aligner front-end): auto = --dtype; "
                          "f32 = fp32 whatever --dtype is (MAS paths identical to the fp32 path)")
@@ -160,7 +161,7 @@ def roofline(prof_summary: dict, steps: int, event_floor_us: float):
         us = d["avg_us"]   # raw event-pair interval (the empty-pair interval is reported beside it, not subtracted)
         sec = us * 1e-6
         flops, nbytes = d["flops"] / d["launches"], d["bytes"] / d["launches"]
-        peak_tf = PEAK["mfma_bf16_TFs"] if "bf16" in label else PEAK["mfma_f32_TFs"]
+        peak_tf = PEAK["mfma_bf16_TFs"] if ("bf16" in label or "split_f16" in label) else PEAK["mfma_f32_TFs"]
         t_mfma, t_hbm = flops / (peak_tf * 1e12), nbytes / (PEAK["hbm_GBs"] * 1e9)
         bound = "mfma" if t_mfma >= t_hbm else "hbm"
         kernels[label] = {"launches_per_step": round(d["launches"] / steps, 2), "avg_us": round(us, 2),
@@ -171,7 +172,7 @@ def roofline(prof_summary: dict, steps: int, event_floor_us: float):
     top = next(iter(kernels))
     k = kernels[top]
     if k["bound"] == "mfma":
-        peak = PEAK["mfma_bf16_TFs"] if "bf16" in top else PEAK["mfma_f32_TFs"]
+        peak = PEAK["mfma_bf16_TFs"] if ("bf16" in top or "split_f16" in top) else PEAK["mfma_f32_TFs"]
         rl = {"kernel": top, "bound": "mfma", "achieved": k["TFLOPs"], "peak": peak, "unit": "TFLOP/s"}
     else:
         rl = {"kernel": top, "bound": "hbm", "achieved": k["GBs"], "peak": PEAK["hbm_GBs"], "unit": "GB/s"}
@@ -244,7 +245,7 @@ def worker(args) -> int:
     model = AcousticModel.init(dims.model_config()).eval()
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
-    cdt = torch.float32 if args.dtype == "f32" else torch.bfloat16
+    cdt = {"f32": torch.float32, "bf16": torch.bfloat16, "split": torch.float16}[args.dtype]
     align_dt = torch.float32 if args.alignment == "f32" else None
     model.set_compute_dtype(cdt, alignment_dtype=align_dt)
 
@@ -542,6 +543,39 @@ def worker(args) -> int:
                 res, state["p32"], state["mel32"] = f32_line()
                 return res
             extra("f32_parity_path", run_f32)
+
+            def parity_path_line():
+                """The parity-grade FAST path: every product of the forward as three fp16 MFMAs over hi / lo terms
+                (`set_compute_dtype(torch.float16)`, csrc/split.hip) - holds the same bars as the exact-fp32 path."""
+                model.set_compute_dtype(torch.float16)
+                try:
+                    g = GraphedForward(model, *fwd_args(d))
+                    sec = timed_graph(g, 10)
+                    o = g.out
+                    res = {"value": round(B * M / sec, 1), "unit": "mel-frames/s", "ms_per_step": round(sec * 1e3, 3), "steps": 10,
+                           "dtype": "split-fp16 (fp32-grade: hi/lo fp16 terms, three MFMAs per product, fp32 accumulation)",
+                           "model_TFLOPs": round(B * M / sec * FLOP_PER_FRAME / 1e12, 2)}
+                    if "p32" in state:
+                        same = (o.aligner_output.attn_hard == state["p32"]).flatten(1).all(1)
+                        res["mel_linf_vs_fp32_path"] = float(f"{(o.mel - state['mel32']).abs().max().item():.3e}")
+                        res["mas_paths_identical_to_fp32_path"] = f"{int(same.sum())}/{B}"
+                    prof = runtime.LaunchProfiler()
+                    runtime.set_profiler(prof)
+                    for _ in range(3):
+                        model(*fwd_args(d)[:6], flow_noise=d["flow_x0"], flow_time=d["flow_t"])
+                    torch.cuda.synchronize()
+                    runtime.set_profiler(None)
+                    rl = roofline(prof.summary(), 3, event_floor(torch))
+                    rl.pop("other_kernels", None)
+                    rl["traffic"] = None
+                    rl["note"] = ("FLOPs are the algorithmic ones (2 M N K per Linear, counted ONCE - the kernel issues three "
+                                  "fp16 MFMAs per product, so frac = 1/3 is this arithmetic's ceiling against the 2.5 PF peak)")
+                    res["roofline"] = rl
+                finally:
+                    runtime.set_profiler(None)
+                    model.set_compute_dtype(cdt, alignment_dtype=align_dt)
+                return res
+            extra("parity_path", parity_path_line)
 
             def run_chain():
                 r = alignment_chain_line()

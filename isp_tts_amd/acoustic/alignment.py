@@ -87,7 +87,10 @@ class ConvAttention(nn.Module, Constructor):
         dt = self.compute_dtype
 
         def build():
-            w2d = [p.detach().permute(0, 2, 1).reshape(p.shape[0], -1).to(dt).contiguous() for p in ps]
+            if dt == torch.float16:   # split fp16 planes [2, O, k*C]
+                w2d = [runtime.split_f16(p.detach().permute(0, 2, 1).reshape(p.shape[0], -1).float().contiguous()) for p in ps]
+            else:
+                w2d = [p.detach().permute(0, 2, 1).reshape(p.shape[0], -1).to(dt).contiguous() for p in ps]
             return w2d[:2], w2d[2:]
         return self._cache.get(dt, ps, build)
 
@@ -96,6 +99,13 @@ class ConvAttention(nn.Module, Constructor):
         nothing from the text encoder, so the model runs it on a second stream beside the encoder stack."""
         _, wq = self._staged()
         gelu, dt = runtime.EP_GELU, self.compute_dtype
+        if dt == torch.float16:   # split-fp16 path: conv operands as hi / lo planes, conv outputs and statistics fp32
+            q = runtime.split_f16(runtime.pad_rows(queries.float(), query_len, channel_first=True))
+            for i in (0, 1):
+                q = runtime.conv5_padded_split(q, wq[i], gelu)
+                q = runtime.split_f16(runtime.masked_instnorm(q, self.query_proj[i].norm.weight, self.query_proj[i].norm.bias,
+                                                              query_len))
+            return runtime.conv5_padded_split(q, wq[2])
         q = runtime.pad_rows(queries.float(), query_len, channel_first=True, out_dtype=dt)
         q = runtime.conv5_padded(q, wq[0], gelu)
         q = runtime.masked_instnorm(q, self.query_proj[0].norm.weight, self.query_proj[0].norm.bias, query_len,
@@ -115,6 +125,13 @@ class ConvAttention(nn.Module, Constructor):
         wk, _ = self._staged()
         max_q, max_k = queries.shape[2], keys.shape[2]
         gelu, dt = runtime.EP_GELU, self.compute_dtype   # bf16 path: bf16 conv operands, fp32 conv outputs / statistics
+        if dt == torch.float16:
+            k = runtime.split_f16(runtime.pad_rows(keys.float(), key_len, channel_first=True))
+            k = runtime.conv5_padded_split(k, wk[0], gelu)
+            k = runtime.split_f16(runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len))
+            k = runtime.conv5_padded_split(k, wk[1])
+            q = q_proj if q_proj is not None else self.project_queries(queries, query_len)
+            return runtime.aligner_scores(q, k, key_len, query_len, max_q, max_k)
         k = runtime.pad_rows(keys.float(), key_len, channel_first=True, out_dtype=dt)
         k = runtime.conv5_padded(k, wk[0], gelu)
         k = runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len, out_dtype=dt)

@@ -74,7 +74,7 @@ class AcousticModel(nn.Module, Constructor):
         mel does not depend on the hard alignment (the decoder input is built from attn_soft and the dense targets,
         temporal_adaptor.py:284-300); the durations and the flow-matching duration target do."""
         chain = alignment_dtype if alignment_dtype is not None else dtype
-        assert chain in (torch.float32, torch.bfloat16)
+        assert chain in (torch.float32, torch.bfloat16, torch.float16)
         self.encoder.set_compute_dtype(chain)
         self.decoder.set_compute_dtype(dtype)
         self.temporal_adaptor.predictor.transformer.set_compute_dtype(dtype)
@@ -86,6 +86,9 @@ class AcousticModel(nn.Module, Constructor):
 
     def _to_mel(self, dec_out: Tensor, dec_mask: Optional[Tensor]) -> Tensor:
         w = self.to_mel.weight
+        if dec_out.dtype == torch.float16:   # split fp16 planes [2, B, T, D] from the decoder's final norm
+            ws = self._cache.get(torch.float16, (w,), lambda: runtime.split_f16(w.detach().float().contiguous()))
+            return runtime.to_mel_split(dec_out, ws, self.to_mel.bias, dec_mask)
         if dec_out.dtype == torch.bfloat16:
             w = self._cache.get(torch.bfloat16, (w,), lambda: w.detach().to(torch.bfloat16).contiguous())
         return runtime.to_mel(dec_out, w, self.to_mel.bias, dec_mask)

@@ -35,6 +35,8 @@ class TransformerTemporalModule(nn.Module, Constructor):
 
     def _weight(self, dtype: torch.dtype) -> Tensor:
         w = self.linear_layer.weight
+        if dtype == torch.float16:   # split fp16 planes
+            return self._cache.get(dtype, (w,), lambda: runtime.split_f16(w.detach().float().contiguous()))
         return self._cache.get(dtype, (w,), lambda: w.detach().to(dtype).contiguous())
 
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, *, key_len: Optional[Tensor] = None,
@@ -46,6 +48,8 @@ class TransformerTemporalModule(nn.Module, Constructor):
         cdt = self.transformer.layers[0].attention.compute_dtype   # bf16 path: the output Linear is an MFMA GEMM too
         out = self.transformer(x, mask=m2, out_dtype=cdt, key_len=key_len if m2 is not None else None).out
         flags = runtime.EP_MASK_ACC if m2 is not None else 0       # (acc + bias) * mask, then + residual
+        if cdt == torch.float16:
+            return runtime.gemm_split(out, self._weight(cdt), bias=self.linear_layer.bias, mask=m2, flags=flags, resid=residual)
         return runtime.gemm(out, self._weight(cdt), bias=self.linear_layer.bias, mask=m2, flags=flags, resid=residual,
                             out_dtype=torch.float32)
 
@@ -71,6 +75,8 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
 
     def _cond_weight(self, dtype: torch.dtype) -> Tensor:
         w = self.transformer.project_emb.weight
+        if dtype == torch.float16:   # split fp16 planes
+            return self._cache.get(dtype, (w,), lambda: runtime.split_f16(w.detach()[:, self.output_dim:].float().contiguous()))
         return self._cache.get(dtype, (w,), lambda: w.detach()[:, self.output_dim:].to(dtype).contiguous())
 
     def _project(self, x_t: Tensor, cond_proj: Tensor) -> Tensor:
@@ -80,6 +86,8 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
     def _cond_projection(self, cond: Tensor) -> Tensor:
         cdt = self.transformer.layers[0].attention.compute_dtype   # bf16 path: bf16 operands, fp32 result (residual stream)
         c = cond.float().contiguous()
+        if cdt == torch.float16:
+            return runtime.gemm_split(runtime.split_f16(c), self._cond_weight(cdt), bias=self.transformer.project_emb.bias)
         if cdt == torch.bfloat16:
             c = runtime.cast_bf16(c)
         return runtime.gemm(c, self._cond_weight(cdt), bias=self.transformer.project_emb.bias, out_dtype=torch.float32)

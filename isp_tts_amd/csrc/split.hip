@@ -25,6 +25,7 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t su32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ f16x8 as_f16x8(const bf16x8& v) { return __builtin_bit_cast(f16x8, v); }
+__device__ __forceinline__ void keep_alive(const bf16x8& v) { asm volatile("" ::"v"(v)); }
 
 // two fp32 values -> packed fp16 hi terms and packed fp16 lo terms (round to nearest even both times; v - hi is exact)
 __device__ __forceinline__ void split_pair(float a, float b, uint32_t& hi, uint32_t& lo) {
@@ -68,18 +69,27 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------ Linear on split planes
 // C = epilogue(A · Wᵀ) with A [M][K] and W [N][K] given as split planes.  Skeleton of gemm_bf16_wide_kernel (gemm.hip): one
-// workgroup = 32 WM activation rows x 64 TN output features, WM x 2 waves, a wave holds 32 rows x TN 32-feature tiles in
-// accumulators, computed transposed (D = W_tile · Xᵀ) so that a lane owns one activation row for the row-coalescing
-// epilogue; operand tiles stream by LDS-DMA (global_load_lds_dwordx4) into a ring of S slots, one raw s_barrier per
-// K chunk.  What is different:
+// workgroup = 32 WM RT activation rows x 64 TN output features on WM x 2 waves, a wave holds RT 32-row tiles x TN 32-feature
+// tiles in accumulators, computed transposed (D = W_tile · Xᵀ) so that a lane owns one activation row for the
+// row-coalescing epilogue; operand tiles stream by LDS-DMA (global_load_lds_dwordx4) into a ring of S slots, one raw
+// s_barrier per K chunk.  What is different:
 //   * a K chunk is 32 deep and an LDS row (128 B) holds BOTH terms of it: 16-byte slots 0-3 = hi k 0..31, slots 4-7 = lo.
 //     A DMA lane picks its plane with its slot, so in HBM the planes stay separate matrices (and a leading stride SMALLER
 //     than K - the sliding-window view that turns a padded channel-last Conv1d into a GEMM - keeps working per plane);
 //     the XOR swizzle (physical slot = logical slot ^ ((row >> 1) & 7)) is applied on the source side as before;
-//   * per 16-deep k-step a wave reads X hi / X lo and W hi / W lo fragments (2 + 2 TN ds_read_b128) for 3 TN MFMAs.
-template <int TN, int WM>
-__global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p) {
-    constexpr int BM = 32 * WM, BN = 64 * TN, NT = WM * 128, NWV = NT / 64;
+//   * per 16-deep k-step a wave reads X hi / X lo and W hi / W lo fragments (2 RT + 2 TN ds_read_b128) for 3 RT TN MFMAs.
+//     Both the LDS fill (4 bytes per operand value, every workgroup streaming its X rows and W rows through LDS) and the
+//     fragment reads (every wave re-reading them) are co-critical with the MFMAs at 128 x 256 blocks (measured:
+//     tools/ablate_split.py), hence RT = 2: 256 x 256 blocks with 64 x 128 wave tiles halve the fill per product and take
+//     the reads from 0.83 to 0.5 per MFMA;
+//   * XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin in launch order, so workgroup `lin` serves row
+//     block 8 (seq / NCB) + lin % 8, column block seq % NCB with seq = lin / 8: the column blocks of one row block run
+//     back to back on ONE XCD and find the X rows in that XCD's L2 after the first fetch.
+// AB: timing probes of the experiments build (tools/ablate_split.py; WRONG results) - 1 no MFMAs, 2 no operand DMA, 3 DMA
+// and barriers only, 5 every workgroup streams the SAME X rows (L2-resident), 6 plain (not XCD-aware) block order
+template <int TN, int WM, int RT, int AB = 0>
+__global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, int nrb, int ncb) {
+    constexpr int BM = 32 * WM * RT, BN = 64 * TN, NT = WM * 128, NWV = NT / 64;
     constexpr int kSlot = (BM + BN) * 128;                       // bytes per ring slot: X rows then W rows, 128 B each
     constexpr int S = 4 * kSlot <= 128 * 1024 ? 4 : (3 * kSlot <= 152 * 1024 ? 3 : 2);
     constexpr int IPL = (BM + BN) / 8 / NWV;
@@ -89,44 +99,63 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * BM;
-    const int nb0 = blockIdx.y * BN;
+    int rb, cb;
+    {
+        const int lin = blockIdx.x, full = AB == 6 ? 0 : (nrb / 8) * 8 * ncb;   // workgroups of the complete groups of 8 row blocks
+        if (lin < full) {
+            const int seq = lin >> 3;
+            rb = (seq / ncb) * 8 + (lin & 7);
+            cb = seq % ncb;
+        } else {                                                  // ragged tail: plain order
+            const int t = lin - full;
+            rb = (AB == 6 ? 0 : (nrb / 8) * 8) + t / ncb;
+            cb = t % ncb;
+        }
+    }
+    const int m0 = rb * BM;
+    const int nb0 = cb * BN;
     const uint16_t* A = static_cast<const uint16_t*>(p.A);
     const uint16_t* W = static_cast<const uint16_t*>(p.W);
 
-    // this lane's part of DMA instruction j: row (8-row group wave*IPL + j, row lane>>3), physical LDS slot lane&7
-    const uint16_t* src_row[IPL];
-    int src_k[IPL];
+    // this lane's part of DMA instruction j: row (8-row group wave*IPL + j, row lane>>3), physical LDS slot lane&7.
+    // Kept as ONE 32-bit element offset per instruction (row, plane and k slot folded in; the launcher checks the range):
+    // 64-bit pointers + k offsets cost 3 registers per instruction, which the 256 x 256 tile does not have.
+    int src_off[IPL];
 #pragma unroll
     for (int j = 0; j < IPL; ++j) {
         const int r = (wave * IPL + j) * 8 + (lane >> 3);       // row of the concatenated [X; W] tile
         const int rr = r < BM ? r : r - BM;
         const int ls = (lane & 7) ^ ((rr >> 1) & 7);             // logical slot: plane ls >> 2, k offset 8 (ls & 3)
-        src_k[j] = (ls & 3) * 8;
         if (r < BM) {
-            const int row = m0 + r < p.M ? m0 + r : p.M - 1;     // rows past the end: a valid row, never stored
-            src_row[j] = A + (int64_t)row * p.lda + (ls >> 2) * p.a_plane;
+            int row = m0 + r < p.M ? m0 + r : p.M - 1;           // rows past the end: a valid row, never stored
+            if constexpr (AB == 5) row = r;
+            src_off[j] = (int)((int64_t)row * p.lda + (ls >> 2) * p.a_plane) + (ls & 3) * 8;
         } else {
             const int n = nb0 + rr < p.N ? nb0 + rr : p.N - 1;
-            src_row[j] = W + (int64_t)n * p.ldw + (ls >> 2) * p.w_plane;
+            src_off[j] = (int)((int64_t)n * p.ldw + (ls >> 2) * p.w_plane) + (ls & 3) * 8;
         }
     }
     auto issue = [&](int kt) {
+        if constexpr (AB == 2) return;           // probe: no operand traffic
         char* slot = smem_raw + (kt % S) * kSlot + wave * (IPL * 1024);
 #pragma unroll
         for (int j = 0; j < IPL; ++j) {
-            const int k = kt * 32 + src_k[j];
-            const uint16_t* src = k < p.K ? src_row[j] + k : g_zero16;
+            const bool isx = (wave * IPL + j) * 8 < BM;                        // wave-uniform: whole 8-row groups
+            const int rr = (wave * IPL + j) * 8 + (lane >> 3) - (isx ? 0 : BM);
+            const int k = kt * 32 + ((((lane & 7) ^ ((rr >> 1) & 7)) & 3) << 3);
+            const uint16_t* src = k < p.K ? (isx ? A : W) + src_off[j] + kt * 32 : g_zero16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(slot + j * 1024), 16, 0, 0);
         }
     };
 
-    f32x16 acc[TN];
+    f32x16 acc[RT][TN];
 #pragma unroll
-    for (int t = 0; t < TN; ++t)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
     const int nk = (p.K + 31) / 32;
 #pragma unroll 1
@@ -137,7 +166,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p) 
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const uint32_t sw = (uint32_t)(((2 * g + h) ^ ((l31 >> 1) & 7)) << 4);
-        xoff[g] = (wm * 32 + l31) * 128 + sw;
+        xoff[g] = (wm * 32 * RT + l31) * 128 + sw;
         woff[g] = (BM + wn * 32 * TN + l31) * 128 + sw;
     }
     for (int kt = 0; kt < nk; ++kt) {
@@ -149,13 +178,20 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p) 
         __builtin_amdgcn_s_barrier();            // publishes chunk kt; every wave is done with chunk kt-1
         asm volatile("" ::: "memory");
         const uint32_t sl = lds_addr(smem_raw) + (uint32_t)((kt % S) * kSlot);
-        bf16x8 fr[4][TN + 1];                    // [group][X, W tile 0 .. TN-1]
+        if constexpr (AB == 3) {                 // probe: operand traffic only
+            if (kt + S - 1 < nk) issue(kt + S - 1);
+            continue;
+        }
+        bf16x8 fr[4][RT + TN];                   // [group][X row tile 0 .. RT-1, W tile 0 .. TN-1]
         auto rd = [&](auto gc) {
             constexpr int g = decltype(gc)::value;
-            lds_read_b128_asm<0>(fr[g][0], sl + xoff[g]);
+            static_for<0, RT>([&](auto rc) {
+                constexpr int rt = decltype(rc)::value;
+                lds_read_b128_asm<rt * 32 * 128>(fr[g][rt], sl + xoff[g]);
+            });
             static_for<0, TN>([&](auto tc) {
                 constexpr int t = decltype(tc)::value;
-                lds_read_b128_asm<t * 32 * 128>(fr[g][1 + t], sl + woff[g]);
+                lds_read_b128_asm<t * 32 * 128>(fr[g][RT + t], sl + woff[g]);
             });
         };
         rd(std::integral_constant<int, 0>{});    // hi, k-step 0
@@ -165,100 +201,118 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p) 
         if (kt + S - 1 < nk) issue(kt + S - 1);  // into the slot chunk kt-1 just left
         static_for<0, 2>([&](auto kc) {
             constexpr int ks = decltype(kc)::value;
-            if constexpr (ks == 0) lds_wait<2 * (TN + 1)>(); else lds_wait<0>();
+            if constexpr (ks == 0) lds_wait<2 * (RT + TN)>(); else lds_wait<0>();
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AB == 1) {             // probe: no MFMAs (the fragments must stay live until they have landed)
 #pragma unroll
-            for (int t = 0; t < TN; ++t)         // W lo · X hi
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[2 + ks][1 + t]), as_f16x8(fr[ks][0]), acc[t], 0, 0, 0);
+                for (int i = 0; i < RT + TN; ++i) {
+                    keep_alive(fr[ks][i]);
+                    keep_alive(fr[2 + ks][i]);
+                }
+                return;
+            }
 #pragma unroll
-            for (int t = 0; t < TN; ++t)         // W hi · X lo
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[ks][1 + t]), as_f16x8(fr[2 + ks][0]), acc[t], 0, 0, 0);
+            for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int t = 0; t < TN; ++t)         // W hi · X hi
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[ks][1 + t]), as_f16x8(fr[ks][0]), acc[t], 0, 0, 0);
+                for (int t = 0; t < TN; ++t)     // W lo · X hi
+                    acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[2 + ks][RT + t]), as_f16x8(fr[ks][rt]), acc[rt][t], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < TN; ++t)     // W hi · X lo
+                    acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[ks][RT + t]), as_f16x8(fr[2 + ks][rt]), acc[rt][t], 0, 0, 0);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+                for (int t = 0; t < TN; ++t)     // W hi · X hi
+                    acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[ks][RT + t]), as_f16x8(fr[ks][rt]), acc[rt][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
     }
     __syncthreads();   // the epilogue's transposition patches alias the ring
 
-    const int m = m0 + wm * 32 + l31;
-    const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
-    if (p.flags & ISPK_EP_ROWS_T) {
-        // rows are [batch][T] frames, T = cpb; output feature n of frame (b, t) goes to C[b][n][t] (to_mel + transpose)
-        float* cb = nullptr;
-        if (m < p.M) {
-            const int bb = m / p.cpb;
-            cb = static_cast<float*>(p.C) + (int64_t)bb * p.bstride + (m - bb * p.cpb);
-        }
-        const float mo = (p.flags & ISPK_EP_MASK_OUT) ? mk : 1.0f;
 #pragma unroll
-        for (int t = 0; t < TN; ++t) store_rows_t(p, cb, nb0 + (wn * TN + t) * 32, acc[t], mo, h);
-    } else if (p.flags & ISPK_EP_OUT_SPLIT) {
-        // split-plane output: two adjacent 32-feature tiles per pass through a pair of wave-private LDS patches
-        char* stage = smem_raw + wave * (2 * kStageBytes);
-        static_assert(TN % 2 == 0 || TN == 3, "tile pairing");
-        uint16_t* Chi = static_cast<uint16_t*>(p.C);
+    for (int rt = 0; rt < RT; ++rt) {
+        const int mw = m0 + (wm * RT + rt) * 32;    // first row of this wave's tile rt
+        const int m = mw + l31;
+        const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+        if (p.flags & ISPK_EP_ROWS_T) {
+            // rows are [batch][T] frames, T = cpb; output feature n of frame (b, t) goes to C[b][n][t] (to_mel + transpose)
+            float* cbp = nullptr;
+            if (m < p.M) {
+                const int bb = m / p.cpb;
+                cbp = static_cast<float*>(p.C) + (int64_t)bb * p.bstride + (m - bb * p.cpb);
+            }
+            const float mo = (p.flags & ISPK_EP_MASK_OUT) ? mk : 1.0f;
 #pragma unroll
-        for (int t = 0; t < TN; t += 2) {
-            const bool pair = t + 1 < TN;
-            const int n0 = nb0 + (wn * TN + t) * 32;
+            for (int t = 0; t < TN; ++t) store_rows_t(p, cbp, nb0 + (wn * TN + t) * 32, acc[rt][t], mo, h);
+        } else if (p.flags & ISPK_EP_OUT_SPLIT) {
+            // split-plane output: two adjacent 32-feature tiles per pass through a pair of wave-private LDS patches
+            char* stage = smem_raw + wave * (2 * kStageBytes);
+            static_assert(TN % 2 == 0 || TN == 3, "tile pairing");
+            uint16_t* Chi = static_cast<uint16_t*>(p.C);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                if (tt == 1 && !pair) break;
+            for (int t = 0; t < TN; t += 2) {
+                const bool pair = t + 1 < TN;
+                const int n0 = nb0 + (wn * TN + t) * 32;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4];
+                for (int tt = 0; tt < 2; ++tt) {
+                    if (tt == 1 && !pair) break;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[t + tt < TN ? t + tt : t][4 * g + e];
-                    const int n = n0 + tt * 32 + 8 * g + 4 * h;
-                    pre_stage(p, n < p.N ? n : 0, v, mk);
-                    if (p.flags & ISPK_EP_MASK_OUT) {
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] *= mk;
+                        for (int e = 0; e < 4; ++e) v[e] = acc[rt][t + tt < TN ? t + tt : t][4 * g + e];
+                        const int n = n0 + tt * 32 + 8 * g + 4 * h;
+                        pre_stage(p, n < p.N ? n : 0, v, mk);
+                        if (p.flags & ISPK_EP_MASK_OUT) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= mk;
+                        }
+                        uint2 oh, ol;
+                        split_pair(v[0], v[1], oh.x, ol.x);
+                        split_pair(v[2], v[3], oh.y, ol.y);
+                        *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = oh;
+                        *reinterpret_cast<uint2*>(stage + kStageBytes + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = ol;
                     }
-                    uint2 oh, ol;
-                    split_pair(v[0], v[1], oh.x, ol.x);
-                    split_pair(v[2], v[3], oh.y, ol.y);
-                    *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = oh;
-                    *reinterpret_cast<uint2*>(stage + kStageBytes + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = ol;
                 }
-            }
-            const int c = lane & 7, n = n0 + 8 * c;
+                const int c = lane & 7, n = n0 + 8 * c;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 8 * i + (lane >> 3), mr = m0 + wm * 32 + r;
-                const uint4 vh = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
-                const uint4 vl = *reinterpret_cast<const uint4*>(stage + kStageBytes + r * kStageRow + c * 16);
-                if (mr < p.M && n < p.N && (pair || c < 4)) {
-                    *reinterpret_cast<uint4*>(Chi + (int64_t)mr * p.ldc + n) = vh;
-                    *reinterpret_cast<uint4*>(Chi + p.c_plane + (int64_t)mr * p.ldc + n) = vl;
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 8 * i + (lane >> 3), mr = mw + r;
+                    const uint4 vh = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
+                    const uint4 vl = *reinterpret_cast<const uint4*>(stage + kStageBytes + r * kStageRow + c * 16);
+                    if (mr < p.M && n < p.N && (pair || c < 4)) {
+                        *reinterpret_cast<uint4*>(Chi + (int64_t)mr * p.ldc + n) = vh;
+                        *reinterpret_cast<uint4*>(Chi + p.c_plane + (int64_t)mr * p.ldc + n) = vl;
+                    }
                 }
             }
+        } else {
+            char* stage = smem_raw + wave * kStageBytes;
+            float mo4[4];
+            mask_rows(p, mw, lane, mo4);
+            float4 rres[TN][4];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) resid_prefetch(p, mw, nb0 + (wn * TN + t) * 32, lane, rres[t]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                store_rows_f32(p, stage, mw, nb0 + (wn * TN + t) * 32, acc[rt][t], mk, lane, nullptr, rres[t], mo4);
         }
-    } else {
-        char* stage = smem_raw + wave * kStageBytes;
-        float mo4[4];
-        mask_rows(p, m0 + wm * 32, lane, mo4);
-        float4 rres[TN][4];
-#pragma unroll
-        for (int t = 0; t < TN; ++t) resid_prefetch(p, m0 + wm * 32, nb0 + (wn * TN + t) * 32, lane, rres[t]);
-#pragma unroll
-        for (int t = 0; t < TN; ++t)
-            store_rows_f32(p, stage, m0 + wm * 32, nb0 + (wn * TN + t) * 32, acc[t], mk, lane, nullptr, rres[t], mo4);
     }
 }
 
-template <int TN, int WM>
+template <int TN, int WM, int RT, int AB = 0>
 int32_t launch_split(const GemmParams& p, hipStream_t s) {
-    constexpr int BM = 32 * WM, BN = 64 * TN;
+    constexpr int BM = 32 * WM * RT, BN = 64 * TN;
     constexpr size_t slot = (size_t)(BM + BN) * 128;
     constexpr size_t lds_tiles = (4 * slot <= 128 * 1024 ? 4 : (3 * slot <= 152 * 1024 ? 3 : 2)) * slot;
     constexpr size_t lds_epi = (size_t)WM * 2 * 2 * kStageBytes;
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");
-    ISPK_RESERVE_LDS((&gemm_split_f16_kernel<TN, WM>), lds, "gemm_split");
-    hipLaunchKernelGGL((gemm_split_f16_kernel<TN, WM>), dim3((p.M + BM - 1) / BM, (p.N + BN - 1) / BN), dim3(WM * 128),
-                       lds, s, p);
+    ISPK_RESERVE_LDS((&gemm_split_f16_kernel<TN, WM, RT, AB>), lds, "gemm_split");
+    const int nrb = (p.M + BM - 1) / BM, ncb = (p.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_split_f16_kernel<TN, WM, RT, AB>), dim3(nrb * ncb), dim3(WM * 128), lds, s, p, nrb, ncb);
     return ispk_launch_status();
 }
 
@@ -277,8 +331,8 @@ extern "C" int32_t ispk_split_f16(const float* x, int64_t ldx, uint16_t* hi, uin
     return ispk_launch_status();
 }
 
-// Tile choice (TN * 10 + WM): the widest feature block that divides N into whole blocks, 128-row blocks while they still
-// give every CU a workgroup, else 64-row blocks.
+// Tile choice (TN * 100 + WM * 10 + RT = 64 TN features x 32 WM RT rows): the widest feature block that divides N into
+// whole blocks; 256-row blocks (RT = 2) while they still give every CU a workgroup, then 128-row, else 64-row blocks.
 extern "C" int32_t ispk_gemm_split_f16_tile(int32_t M, int32_t N, int32_t K) {
     (void)K;
     if (const char* e = ispk_knob("ISPK_SPLIT_TILE")) return atoi(e);  // experiments only
@@ -287,8 +341,10 @@ extern "C" int32_t ispk_gemm_split_f16_tile(int32_t M, int32_t N, int32_t K) {
     else if (N % 192 == 0) tn = 3;
     else if (N > 128 && N % 128 != 0 && N <= 192) tn = 3;
     else tn = 2;
-    const int64_t blocks128 = (int64_t)((M + 127) / 128) * ((N + 64 * tn - 1) / (64 * tn));
-    return tn * 10 + (blocks128 >= 200 ? 4 : 2);
+    const int64_t ncb = (N + 64 * tn - 1) / (64 * tn);
+    if ((int64_t)((M + 255) / 256) * ncb >= 240) return tn * 100 + 42;
+    if ((int64_t)((M + 127) / 128) * ncb >= 200) return tn * 100 + 41;
+    return tn * 100 + 21;
 }
 
 extern "C" int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a_plane, const uint16_t* W, int64_t ldw,
@@ -304,6 +360,8 @@ extern "C" int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a
     ISPK_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && a_plane % 8 == 0 && w_plane % 8 == 0 && lda >= 1 && ldw >= K, ISPK_E_ALIGN,
                  "gemm_split: lda / ldw / plane offsets must be multiples of 8 (ldw >= K)");
     ISPK_REQUIRE(ispk_aligned(A, 16) && ispk_aligned(W, 16), ISPK_E_ALIGN, "gemm_split: A/W must be 16-byte aligned");
+    ISPK_REQUIRE((int64_t)M * lda + a_plane + K < (int64_t)1 << 31 && (int64_t)N * ldw + w_plane + K < (int64_t)1 << 31 && a_plane >= 0 &&
+                     w_plane >= 0, ISPK_E_SHAPE, "gemm_split: operands beyond 2^31 elements (32-bit in-kernel offsets)");
     ISPK_REQUIRE(!((flags & (ISPK_EP_MASK_ACC | ISPK_EP_MASK_OUT)) && !mask), ISPK_E_NULL, "gemm_split: mask flag without mask");
     ISPK_REQUIRE(!(flags & (ISPK_EP_OUT_BF16 | ISPK_EP_RESID_BF16 | ISPK_EP_BIAS_ROW | ISPK_EP_MASK_COL)), ISPK_E_UNSUPPORTED,
                  "gemm_split: bf16 output / residual, row bias and column mask are not built");
@@ -323,15 +381,32 @@ extern "C" int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a
     }
     if (M == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    switch (ispk_gemm_split_f16_tile(M, N, K)) {
-        case 44: return launch_split<4, 4>(p, s);
-        case 42: return launch_split<4, 2>(p, s);
-        case 34: return launch_split<3, 4>(p, s);
-        case 32: return launch_split<3, 2>(p, s);
-        case 24: return launch_split<2, 4>(p, s);
-        case 64: return launch_split<6, 4>(p, s);
+#ifdef ISPK_EXPERIMENTS
+    if (const char* e = ispk_knob("ISPK_SPLIT_ABLATE")) {   // timing probes only: WRONG results
+        const int ab = atoi(e), tile = ispk_gemm_split_f16_tile(M, N, K);
+#define ISPK_AB_CASE(T, TN_, WM_, RT_)                                                   \
+        if (tile == T) {                                                                 \
+            if (ab == 1) return launch_split<TN_, WM_, RT_, 1>(p, s);                    \
+            if (ab == 2) return launch_split<TN_, WM_, RT_, 2>(p, s);                    \
+            if (ab == 3) return launch_split<TN_, WM_, RT_, 3>(p, s);                    \
+            if (ab == 5) return launch_split<TN_, WM_, RT_, 5>(p, s);                    \
+            if (ab == 6) return launch_split<TN_, WM_, RT_, 6>(p, s);                    \
+        }
+        ISPK_AB_CASE(441, 4, 4, 1) ISPK_AB_CASE(442, 4, 4, 2) ISPK_AB_CASE(341, 3, 4, 1) ISPK_AB_CASE(342, 3, 4, 2)
+#undef ISPK_AB_CASE
     }
-    return launch_split<2, 2>(p, s);
+#endif
+    switch (ispk_gemm_split_f16_tile(M, N, K)) {
+        case 442: return launch_split<4, 4, 2>(p, s);
+        case 342: return launch_split<3, 4, 2>(p, s);
+        case 242: return launch_split<2, 4, 2>(p, s);
+        case 441: return launch_split<4, 4, 1>(p, s);
+        case 341: return launch_split<3, 4, 1>(p, s);
+        case 241: return launch_split<2, 4, 1>(p, s);
+        case 421: return launch_split<4, 2, 1>(p, s);
+        case 321: return launch_split<3, 2, 1>(p, s);
+    }
+    return launch_split<2, 2, 1>(p, s);
 }
 
 namespace {

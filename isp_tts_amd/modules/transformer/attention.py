@@ -76,8 +76,12 @@ class Attention(nn.Module, Constructor):
 
         def build():
             with torch.no_grad():
-                wqkv = torch.cat([self.to_q.weight, self.to_kv.weight], dim=0).to(dtype).contiguous()
-                wo = self.to_out.weight.detach().to(dtype).contiguous()
+                if dtype == torch.float16:   # split fp16 planes [2, N, K] (hi, lo) for the split-fp16 kernels
+                    wqkv = runtime.split_f16(torch.cat([self.to_q.weight, self.to_kv.weight], dim=0).float().contiguous())
+                    wo = runtime.split_f16(self.to_out.weight.detach().float().contiguous())
+                else:
+                    wqkv = torch.cat([self.to_q.weight, self.to_kv.weight], dim=0).to(dtype).contiguous()
+                    wo = self.to_out.weight.detach().to(dtype).contiguous()
                 slopes = (self.rel_pos.head_slopes() if self.rel_pos is not None
                           else torch.zeros(self.heads, device=wo.device)).detach()
             return wqkv, wo, slopes
@@ -104,6 +108,20 @@ class Attention(nn.Module, Constructor):
         wqkv, wo, slopes = self._staged(dt)
         if mask is not None and key_len is None:
             key_len = mask.sum(dim=1)
+        if dt == torch.float16:   # split-fp16 path (x fp32, or already split planes [2, B, N, dim])
+            if x.dtype == torch.float16:
+                b, n = x.shape[1], x.shape[2]
+                xs = x
+            else:
+                xs = runtime.split_f16(x.float().contiguous())
+            qkv = runtime.gemm_split(xs, wqkv)
+            o = runtime.alibi_mqa_attention_split(qkv, self.heads, slopes, key_len)
+            out = o if defer_out else runtime.gemm_split(o, wo, resid=residual, mask=mask,
+                                                         flags=runtime.EP_MASK_ACC if mask is not None else 0)
+            hq = self.heads * 64
+            inter = AttentionIntermediates(queries=qkv[..., :hq].view(b, n, self.heads, 64).transpose(1, 2),
+                                           keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])
+            return out, inter, AttentionSharedIntermediates(rel_pos_bias=None)
         if prenorm is not None:
             assert dt == torch.bfloat16 and x.dtype == torch.float32
             qkv = runtime.gemm_lnin(x, prenorm[0], prenorm[1], prenorm[2], wqkv, ln_eps=prenorm[3])

@@ -55,6 +55,9 @@ class FeedForward(nn.Module, Constructor):
 
     def _staged(self, dtype: torch.dtype):
         ps = (self.net[0].weight, self.net[3].weight)
+        if dtype == torch.float16:   # split fp16 planes [2, N, K] for the split-fp16 kernels
+            return self._cache.get(dtype, ps, lambda: (runtime.split_f16(ps[0].detach().float().contiguous()),
+                                                       runtime.split_f16(ps[1].detach().float().contiguous())))
         return self._cache.get(dtype, ps, lambda: (ps[0].detach().to(dtype).contiguous(),
                                                    ps[1].detach().to(dtype).contiguous()))
 
@@ -173,6 +176,11 @@ class FeedForward(nn.Module, Constructor):
             raise NotImplementedError("feed-forward dropout (training) is outside the forward-path scope")
         dt = self.compute_dtype
         w1, w2 = self._staged(dt)
+        if dt == torch.float16:   # split-fp16 path: x fp32 or split planes
+            xs = x if x.dtype == torch.float16 else runtime.split_f16(x.float().contiguous())
+            hidden = runtime.gemm_split(xs, w1, bias=self.net[0].bias, flags=self.act_flag, out_split=True)
+            return runtime.gemm_split(hidden, w2, bias=self.net[3].bias, resid=residual, mask=mask,
+                                      flags=runtime.EP_MASK_OUT if mask is not None else 0)
         if x.dtype != dt:
             x = runtime.cast_bf16(x) if dt == torch.bfloat16 else x.float()
         rows = x.numel() // x.shape[-1]

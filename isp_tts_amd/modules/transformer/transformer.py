@@ -91,6 +91,10 @@ class TransformerLayer(nn.Module, Constructor):
         cdt = self.attention.compute_dtype
         if mask is not None and key_len is None:
             key_len = mask.sum(dim=1)
+        if cdt == torch.float16:
+            if context is not None or attention_mask is not None:
+                raise NotImplementedError("cross-attention / explicit attention masks are not on the forward path")
+            return self._forward_split(x, mask, key_len, adaptive_condition, ada)
         kw1 = {"scale_shift": ada[0]} if ada is not None else {}
         kw2 = {"scale_shift": ada[1]} if ada is not None else {}
         handed = normed is not None and normed.dtype == torch.float32 and normed.shape[-1] == 2
@@ -151,6 +155,44 @@ class TransformerLayer(nn.Module, Constructor):
         return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                       shared_intermediates=shared, next_normed=hn)
 
+
+    def _norm_split(self, norm, x: Tensor, condition: Optional[Tensor], scale_shift: Optional[tuple],
+                    row_mask: Optional[Tensor]) -> Tensor:
+        """LayerNorm / AdaptiveLayerNorm with the result as split fp16 planes (ispk_layernorm_f32_split)."""
+        if isinstance(norm, AdaptiveLayerNorm):
+            if scale_shift is None and condition is not None:
+                cond = condition.reshape(-1, condition.shape[-1]).float().contiguous()
+                scale_shift = (runtime.linear_small(cond, norm.weight.weight, norm.weight.bias),
+                               runtime.linear_small(cond, norm.bias.weight, norm.bias.bias) if norm.bias is not None else None)
+            if scale_shift is None:
+                return runtime.layernorm_split(x, None, None, row_mask=row_mask, eps=norm.eps)
+            rows_per_batch = x.numel() // (x.shape[0] * x.shape[-1])
+            return runtime.layernorm_split(x, None, None, scale_shift[0], scale_shift[1], rows_per_batch, row_mask, norm.eps)
+        return runtime.layernorm_split(x, norm.weight, norm.bias, row_mask=row_mask, eps=norm.eps)
+
+    def _forward_split(self, x: Tensor, mask: Optional[Tensor], key_len: Optional[Tensor],
+                       adaptive_condition: Optional[Tensor], ada: Optional[tuple]) -> "TransformerLayerOutput":
+        """The layer on the split-fp16 kernels (csrc/split.hip: fp32-grade products, three fp16 MFMAs each) - the same seven
+        launches as the exact-fp32 path, the operands of every product carried as hi / lo fp16 planes:
+            h  = LN(x) -> planes;  qkv = h [Wq;Wkv]^T (fp32);  o = attention(qkv) -> planes
+            x1 = x + mask * (o Wo^T);  h2 = mask * LN(x1) -> planes;  f = gelu(h2 W1^T) -> planes;  y = mask * (x1 + f W2^T)"""
+        att, ff = self.attention, self.feed_forward
+        wqkv, wo, slopes = att._staged(torch.float16)
+        w1, w2 = ff._staged(torch.float16)
+        b, n, _ = x.shape
+        h = self._norm_split(self.attention_norm, x, adaptive_condition, None if ada is None else ada[0], None)
+        qkv = runtime.gemm_split(h, wqkv)
+        o = runtime.alibi_mqa_attention_split(qkv, att.heads, slopes, key_len)
+        x1 = runtime.gemm_split(o, wo, resid=x, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
+        h2 = self._norm_split(self.feed_forward_norm, x1, adaptive_condition, None if ada is None else ada[1], mask)
+        f = runtime.gemm_split(h2, w1, bias=ff.net[0].bias, flags=ff.act_flag, out_split=True)
+        y = runtime.gemm_split(f, w2, bias=ff.net[3].bias, resid=x1, mask=mask,
+                               flags=runtime.EP_MASK_OUT if mask is not None else 0)
+        hq = att.heads * 64
+        inter = AttentionIntermediates(queries=qkv[..., :hq].view(b, n, att.heads, 64).transpose(1, 2),
+                                       keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])
+        return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
+                                      shared_intermediates=AttentionSharedIntermediates(rel_pos_bias=None), next_normed=None)
 
     def forward_fused(self, x: Tensor, h: Tensor, mask: Optional[Tensor], key_len: Optional[Tensor], next_norm: tuple):
         """bf16 path with LayerNorms fused into the producing GEMMs (5 launches per layer instead of 7):
@@ -256,7 +298,9 @@ class Transformer(nn.Module, Constructor):
                         for l in self.layers) and self.norm.eps == 1e-5)
 
     def set_compute_dtype(self, dtype: torch.dtype):
-        assert dtype in (torch.float32, torch.bfloat16)
+        """fp32 (exact-fp32 MFMAs), bf16 (throughput path) or fp16 = the split-fp16 path: fp32-grade products as three fp16
+        MFMAs over hi / lo terms (csrc/split.hip)."""
+        assert dtype in (torch.float32, torch.bfloat16, torch.float16)
         for layer in self.layers:
             layer.attention.compute_dtype = dtype
             layer.feed_forward.compute_dtype = dtype
@@ -322,6 +366,9 @@ class Transformer(nn.Module, Constructor):
             if return_intermediates:
                 intermediates.append(res.intermediates)
         if normed is None:
-            normed = runtime.layernorm(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps,
-                                       out_dtype=out_dtype)
+            if out_dtype == torch.float16:   # split fp16 planes [2, B, N, D] for a split-fp16 consumer GEMM
+                normed = runtime.layernorm_split(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps)
+            else:
+                normed = runtime.layernorm(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps,
+                                           out_dtype=out_dtype)
         return TransformerOutput(out=normed, intermediates=intermediates)

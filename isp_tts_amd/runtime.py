@@ -693,7 +693,7 @@ def layernorm_split(x: Tensor, gamma: Optional[Tensor], beta: Optional[Tensor], 
 
 def _split_label(M: int, N: int, K: int) -> str:
     t = lib().ispk_gemm_split_f16_tile(M, N, K)
-    return f"gemm_split_f16_kernel<{t // 10},{t % 10}>"
+    return f"gemm_split_f16_kernel<{t // 100},{t // 10 % 10},{t % 10}>"
 
 
 def gemm_split(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Optional[Tensor] = None,

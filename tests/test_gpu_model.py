@@ -220,6 +220,27 @@ def test_headline_config_fp32_path_against_the_oracle(gpu_model, headline_case):
     assert same >= 60 and torch.equal(out.aligner_output.attn_hard_duration.sum(1).cpu(), inp["mel_len"])
 
 
+def test_headline_config_split_fp16_path_against_the_oracle(gpu_model, headline_case):
+    """The parity-grade FAST path (`set_compute_dtype(torch.float16)`: every product three fp16 MFMAs over hi / lo terms,
+    csrc/split.hip) at the benchmark configuration: the same north-star bars as the exact-fp32 path - mel L-inf < 1e-4 and
+    the oracle's MAS alignments on all 64 utterances."""
+    inp, ref = headline_case
+    try:
+        gpu_model.set_compute_dtype(torch.float16)
+        out = _run_headline(gpu_model, inp)
+    finally:
+        gpu_model.set_compute_dtype(torch.float32)
+    d = _maxdiff(out.mel, ref.mel)
+    dl = _maxdiff(out.aligner_output.attn_logits, ref.aligner.attn_logits)
+    same = _identical_paths(out.aligner_output.attn_hard, ref.aligner.attn_hard)
+    print(f"B=64 split-fp16: mel L-inf vs oracle = {d:.3e}, attn_logits {dl:.3e}, {same}/64 alignments identical to the oracle's")
+    assert d < MEL_TOL
+    assert torch.equal(out.adaptor_output.dec_lengths.cpu(), ref.adaptor.dec_lengths)
+    assert _maxdiff(out.aligner_output.attn_soft, ref.aligner.attn_soft) < 1e-4
+    assert same == 64
+    assert torch.equal(out.aligner_output.attn_hard_duration.cpu(), ref.aligner.attn_hard_duration)
+
+
 def test_headline_config_bf16_path_against_the_oracle(gpu_model, headline_case):
     """The benchmarked configuration (bf16 operands in every stack and in the aligner front-end) against the ORACLE on all 64
     utterances - mel does not depend on the hard alignment (the decoder input is built from `attn_soft` and the dense

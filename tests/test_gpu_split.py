@@ -66,6 +66,24 @@ def test_gemm_split_against_float64(M, N, K):
         assert (_join(outp) - F.gelu(ref + bias.double())).abs().max().item() < 3e-6 * max(scale, 1.0)
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(32768, 512, 96, 442), (31000, 384, 64, 342), (32768, 1536, 64, 442), (65536, 128, 64, 242)])
+def test_gemm_split_256_row_blocks(M, N, K, tile):
+    """Decoder-sized row counts take 256 x (64 TN) blocks (two 32-row tiles per wave, XCD-aware block order): every row and
+    feature once, against float64."""
+    assert runtime.lib().ispk_gemm_split_f16_tile(M, N, K) == tile
+    a = synth._normal(f"split/big/a/{M}/{K}", (M, K))
+    w = synth._normal(f"split/big/w/{N}/{K}", (N, K), K ** -0.5)
+    resid = synth._normal(f"split/big/r/{M}/{N}", (M, N))
+    mask = (torch.arange(M) % 5 != 1)
+    ap, wp = runtime.split_f16(a.to(DEV)), runtime.split_f16(w.to(DEV))
+    ref = a.double() @ w.double().t()
+    out = runtime.gemm_split(ap, wp, resid=resid.to(DEV), mask=mask.to(DEV), flags=runtime.EP_MASK_ACC)
+    assert (out.double().cpu() - (ref * mask[:, None] + resid.double())).abs().max().item() < 3e-6 * max(ref.abs().max().item(), 1.0)
+    outp = runtime.gemm_split(ap, wp, flags=runtime.EP_GELU, out_split=True)
+    torch.cuda.synchronize()
+    assert (_join(outp) - F.gelu(ref)).abs().max().item() < 3e-6 * max(ref.abs().max().item(), 1.0)
+
+
 def test_gemm_split_transposed_frames_output():
     """to_mel: Linear + transpose(1, 2) + mask (model.py:167-168) with frame-contiguous stores."""
     B, T, D, C = 3, 200, 384, 80

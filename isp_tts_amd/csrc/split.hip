@@ -16,6 +16,8 @@
 // Replaces, on the parity path, the exact-fp32 kernels behind the same reference call sites: nn.Linear (attention.py:105,
 // 111,168; feedforward.py:33-36; transformer.py:170; model.py:167-168; the aligner's Conv1d as a GEMM, alignment.py:69-83)
 // and Attend.efficient_attn (attend.py:49-122).
+#include <stdlib.h>
+
 #include "gemm_common.h"
 
 namespace {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.f;
 
-    const int nk = (p.K + 31) / 32;
+    const int nk = AB == 8 ? 0 : (p.K + 31) / 32;   // (probe 8: epilogue only)
 #pragma unroll 1
     for (int kt = 0; kt < nk && kt < S - 1; ++kt) issue(kt);
 
@@ -169,7 +171,10 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
         xoff[g] = (wm * 32 * RT + l31) * 128 + sw;
         woff[g] = (BM + wn * 32 * TN + l31) * 128 + sw;
     }
+    [[maybe_unused]] uint64_t st_t[6] = {0, 0, 0, 0, 0, 0}, st_a = 0, st_b = 0, st_0 = 0;
+    if constexpr (AB == 7) st_0 = __builtin_readcyclecounter();
     for (int kt = 0; kt < nk; ++kt) {
+        if constexpr (AB == 7) st_a = __builtin_readcyclecounter();
         const int after = (nk - 1 - kt) < (S - 2) ? (nk - 1 - kt) : (S - 2);   // younger chunks this wave has in flight
         if (S >= 4 && after >= 2) vm_wait<2 * IPL>();
         else if (S >= 3 && after == 1) vm_wait<IPL>();
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();            // publishes chunk kt; every wave is done with chunk kt-1
         asm volatile("" ::: "memory");
+        if constexpr (AB == 7) { st_b = __builtin_readcyclecounter(); st_t[0] += st_b - st_a; st_a = st_b; }
         const uint32_t sl = lds_addr(smem_raw) + (uint32_t)((kt % S) * kSlot);
         if constexpr (AB == 3) {                 // probe: operand traffic only
             if (kt + S - 1 < nk) issue(kt + S - 1);
@@ -203,6 +209,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
             constexpr int ks = decltype(kc)::value;
             if constexpr (ks == 0) lds_wait<2 * (RT + TN)>(); else lds_wait<0>();
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AB == 7) { st_b = __builtin_readcyclecounter(); st_t[1 + 2 * ks] += st_b - st_a; st_a = st_b; __builtin_amdgcn_sched_barrier(0); }
             if constexpr (AB == 1) {             // probe: no MFMAs (the fragments must stay live until they have landed)
 #pragma unroll
                 for (int i = 0; i < RT + TN; ++i) {
@@ -227,9 +234,11 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
                 for (int t = 0; t < TN; ++t)     // W hi · X hi
                     acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(fr[ks][RT + t]), as_f16x8(fr[ks][rt]), acc[rt][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (AB == 7) { st_b = __builtin_readcyclecounter(); st_t[2 + 2 * ks] += st_b - st_a; st_a = st_b; __builtin_amdgcn_sched_barrier(0); }
         });
     }
     __syncthreads();   // the epilogue's transposition patches alias the ring
+    if constexpr (AB == 7) { st_b = __builtin_readcyclecounter(); st_t[5] = st_b - st_0; st_a = st_b; }
 
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) {
@@ -298,6 +307,14 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
 #pragma unroll
             for (int t = 0; t < TN; ++t)
                 store_rows_f32(p, stage, mw, nb0 + (wn * TN + t) * 32, acc[rt][t], mk, lane, nullptr, rres[t], mo4);
+        }
+    }
+    if constexpr (AB == 7) {   // [workgroup][wave][8]: wait+barrier, reads ks0, mfma ks0, wait ks1, mfma ks1, main loop total, epilogue, start
+        if (lane == 0 && p.ln_out) {
+            uint64_t* o = static_cast<uint64_t*>(p.ln_out) + ((int64_t)blockIdx.x * NWV + wave) * 8;
+            for (int i = 0; i < 6; ++i) o[i] = st_t[i];
+            o[6] = __builtin_readcyclecounter() - st_a;
+            o[7] = st_0;
         }
     }
 }
@@ -384,6 +401,7 @@ extern "C" int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a
 #ifdef ISPK_EXPERIMENTS
     if (const char* e = ispk_knob("ISPK_SPLIT_ABLATE")) {   // timing probes only: WRONG results
         const int ab = atoi(e), tile = ispk_gemm_split_f16_tile(M, N, K);
+        if (const char* st = ispk_knob("ISPK_SPLIT_STAMPS")) p.ln_out = reinterpret_cast<void*>(strtoull(st, nullptr, 16));
 #define ISPK_AB_CASE(T, TN_, WM_, RT_)                                                   \
         if (tile == T) {                                                                 \
             if (ab == 1) return launch_split<TN_, WM_, RT_, 1>(p, s);                    \
@@ -391,6 +409,8 @@ extern "C" int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a
             if (ab == 3) return launch_split<TN_, WM_, RT_, 3>(p, s);                    \
             if (ab == 5) return launch_split<TN_, WM_, RT_, 5>(p, s);                    \
             if (ab == 6) return launch_split<TN_, WM_, RT_, 6>(p, s);                    \
+            if (ab == 7) return launch_split<TN_, WM_, RT_, 7>(p, s);                    \
+            if (ab == 8) return launch_split<TN_, WM_, RT_, 8>(p, s);                    \
         }
         ISPK_AB_CASE(441, 4, 4, 1) ISPK_AB_CASE(442, 4, 4, 2) ISPK_AB_CASE(341, 3, 4, 1) ISPK_AB_CASE(342, 3, 4, 2)
 #undef ISPK_AB_CASE
@@ -420,8 +440,8 @@ namespace {
 //     [key][64] fp16, 128-B rows, XOR-swizzled 16-B slots as in attn_bf16_kernel: K by (row >> 1) & 7, V by
 //     ((row >> 1) & 1) << 2) and shared by all 2 H waves;
 //   * Q (pre-scaled by 1/8, exact) is split once per wave into 4 + 4 register fragments;
-//   * Sᵀ = K hi Q hi + K hi Q lo + K lo Q hi: 12 MFMAs per 32 x 32 block; softmax in fp32 with the exact running maximum
-//     (exp through v_exp_f32 on log2-domain differences: relative error ~1e-6 on probabilities that are summed in fp32);
+//   * Sᵀ = K hi Q hi + K hi Q lo + K lo Q hi: 12 MFMAs per 32 x 32 block; softmax in fp32 against a lazily raised reference
+//     maximum (exp through v_exp_f32 on log2-domain arguments: relative error ~1e-6 on probabilities that are summed in fp32);
 //   * P is split in registers (p in [0, 1]: no clamp) and Oᵀ += V hi P hi + V hi P lo + V lo P hi with V read through the
 //     transposing ds_read_b64_tr_b16 in the accumulator's key order (guide T10): 12 MFMAs per block.
 // Output: fp32 rows, or split planes for the out-projection GEMM.
@@ -476,18 +496,16 @@ __global__ __launch_bounds__(MAXT) void attn_split_f16_kernel(const float* __res
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m_run = ninf, l_run = 0.f;
-
     const float* kb = k + (int64_t)b * N * ldkv;
     const float* vb = v + (int64_t)b * N * ldkv;
     const int ntiles = (klen + kSaKeys - 1) / kSaKeys;
 
     // staging: the fp32 loads of tile t+1 are issued before tile t is computed; split + LDS writes happen after it
     f32x4 sreg[NS];
-    auto stage_load = [&](int t) {
+    auto stage_load = [&](int t, int round = 0) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int idx = tid + i * nthreads;
+            const int idx = tid + (round * NS + i) * nthreads;
             const int isv = idx >> 10, rem = idx & 1023;
             const int row = rem >> 4, c4 = (rem & 15) * 4;
             const int key = t * kSaKeys + row;
@@ -496,10 +514,10 @@ __global__ __launch_bounds__(MAXT) void attn_split_f16_kernel(const float* __res
             sreg[i] = val;
         }
     };
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, int round = 0) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int idx = tid + i * nthreads;
+            const int idx = tid + (round * NS + i) * nthreads;
             const int isv = idx >> 10, rem = idx & 1023;
             const int row = rem >> 4, c4 = (rem & 15) * 4;
             if (idx < 2048) {
@@ -516,19 +534,33 @@ __global__ __launch_bounds__(MAXT) void attn_split_f16_kernel(const float* __res
 
     // per-lane LDS byte offsets inside a buffer.  K fragment of k-step ks: row l31 (+ 32 per block), logical slot 2 ks + h
     const uint32_t lbase = lds_addr(smem_raw);
-    uint32_t koff[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * 128 + (((2 * ks + h) ^ ((l31 >> 1) & 7)) << 4);
+    // ((2 ks + h) ^ sw) << 4 = ((h ^ sw) << 4) ^ (ks << 5): one register, the k-step is a constant XOR
+    const uint32_t koff0 = l31 * 128 + ((h ^ ((l31 >> 1) & 7)) << 4);
     // V transposing read (as attn_bf16_kernel): 16-lane group = (h, dim half dh); lane 4 qq + pp of the group points at key
     // row 4 h + qq, dims 4 pp .. 4 pp + 3 of the group's 16-dim block = logical slot 4 dt + 2 dh + (pp >> 1), byte 8 (pp & 1)
     const int qq = (lane & 15) >> 2, pp = lane & 3, dh = (lane >> 4) & 1;
-    uint32_t voff[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-        voff[dt] = 2 * kSaPlane + (4 * h + qq) * 128 + (((4 * dt + 2 * dh + (pp >> 1)) ^ ((qq >> 1) << 2)) << 4) + 8 * (pp & 1);
+    const uint32_t voff0 = 2 * kSaPlane + (4 * h + qq) * 128 + (((2 * dh + (pp >> 1)) ^ ((qq >> 1) << 2)) << 4) + 8 * (pp & 1);   // dim tile dt: ^ (dt << 6)
 
-    stage_load(0);
-    stage_store(0);
+    // Softmax bookkeeping kept small, as in attn_bf16_kernel (the loop is otherwise VALU-bound: ~300 vector instructions
+    // against 24 MFMAs per block with a plain online softmax):
+    //   * the ALiBi bias enters the first score MFMA as its C operand: away from the diagonal block key - query has a fixed
+    //     sign, so the bias is "a per-lane base -/+ slope * (register's key offset)" - the offsets are a constant vector,
+    //     the base rides in the FMA that turns a score into the exp2 argument; only the key0 == q0 block pays for |.|;
+    //   * m_ref is a LAZY reference maximum, raised (and O, l rescaled) only when a block exceeds it by more than 2^kLazy:
+    //     probabilities stay <= 2^kLazy = 256 (inside fp16's range for the split), the true row maximum contributes >= 1;
+    //   * keys beyond key_len are masked only in the one block that straddles it.
+    constexpr float kLazy = 8.0f;
+    const float nsl = -slope;                              // bias per unit of |key - query|, natural-log units
+    float mref2 = 0.f;                                     // = -m_ref in exp2 units
+    float l2a = 0.f, l2b = 0.f;                            // row sum, two chains
+
+    // a tile is 2048 float4: ceil(2048 / (NS threads)) rounds of NS registers per thread (one round at the recipes' head
+    // counts); round 0 of the next tile is prefetched under this tile's products
+    const int rounds = (2048 + NS * nthreads - 1) / (NS * nthreads);
+    for (int rd0 = 0; rd0 < rounds; ++rd0) {
+        stage_load(0, rd0);
+        stage_store(0, rd0);
+    }
     __syncthreads();
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
@@ -538,82 +570,111 @@ __global__ __launch_bounds__(MAXT) void attn_split_f16_kernel(const float* __res
             const int key0 = t * kSaKeys + kblk * 32;
             if (key0 >= klen) break;  // wave-uniform
             const uint32_t blk = lbase + (uint32_t)(buf * kSaBuf + kblk * 32 * 128);
-            // ---- Sᵀ[key][query]
+            // ---- Sᵀ[key][query] (+ ALiBi bias through the C operand)
             f32x16 s;
+            float base2;                                   // exp2 argument = fma(s, log2e, base2)
+            const float d0 = (float)(key0 + 4 * h - qi);   // key - query of accumulator register 0
+            if (key0 == q0) {                              // wave-uniform: the block that straddles the diagonal
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.f;
+                for (int r = 0; r < 16; ++r) s[r] = fabsf(d0 + (float)((r & 3) + 8 * (r >> 2))) * nsl;
+                base2 = mref2;
+            } else {                                       // keys before (sgn = -1) or after the queries: |d| = sgn (d0 + off_r)
+                const float sn = key0 < q0 ? slope : nsl;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = sn * (float)((r & 3) + 8 * (r >> 2));
+                base2 = fmaf(sn * kLog2e, d0, mref2);
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 bf16x8 kh, kl;
-                lds_read_b128_asm<0>(kh, blk + koff[ks]);
-                lds_read_b128_asm<kSaPlane>(kl, blk + koff[ks]);
+                lds_read_b128_asm<0>(kh, blk + (koff0 ^ (uint32_t)(ks << 5)));
+                lds_read_b128_asm<kSaPlane>(kl, blk + (koff0 ^ (uint32_t)(ks << 5)));
                 lds_wait<0>();
                 __builtin_amdgcn_sched_barrier(0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(kl), qh[ks], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(kh), ql[ks], s, 0, 0, 0);
                 s = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_f16x8(kh), qh[ks], s, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // V fragments for the second product: requested now, they land during the softmax
-            su32x2 vh[2][2][2], vl[2][2][2];   // [k-step st][dim tile][run]
-            static_for<0, 8>([&](auto ic) {
-                constexpr int i8 = decltype(ic)::value, st = i8 >> 2, dt = (i8 >> 1) & 1, run = i8 & 1;
-                sa_read_tr16_b64<(16 * st + 8 * run) * 128>(vh[st][dt][run], blk + voff[dt]);
-                sa_read_tr16_b64<(16 * st + 8 * run) * 128 + kSaPlane>(vl[st][dt][run], blk + voff[dt]);
-            });
-            // ---- bias, mask, online softmax (per query = per lane pair)
-            float smax = ninf;
+            // V fragments of the first k-step of the second product: requested now, they land during the softmax
+            su32x2 vh[2][2], vl[2][2];   // [dim tile][run]
+            auto rdv = [&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                static_for<0, 4>([&](auto ic) {
+                    constexpr int i4 = decltype(ic)::value, dt = i4 >> 1, run = i4 & 1;
+                    sa_read_tr16_b64<(16 * st + 8 * run) * 128>(vh[dt][run], blk + (voff0 ^ (uint32_t)(dt << 6)));
+                    sa_read_tr16_b64<(16 * st + 8 * run) * 128 + kSaPlane>(vl[dt][run], blk + (voff0 ^ (uint32_t)(dt << 6)));
+                });
+            };
+            rdv(std::integral_constant<int, 0>{});
+            if (key0 + 32 > klen) {   // the one block that straddles key_len (wave-uniform test)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int dist = key > qi ? key - qi : qi - key;
-                float val = s[r] - slope * (float)dist;
-                val = key < klen ? val : ninf;
-                s[r] = val;
-                smax = fmaxf(smax, val);
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    s[r] = key < klen ? s[r] : ninf;
+                }
             }
-            smax = fmaxf(smax, __shfl_xor(smax, 32, 64));
-            const float m_new = fmaxf(m_run, smax);
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * kLog2e);  // first block: exp2(-inf) = 0
-            float psum = 0.f;
+            float bmax = fmaxf(fmaxf(s[0], s[1]), s[2]);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pexp = __builtin_amdgcn_exp2f((s[r] - m_new) * kLog2e);
-                s[r] = pexp;
-                psum += pexp;
+            for (int r = 3; r < 15; r += 2) bmax = fmaxf(fmaxf(bmax, s[r]), s[r + 1]);
+            // this lane half's block maximum in exp2 units relative to m_ref (the base differs between the halves), then the row's
+            bmax = fmaf(fmaxf(bmax, s[15]), kLog2e, base2);
+            bmax = fmaxf(bmax, __shfl_xor(bmax, 32, 64));
+            const bool first = key0 == 0;
+            if (first || __builtin_amdgcn_ballot_w64(bmax > kLazy) != 0) {   // wave-uniform
+                // raise the reference to this block's row maximum (block 0: set it), rescale what was accumulated
+                const float delta = first ? bmax : fmaxf(bmax, 0.f);
+                const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
+                mref2 -= delta;
+                base2 -= delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+                l2a *= alpha;
+                l2b *= alpha;
             }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
+            for (int j = 0; j < 8; ++j) {
+                s[2 * j] = __builtin_amdgcn_exp2f(fmaf(s[2 * j], kLog2e, base2));
+                s[2 * j + 1] = __builtin_amdgcn_exp2f(fmaf(s[2 * j + 1], kLog2e, base2));
+                l2a += s[2 * j];
+                l2b += s[2 * j + 1];
             }
-            // ---- P -> split B-operand fragments (k-step st = registers 8 st .. 8 st + 7)
-            union { uint32_t u[4]; f16x8 f; } ph[2], pl[2];
+            // ---- P -> split B-operand fragments (k-step st = registers 8 st .. 8 st + 7), Oᵀ += Vᵀ P
+            static_for<0, 2>([&](auto sc) {
+                constexpr int st = decltype(sc)::value;
+                union { uint32_t u[4]; f16x8 f; } ph, pl;
 #pragma unroll
-            for (int st = 0; st < 2; ++st)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) split_pair_nc(s[8 * st + 2 * e], s[8 * st + 2 * e + 1], ph[st].u[e], pl[st].u[e]);
-            lds_wait<0>();
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int st = 0; st < 2; ++st) {
+                for (int e = 0; e < 4; ++e) split_pair_nc(s[8 * st + 2 * e], s[8 * st + 2 * e + 1], ph.u[e], pl.u[e]);
                 union { uint32_t u[4]; f16x8 f; } ah0, ah1, al0, al1;
-                ah0.u[0] = vh[st][0][0][0]; ah0.u[1] = vh[st][0][0][1]; ah0.u[2] = vh[st][0][1][0]; ah0.u[3] = vh[st][0][1][1];
-                ah1.u[0] = vh[st][1][0][0]; ah1.u[1] = vh[st][1][0][1]; ah1.u[2] = vh[st][1][1][0]; ah1.u[3] = vh[st][1][1][1];
-                al0.u[0] = vl[st][0][0][0]; al0.u[1] = vl[st][0][0][1]; al0.u[2] = vl[st][0][1][0]; al0.u[3] = vl[st][0][1][1];
-                al1.u[0] = vl[st][1][0][0]; al1.u[1] = vl[st][1][0][1]; al1.u[2] = vl[st][1][1][0]; al1.u[3] = vl[st][1][1][1];
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0.f, ph[st].f, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1.f, ph[st].f, o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0.f, pl[st].f, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1.f, pl[st].f, o1, 0, 0, 0);
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0.f, ph[st].f, o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1.f, ph[st].f, o1, 0, 0, 0);
+                lds_wait<0>();
+                __builtin_amdgcn_sched_barrier(0);
+                ah0.u[0] = vh[0][0][0]; ah0.u[1] = vh[0][0][1]; ah0.u[2] = vh[0][1][0]; ah0.u[3] = vh[0][1][1];
+                ah1.u[0] = vh[1][0][0]; ah1.u[1] = vh[1][0][1]; ah1.u[2] = vh[1][1][0]; ah1.u[3] = vh[1][1][1];
+                al0.u[0] = vl[0][0][0]; al0.u[1] = vl[0][0][1]; al0.u[2] = vl[0][1][0]; al0.u[3] = vl[0][1][1];
+                al1.u[0] = vl[1][0][0]; al1.u[1] = vl[1][0][1]; al1.u[2] = vl[1][1][0]; al1.u[3] = vl[1][1][1];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0.f, ph.f, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1.f, ph.f, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0.f, pl.f, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1.f, pl.f, o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0.f, ph.f, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1.f, ph.f, o1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (st == 0) rdv(std::integral_constant<int, 1>{});   // (the MFMAs above have read their operands)
+            });
+        }
+        if (t + 1 < ntiles) {
+            stage_store(buf ^ 1);
+            for (int rd1 = 1; rd1 < rounds; ++rd1) {
+                stage_load(t + 1, rd1);
+                stage_store(buf ^ 1, rd1);
             }
         }
-        if (t + 1 < ntiles) stage_store(buf ^ 1);
         __syncthreads();
     }
+    const float l_run = l2a + l2b;
 
     // ---- normalise and store: lane (query, half) holds d = tile * 32 + (r & 3) + 8 (r >> 2) + 4 h
     const float lsum = l_run + __shfl_xor(l_run, 32, 64);
@@ -664,6 +725,13 @@ extern "C" int32_t ispk_alibi_mqa_attn_split_f16(const float* q, int64_t ldq, co
     ISPK_REQUIRE(ispk_aligned(q, 16) && ispk_aligned(k, 16) && ispk_aligned(v, 16) && ispk_aligned(out, 16), ISPK_E_ALIGN,
                  "attn_split: pointers must be 16-byte aligned");
     if (B == 0) return 0;
+    if (H == 5 || H >= 7) {   // head counts the recipes do not use: two calls over head ranges (K / V are staged twice)
+        const int h0 = H == 5 ? 4 : 6;
+        const int64_t oe = o_plane != 0 ? 2 : 4;   // bytes per output element
+        if (int32_t rc = ispk_alibi_mqa_attn_split_f16(q, ldq, k, v, ldkv, slopes, key_len, out, ldo, o_plane, B, N, h0, stream)) return rc;
+        return ispk_alibi_mqa_attn_split_f16(q + h0 * 64, ldq, k, v, ldkv, slopes + h0, key_len,
+                                             static_cast<char*>(out) + (int64_t)h0 * 64 * oe, ldo, o_plane, B, N, H - h0, stream);
+    }
     constexpr size_t lds = (size_t)2 * kSaBuf;   // 64 KB
     dim3 grid((N + 63) / 64, B), block(2 * H * 64);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -680,10 +748,8 @@ extern "C" int32_t ispk_alibi_mqa_attn_split_f16(const float* q, int64_t ldq, co
                                slopes, key_len, out, ldo, o_plane, N, H);                                                \
         }                                                                                                                \
     } while (0)
-    if (H >= 7) ISPK_SA_GO(1024, 3);
-    else if (H >= 4) ISPK_SA_GO(768, 4);
-    else if (H >= 2) ISPK_SA_GO(384, 8);
-    else ISPK_SA_GO(128, 16);
+    if (H == 6) ISPK_SA_GO(768, 3);     // 12 waves: one staging round of 3 float4 per thread
+    else ISPK_SA_GO(512, 4);            // H <= 4: 2 H waves; one round at H = 4, more with fewer threads
 #undef ISPK_SA_GO
     return ispk_launch_status();
 }

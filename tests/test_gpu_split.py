@@ -136,6 +136,8 @@ def test_attention_split_against_the_oracle_and_float64(B, N, H, ragged):
     bias = slopes.double().view(H, 1, 1) * orc.alibi_int_bias(N, N).double()
     ref = orc.attend(q, k, v, mask, bias).transpose(1, 2).reshape(B, N, H * 64)
     valid = torch.ones(B, N, dtype=torch.bool) if lens is None else torch.arange(N)[None] < lens[:, None]
+    # outputs reach |6| here: 1e-5 absolute is 2e-6 of the scale (v_exp_f32 on arguments down to -100 sets the floor; the
+    # exact-fp32 kernel's own bound in test_gpu_kernels.py is 2e-5)
     err = ((out.double().cpu() - ref).abs() * valid[..., None]).max().item()
-    assert err < 5e-6, err
-    assert ((_join(outp) - ref).abs() * valid[..., None]).max().item() < 5e-6
+    assert err < 1e-5, err
+    assert ((_join(outp) - ref).abs() * valid[..., None]).max().item() < 1e-5

@@ -93,18 +93,23 @@ class AttentionCTCLoss(torch.nn.Module):
         return self.weight * _CTCLossFunction.apply(attn_logits, text_lengths, mel_lengths, float(self.blank_logprob))
 
 
+_DEFAULT = object()   # "argument not given" (None means: criterion disabled, as in the reference)
+
+
 class AcousticModelLoss(torch.nn.Module):
     """`AcousticModelLoss` of models/acoustic/loss.py:122-182: mel loss + the adaptor's own losses (the flow loss) + attention CTC
     loss + attention binarisation loss, each a kernel; returns (loss, {"model/mel_loss", "adaptor/...", "aligner/attention_loss",
     "aligner/kl_loss"}) like the reference.  `inputs` needs `.mel`, `.mel_len`, `.text_len` (a dict or any object with those
     attributes: the collator's batch through `AcousticModel.prepare_inputs`); `outputs` is the model's `AcousticModelOutput`."""
 
-    def __init__(self, mel_loss: Optional[dict] = None, attention_loss: Optional[dict] = None,
-                 attention_kl_loss: Optional[dict] = None, use_attention_loss: bool = True, use_attention_kl_loss: bool = True):
+    def __init__(self, mel_loss=_DEFAULT, attention_loss=_DEFAULT, attention_kl_loss=_DEFAULT):
+        """Each argument is that criterion's config (a dict of its constructor arguments); as in the reference (loss.py:140-150)
+        `attention_loss=None` / `attention_kl_loss=None` DISABLE the term, leaving the argument out takes the defaults."""
         super().__init__()
-        self.mel_criterion = MelLoss(**(mel_loss or {}))
-        self.attention_criterion = AttentionCTCLoss(**(attention_loss or {})) if use_attention_loss else None
-        self.attention_kl_criterion = AttentionBinarizationLoss(**(attention_kl_loss or {})) if use_attention_kl_loss else None
+        cfg = lambda c: {} if c is _DEFAULT or c is None else dict(c)   # noqa: E731
+        self.mel_criterion = MelLoss(**cfg(mel_loss))
+        self.attention_criterion = None if attention_loss is None else AttentionCTCLoss(**cfg(attention_loss))
+        self.attention_kl_criterion = None if attention_kl_loss is None else AttentionBinarizationLoss(**cfg(attention_kl_loss))
 
     def forward(self, inputs, outputs, step=None):
         get = (lambda k: inputs[k]) if isinstance(inputs, dict) else (lambda k: getattr(inputs, k))

@@ -4,8 +4,8 @@
   * "model/mel_loss" and "adaptor/flow_loss" are differentiable - their gradients reach every parameter outside the aligner:
     text embedding, TextEncoder, the adaptor's embedding module and flow predictor, MelDecoder, to_mel;
   * "aligner/attention_loss" (CTC) and "aligner/kl_loss" (binarisation) train the aligner front-end (train/aligner.py), which
-    the mel loss also reaches through attn_soft (length regulator, soft averages); with `train_aligner=False` the aligner is
-    frozen and the two terms are values.
+    the mel loss also reaches through attn_soft in the length regulator (the pitch / energy averages are detached, as in the
+    reference); with `train_aligner=False` the aligner is frozen and the two terms are values.
 """
 from __future__ import annotations
 
@@ -16,7 +16,7 @@ from torch import Tensor
 
 from .. import runtime
 from .loss import AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
-from .aligner import SoftAverageFunction, conv_attention_train
+from .aligner import conv_attention_train
 from .predictor import flow_predictor_loss
 from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction,
                     transformer_train_forward)
@@ -34,14 +34,15 @@ def acoustic_train_forward(model, text: Tensor, text_len: Tensor, mel: Tensor, m
     keys_t = enc_out.detach().transpose(1, 2)          # model.py:139: the aligner sees the DETACHED encoder output
     if train_aligner:
         attn_soft, attn_logits = conv_attention_train(model.aligner.attention, mel, keys_t, mel_len, text_len)
-        feats = SoftAverageFunction.apply(attn_soft, pitch, energy, text_len)          # pitch / energy targets, differentiable
     with torch.no_grad():
         if not train_aligner:
             attn_soft, attn_logits = model.aligner.attention(mel, keys_t, mel_len, text_len)
         attn_hard, dur = model.aligner.binarize_attention_parallel(attn_logits.detach(), text_len, mel_len, return_duration=True)
         targets = runtime.soft_average(attn_soft.detach(), pitch, energy, dur, text_len)       # [log1p duration, pitch, energy]
-    if not train_aligner:
-        feats = targets
+    # The averaged pitch / energy enter the embedding stack DETACHED (temporal_adaptor.py:284, :292 `pitch_target.detach()`,
+    # `energy_target.detach()`), like the predictor's targets (:112): the mel loss reaches attn_soft - and through it the
+    # aligner - only by way of the length regulator (:300).
+    feats = targets
     b, l = text.shape
     x0 = flow_noise if flow_noise is not None else torch.randn(b, l, 3, device=text.device)
     t = flow_time if flow_time is not None else torch.rand(b, device=text.device)

@@ -262,6 +262,86 @@ def gen_infer(model, sd):
     np.savez_compressed(os.path.join(OUT, "infer.npz"), **out)
 
 
+# --------------------------------------------------------------------------------------------- training step (row f2)
+def _sample(t: torch.Tensor, n: int = 192) -> np.ndarray:
+    """A strided sample of a tensor's flattened values: first element, then every ceil(numel / n)-th."""
+    f = t.detach().reshape(-1)
+    step = max(1, -(-f.numel() // n))
+    return f[::step].numpy().copy()
+
+
+def gen_train(sd):
+    """The reference's training step on the B=2 golden inputs: `AcousticModel.forward` under autograd (eval mode: no
+    dropout draws), `AcousticModelLoss` (models/acoustic/loss.py:122-182), `.backward()`, the weight-decay grouping of
+    experiments/optimizers.py:15-20 and one torch.optim.AdamW step with `clip_grad_norm_` on param_groups[0] only
+    (optimizers.py:230-244; recipes/default.yaml: lr 2e-4, weight_decay 1e-2, grad_clip 1.0).  -> tests/golden/train.npz:
+    loss values, per-parameter gradient norms + strided samples, the grouping, parameters after the step."""
+    print("training step (B=2, L=(100,73), M=(512,390))")
+    from tts.experiments.optimizers import group_weight_decayable_params  # noqa: E402  (reference)
+    from tts.models.acoustic.loss import AcousticModelLoss  # noqa: E402  (reference)
+    from oracle import train_oracle as torc
+    model = AcousticModel.init(DictConfig(AcousticDims().model_config())).eval()
+    model.load_state_dict(sd, strict=True)
+    # On CPU the reference's MAS branch receives `attn_logits.detach().cpu().numpy()` - a VIEW of the autograd tensor's own
+    # memory - and overwrites it in place (alignment.py:308, mas.py:12-16), so its CTC loss would read MAS's running sums
+    # (with -inf entries: NaN gradients).  On the reference's training device (CUDA) `.cpu()` copies and the CUDA branch
+    # clones (:320): the losses see the logits as the attention produced them.  The fixture holds THAT semantics: MAS gets a
+    # copy.  (gen_forward captures the pre-MAS logits through a hook for the same reason.)
+    cpu_mas = type(model.aligner).cpu_binarize_attention_parallel
+    model.aligner.cpu_binarize_attention_parallel = lambda logits, tl, ml: cpu_mas(logits.clone(), tl, ml)
+    criterion = AcousticModelLoss()
+    inp = synth.make_inputs(2, 100, 512)
+    text_len, mel_len = torch.tensor([100, 73]), torch.tensor([512, 390])
+    tm = torch.arange(100)[None] < text_len[:, None]
+    mm = torch.arange(512)[None] < mel_len[:, None]
+    text, mel = inp["text"] * tm, inp["mel"] * mm[:, None]
+    pitch, energy = inp["pitch"] * mm, inp["energy"] * mm
+    names = [n for n, _ in model.named_parameters()]
+    with torch.enable_grad():
+        with _Noise(inp["flow_x0"], inp["flow_t"]):
+            outputs = model(text, text_len, mel, mel_len, pitch=pitch, energy=energy)
+        loss, losses = criterion({"text": text, "text_len": text_len, "mel": mel, "mel_len": mel_len, "pitch": pitch,
+                                  "energy": energy}, outputs)
+        loss.backward()
+    grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    assert all(g is not None and bool(torch.isfinite(g).all()) for g in grads.values())
+    # the oracle's restatement of the same step (autograd over the oracle's forward, composed as the reference composes it)
+    osd = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith("freq_scale") else v.clone())
+           for k, v in sd.items()}
+    with torch.enable_grad():
+        ototal, oterms = torc.acoustic_losses(osd, text, text_len, mel, mel_len, pitch, energy, inp["flow_x0"], inp["flow_t"])
+        ototal.backward()
+    report("train.total_loss", loss.detach(), ototal.detach())
+    for k in losses:
+        report(f"train.{k}", losses[k].detach(), oterms[k].detach())
+    worst = max(((grads[n] - osd[n].grad).abs().max().item() / max(grads[n].abs().max().item(), 1e-12), n) for n in names)
+    print(f"  oracle-vs-reference gradients: worst relative max|diff| over {len(names)} tensors = {worst[0]:.3e} ({worst[1]})")
+    # optimizer: the reference's grouping, clip of group 0, one AdamW step
+    params = list(model.parameters())
+    wd, no_wd = group_weight_decayable_params(params)
+    wd_ids = {id(p) for p in wd}
+    opt = torch.optim.AdamW([{"params": wd}, {"params": no_wd, "weight_decay": 0.}], lr=2e-4, weight_decay=1e-2)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    grad_norm = torch.nn.utils.clip_grad_norm_(opt.param_groups[0]["params"], 1.0)
+    opt.step()
+    out = {"text_len": text_len.numpy(), "mel_len": mel_len.numpy(),
+           "inputs_crc": np.array([crc(text), crc(mel), crc(pitch), crc(energy)], dtype=np.int64),
+           "loss_total": loss.detach().numpy(), "grad_norm_group0": grad_norm.numpy(),
+           "names": np.array(names), "in_decay_group": np.array([id(p) in wd_ids for p in params]),
+           "lr": np.array(2e-4), "weight_decay": np.array(1e-2), "grad_clip": np.array(1.0)}
+    for k, v in losses.items():
+        out["loss_" + k.replace("/", "_")] = v.detach().numpy()
+    out["grad_norm"] = np.array([grads[n].double().norm().item() for n in names])
+    out["grad_absmax"] = np.array([grads[n].abs().max().item() for n in names])
+    out["update_norm"] = np.array([(p.detach() - before[n]).double().norm().item() for n, p in model.named_parameters()])
+    for i, (n, p) in enumerate(model.named_parameters()):
+        out[f"g{i}"] = _sample(grads[n])
+        out[f"u{i}"] = _sample(p.detach() - before[n])          # the update of one optimizer step, same stride
+    np.savez_compressed(os.path.join(OUT, "train.npz"), **out)
+    print(f"  losses: total {loss.item():.6f} " + " ".join(f"{k}={v.item():.6f}" for k, v in losses.items())
+          + f"; clip norm of group 0 = {grad_norm.item():.4f}; {int(out['in_decay_group'].sum())} of {len(names)} tensors decay")
+
+
 def gen_known_answers():
     print("known answers")
     dims = AcousticDims(vocab=77)
@@ -299,5 +379,6 @@ if __name__ == "__main__":
     gen_ops(model, sd)
     gen_forward(model, sd)
     gen_infer(model, sd)
+    gen_train(sd)
     for f in sorted(os.listdir(OUT)):
         print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")

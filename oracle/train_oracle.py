@@ -6,8 +6,11 @@
   * `adamw_flat` / `sqnorm_flat`: the same AdamW arithmetic on flat arenas - the stand-in the CPU (gloo) test plugs into
     `FlatAdamW` so that the gradient exchange runs without a GPU.
 Gradients of the transformer stacks come from autograd over `acoustic_oracle.transformer` (no separate restatement).
-Parity is pinned through torch.optim.AdamW / torch autograd themselves (the reference calls exactly these); the
-reference holds no fixtures for its training step.
+  * `acoustic_losses`: the reference's total objective (model.py:116-174 + loss.py:140-182) over the oracle's forward.
+Pinned against the REAL reference: oracle/make_goldens.py runs the reference's `AcousticModel.forward`, `AcousticModelLoss`,
+`.backward()`, `group_weight_decayable_params` and one clipped AdamW step and writes tests/golden/train.npz (losses, every
+parameter's gradient norm + a strided sample, the decay grouping, the update of one step); tests/test_oracle_goldens.py holds
+this module to it on CPU, tests/test_gpu_train.py the HIP step on the GPU.
 
 Only tests/ may import this module.
 """
@@ -73,6 +76,41 @@ def attention_binarization_loss(soft: Tensor, hard: Tensor, eps: float = 1e-6) -
     """loss.py:100-107."""
     log_sum = torch.log(torch.clamp(soft[hard == 1], min=eps)).sum()
     return -log_sum / hard.sum()
+
+
+def acoustic_losses(sd: dict, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor, energy: Tensor,
+                    flow_x0: Tensor, flow_t: Tensor):
+    """The reference's training objective on the oracle's forward, differentiable w.r.t. the tensors of `sd` that require
+    grad: `AcousticModel.forward` (model.py:116-174) composed with its detach points - the aligner sees the DETACHED encoder
+    output (:139), the flow predictor's targets are detached (temporal_adaptor.py:112), and the pitch / energy averages
+    enter the embedding stack DETACHED (:284, :292), so the mel loss reaches attn_soft only through the length regulator
+    (:300) - under `AcousticModelLoss.forward` (loss.py:140-182).  -> (total, {the reference's four loss keys}).
+    Pinned against the reference's own forward + loss + backward by tests/golden/train.npz (oracle/make_goldens.py)."""
+    from . import acoustic_oracle as orc
+    from . import mas_oracle
+    emb = F.embedding(text, sd["text_embedding.weight"], padding_idx=0)
+    enc_mask = torch.arange(text.shape[1])[None, :] < text_len[:, None]
+    m3 = enc_mask[..., None]
+    enc_out = orc.transformer(sd, "encoder", emb, enc_mask)
+    soft, logits = orc.conv_attention(sd, mel, enc_out.detach().transpose(1, 2), mel_len, text_len)
+    hard = torch.from_numpy(mas_oracle.b_mas(logits.detach().numpy(), text_len.numpy(), mel_len.numpy()))
+    dur = hard.sum(dim=1)
+    if not torch.all(dur.sum(dim=1) == mel_len):               # alignment.py:278-282
+        dur[:, 0] += mel_len - dur.sum(dim=1)
+    pt = orc.soft_average(pitch[:, None], soft).transpose(1, 2) * m3
+    et = orc.soft_average(energy[:, None], soft).transpose(1, 2) * m3
+    targets = torch.cat([torch.log1p(dur.float())[..., None], pt, et], dim=-1)
+    _, flow_loss = orc.predictor_forward(sd, enc_out, targets.detach(), enc_mask, flow_x0, flow_t)
+    x = enc_out + orc.embedding_module(sd, torch.cat([pt.detach(), et.detach()], dim=-1), enc_mask)
+    dec_lens = torch.clamp_max((dur.sum(dim=1).float() + 0.5).long(), mel.shape[2])
+    dec_in = soft @ x
+    dec_mask = torch.arange(mel.shape[2])[None, :] < dec_lens[:, None]
+    dec = orc.transformer(sd, "decoder", dec_in, dec_mask)
+    mel_out = F.linear(dec, sd["to_mel.weight"], sd["to_mel.bias"]).transpose(1, 2) * dec_mask[:, None]
+    terms = {"model/mel_loss": mel_loss(mel_out, mel, mel_len), "adaptor/flow_loss": flow_loss,
+             "aligner/attention_loss": attention_ctc_loss(logits, text_len, mel_len),
+             "aligner/kl_loss": attention_binarization_loss(soft, hard)}
+    return sum(terms.values()), terms
 
 
 def sqnorm_flat(g: Tensor, out: Tensor) -> Tensor:

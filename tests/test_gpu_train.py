@@ -654,8 +654,9 @@ def test_mel_plus_flow_loss_gradients_of_the_model_match_autograd(state_dict):
 def test_full_training_loss_gradients_match_autograd(state_dict):
     """`train.acoustic_train_forward(train_aligner=True)`: the reference's TOTAL loss (mel + flow + CTC + binarisation,
     loss.py:140-182) and its gradient for EVERY parameter of the model (206 tensors, the aligner's 11 included) against torch
-    autograd over the oracle's forward composed as the reference composes it (aligner on the detached encoder output,
-    model.py:139; flow targets detached, temporal_adaptor.py:112)."""
+    autograd over the oracle's forward composed as the reference composes it (`train_oracle.acoustic_losses`: aligner on the
+    detached encoder output, model.py:139; flow targets and the embedding stack's pitch / energy inputs detached,
+    temporal_adaptor.py:112, :284, :292 - the composition tests/golden/train.npz pins against the reference itself)."""
     from isp_tts_amd.acoustic import AcousticModel
     from isp_tts_amd.config import AcousticDims
     from oracle import mas_oracle
@@ -663,26 +664,7 @@ def test_full_training_loss_gradients_match_autograd(state_dict):
     text, text_len, mel, mel_len, pitch, energy = (inp[k] for k in ("text", "text_len", "mel", "mel_len", "pitch", "energy"))
     sd = {k: (v.clone().requires_grad_() if v.is_floating_point() and not k.endswith("freq_scale") else v.clone())
           for k, v in state_dict.items()}
-    emb = F.embedding(text, sd["text_embedding.weight"], padding_idx=0)
-    enc_mask = torch.arange(text.shape[1])[None, :] < text_len[:, None]
-    m3 = enc_mask[..., None]
-    enc_out = orc.transformer(sd, "encoder", emb, enc_mask)
-    soft, logits = orc.conv_attention(sd, mel, enc_out.detach().transpose(1, 2), mel_len, text_len)
-    hard = torch.from_numpy(mas_oracle.b_mas(logits.detach().numpy(), text_len.numpy(), mel_len.numpy()))
-    dur = hard.sum(dim=1)
-    pt = orc.soft_average(pitch[:, None], soft).transpose(1, 2) * m3
-    et = orc.soft_average(energy[:, None], soft).transpose(1, 2) * m3
-    targets = torch.cat([torch.log1p(dur.float())[..., None], pt, et], dim=-1)
-    _, flow_loss = orc.predictor_forward(sd, enc_out, targets.detach(), enc_mask, inp["flow_x0"], inp["flow_t"])
-    x = enc_out + orc.embedding_module(sd, torch.cat([pt, et], dim=-1), enc_mask)
-    dec_in = soft @ x
-    dec_mask = torch.arange(mel.shape[2])[None, :] < mel_len[:, None]
-    dec = orc.transformer(sd, "decoder", dec_in, dec_mask)
-    mel_ref = F.linear(dec, sd["to_mel.weight"], sd["to_mel.bias"]).transpose(1, 2) * dec_mask[:, None]
-    terms = {"model/mel_loss": torc.mel_loss(mel_ref, mel, mel_len), "adaptor/flow_loss": flow_loss,
-             "aligner/attention_loss": torc.attention_ctc_loss(logits, text_len, mel_len),
-             "aligner/kl_loss": torc.attention_binarization_loss(soft, hard)}
-    total_ref = sum(terms.values())
+    total_ref, terms = torc.acoustic_losses(sd, text, text_len, mel, mel_len, pitch, energy, inp["flow_x0"], inp["flow_t"])
     total_ref.backward()
 
     model = AcousticModel.init(AcousticDims().model_config())
@@ -843,3 +825,64 @@ def test_attention_training_pair_with_bf16_operands(B, N, H, lens, p):
     _close(ds16, ds32, 2e-2, "d log-slope")
     again, _ = runtime.alibi_mqa_attention_bwd(qkv, o16, d_o, H, slopes, key_len, lse=lse16, dropout_p=p, seed=1234, bf16=True)
     assert torch.equal(again, dq16)
+
+
+def test_training_step_against_the_reference_fixture(state_dict):
+    """SURVEY row f2 against the REAL reference: `train.acoustic_train_forward` (HIP forward + backward of the whole model,
+    train_aligner=True, no dropout) and one `FlatAdamW` step (clip of the decay group + fused AdamW) on the B=2 golden inputs,
+    compared with tests/golden/train.npz - what the reference's own AcousticModel.forward, AcousticModelLoss, .backward(),
+    group_weight_decayable_params and a clipped torch.optim.AdamW step produce on them (oracle/make_goldens.py `gen_train`):
+    the four losses, all 206 gradients (norm within 2e-3, strided sample within 2e-3 of the tensor's scale), the clip norm,
+    the decay grouping and the parameter update."""
+    import numpy as np
+    from conftest import crc, golden
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    g = golden("train.npz")
+    inp = synth.make_inputs(2, 100, 512)
+    text_len, mel_len = torch.tensor(g["text_len"]), torch.tensor(g["mel_len"])
+    tm = torch.arange(100)[None] < text_len[:, None]
+    mm = torch.arange(512)[None] < mel_len[:, None]
+    text, mel = inp["text"] * tm, inp["mel"] * mm[:, None]
+    pitch, energy = inp["pitch"] * mm, inp["energy"] * mm
+    assert [crc(text), crc(mel), crc(pitch), crc(energy)] == [int(v) for v in g["inputs_crc"]]
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model = model.to(DEV).eval()
+    names = [str(n) for n in g["names"]]
+    params = dict(model.named_parameters())
+    assert list(params) == names
+    opt = train.FlatAdamW([params[n] for n in names], lr=float(g["lr"]), weight_decay=float(g["weight_decay"]),
+                          grad_clip=float(g["grad_clip"]))
+    # the decay grouping of experiments/optimizers.py:15-20 as the reference computed it
+    decay = {id(p) for p in opt.flat.params[:opt.flat.n_decay_tensors]}
+    assert [id(params[n]) in decay for n in names] == [bool(v) for v in g["in_decay_group"]]
+    before = {n: params[n].detach().clone() for n in names}
+    _, total, losses = train.acoustic_train_forward(model, text.to(DEV), text_len.to(DEV), mel.to(DEV), mel_len.to(DEV),
+                                                    pitch.to(DEV), energy.to(DEV), flow_noise=inp["flow_x0"].to(DEV),
+                                                    flow_time=inp["flow_t"].to(DEV), train_aligner=True)
+    for k, v in losses.items():
+        ref = float(g["loss_" + k.replace("/", "_")])
+        assert abs(v.item() - ref) < 2e-4 * max(abs(ref), 1.0), (k, v.item(), ref)
+    assert abs(total.item() - float(g["loss_total"])) < 2e-4 * float(g["loss_total"])
+    total.backward()
+
+    def sample(t, n=192):
+        f = t.detach().reshape(-1)
+        return f[::max(1, -(-f.numel() // n))].cpu()
+    worst = 0.0
+    for i, n in enumerate(names):
+        gr, scale = params[n].grad, float(g["grad_absmax"][i])
+        assert gr is not None, n
+        assert abs(gr.double().norm().item() - float(g["grad_norm"][i])) <= 2e-3 * float(g["grad_norm"][i]) + 1e-7, n
+        err = (sample(gr) - torch.from_numpy(g[f"g{i}"])).abs().max().item() / max(scale, 1e-12)
+        worst = max(worst, err)
+        assert err <= 2e-3, (n, err)
+    print(f"HIP backward vs the reference's gradients: worst sampled error = {worst:.2e} of the tensor's scale")
+    norm = opt.step(None)          # gradients are already in place
+    torch.cuda.synchronize()
+    if norm is not None:
+        assert abs(float(norm) - float(g["grad_norm_group0"])) < 2e-3 * float(g["grad_norm_group0"])
+    for i, n in enumerate(names):
+        upd = params[n].detach() - before[n].to(params[n].device)
+        assert (sample(upd) - torch.from_numpy(g[f"u{i}"])).abs().max().item() <= 2e-2 * float(g["lr"]), n

@@ -75,6 +75,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-iters", type=int, default=5)
     ap.add_argument("--c4-batch", type=int, default=256, help="config 4: utterances in total")
     ap.add_argument("--c4-frames", type=int, default=32768, help="config 4: padded frames per micro-batch (n x M_pad)")
+    ap.add_argument("--gather-dtype", choices=["f32", "bf16"], default="f32",
+                    help="dtype of the mel message of the per-step RCCL gather (bf16 halves the xGMI bytes; the lengths stay int64)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -92,11 +94,27 @@ def launch_workers(args) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--worker"]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
+    # Rank 0's stdout is ONE JSON line at the very end, so it cannot fill the pipe while we poll.  Every rank is polled:
+    # the first non-zero exit (a rank that dies before the rendezvous would otherwise leave the others blocked until the
+    # process group's 300-s timeout) takes the siblings down with it.
+    rc = 0
+    live = list(procs)
+    while live and rc == 0:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is not None:
+                live.remove(p)
+                rc = rc or code
+    for p in live:           # only reached with rc != 0: siblings of a failed rank
+        p.terminate()
+    for p in live:
+        try:
+            p.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+    out = procs[0].stdout.read() if procs[0].stdout is not None else ""
     sys.stdout.write(out)
     sys.stdout.flush()
     return rc
@@ -290,7 +308,8 @@ def worker(args) -> int:
     def fixed_batch_runner(batch, in_flight, seed_shift=0):
         """Config-3 style stream of fixed-shape batches: graph instance(s) + the overlapped gather. -> (step_fn, pipes, lanes)"""
         d = to_dev(synth.make_inputs(batch, L, M, seed=synth.SEED + rank + seed_shift))   # each rank: its own utterances
-        pipe = MelGatherPipeline(batch, dims.mel_dim, M, dev, root=gather_root) if use_dist else None
+        pipe = MelGatherPipeline(batch, dims.mel_dim, M, dev, root=gather_root,
+                                 dtype=torch.bfloat16 if args.gather_dtype == "bf16" else torch.float32) if use_dist else None
         if args.no_graph:
             def step():
                 out = model(*fwd_args(d)[:6], flow_noise=d["flow_x0"], flow_time=d["flow_t"])
@@ -498,13 +517,27 @@ def worker(args) -> int:
             d2 = to_dev(synth.make_inputs(B, L, M))
             dur = torch.full((B, L), M // L, dtype=torch.int64, device=dev)
             dur[:, : M - (M // L) * L] += 1                                      # every row sums to M frames
-            g = GraphedCall(lambda: model.infer(d2["text"], text_lengths=d2["text_len"], duration_target=dur, steps=4,
-                                                flow_noise=d2["flow_x0"], max_dec_len=M))
+            call = lambda: model.infer(d2["text"], text_lengths=d2["text_len"], duration_target=dur, steps=4,   # noqa: E731
+                                       flow_noise=d2["flow_x0"], max_dec_len=M)
+            g = GraphedCall(call)
             sec = timed_graph(g, 10)
             mel, ao = g.out
             assert mel.shape == (B, dims.mel_dim, M) and bool((ao.dec_lengths == M).all())
+            mel = mel.clone()
+            acc = None
+            if cdt != torch.float32:      # the same call on the exact-fp32 path of this build, for the accuracy figure
+                model.set_compute_dtype(torch.float32)
+                try:
+                    ref32 = call()[0]
+                    torch.cuda.synchronize()
+                finally:
+                    model.set_compute_dtype(cdt, alignment_dtype=align_dt)
+                err = (mel - ref32).abs()
+                acc = {"mel_linf_vs_fp32": float(f"{err.max().item():.3e}"),
+                       "mel_rel_rms_vs_fp32": float(f"{(err.pow(2).mean().sqrt() / ref32.pow(2).mean().sqrt()).item():.3e}")}
             v = B * M / sec
             return {"value": round(v, 1), "unit": "mel-frames/s", "ms_per_step": round(sec * 1e3, 3), "steps": 10,
+                    "accuracy_vs_fp32_path": acc,
                     "model_TFLOPs": round(v * FLOP_PER_FRAME_INFER / 1e12, 2),
                     "workload": f"AcousticModel.infer(steps=4, duration_target sum={M}), B={B}, {args.dtype}: 4 Euler steps of "
                                 "the flow predictor, no aligner / MAS (model.py:177-238)"}

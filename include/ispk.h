@@ -331,6 +331,21 @@ int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const 
  *                       loss_ratio[b] = sum over valid (l, c) of (pf - flow)^2 / max(C * valid_l, 1e-5): masked_mean of the
  *                       MSE (:146, utils/functions.py:44-58) before its final mean over the batch; loss_mean[0] (or NULL)
  *                       = that mean, the flow loss itself.  mask uint8 [B][L]. */
+/* infer (temporal_adaptor.py:140-170, :351-384):
+ * ispk_flow_euler_f32      one Euler step of FlowTransformerTemporalModule.infer: out = x_t + velocity * dt (:166-168; product and
+ *                          sum each rounded once), times the [B][L] row mask when given (the `* mask` after the last step, :170).
+ *                          dt is a host value: the warped time grid (:150-156) depends only on (steps, step_factor).
+ * ispk_infer_features_f32  FlowTemporalAdaptor.infer between predictor and embedding stack (:351-384), pred [B][L][3]:
+ *                          duration[b][l] = max(duration_factor * (exp(pred[..,0]) - 1), 0), replaced by the duration target
+ *                          (fp32 or int64, at most one given) wherever that is >= 0 (:355-362); features [B][L][2] =
+ *                          { (pitch_target | pred[..,1]) * pitch_factor + pitch_delta, (energy_target | pred[..,2]) *
+ *                          energy_factor + energy_delta } (:366-381) - the embedding stack's input. */
+int32_t ispk_flow_euler_f32(const float* x_t, const float* velocity, float dt, const uint8_t* mask, float* out, int32_t B,
+                            int32_t L, int32_t C, ispk_stream_t stream);
+int32_t ispk_infer_features_f32(const float* pred, const float* duration_target_f32, const int64_t* duration_target_i64,
+                                const float* pitch_target, const float* energy_target, float duration_factor, float pitch_factor,
+                                float pitch_delta, float energy_factor, float energy_delta, float* duration, float* features,
+                                int32_t B, int32_t L, ispk_stream_t stream);
 int32_t ispk_flow_mix_f32(const float* x0, const float* x1, const float* t, float sigma, float* x_t, float* flow, int32_t B,
                           int32_t L, int32_t C, ispk_stream_t stream);
 int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow, const float* x0, const uint8_t* mask, float* pred,

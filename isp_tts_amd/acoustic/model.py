@@ -207,7 +207,7 @@ class AcousticModel(nn.Module, Constructor):
         batch_infer = input_sequence.shape[0] > 1
         token_emb, enc_mask = runtime.embed_tokens(input_sequence, self.text_embedding.weight,
                                                    text_lengths if batch_infer else None, want_mask=batch_infer)
-        enc_out = self.encoder(token_emb, mask=enc_mask).out
+        enc_out = self.encoder(token_emb, mask=enc_mask, key_len=text_lengths if batch_infer else None).out
         if pitch_normalize:
             if pitch_target is not None:
                 pitch_target = (pitch_target - self.pitch_mean) / self.pitch_std
@@ -215,9 +215,11 @@ class AcousticModel(nn.Module, Constructor):
         adaptor_output = self.temporal_adaptor.infer(
             enc_out=enc_out, enc_mask=enc_mask, duration_target=duration_target, pitch_target=pitch_target,
             energy_target=energy_target, duration_factor=duration_factor, pitch_factor=pitch_factor,
-            pitch_delta=pitch_delta, steps=steps, noise=flow_noise, max_dec_len=max_dec_len)
+            pitch_delta=pitch_delta, steps=steps, noise=flow_noise, max_dec_len=max_dec_len,
+            enc_len=text_lengths if batch_infer else None)
         dec_mask = adaptor_output.dec_mask if batch_infer else None
-        dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, out_dtype=self.compute_dtype).out
+        dec_out = self.decoder(adaptor_output.enc_out, mask=dec_mask, key_len=adaptor_output.dec_lengths if batch_infer else None,
+                               out_dtype=self.compute_dtype).out
         return self._to_mel(dec_out, dec_mask), adaptor_output
 
     # ---- checkpoint drop-in (tts/models/base.py:39-108 of the reference; trainer.py:361-372 writes the file) ----

@@ -72,6 +72,7 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         self.linear_layer = nn.Linear(self.transformer.dim, output_dim, bias=True)
         self.output_dim, self.sigma, self.detach_inputs = output_dim, sigma, detach_inputs
         self._cache = StagedWeights()
+        self._grids: dict = {}
 
     def _cond_weight(self, dtype: torch.dtype) -> Tensor:
         w = self.transformer.project_emb.weight
@@ -114,33 +115,53 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         pred, self._duration_estimate, _, loss = runtime.flow_finish(raw, flow, x0, mask)
         return pred, {"flow_loss": loss}
 
-    def euler_grid(self, steps: int, step_factor: float, device) -> Tensor:
-        """temporal_adaptor.py:150-156 (steps=4, factor .75 -> [0, .3657, .6400, .8457, 1])."""
+    def euler_grid(self, steps: int, step_factor: float, device=None) -> Tensor:
+        """temporal_adaptor.py:150-156 (steps=4, factor .75 -> [0, .3657, .6400, .8457, 1]): a function of (steps, step_factor)
+        alone, evaluated ONCE on the host with the reference's fp32 expression and cached - no device launches."""
         assert step_factor <= 1.
-        if step_factor == 1.:
-            return torch.linspace(0, 1, steps + 1, device=device)
-        ts = -torch.diff(torch.logspace(0, steps, steps + 1, base=step_factor, device=device))
-        ts = torch.cat([torch.zeros(1, device=device), ts])
-        return torch.cumsum(ts / ts.sum(), dim=0)
+        key = (int(steps), float(step_factor))
+        grid = self._grids.get(key)
+        if grid is None:
+            if step_factor == 1.:
+                grid = torch.linspace(0, 1, steps + 1)
+            else:
+                ts = -torch.diff(torch.logspace(0, steps, steps + 1, base=step_factor))
+                ts = torch.cat([torch.zeros(1), ts])
+                grid = torch.cumsum(ts / ts.sum(), dim=0)
+            self._grids[key] = grid
+        return grid if device is None else grid.to(device)
 
     def infer(self, x: Tensor, mask: Optional[Tensor] = None, steps: int = 4, step_factor: float = 0.75, *,
-              noise: Optional[Tensor] = None) -> Tensor:
-        if mask is None:
-            mask = torch.ones(x.shape[:2], dtype=torch.bool, device=x.device)
-        elif mask.ndim == 3:
+              noise: Optional[Tensor] = None, key_len: Optional[Tensor] = None) -> Tensor:
+        """temporal_adaptor.py:140-170.  Every launch is a libispk kernel: the time grid lives on the host (its `steps`
+        embeddings come from ONE `ispk_time_embedding_f32` launch), an Euler step is `ispk_flow_euler_f32`; `key_len`
+        (= mask.sum(1), when the caller has the lengths) saves the reduction."""
+        dev = x.device
+        if mask is not None and mask.ndim == 3:
             mask = mask.squeeze(-1)
-        x_t = (torch.randn(x.shape[0], x.shape[1], self.output_dim, device=x.device) if noise is None
-               else noise.to(device=x.device, dtype=torch.float32))
-        ts = self.euler_grid(steps, step_factor, x.device)
+        x_t = (torch.randn(x.shape[0], x.shape[1], self.output_dim, device=dev) if noise is None
+               else noise.to(device=dev, dtype=torch.float32))
+        dts = self._grids.get(("dt", int(steps), float(step_factor)))
+        if dts is None:                                                # fp32 differences, as the reference forms them (cached)
+            ts = self.euler_grid(steps, step_factor)
+            dts = self._grids[("dt", int(steps), float(step_factor))] = (ts[1:] - ts[:-1]).tolist()
+        temb = self.time_embedding(self._grid_on(dev, steps, step_factor)[:steps])     # [steps, emb]: one launch
         cond_proj = self._cond_projection(x)
-        key_len = mask.sum(dim=1)
+        if mask is not None and key_len is None:
+            key_len = mask.sum(dim=1)
         for i in range(steps):
-            dt = ts[i + 1] - ts[i]
-            time_emb = self.time_embedding(ts[i].view(1, 1))
-            out = self.transformer(None, mask=mask, adaptive_condition=time_emb, projected=self._project(x_t, cond_proj),
-                                   key_len=key_len).out
-            x_t = x_t + runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias) * dt
-        return x_t * mask[..., None]
+            out = self.transformer(None, mask=mask, adaptive_condition=temb[i].view(1, 1, -1),
+                                   projected=self._project(x_t, cond_proj), key_len=key_len).out
+            vel = runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias)
+            x_t = runtime.flow_euler(x_t, vel, dts[i], mask if i == steps - 1 else None)
+        return x_t
+
+    def _grid_on(self, device, steps: int, step_factor: float) -> Tensor:
+        key = (str(device), int(steps), float(step_factor))
+        g = self._grids.get(key)
+        if g is None:
+            g = self._grids[key] = self.euler_grid(steps, step_factor).to(device)
+        return g
 
 
 class TemporalAdaptorOutput(NamedTuple):
@@ -285,23 +306,23 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
               duration_factor: float = 1.0, pitch_target: Optional[Tensor] = None, pitch_factor: float = 1.0,
               pitch_delta: float = 0., energy_target: Optional[Tensor] = None, energy_factor: float = 1.0,
               energy_delta: float = 0., steps: int = 4, *, noise: Optional[Tensor] = None,
-              max_dec_len: Optional[int] = None) -> TemporalAdaptorOutput:
+              max_dec_len: Optional[int] = None, enc_len: Optional[Tensor] = None) -> TemporalAdaptorOutput:
         """temporal_adaptor.py:331-408.  Durations stay fractional (soft_duration, :355-356); the embedding transformer
         gets NO mask even when batched (:384).  `max_dec_len` (optional) fixes the decoder length without reading
         `dec_lens.max()` back to the host."""
         m3 = enc_mask[..., None] if enc_mask is not None else None
-        pred = self.predictor.infer(enc_out, mask=m3, steps=steps, noise=noise)
-        # :351-364.  The reference tests `(duration_target < 0).any()` on the host and only then fills the negative entries
-        # with predictions; selecting per element on the device gives the same values without the round trip, which keeps
-        # the call capturable in a HIP graph.  (Integer targets come back as fp32 - exact for any frame count.)
-        duration_pred = torch.clamp(duration_factor * (torch.exp(pred[..., 0]) - 1), min=0)
-        if duration_target is not None:
-            tgt = duration_target if duration_target.is_floating_point() else duration_target.to(duration_pred.dtype)
-            duration_pred = torch.where(tgt < 0, duration_pred.to(tgt.dtype), tgt)
-        pitch = (pred[..., 1:2] if pitch_target is None else pitch_target.unsqueeze(-1)) * pitch_factor + pitch_delta
-        energy = (pred[..., 2:3] if energy_target is None else energy_target.unsqueeze(-1)) * energy_factor + energy_delta
-        enc_out = self.embedding(torch.cat([pitch, energy], dim=-1), residual=enc_out)      # no mask, even batched (:384)
-        enc_lens = None if enc_mask is None else enc_mask.sum(dim=1)
+        pred = self.predictor.infer(enc_out, mask=m3, steps=steps, noise=noise, key_len=enc_len)
+        # :351-381 in ONE kernel: duration = clamp(duration_factor * (exp(pred[..., 0]) - 1), 0) with the given targets
+        # taking the place of predictions where they are >= 0 (the reference tests `(duration_target < 0).any()` on the host
+        # and fills only the negative entries; per element on the device that is the same values without the round trip,
+        # which keeps the call capturable in a HIP graph), and the embedding stack's [pitch, energy] input.
+        duration_pred, feats = runtime.infer_features(pred, duration_target, pitch_target, energy_target, duration_factor,
+                                                      pitch_factor, pitch_delta, energy_factor, energy_delta)
+        pitch, energy = feats[..., 0:1], feats[..., 1:2]
+        enc_out = self.embedding(feats, residual=enc_out)                                   # no mask, even batched (:384)
+        enc_lens = enc_len
+        if enc_lens is None and enc_mask is not None:
+            enc_lens = enc_mask.sum(dim=1)
         if max_dec_len is None:   # the output shape is data: like the reference, read the longest decoder length back
             max_dec_len = int((duration_pred.sum(dim=1) + 0.5).long().max().item())
         # :388-397: soft path (generate_soft_path) and length regulation in one kernel

@@ -532,6 +532,45 @@ __global__ __launch_bounds__(1024) void flow_finish_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ infer: Euler update, features
+// FlowTransformerTemporalModule.infer (temporal_adaptor.py:158-170): x_t <- x_t + velocity * dt per step, `* mask` after the
+// last one.  dt comes from the host (the warped grid depends only on (steps, step_factor): :150-156).
+__global__ __launch_bounds__(256) void flow_euler_kernel(const float* __restrict__ xt, const float* __restrict__ vel, float dt,
+                                                         const uint8_t* __restrict__ mask, float* __restrict__ out, int C,
+                                                         int64_t total) {
+#pragma clang fp contract(off)   // the reference rounds the product, then the sum
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float step = vel[i] * dt;
+    float v = xt[i] + step;
+    if (mask) v = mask[i / C] ? v : v * 0.0f;
+    out[i] = v;
+}
+
+// FlowTemporalAdaptor.infer (temporal_adaptor.py:351-384) between the predictor and the embedding stack, one thread per token:
+//   duration = clamp(duration_factor * (exp(pred[..., 0]) - 1), min 0), replaced by the target where one is given (>= 0; the
+//              reference fills only the negative entries of a target with predictions, :355-362)
+//   features = [ (pitch_target | pred[..., 1]) * pitch_factor + pitch_delta, (energy_target | pred[..., 2]) * ef + ed ]
+__global__ __launch_bounds__(256) void infer_features_kernel(const float* __restrict__ pred, const float* __restrict__ dur_f,
+                                                             const int64_t* __restrict__ dur_i, const float* __restrict__ pitch_t,
+                                                             const float* __restrict__ energy_t, float df, float pf, float pd,
+                                                             float ef, float ed, float* __restrict__ duration,
+                                                             float* __restrict__ feats, int64_t n) {
+#pragma clang fp contract(off)
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float e = expf(pred[3 * i]) - 1.0f;
+    float d = fmaxf(df * e, 0.0f);
+    if (dur_f) { const float t = dur_f[i]; d = t < 0.0f ? d : t; }
+    if (dur_i) { const int64_t t = dur_i[i]; d = t < 0 ? d : (float)t; }
+    duration[i] = d;
+    const float p = pitch_t ? pitch_t[i] : pred[3 * i + 1], q = energy_t ? energy_t[i] : pred[3 * i + 2];
+    const float pm = p * pf, qm = q * ef;
+    feats[2 * i] = pm + pd;
+    feats[2 * i + 1] = qm + ed;
+}
+
 }  // namespace
 
 extern "C" int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t stride_t, int64_t stride_c,
@@ -667,5 +706,31 @@ extern "C" int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow
     if (B == 0) return 0;
     hipLaunchKernelGGL(flow_finish_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pred_raw, flow, x0,
                        mask, pred, duration, loss_ratio, loss_mean, B, L, C);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_flow_euler_f32(const float* x_t, const float* velocity, float dt, const uint8_t* mask, float* out,
+                                       int32_t B, int32_t L, int32_t C, ispk_stream_t stream) {
+    ISPK_REQUIRE(x_t && velocity && out, ISPK_E_NULL, "flow_euler: null pointer");
+    ISPK_REQUIRE(B >= 0 && L >= 1 && C >= 1, ISPK_E_SHAPE, "flow_euler: bad shape B=%d L=%d C=%d", B, L, C);
+    if (B == 0) return 0;
+    const int64_t total = (int64_t)B * L * C;
+    hipLaunchKernelGGL(flow_euler_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), x_t, velocity, dt, mask, out, C, total);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_infer_features_f32(const float* pred, const float* duration_target_f32, const int64_t* duration_target_i64,
+                                           const float* pitch_target, const float* energy_target, float duration_factor,
+                                           float pitch_factor, float pitch_delta, float energy_factor, float energy_delta,
+                                           float* duration, float* features, int32_t B, int32_t L, ispk_stream_t stream) {
+    ISPK_REQUIRE(pred && duration && features, ISPK_E_NULL, "infer_features: null pointer");
+    ISPK_REQUIRE(!(duration_target_f32 && duration_target_i64), ISPK_E_UNSUPPORTED, "infer_features: one duration target at most");
+    ISPK_REQUIRE(B >= 0 && L >= 1, ISPK_E_SHAPE, "infer_features: bad shape B=%d L=%d", B, L);
+    if (B == 0) return 0;
+    const int64_t n = (int64_t)B * L;
+    hipLaunchKernelGGL(infer_features_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), pred, duration_target_f32, duration_target_i64, pitch_target,
+                       energy_target, duration_factor, pitch_factor, pitch_delta, energy_factor, energy_delta, duration, features, n);
     return ispk_launch_status();
 }

@@ -141,6 +141,10 @@ class MelGatherPipeline:
     process group's communication stream while batch i+1 is being computed (xGMI and the CUs work at the same time; a
     blocking exchange of 8 x 10.5 MB per step would add its full transfer time to every step).
 
+    `dtype` = torch.bfloat16 sends the mel values rounded to bf16 (half the xGMI bytes: 5.2 instead of 10.5 MB per rank and
+    step; what a bf16 compute path's mel is worth anyway), the lengths stay exact int64; the gathered mel comes back in
+    that dtype.
+
     `root` = rank that collects (the "RCCL gather of mel outputs" of the north star: every other rank SENDS its 10.5 MB
     over its direct xGMI link to the root and receives nothing - one grouped send/recv, the root's seven links work in
     parallel), or None for an all-gather (every rank ends up with every utterance; 8 x the fabric traffic).  mel and
@@ -154,13 +158,14 @@ class MelGatherPipeline:
 
     def __init__(self, batch: int, channels: int, frames: int, device, dtype: torch.dtype = torch.float32,
                  group: Optional[dist.ProcessGroup] = None, root: Optional[int] = None):
-        assert dtype == torch.float32, "the packed message carries int64 lengths behind fp32 mel values"
+        assert dtype in (torch.float32, torch.bfloat16), "the packed message carries int64 lengths behind fp32 / bf16 mel values"
         self.group, self.root = group, root
         self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.shape = (batch, channels, frames)
-        self.n_mel = batch * channels * frames                     # fp32 elements; the int64 lengths follow (8-byte aligned)
-        assert self.n_mel % 2 == 0
-        self.n_msg = self.n_mel + 2 * batch
+        per8 = 8 // torch.empty((), dtype=dtype).element_size()    # message elements per int64 length
+        self.n_mel = batch * channels * frames                     # mel elements; the int64 lengths follow (8-byte aligned)
+        assert self.n_mel % per8 == 0
+        self.n_msg = self.n_mel + per8 * batch
         self.stage = [torch.empty((self.n_msg,), dtype=dtype, device=device) for _ in range(2)]
         self.receives = root is None or self.rank == root
         self.out = [torch.empty((self.world, self.n_msg), dtype=dtype, device=device) if self.receives else None

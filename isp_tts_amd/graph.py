@@ -32,8 +32,11 @@ class GraphedCall:
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # No cyclic garbage collection while the stream is capturing: collecting an unreachable OLD graph there runs
-        # hipGraphDestroy inside the capture ("operation not permitted when stream is capturing": abort, or a segfault in a
-        # later replay).  Collect first, at a point where the device is idle, then hold the collector off.
+        # hipGraphDestroy inside the capture ("operation not permitted when stream is capturing": the abort recorded in
+        # round 2's r2_b7.err; the SIGSEGV of r2_b6.err was a replay AFTER such a capture had gone wrong in the same
+        # process).  Collect first, at a point where the device is idle, then hold the collector off.  Destroying a graph
+        # BETWEEN replays of other graphs, with the device idle, is safe on this runtime (ROCm 7.2) - both cases are held
+        # by tests/test_gpu_model.py::test_graph_lifetime_old_graphs_die_outside_captures_and_replays.
         gc.collect()
         gc_was_on = gc.isenabled()
         gc.disable()
@@ -80,7 +83,7 @@ class GraphedForward(GraphedCall):
 
 
 class SegmentedForward:
-    """One forward as THREE HIP graphs on two streams (same kernels, same results as `GraphedForward`):
+    r"""One forward as THREE HIP graphs on two streams (same kernels, same results as `GraphedForward`):
 
         main stream:  [front: embedding, text encoder, aligner front-end, soft averages] ........ [back: embedding stack,
                                                                        \                          length regulator,

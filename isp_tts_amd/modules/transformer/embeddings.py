@@ -79,10 +79,9 @@ class SinusoidalEmbedding(nn.Module):
         self.register_buffer("inv_freq", theta ** -(torch.arange(half).float() / half), persistent=False)
 
     def forward(self, x: Tensor) -> Tensor:
-        pos = x.type_as(self.inv_freq)
-        emb = pos.unsqueeze(-1) * self.freq_scale * self.inv_freq
-        emb = torch.cat((emb.sin(), emb.cos()), dim=-1)
-        return torch.cat((pos[:, None], emb), dim=-1) if self.with_positions else emb
+        raise NotImplementedError("SinusoidalEmbedding only owns the `freq_scale` / `inv_freq` buffers here (the reference's "
+                                  "state_dict names): the sinusoid is evaluated inside ispk_time_embedding_f32 "
+                                  "(TimePositionalEmbedding.forward); there is no PyTorch path to fall back to")
 
 
 class TimePositionalEmbedding(nn.Module):

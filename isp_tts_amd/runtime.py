@@ -61,6 +61,8 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_split_f16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
     "ispk_flow_mix_f32": [_P, _P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
     "ispk_flow_finish_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_flow_euler_f32": [_P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_infer_features_f32": [_P, _P, _P, _P, _P, _F32, _F32, _F32, _F32, _F32, _P, _P, _I32, _I32, _P],
     "ispk_embed_tokens_f32": [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _I32, _P],
     "ispk_time_embedding_f32": [_P, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P],
     "ispk_length_regulate_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
@@ -886,6 +888,45 @@ def flow_finish(pred_raw: Tensor, flow: Tensor, x0: Tensor, mask: Tensor):
             x0c.data_ptr(), mk.data_ptr(), pred.data_ptr(), dur.data_ptr(), ratio.data_ptr(), loss.data_ptr(), B, L, C,
             _stream())
     return pred, dur, ratio, loss
+
+
+def flow_euler(x_t: Tensor, velocity: Tensor, dt: float, mask: Optional[Tensor] = None) -> Tensor:
+    """ispk_flow_euler_f32: x_t + velocity * dt [* mask[..., None]] (one Euler step of the flow predictor's `infer`)."""
+    _dev(x_t, velocity, mask)
+    B, L, C = x_t.shape
+    xc, vc = x_t.float().contiguous(), velocity.float().contiguous()
+    out = torch.empty_like(xc)
+    if mask is not None:
+        mask = mask.contiguous()
+        assert mask.dtype == torch.bool and mask.shape == (B, L)
+    _launch("flow_euler_kernel", 0.0, 12.0 * B * L * C, lib().ispk_flow_euler_f32, xc.data_ptr(), vc.data_ptr(), float(dt),
+            _ptr(mask), out.data_ptr(), B, L, C, _stream())
+    return out
+
+
+def infer_features(pred: Tensor, duration_target: Optional[Tensor], pitch_target: Optional[Tensor],
+                   energy_target: Optional[Tensor], duration_factor: float = 1.0, pitch_factor: float = 1.0,
+                   pitch_delta: float = 0.0, energy_factor: float = 1.0, energy_delta: float = 0.0):
+    """ispk_infer_features_f32: pred [B, L, 3] -> (duration fp32 [B, L], features fp32 [B, L, 2])."""
+    _dev(pred, duration_target, pitch_target, energy_target)
+    B, L, C = pred.shape
+    assert C == 3 and pred.dtype == torch.float32
+    pc = pred.contiguous()
+    dur_f = dur_i = None
+    if duration_target is not None:
+        assert duration_target.shape == (B, L)
+        if duration_target.dtype == torch.int64:
+            dur_i = duration_target.contiguous()
+        else:
+            dur_f = duration_target.float().contiguous()
+    pt = None if pitch_target is None else pitch_target.float().reshape(B, L).contiguous()
+    et = None if energy_target is None else energy_target.float().reshape(B, L).contiguous()
+    duration = torch.empty((B, L), dtype=torch.float32, device=pred.device)
+    feats = torch.empty((B, L, 2), dtype=torch.float32, device=pred.device)
+    _launch("infer_features_kernel", 0.0, 24.0 * B * L, lib().ispk_infer_features_f32, pc.data_ptr(), _ptr(dur_f), _ptr(dur_i),
+            _ptr(pt), _ptr(et), float(duration_factor), float(pitch_factor), float(pitch_delta), float(energy_factor),
+            float(energy_delta), duration.data_ptr(), feats.data_ptr(), B, L, _stream())
+    return duration, feats
 
 
 # ------------------------------------------------------------------------------------------------- between the stacks

@@ -157,6 +157,14 @@ def _rank_main(rank, world, port, q):
             ok = ok and all(torch.equal(res[1][r], mel_len[:2] + 2) for r in range(world))
         else:
             ok = ok and res is None
+        # the same gather with a bf16 message (half the bytes over xGMI): values arrive rounded to bf16, lengths exact
+        pipe = idist.MelGatherPipeline(2, 80, want.shape[2], "cpu", root=0, dtype=torch.bfloat16)
+        pipe.submit(want[:2] + rank, mel_len[:2] + 7)
+        res = pipe.wait()
+        if rank == 0:
+            ok = ok and res[0].dtype == torch.bfloat16
+            ok = ok and all(torch.equal(res[0][r], (want[:2] + r).to(torch.bfloat16)) for r in range(world))
+            ok = ok and all(torch.equal(res[1][r], mel_len[:2] + 7) for r in range(world))
         # BASELINE config 4 as bench.py runs it: cost-balanced shards cut into micro-batches that are padded to their OWN
         # maximum, outputs written into one fixed [slot, 80, M_max] block per rank, ONE gather of the blocks, unshard
         tl4, ml4 = synth.make_lengths(21, 40, 96, variable=True, seed=5)
@@ -402,3 +410,23 @@ def test_sharded_adamw_world_size_2_gloo_matches_ddp_plus_adamw():
         p.join(120)
         assert p.exitcode == 0
     assert sorted(q.get(timeout=10) for _ in range(2)) == [(0, True), (1, True)]
+
+
+def test_bench_launcher_takes_siblings_down_when_a_rank_fails(tmp_path):
+    """`launch_workers`: a rank that exits non-zero before the rendezvous must not leave its siblings waiting for the process
+    group's timeout - the parent polls every rank and terminates the others.  Driven with a stand-in worker script (rank 1
+    fails at once, rank 0 would sleep for minutes)."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "bench.py"
+    src = open(os.path.join(root, "bench.py")).read()
+    # the same launcher code, with the worker replaced by a stub
+    src = src.replace("def worker(args) -> int:", "def worker(args) -> int:\n    import time as _t\n    if os.environ['RANK'] == '1':\n"
+                      "        return 7\n    _t.sleep(600)\n    return 0\n\n\ndef _unused_worker(args) -> int:")
+    fake.write_text(src)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(fake), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 7 and time.time() - t0 < 60

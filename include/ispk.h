@@ -484,6 +484,11 @@ int32_t ispk_gemm_tn_f32(const float* A, int64_t lda, const float* B, int64_t ld
 int32_t ispk_gemm_tn_bf16(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
                           int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
                           int64_t workspace_floats, ispk_stream_t stream);
+/* ... and with operands that ARE bf16 in memory (the activations an AMP step keeps in bf16 as their producers wrote them: half
+ * the operand bytes of a kernel that is bound by them).  lda, ldb multiples of 4, A and B 8-byte aligned. */
+int32_t ispk_gemm_tn_b16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
+                         int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
+                         int64_t workspace_floats, ispk_stream_t stream);
 /* The same product for `batch` independent pairs (A_b, B_b) at element strides stride_a / stride_b, C_b at stride_c - e.g. the
  * backward of the length regulator (temporal_adaptor.py:419-421: out_b = A_b x_b): d x_b = A_b^T d out_b per utterance.
  * row_mask (or NULL) is [batch][M]; workspace >= batch * N1 * N2 floats. */
@@ -498,6 +503,11 @@ int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int
 int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, float dropout_p, uint64_t seed,
                           ispk_stream_t stream);
+/* The AMP step's forms (recipes/default.yaml:56: under autocast the feed-forward activation and its gradient are bf16 GEMM
+ * operands): a / da / du in bf16 as their consumers take them, the pre-activation u stays fp32; same arithmetic, same mask. */
+int32_t ispk_gelu_f32_bf16(const float* u, uint16_t* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
+int32_t ispk_gelu_bwd_bf16(const uint16_t* da, const float* u, uint16_t* du, int64_t n, float dropout_p, uint64_t seed,
+                           ispk_stream_t stream);
 int32_t ispk_dropout_mask_u8(uint8_t* out, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_alibi_mqa_attn_train_f32(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len, float* o,
                                       int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H, float dropout_p, uint64_t seed,

@@ -162,15 +162,37 @@ __device__ __forceinline__ void tn_read_tr(tn_u32x2& dst, uint32_t addr) {
 }
 constexpr int kTnImg = kTnRows * 256;            // bytes of one operand's chunk image
 
-template <bool kMask>
-__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+// IN16: the operands are ALREADY bf16 in memory (activations an AMP step keeps in bf16 as their producers wrote them): half the
+// operand bytes of a kernel that is bound by them (a 128 x 128 tile re-reads both operands once per tile of the other axis).
+template <bool kMask, bool IN16 = false>
+__global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const void* __restrict__ Av, int64_t lda, const void* __restrict__ Bv,
                                                            int64_t ldb, float* __restrict__ part, int M, int N1, int N2,
                                                            int rows_per_split, const uint8_t* __restrict__ mask, int splits,
-                                                           int64_t stride_a, int64_t stride_b) {
+                                                           int64_t stride_a, int64_t stride_b, int nz) {
+    typedef typename std::conditional<IN16, uint16_t, float>::type in_t;
+    const in_t* A = static_cast<const in_t*>(Av);
+    const in_t* B = static_cast<const in_t*>(Bv);
     extern __shared__ __attribute__((aligned(16))) char ldsb[];      // [2 buffers][A image | B image]
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, c = l & 31, hf = l >> 5;
-    const int n1 = blockIdx.x * 128, n2 = blockIdx.y * 128, wa = (wave >> 1) * 64, wb = (wave & 1) * 64;
-    const int bz = blockIdx.z / splits, split = blockIdx.z - bz * splits;
+    // XCD-aware order (1-D grid): workgroups go to the 8 XCDs round-robin in launch order, and the T tiles of one row range
+    // read the SAME rows of A and B - so row range 8 g + (lin % 8) takes tiles (lin / 8) % T: a row range's tiles run on ONE
+    // XCD and find its rows in that L2 after the first fetch (in plain order every L2 fetched every row range).
+    const int tx = (N1 + 127) / 128, ty = (N2 + 127) / 128, T = tx * ty;
+    int zz, tile;
+    {
+        const int lin = blockIdx.x, full = (nz / 8) * 8 * T;
+        if (lin < full) {
+            const int g = lin / (8 * T), r = lin - g * 8 * T;
+            zz = g * 8 + (r & 7);
+            tile = r >> 3;
+        } else {
+            const int t = lin - full;
+            zz = (nz / 8) * 8 + t / T;
+            tile = t % T;
+        }
+    }
+    const int n1 = (tile % tx) * 128, n2 = (tile / tx) * 128, wa = (wave >> 1) * 64, wb = (wave & 1) * 64;
+    const int bz = zz / splits, split = zz - bz * splits;
     A += (int64_t)bz * stride_a;
     B += (int64_t)bz * stride_b;
     if (kMask) mask += (int64_t)bz * M;
@@ -184,18 +206,25 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const float* __restri
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    f32x4 ra[4], rb[4];
+    f32x4 ra[IN16 ? 1 : 4], rb[IN16 ? 1 : 4];
+    uint2 qa[IN16 ? 4 : 1], qb[IN16 ? 4 : 1];     // IN16: four bf16 per row piece, as loaded
     auto fetch = [&](int m0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int m = m0 + sr + 8 * j;
             const bool ok = m < m_end;
-            float sc = 1.f;
-            if (kMask) sc = (ok && mask[m]) ? 1.f : 0.f;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            ra[j] = (ok && a_ok) ? *reinterpret_cast<const f32x4*>(A + (int64_t)m * lda + n1 + sq) : z;
-            rb[j] = (ok && b_ok) ? *reinterpret_cast<const f32x4*>(B + (int64_t)m * ldb + n2 + sq) : z;
-            if (kMask) ra[j] *= sc;
+            if constexpr (IN16) {
+                const bool keep = ok && (!kMask || mask[m]);
+                qa[j] = (keep && a_ok) ? *reinterpret_cast<const uint2*>(A + (int64_t)m * lda + n1 + sq) : make_uint2(0u, 0u);
+                qb[j] = (ok && b_ok) ? *reinterpret_cast<const uint2*>(B + (int64_t)m * ldb + n2 + sq) : make_uint2(0u, 0u);
+            } else {
+                float sc = 1.f;
+                if (kMask) sc = (ok && mask[m]) ? 1.f : 0.f;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                ra[j] = (ok && a_ok) ? *reinterpret_cast<const f32x4*>(A + (int64_t)m * lda + n1 + sq) : z;
+                rb[j] = (ok && b_ok) ? *reinterpret_cast<const f32x4*>(B + (int64_t)m * ldb + n2 + sq) : z;
+                if (kMask) ra[j] *= sc;
+            }
         }
     };
     auto pack2 = [](float lo, float hi) {
@@ -213,8 +242,13 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const float* __restri
             const int row = sr + 8 * j;
             const uint32_t off = tn_img_off(row, sq >> 3) + 8 * ((sq >> 2) & 1);
             uint2 pa, pb;
-            pa.x = pack2(ra[j][0], ra[j][1]); pa.y = pack2(ra[j][2], ra[j][3]);
-            pb.x = pack2(rb[j][0], rb[j][1]); pb.y = pack2(rb[j][2], rb[j][3]);
+            if constexpr (IN16) {
+                pa = qa[j];
+                pb = qb[j];
+            } else {
+                pa.x = pack2(ra[j][0], ra[j][1]); pa.y = pack2(ra[j][2], ra[j][3]);
+                pb.x = pack2(rb[j][0], rb[j][1]); pb.y = pack2(rb[j][2], rb[j][3]);
+            }
             *reinterpret_cast<uint2*>(sa + off) = pa;
             *reinterpret_cast<uint2*>(sb + off) = pb;
         }
@@ -274,7 +308,7 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const float* __restri
         __syncthreads();
         buf ^= 1;
     }
-    float* out = part + (int64_t)blockIdx.z * N1 * N2;
+    float* out = part + (int64_t)zz * N1 * N2;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -382,6 +416,93 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// The same backward with 16-byte accesses: TWO rows per wavefront (32 lanes each, NV4 = D / 128 float4 per lane), as the
+// forward's layernorm_vec_kernel - the scalar kernel above moved 4 bytes per lane per instruction and ran the 32,768-row decoder
+// norms at 2.5 TB/s (200 MB per launch with the accumulate-into-dx form).  Same arithmetic per element; the statistics' and
+// the (d gamma, d beta) partial sums' orders differ from the scalar kernel's (fixed, deterministic).
+template <int NV4>
+__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+                                                                int64_t lddy, const float* __restrict__ gamma,
+                                                                const uint8_t* __restrict__ mask, float* __restrict__ dx,
+                                                                int64_t lddx, int add_to_dx, float* __restrict__ part, int rows,
+                                                                float eps) {
+    constexpr int D = NV4 * 128;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l = lane & 31, hf = lane >> 5;
+    auto hsum = [](float v) {
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    };
+    f32x4 gm[NV4], dg[NV4], db[NV4];
+#pragma unroll
+    for (int c = 0; c < NV4; ++c) {
+        gm[c] = gamma ? *reinterpret_cast<const f32x4*>(gamma + 4 * (l + 32 * c)) : f32x4{1.f, 1.f, 1.f, 1.f};
+        dg[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int row0 = blockIdx.x * 64;
+    for (int rr = wave * 2 + hf; rr < 64; rr += 8) {
+        const int row_raw = row0 + rr;
+        const bool live = row_raw < rows;                         // (half-waves of the last block: computed on the last row, not stored)
+        const int row = live ? row_raw : rows - 1;
+        const float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
+        f32x4 xv[NV4], gv[NV4], old[NV4];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV4; ++c) {
+            xv[c] = *reinterpret_cast<const f32x4*>(x + (int64_t)row * ldx + 4 * (l + 32 * c));
+            gv[c] = *reinterpret_cast<const f32x4*>(dy + (int64_t)row * lddy + 4 * (l + 32 * c)) * mk;
+            if (add_to_dx) old[c] = *reinterpret_cast<const f32x4*>(dx + (int64_t)row * lddx + 4 * (l + 32 * c));
+            s += (xv[c][0] + xv[c][1]) + (xv[c][2] + xv[c][3]);
+        }
+        const float mean = hsum(s) * (1.f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV4; ++c) {
+            xv[c] -= mean;
+            q += (xv[c][0] * xv[c][0] + xv[c][1] * xv[c][1]) + (xv[c][2] * xv[c][2] + xv[c][3] * xv[c][3]);
+        }
+        const float rstd = 1.f / sqrtf(hsum(q) * (1.f / D) + eps);
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NV4; ++c) {
+            xv[c] *= rstd;                 // xhat
+            if (live) {
+                dg[c] += gv[c] * xv[c];
+                db[c] += gv[c];
+            }
+            gv[c] *= gm[c];                // g
+            c1 += (gv[c][0] + gv[c][1]) + (gv[c][2] + gv[c][3]);
+            c2 += (gv[c][0] * xv[c][0] + gv[c][1] * xv[c][1]) + (gv[c][2] * xv[c][2] + gv[c][3] * xv[c][3]);
+        }
+        c1 = hsum(c1) * (1.f / D);
+        c2 = hsum(c2) * (1.f / D);
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < NV4; ++c) {
+                f32x4 v = (gv[c] - c1 - xv[c] * c2) * rstd;
+                if (add_to_dx) v += old[c];
+                *reinterpret_cast<f32x4*>(dx + (int64_t)row * lddx + 4 * (l + 32 * c)) = v;
+            }
+        }
+    }
+    if (!part) return;
+    __shared__ float red[8][2][D];        // [wave * 2 + half][d gamma | d beta][column]
+#pragma unroll
+    for (int c = 0; c < NV4; ++c) {
+        *reinterpret_cast<f32x4*>(&red[wave * 2 + hf][0][4 * (l + 32 * c)]) = dg[c];
+        *reinterpret_cast<f32x4*>(&red[wave * 2 + hf][1][4 * (l + 32 * c)]) = db[c];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+        const int w = i / D, col = i % D;
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][w][col];
+        part[(int64_t)blockIdx.x * 2 * D + i] = t;
+    }
+}
+
 // d gamma / d beta: thread i of [2 * D] adds its column of the `nparts` partial rows, 8 interleaved running sums.
 __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ part, int nparts, int twoD,
                                                                    float* __restrict__ dgamma, float* __restrict__ dbeta) {
@@ -405,12 +526,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
 // ------------------------------------------------------------------------------------------------ GELU backward
 // With dropout (feedforward.py:35: Linear -> GELU -> Dropout -> Linear): a = gelu(u) * keep / (1 - p), and backward
 // du = da * keep / (1 - p) * gelu'(u); keep = drop_keep(seed, element index).
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ da, const float* __restrict__ u,
-                                                       float* __restrict__ du, int64_t n4, uint32_t thresh, float inv_keep,
+template <bool IO16 = false>   // IO16: da and du are bf16 (both are only ever GEMM operands of an AMP step)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ da, const float* __restrict__ u,
+                                                       void* __restrict__ du, int64_t n4, uint32_t thresh, float inv_keep,
                                                        uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    const f32x4 a = reinterpret_cast<const f32x4*>(da)[i], x = reinterpret_cast<const f32x4*>(u)[i];
+    const f32x4 x = reinterpret_cast<const f32x4*>(u)[i];
+    f32x4 a;
+    if constexpr (IO16) {
+        const uint2 q = reinterpret_cast<const uint2*>(da)[i];
+        a[0] = bf16_to_f32((uint16_t)(q.x & 0xffffu)); a[1] = bf16_to_f32((uint16_t)(q.x >> 16));
+        a[2] = bf16_to_f32((uint16_t)(q.y & 0xffffu)); a[3] = bf16_to_f32((uint16_t)(q.y >> 16));
+    } else {
+        a = reinterpret_cast<const f32x4*>(da)[i];
+    }
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -420,11 +550,19 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__
         if (thresh) g = drop_keep(seed, (uint32_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
         o[k] = g;
     }
-    reinterpret_cast<f32x4*>(du)[i] = o;
+    if constexpr (IO16) {
+        uint2 pk;
+        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        reinterpret_cast<uint2*>(du)[i] = pk;
+    } else {
+        reinterpret_cast<f32x4*>(du)[i] = o;
+    }
 }
 
 // the training forward keeps the pre-activation u (for the line above), so its GELU is a pass of its own: a = gelu(u)
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ a, int64_t n4,
+template <bool OUT16 = false>   // OUT16: a is bf16 (an AMP step keeps the activation its second Linear multiplies in bf16)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, void* __restrict__ a, int64_t n4,
                                                        uint32_t thresh, float inv_keep, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
@@ -436,7 +574,14 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__
         if (thresh) g = drop_keep(seed, (uint32_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
         o[k] = g;
     }
-    reinterpret_cast<f32x4*>(a)[i] = o;
+    if constexpr (OUT16) {
+        uint2 pk;
+        pk.x = (uint32_t)f32_to_bf16(o[0]) | ((uint32_t)f32_to_bf16(o[1]) << 16);
+        pk.y = (uint32_t)f32_to_bf16(o[2]) | ((uint32_t)f32_to_bf16(o[3]) << 16);
+        reinterpret_cast<uint2*>(a)[i] = pk;
+    } else {
+        reinterpret_cast<f32x4*>(a)[i] = o;
+    }
 }
 
 __global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t thresh, uint64_t seed) {
@@ -838,10 +983,10 @@ extern "C" int32_t ispk_transpose_f32(const float* x, int64_t ldx, float* y, int
     return ispk_launch_status();
 }
 
-static int32_t gemm_tn_launch(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb, int64_t stride_b, float* C,
+static int32_t gemm_tn_launch(const void* A, int64_t lda, int64_t stride_a, const void* B, int64_t ldb, int64_t stride_b, float* C,
                               int64_t ldc, int64_t stride_c, int batch, int M, int N1, int N2, const uint8_t* row_mask,
                               int accumulate, float* workspace, int64_t workspace_floats, hipStream_t s, const char* who,
-                              bool bf16_operands = false) {
+                              bool bf16_operands = false, bool in16 = false) {
     ISPK_REQUIRE(A && B && C && workspace, -1, "%s: null pointer", who);
     // (ldb < N2 is allowed: overlapping rows, i.e. the 5-tap windows of a padded convolution input)
     ISPK_REQUIRE(batch >= 1 && M >= 1 && N1 >= 4 && N2 >= 4 && N1 % 4 == 0 && N2 % 4 == 0 && lda >= N1 && ldb >= 4 && ldc >= N2 &&
@@ -862,15 +1007,24 @@ static int32_t gemm_tn_launch(const float* A, int64_t lda, int64_t stride_a, con
     rows_per = (rows_per + kTnRows - 1) / kTnRows * kTnRows;
     splits = (M + rows_per - 1) / rows_per;
     ISPK_REQUIRE(splits * batch <= 65535, -4, "%s: batch %d x %lld row ranges exceed the grid limit", who, batch, (long long)splits);
-    const dim3 grid((N1 + 127) / 128, (N2 + 127) / 128, (unsigned)(splits * batch));
+    const dim3 grid3((N1 + 127) / 128, (N2 + 127) / 128, (unsigned)(splits * batch));
     if (bf16_operands) {
         constexpr size_t lds16 = 2 * 2 * kTnImg;                  // 32 KB
-        if (row_mask)
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<true>, grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
-                               row_mask, (int)splits, stride_a, stride_b);
+        const int nz = (int)(splits * batch);
+        const dim3 grid(grid3.x * grid3.y * grid3.z);             // 1-D: the kernel orders (row range, tile) itself
+        if (in16) {
+            if (row_mask)
+                hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2,
+                                   rows_per, row_mask, (int)splits, stride_a, stride_b, nz);
+            else
+                hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, true>), grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2,
+                                   rows_per, row_mask, (int)splits, stride_a, stride_b, nz);
+        } else if (row_mask)
+            hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, false>), grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
+                               row_mask, (int)splits, stride_a, stride_b, nz);
         else
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<false>, grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
-                               row_mask, (int)splits, stride_a, stride_b);
+            hipLaunchKernelGGL((gemm_tn_bf16_kernel<false, false>), grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
+                               row_mask, (int)splits, stride_a, stride_b, nz);
         hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((tile + 255) / 256), batch), dim3(256), 0, s, workspace, (int)splits,
                            tile, N2, C, ldc, accumulate, stride_c);
         return ispk_launch_status();
@@ -878,11 +1032,13 @@ static int32_t gemm_tn_launch(const float* A, int64_t lda, int64_t stride_a, con
     constexpr size_t lds_bytes = 2 * kTnStage * sizeof(float);   // 80 KB: two workgroups per CU
     if (row_mask) {
         ISPK_RESERVE_LDS(gemm_tn_kernel<true>, lds_bytes, "ispk_gemm_tn_f32");
-        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, dim3(256), lds_bytes, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, grid3, dim3(256), lds_bytes, s, static_cast<const float*>(A), lda,
+                           static_cast<const float*>(B), ldb, workspace, M, N1, N2, rows_per,
                            row_mask, (int)splits, stride_a, stride_b);
     } else {
         ISPK_RESERVE_LDS(gemm_tn_kernel<false>, lds_bytes, "ispk_gemm_tn_f32");
-        hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, dim3(256), lds_bytes, s, A, lda, B, ldb, workspace, M, N1, N2, rows_per,
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, grid3, dim3(256), lds_bytes, s, static_cast<const float*>(A), lda,
+                           static_cast<const float*>(B), ldb, workspace, M, N1, N2, rows_per,
                            row_mask, (int)splits, stride_a, stride_b);
     }
     hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)((tile + 255) / 256), batch), dim3(256), 0, s, workspace, (int)splits,
@@ -902,6 +1058,13 @@ extern "C" int32_t ispk_gemm_tn_bf16(const float* A, int64_t lda, const float* B
                                      int64_t workspace_floats, ispk_stream_t stream) {
     return gemm_tn_launch(A, lda, 0, B, ldb, 0, C, ldc, 0, 1, M, N1, N2, row_mask, accumulate, workspace, workspace_floats,
                           reinterpret_cast<hipStream_t>(stream), "ispk_gemm_tn_bf16", true);
+}
+
+extern "C" int32_t ispk_gemm_tn_b16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
+                                    int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
+                                    int64_t workspace_floats, ispk_stream_t stream) {
+    return gemm_tn_launch(A, lda, 0, B, ldb, 0, C, ldc, 0, 1, M, N1, N2, row_mask, accumulate, workspace, workspace_floats,
+                          reinterpret_cast<hipStream_t>(stream), "ispk_gemm_tn_b16", true, true);
 }
 
 extern "C" int32_t ispk_gemm_tn_batched_f32(const float* A, int64_t lda, int64_t stride_a, const float* B, int64_t ldb,
@@ -925,7 +1088,15 @@ extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const flo
                  "ispk_layernorm_bwd_f32: workspace needs %lld floats", (long long)blocks * 2 * dim);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* part = want ? workspace : nullptr;
-    if (dim == 384)
+    const bool vec = ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ispk_aligned(x, 16) && ispk_aligned(dy, 16) &&
+                     ispk_aligned(dx, 16) && (!gamma || ispk_aligned(gamma, 16));
+    if (vec && dim == 384)
+        hipLaunchKernelGGL(layernorm_bwd_vec_kernel<3>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
+                           add_to_dx, part, (int)rows, eps);
+    else if (vec)
+        hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
+                           add_to_dx, part, (int)rows, eps);
+    else if (dim == 384)
         hipLaunchKernelGGL(layernorm_bwd_kernel<6>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
                            add_to_dx, part, (int)rows, eps);
     else
@@ -956,7 +1127,18 @@ extern "C" int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du,
                  "ispk_gelu_bwd_f32: n must be a multiple of 4 and the arrays 16-byte aligned");
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_bwd_f32: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(gelu_bwd_kernel<false>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
+    return ispk_launch_status();
+}
+extern "C" int32_t ispk_gelu_bwd_bf16(const uint16_t* da, const float* u, uint16_t* du, int64_t n, float dropout_p, uint64_t seed,
+                                      ispk_stream_t stream) {
+    ISPK_REQUIRE(da && u && du, -1, "ispk_gelu_bwd_bf16: null pointer");
+    ISPK_REQUIRE(n >= 0 && n % 4 == 0 && ispk_aligned(da, 8) && ispk_aligned(u, 16) && ispk_aligned(du, 8), -2,
+                 "ispk_gelu_bwd_bf16: n must be a multiple of 4, u 16-byte and da / du 8-byte aligned");
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_bwd_bf16: dropout_p must be in [0, 1)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gelu_bwd_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
     return ispk_launch_status();
 }
@@ -967,7 +1149,17 @@ extern "C" int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, float drop
                  "ispk_gelu_f32: n must be a multiple of 4 and the arrays 16-byte aligned");
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_f32: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
-    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+    hipLaunchKernelGGL(gelu_fwd_kernel<false>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
+    return ispk_launch_status();
+}
+extern "C" int32_t ispk_gelu_f32_bf16(const float* u, uint16_t* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream) {
+    ISPK_REQUIRE(u && a, -1, "ispk_gelu_f32_bf16: null pointer");
+    ISPK_REQUIRE(n >= 0 && n % 4 == 0 && ispk_aligned(u, 16) && ispk_aligned(a, 8), -2,
+                 "ispk_gelu_f32_bf16: n must be a multiple of 4, u 16-byte and a 8-byte aligned");
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_f32_bf16: dropout_p must be in [0, 1)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(gelu_fwd_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
     return ispk_launch_status();
 }

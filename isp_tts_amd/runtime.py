@@ -75,6 +75,9 @@ SIGNATURES = {
     "ispk_transpose_f32": [_P, _I64, _P, _I64, _I32, _I32, _P],
     "ispk_gemm_tn_f32": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_gemm_tn_bf16": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
+    "ispk_gemm_tn_b16": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
+    "ispk_gelu_f32_bf16": [_P, _P, _I64, _F32, _U64, _P],
+    "ispk_gelu_bwd_bf16": [_P, _P, _P, _I64, _F32, _U64, _P],
     "ispk_gemm_tn_batched_f32": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_layernorm_bwd_f32": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _I64, _I32, _F32, _P],
     "ispk_gelu_f32": [_P, _P, _I64, _F32, _U64, _P],
@@ -1033,7 +1036,8 @@ def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Option
     `bf16`: ispk_gemm_tn_bf16, the operands rounded to bf16 in flight (autocast's weight gradient), fp32 accumulation."""
     _dev(a, b, row_mask, out)
     a2, b2 = _rows2d(a), _rows2d(b)
-    assert a2.dtype == torch.float32 and b2.dtype == torch.float32 and a2.shape[0] == b2.shape[0]
+    in16 = a2.dtype == torch.bfloat16
+    assert a2.dtype == b2.dtype and a2.dtype in (torch.float32, torch.bfloat16) and a2.shape[0] == b2.shape[0]
     M, N1 = a2.shape
     N2 = b2.shape[1]
     if out is None:
@@ -1044,8 +1048,9 @@ def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Option
         row_mask = row_mask.reshape(-1).contiguous()
         assert row_mask.dtype == torch.bool and row_mask.numel() == M
     ws = workspace(a.device, N1 * N2)
-    _launch(f"gemm_tn_{'bf16_' if bf16 else ''}kernel<{N1}x{N2}>", 2.0 * M * N1 * N2, 4.0 * (a2.numel() + b2.numel() + out.numel()),
-            lib().ispk_gemm_tn_bf16 if bf16 else lib().ispk_gemm_tn_f32, a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), out.data_ptr(), out.stride(0), M,
+    fn = lib().ispk_gemm_tn_b16 if in16 else (lib().ispk_gemm_tn_bf16 if bf16 else lib().ispk_gemm_tn_f32)
+    _launch(f"gemm_tn_{'b16_' if in16 else ('bf16_' if bf16 else '')}kernel<{N1}x{N2}>", 2.0 * M * N1 * N2,
+            float(a2.element_size()) * (a2.numel() + b2.numel()) + 4.0 * out.numel(), fn, a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), out.data_ptr(), out.stride(0), M,
             N1, N2, _ptr(row_mask), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
     return out
 
@@ -1142,13 +1147,15 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], row_mask: Opti
     return dx, dg, db
 
 
-def gelu(u: Tensor, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
-    """ispk_gelu_f32: exact-erf GELU as its own pass (the training forward keeps u), optionally followed by dropout."""
+def gelu(u: Tensor, dropout_p: float = 0.0, seed: int = 0, out_dtype: torch.dtype = torch.float32) -> Tensor:
+    """ispk_gelu_f32 / ispk_gelu_f32_bf16: exact-erf GELU as its own pass (the training forward keeps u), optionally followed
+    by dropout; `out_dtype=torch.bfloat16`: the result as the bf16 operand an AMP step's second Linear takes."""
     _dev(u)
-    assert u.dtype == torch.float32 and u.is_contiguous()
-    a = torch.empty_like(u)
-    _launch("gelu_fwd_kernel", 0.0, 8.0 * u.numel(), lib().ispk_gelu_f32, u.data_ptr(), a.data_ptr(), u.numel(), dropout_p,
-            seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    assert u.dtype == torch.float32 and u.is_contiguous() and out_dtype in (torch.float32, torch.bfloat16)
+    a = torch.empty(u.shape, dtype=out_dtype, device=u.device)
+    _launch("gelu_fwd_kernel", 0.0, (4.0 + a.element_size()) * u.numel(),
+            lib().ispk_gelu_f32 if out_dtype == torch.float32 else lib().ispk_gelu_f32_bf16, u.data_ptr(), a.data_ptr(), u.numel(),
+            dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return a
 
 
@@ -1181,12 +1188,14 @@ def alibi_mqa_attention_train(qkv: Tensor, heads: int, slopes: Tensor, key_len: 
 def gelu_bwd(da: Tensor, u: Tensor, out: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
     """ispk_gelu_bwd_f32: du = da * [keep / (1 - p)] * gelu'(u) (exact erf); `out` may alias `da`."""
     _dev(da, u, out)
-    assert da.dtype == torch.float32 and u.dtype == torch.float32 and da.is_contiguous() and u.is_contiguous()
+    assert da.dtype in (torch.float32, torch.bfloat16) and u.dtype == torch.float32 and da.is_contiguous() and u.is_contiguous()
     assert da.shape == u.shape
     if out is None:
         out = torch.empty_like(da)
-    _launch("gelu_bwd_kernel", 0.0, 12.0 * da.numel(), lib().ispk_gelu_bwd_f32, da.data_ptr(), u.data_ptr(), out.data_ptr(),
-            da.numel(), dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    assert out.dtype == da.dtype
+    b16 = da.dtype == torch.bfloat16      # ispk_gelu_bwd_bf16: da and du are bf16 GEMM operands of an AMP step
+    _launch("gelu_bwd_kernel", 0.0, (4.0 + 2 * da.element_size()) * da.numel(), lib().ispk_gelu_bwd_bf16 if b16 else lib().ispk_gelu_bwd_f32,
+            da.data_ptr(), u.data_ptr(), out.data_ptr(), da.numel(), dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return out
 
 

@@ -69,13 +69,21 @@ class FlatParameters:
                 view = self.data[o:o + p.numel()].view(p.shape)
                 view.copy_(p)
                 p.data = view
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+                self._attach_grad(p, o)
+
+    def _attach_grad(self, p, o) -> None:
+        g = self.grad[o:o + p.numel()].view(p.shape)
+        g._ispk_grad_arena = True        # backward kernels may write this buffer directly (train/stack.py `_deliver`)
+        g._ispk_dirty = False            # ... overwriting while nothing has been delivered since the arena was zeroed
+        p.grad = g
 
     def zero_grad(self) -> None:
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):      # someone may have set .grad to None / another tensor
-            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o or not getattr(p.grad, "_ispk_grad_arena", False):
+                self._attach_grad(p, o)
+            else:
+                p.grad._ispk_dirty = False
 
     def mark_updated(self) -> None:
         """The arena was written behind autograd's back: bump every parameter's version so that staged weight images

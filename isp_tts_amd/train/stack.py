@@ -52,12 +52,35 @@ def stack_parameters(tr: Transformer) -> list:
     return ps + [tr.norm.weight, tr.norm.bias]
 
 
-def _mm(a32: Tensor, w32: Tensor, w16: Optional[Tensor], **kw) -> Tensor:
-    """a . w^T -> fp32.  `w16` given (bf16 AMP): operands rounded to bf16 (one cast launch for the activation), fp32
-    accumulation and output; residual / mask epilogues as in the fp32 GEMM."""
+def _mm(a: Tensor, w32: Tensor, w16: Optional[Tensor], out_dtype: torch.dtype = torch.float32, **kw) -> Tensor:
+    """a . w^T.  fp32 step (`w16` None): fp32 operands and result.  AMP step: `a` is ALREADY bf16 - written in bf16 by the
+    kernel that produced it (LayerNorm, GELU, one cast of an attention / residual-gradient tensor that the weight gradient
+    shares) - `w16` the staged bf16 weight, fp32 accumulation; the result fp32 or, where it is only a GEMM operand again, bf16."""
+    if w16 is None:
+        return runtime.gemm(a, w32, **kw)
+    assert a.dtype == torch.bfloat16
+    return runtime.gemm(a, w16, out_dtype=out_dtype, **kw)
+
+
+def _mm_cast(a32: Tensor, w32: Tensor, w16: Optional[Tensor], **kw) -> Tensor:
+    """`_mm` for an fp32 activation that no producer hands over in bf16 (the 6,400-row adaptive-norm stack of the flow
+    predictor): under AMP one cast launch in front of the GEMM."""
     if w16 is None:
         return runtime.gemm(a32, w32, **kw)
     return runtime.gemm(runtime.cast_bf16(a32), w16, out_dtype=torch.float32, **kw)
+
+
+def _deliver(param: Tensor, producer, *args, **kw):
+    """A parameter's gradient.  When the parameter's .grad is a preallocated buffer of an optimizer arena
+    (`FlatParameters` marks it `_ispk_grad_arena`), the producing kernel writes - or adds, if something has been delivered
+    since the arena was zeroed - straight into it and autograd is handed None: no AccumulateGrad launch per parameter
+    (206 element-wise ATen adds per step otherwise).  Else the gradient is returned for autograd to place."""
+    g = param.grad
+    if g is not None and getattr(g, "_ispk_grad_arena", False) and producer is runtime.gemm_tn:
+        runtime.gemm_tn(*args, out=g, accumulate=getattr(g, "_ispk_dirty", False), **kw)
+        g._ispk_dirty = True
+        return None
+    return producer(*args, **kw)
 
 
 class TransformerStackFunction(torch.autograd.Function):
@@ -84,7 +107,8 @@ class TransformerStackFunction(torch.autograd.Function):
             w1, w2 = ff._staged(torch.float32)
             wqkv16, wo16, _ = att._staged(torch.bfloat16) if amp else (None, None, None)
             w116, w216 = ff._staged(torch.bfloat16) if amp else (None, None)
-            h = runtime.layernorm(out, an.weight, an.bias, eps=an.eps)
+            adt = torch.bfloat16 if amp else torch.float32        # dtype of the tensors that are GEMM operands only
+            h = runtime.layernorm(out, an.weight, an.bias, eps=an.eps, out_dtype=adt)
             qkv = _mm(h, wqkv, wqkv16)
             p_att = float(att.attend.dropout) if layer.training else 0.0
             p_ff = float(ff.dropout_p) if layer.training else 0.0
@@ -95,12 +119,13 @@ class TransformerStackFunction(torch.autograd.Function):
                 o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att, bf16=amp)
             else:
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
-            x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
-            h2 = runtime.layernorm(x1, fn.weight, fn.bias, row_mask=mask, eps=fn.eps)
+            og = runtime.cast_bf16(o) if amp else o            # the out-projection's operand AND the one of its weight gradient
+            x1 = _mm(og, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
+            h2 = runtime.layernorm(x1, fn.weight, fn.bias, row_mask=mask, eps=fn.eps, out_dtype=adt)
             u = _mm(h2, w1, w116)
-            a = runtime.gelu(u, p_ff, seed_ff)                       # GELU, then nn.Dropout (feedforward.py:35)
+            a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)        # GELU, then nn.Dropout (feedforward.py:35)
             y = _mm(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
-            tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
+            tape.append((out, h, qkv, o, og, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
         final = runtime.layernorm(out, tr.norm.weight, tr.norm.bias, row_mask=mask, eps=tr.norm.eps)
         ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last, ctx.amp = tr, mask, key_len, tape, out, amp
@@ -113,8 +138,8 @@ class TransformerStackFunction(torch.autograd.Function):
         grads: list = []
         dy, dgf, dbf = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask,
                                              eps=tr.norm.eps)
-        for layer, (xin, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff) in zip(reversed(tr.layers),
-                                                                                               reversed(ctx.tape)):
+        for layer, (xin, h, qkv, o, og, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff) in zip(reversed(tr.layers),
+                                                                                                   reversed(ctx.tape)):
             att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
             wqkv, wo, slopes = att._staged(torch.float32)
             w1, w2 = ff._staged(torch.float32)
@@ -127,20 +152,26 @@ class TransformerStackFunction(torch.autograd.Function):
                                               lambda: t16(wqkv_t, wo_t)) if amp else (None, None)
             w1_t16, w2_t16 = ff._cache.get("t16", (ff.net[0].weight, ff.net[3].weight),
                                            lambda: t16(w1_t, w2_t)) if amp else (None, None)
+            gdt = torch.bfloat16 if amp else torch.float32
+            # Under AMP every tensor that is ONLY a GEMM operand lives in bf16 - a (forward), da / du (their producers write
+            # bf16), and ONE bf16 copy each of the fp32 tensors that a dX GEMM and a weight gradient both read (dy, dx1, dqkv).
             # feed-forward block
-            dw2 = runtime.gemm_tn(dy, a, row_mask=mask, bf16=amp)                         # [dim, inner]
-            da = _mm(dy, w2_t, w2_t16, mask=mask, flags=mflag)                   # (m dy) W2
+            dyg = runtime.cast_bf16(dy) if amp else dy
+            dw2 = _deliver(ff.net[3].weight, runtime.gemm_tn, dyg, a, row_mask=mask, bf16=amp)        # [dim, inner]
+            da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)                         # (m dy) W2
             du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
-            dw1 = runtime.gemm_tn(du, h2, bf16=amp)                                        # [inner, dim]
+            dw1 = _deliver(ff.net[0].weight, runtime.gemm_tn, du, h2, bf16=amp)                         # [inner, dim]
             dh2 = _mm(du, w1_t, w1_t16)
             dx1, dg2, db2 = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps)
             # attention block
-            dwo = runtime.gemm_tn(dx1, o, row_mask=mask, bf16=amp)                         # [dim, heads*64]
-            d_o = _mm(dx1, wo_t, wo_t16, mask=mask, flags=mflag)
+            dx1g = runtime.cast_bf16(dx1) if amp else dx1
+            dwo = _deliver(att.to_out.weight, runtime.gemm_tn, dx1g, og, row_mask=mask, bf16=amp)      # [dim, heads*64]
+            d_o = _mm(dx1g, wo_t, wo_t16, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
                                                         seed=seed_att, bf16=amp)
-            dwqkv = runtime.gemm_tn(dqkv, h, bf16=amp)                                     # [heads*64 + 128, dim]
-            dh = _mm(dqkv, wqkv_t, wqkv_t16)
+            dqkvg = runtime.cast_bf16(dqkv) if amp else dqkv
+            dwqkv = runtime.gemm_tn(dqkvg, h, bf16=amp)                                     # [heads*64 + 128, dim]
+            dh = _mm(dqkvg, wqkv_t, wqkv_t16)
             dy, dg1, db1 = runtime.layernorm_bwd(xin, dh, an.weight, dx=dx1, add_to_dx=True, eps=an.eps)
             hq = att.heads * 64
             ls = att.rel_pos.learned_logslopes

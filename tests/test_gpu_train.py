@@ -886,3 +886,31 @@ def test_training_step_against_the_reference_fixture(state_dict):
     for i, n in enumerate(names):
         upd = params[n].detach() - before[n].to(params[n].device)
         assert (sample(upd) - torch.from_numpy(g[f"u{i}"])).abs().max().item() <= 2e-2 * float(g["lr"]), n
+
+
+@pytest.mark.parametrize("M,N1,N2,masked", [(1000, 80, 384, False), (4099, 384, 1536, True), (64, 512, 384, True)])
+def test_gemm_tn_with_operands_stored_in_bf16(M, N1, N2, masked):
+    """`ispk_gemm_tn_b16` (the AMP step's weight gradient over activations kept in bf16): bit-equal to `ispk_gemm_tn_bf16` on
+    the fp32 images of the same bf16 values - same products, same summation order - and within bf16 grade of float64."""
+    a = _rand((M, N1), 301).to(torch.bfloat16)
+    b = _rand((M, N2), 302).to(torch.bfloat16)
+    mask = (torch.arange(M) % 5 != 2) if masked else None
+    md = None if mask is None else mask.to(DEV)
+    got = runtime.gemm_tn(a.to(DEV), b.to(DEV), row_mask=md)
+    same = runtime.gemm_tn(a.float().to(DEV), b.float().to(DEV), row_mask=md, bf16=True)
+    assert torch.equal(got, same)
+    am = a.double() if mask is None else a.double() * mask[:, None]
+    ref = am.t() @ b.double()
+    assert (got.double().cpu() - ref).abs().max().item() < 1e-5 * max(ref.abs().max().item(), 1.0) * (M ** 0.5)
+
+
+def test_gelu_bf16_forms_match_the_fp32_forms():
+    u = _rand((300, 1536), 311, 2.0).to(DEV)
+    da = _rand((300, 1536), 312).to(DEV)
+    for p, seed in ((0.0, 0), (0.1, 1234)):
+        a32 = runtime.gelu(u, p, seed)
+        a16 = runtime.gelu(u, p, seed, out_dtype=torch.bfloat16)
+        assert torch.equal(a16, a32.to(torch.bfloat16))
+        du32 = runtime.gelu_bwd(da.to(torch.bfloat16).float(), u, dropout_p=p, seed=seed)
+        du16 = runtime.gelu_bwd(da.to(torch.bfloat16), u, dropout_p=p, seed=seed)
+        assert torch.equal(du16, du32.to(torch.bfloat16))

@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""One AMP training step at the headline batch (64 x 100 x 512): wall time per step, and per-kernel time of one step from HIP
+events around every libispk launch (eager).  GPU box."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from isp_tts_amd import runtime, synth, train
+from isp_tts_amd.acoustic import AcousticModel
+from isp_tts_amd.config import AcousticDims
+
+B = int(os.environ.get("B", 64))
+torch.set_num_threads(8)
+dev = "cuda"
+model = AcousticModel.init(AcousticDims().model_config())
+model.load_state_dict(synth.make_state_dict(), strict=True)
+model = model.to(dev).train()
+d = {k: v.to(dev) for k, v in synth.make_inputs(B, 100, 512).items()}
+opt = train.FlatAdamW(list(model.parameters()), lr=2e-4, weight_decay=1e-2, grad_clip=1.0)
+opt.check_finite = False
+amp = os.environ.get("AMP", "1") == "1"
+
+
+def step():
+    _, total, _ = train.acoustic_train_forward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
+                                               flow_noise=d["flow_x0"], flow_time=d["flow_t"], amp=amp)
+    opt.step(total)
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 5
+for _ in range(n):
+    step()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / n
+prof = runtime.LaunchProfiler()
+runtime.set_profiler(prof)
+step()
+torch.cuda.synchronize()
+runtime.set_profiler(None)
+summ = prof.summary()
+tot = sum(v["total_ms"] for v in summ.values())
+nl = sum(v["launches"] for v in summ.values())
+print(f"B={B} amp={amp}: wall {wall * 1e3:.2f} ms/step; libispk launches {nl}, summed kernel time {tot:.2f} ms")
+for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:40]:
+    print(f"  {k:48s} x{v['launches']:4d}  {v['total_ms']:7.3f} ms  avg {v['avg_us']:7.1f} us")

@@ -93,7 +93,9 @@ template <int TN, int WM, int RT, int AB = 0>
 __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, int nrb, int ncb) {
     constexpr int BM = 32 * WM * RT, BN = 64 * TN, NT = WM * 128, NWV = NT / 64;
     constexpr int kSlot = (BM + BN) * 128;                       // bytes per ring slot: X rows then W rows, 128 B each
-    constexpr int S = 4 * kSlot <= 128 * 1024 ? 4 : (3 * kSlot <= 152 * 1024 ? 3 : 2);
+    // ring depth: as many slots as fit; small tiles stop at three (72 KB) so that TWO workgroups share a CU - their phases
+    // (prologue fetch, K loop, epilogue stores) then overlap, which is what the short 6,400-row launches lack
+    constexpr int S = kSlot <= 24 * 1024 ? 3 : (4 * kSlot <= 128 * 1024 ? 4 : (3 * kSlot <= 152 * 1024 ? 3 : 2));
     constexpr int IPL = (BM + BN) / 8 / NWV;
     static_assert((BM + BN) / 8 % NWV == 0 && (S - 1) * IPL <= 63, "DMA split / vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -323,7 +325,7 @@ template <int TN, int WM, int RT, int AB = 0>
 int32_t launch_split(const GemmParams& p, hipStream_t s) {
     constexpr int BM = 32 * WM * RT, BN = 64 * TN;
     constexpr size_t slot = (size_t)(BM + BN) * 128;
-    constexpr size_t lds_tiles = (4 * slot <= 128 * 1024 ? 4 : (3 * slot <= 152 * 1024 ? 3 : 2)) * slot;
+    constexpr size_t lds_tiles = (slot <= 24 * 1024 ? 3 : (4 * slot <= 128 * 1024 ? 4 : (3 * slot <= 152 * 1024 ? 3 : 2))) * slot;
     constexpr size_t lds_epi = (size_t)WM * 2 * 2 * kStageBytes;
     constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
     static_assert(lds <= 160 * 1024, "LDS budget");

@@ -75,13 +75,15 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, int64_t n_decay,
                                                     const float* __restrict__ sqnorm, AdamArgs a) {
-    // clip coefficient of the decay group: min(1, max_norm / (norm + 1e-6)) on the SCALED gradients (torch
-    // clip_grad_norm_); non-finite norm -> the coefficient is NaN-free only if the gradients are; as in torch, nothing is
-    // skipped (the reference runs bf16/fp32 without a loss scaler on this path)
+    // clip coefficient of the decay group: clamp(max_norm / (norm + 1e-6), max = 1) on the SCALED gradients (torch
+    // clip_grad_norm_).  torch.clamp PROPAGATES a NaN norm (every clipped gradient, and with it the group, turns NaN - the
+    // reference's step() then reports grad_norm None, optimizers.py:238-239, but has already stepped); fminf(NaN, 1) would
+    // return 1 and hide it, so the NaN is passed on explicitly.  An infinite norm gives 0, as in torch.
     float clip = 1.f;
     if (sqnorm) {
         const float norm = sqrtf(sqnorm[0]) * a.grad_scale;
-        clip = fminf(a.max_norm / (norm + 1e-6f), 1.f);
+        const float c = a.max_norm / (norm + 1e-6f);
+        clip = c != c ? c : fminf(c, 1.f);
     }
     const float g_decay = a.grad_scale * clip, g_rest = a.grad_scale;
     const int64_t n4 = n >> 2;

@@ -69,11 +69,16 @@ class BatchIngest:
         self.head = 0          # next slot to submit into
         self.tail = 0          # next slot to hand out
         self.pending = 0
+        self.handed_out = [False] * slots   # get() returned this slot's device views and done() has not been called for it
 
     def submit(self, batch: dict) -> None:
         """Stages one collated batch (the reference collator's dict; `pitch` / `energy` required, as in the recipes)."""
         assert self.pending < self.slots, "every slot holds a batch that has not been taken with get() yet"
         k = self.head
+        # contract: get() -> queue the compute that reads the views -> done(); only then may the slot be staged again (the
+        # `consumed` event that protects the device buffers is recorded by done() alone)
+        assert not self.handed_out[k], ("BatchIngest: slot %d was handed out by get() and done() has not been called for it - "
+                                        "its device buffers may still be read by queued work" % k)
         if self.on_gpu:
             # the HOST only waits for this pinned slot's own previous upload (long finished); the slot's DEVICE buffers are
             # protected on the copy stream below - waiting here for `consumed` would hold the host until the forward that is
@@ -112,6 +117,7 @@ class BatchIngest:
         self.tail = (k + 1) % self.slots
         self.pending -= 1
         self._last = k
+        self.handed_out[k] = True
         return out
 
     def done(self) -> None:
@@ -119,6 +125,7 @@ class BatchIngest:
         may be overwritten by a later submit()."""
         if self.on_gpu:
             self.consumed[self._last].record()
+        self.handed_out[self._last] = False
 
 
 def model_inputs(batch: dict) -> dict:

@@ -1022,8 +1022,10 @@ _workspaces: dict = {}
 
 
 def workspace(device, floats: int) -> Tensor:
-    """Per-device scratch for the backward kernels' partial sums (grown on demand, reused; stream-ordered use only)."""
-    key = (torch.device(device).index or 0)
+    """Scratch for the backward kernels' partial sums, one buffer per (device, CURRENT STREAM): launches on one stream use it
+    in order; a backward node that autograd runs on another stream (its forward ran there) gets its own buffer instead of
+    racing on the partial sums.  Grown on demand, reused."""
+    key = (torch.device(device).index or 0, torch.cuda.current_stream(device).cuda_stream if torch.cuda.is_available() else 0)
     w = _workspaces.get(key)
     if w is None or w.numel() < floats:
         w = _workspaces[key] = torch.empty((max(floats, _TN_WORKSPACE_FLOATS),), dtype=torch.float32, device=device)

@@ -41,12 +41,20 @@ class FlatParameters:
     """Parameters and gradients of a model as views into two flat fp32 arenas: [decay group | rest | zero padding]."""
 
     def __init__(self, params: Iterable[nn.Parameter], group_wd_params: bool = True, multiple_of: int = 1):
-        seen, plist = set(), []
+        seen, plist, everything = set(), [], []
         for p in params:
-            if p.requires_grad and id(p) not in seen:
-                seen.add(id(p))
+            if id(p) in seen:
+                continue
+            seen.add(id(p))
+            everything.append(p)               # frozen ones too: torch.optim numbers EVERY tensor it is handed
+            if p.requires_grad:
                 plist.append(p)
         assert plist, "no trainable parameters"
+        # torch.optim.AdamW's index space (what a reference checkpoint's optimizer state is keyed by): the tensors as handed
+        # over, decay group first (optimizers.py:34-40), frozen ones included - `freeze()` (row f3) must not shift it
+        wd_all, no_wd_all = group_weight_decayable_params(everything) if group_wd_params else (everything, [])
+        self.torch_index = {id(p): i for i, p in enumerate(wd_all + no_wd_all)}
+        self.torch_group_sizes = (len(wd_all), len(no_wd_all))
         dev = plist[0].device
         assert all(p.dtype == torch.float32 and p.device == dev for p in plist), "fp32 master parameters on one device"
         wd, no_wd = group_weight_decayable_params(plist) if group_wd_params else (plist, [])
@@ -196,13 +204,15 @@ class FlatAdamW:
         m, v = self._full_moments()
         f = self.flat
         state = {}
-        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
-            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": m[o:o + p.numel()].view(p.shape).clone(),
-                        "exp_avg_sq": v[o:o + p.numel()].view(p.shape).clone()}
+        for p, o in zip(f.params, f.offsets):     # keyed like torch.optim: index among ALL tensors handed over (frozen included)
+            state[f.torch_index[id(p)]] = {"step": torch.tensor(float(self.step_count)),
+                                           "exp_avg": m[o:o + p.numel()].view(p.shape).clone(),
+                                           "exp_avg_sq": v[o:o + p.numel()].view(p.shape).clone()}
         common = {"lr": self.lr, "betas": self.betas, "eps": self.eps, "amsgrad": False, "initial_lr": self.base_lr}
-        groups = [dict(common, weight_decay=self.weight_decay, params=list(range(f.n_decay_tensors)))]
-        if f.n_decay_tensors < len(f.params):
-            groups.append(dict(common, weight_decay=0., params=list(range(f.n_decay_tensors, len(f.params)))))
+        n0, n1 = f.torch_group_sizes
+        groups = [dict(common, weight_decay=self.weight_decay, params=list(range(n0)))]
+        if n1:
+            groups.append(dict(common, weight_decay=0., params=list(range(n0, n0 + n1))))
         return {"optimizer": {"state": state, "param_groups": groups},
                 "lr_scheduler": {"gamma": self.gamma, "last_epoch": self.last_epoch, "base_lrs": [self.base_lr] * len(groups)}}
 
@@ -212,10 +222,11 @@ class FlatAdamW:
         m = torch.zeros(f.total, dtype=torch.float32, device=f.data.device)
         v = torch.zeros_like(m)
         steps = set()
-        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
-            st = opt["state"].get(i)
+        for p, o in zip(f.params, f.offsets):
+            st = opt["state"].get(f.torch_index[id(p)])
             if st is None:
                 continue
+            assert tuple(st["exp_avg"].shape) == tuple(p.shape), "optimizer state does not belong to this parameter"
             m[o:o + p.numel()].view(p.shape).copy_(st["exp_avg"])
             v[o:o + p.numel()].view(p.shape).copy_(st["exp_avg_sq"])
             steps.add(int(st["step"]))
@@ -227,6 +238,8 @@ class FlatAdamW:
         if restore_lr and sched is not None:
             self.last_epoch = int(sched.get("last_epoch", 0))
             self.lr = opt["param_groups"][0]["lr"]
+            # ExponentialLR's closed form lr = initial_lr * gamma ** epoch restarts from the CHECKPOINT's initial_lr
+            self.base_lr = float(opt["param_groups"][0].get("initial_lr", self.base_lr))
 
     def set_progress(self, iteration: int, epoch: int) -> None:
         self.step_count, self.last_epoch = iteration, epoch

@@ -221,6 +221,27 @@ def test_flat_adamw_matches_torch_adamw():
     opt2 = train.FlatAdamW([torch.nn.Parameter(p.detach().clone()) for p in gpu_p], lr=2e-3, weight_decay=1e-2)
     opt2.load_state_dict(sd)
     assert opt2.step_count == 6 and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    # Frozen tensors (AcousticModel.freeze, row f3) keep their place in torch.optim's numbering: the state of a torch AdamW over
+    # ALL tensors (two of them frozen) loads into the right arena slots, and the saved layout numbers like torch's.
+    ref_p2 = [torch.nn.Parameter(_rand(s, 70 + i, 0.3)) for i, s in enumerate(shapes)]
+    for i in (0, 3):
+        ref_p2[i].requires_grad_(False)
+    ref2 = torc.reference_optimizer(ref_p2, lr=2e-3, weight_decay=1e-2)
+    for i, a in enumerate(ref_p2):
+        if a.requires_grad:
+            a.grad = _rand(a.shape, 900 + i, 1e-2)
+    torc.reference_step(ref2, 1.0)
+    gpu_p2 = [torch.nn.Parameter(p.detach().clone().to(DEV), requires_grad=p.requires_grad) for p in ref_p2]
+    opt3 = train.FlatAdamW(gpu_p2, lr=1e-3, weight_decay=1e-2)
+    ref2_sd = ref2.state_dict()
+    ref2_sd["param_groups"][0]["initial_lr"] = 5e-3
+    opt3.load_state_dict({"optimizer": ref2_sd, "lr_scheduler": {"gamma": 0.995, "last_epoch": 3}})
+    assert opt3.base_lr == 5e-3 and opt3.last_epoch == 3
+    sd3 = opt3.state_dict()["optimizer"]
+    assert [g["params"] for g in sd3["param_groups"]] == [g["params"] for g in ref2_sd["param_groups"]]
+    assert sorted(sd3["state"]) == sorted(ref2_sd["state"])
+    for k in ref2_sd["state"]:
+        assert torch.equal(sd3["state"][k]["exp_avg"].cpu(), ref2_sd["state"][k]["exp_avg"])
 
 
 def test_stack_training_steps_reduce_the_loss(state_dict):

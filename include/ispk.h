@@ -122,18 +122,6 @@ int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_
                        const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N,
                        int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);
 
-/* Linear + the NEXT LayerNorm in one kernel (bf16 operands):  C = epilogue(A·Wᵀ) exactly as ispk_gemm_bf16 with an fp32
- * row-major C, and additionally  ln_out[i][:] = [mask[i]] * ( (C[i][:] - mean_i) / sqrt(var_i + ln_eps) * ln_gamma + ln_beta ).
- * Replaces, on the bf16 path, the LayerNorm that the reference applies to this Linear's output before the next Linear:
- * transformer.py:91-102 (to_out + residual -> feed_forward_norm -> * mask), :105-110 + :79 of the next layer (second FFN
- * Linear + residual + mask -> next attention_norm) and :205-206 (final norm * mask).  N must be 256 or 384 (a workgroup
- * holds whole rows); statistics are two-pass fp32 over the fp32 result.  ln_flags: 1 = multiply ln_out rows by `mask`,
- * 2 = ln_out is bf16 (else fp32).  ln_ld: leading stride of ln_out. */
-int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc,
-                          const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N,
-                          int32_t K, uint32_t flags, const float* ln_gamma, const float* ln_beta, float ln_eps, void* ln_out,
-                          int64_t ln_ld, uint32_t ln_flags, ispk_stream_t stream);
-
 /* The whole feed-forward block in one kernel (bf16 operands, fp32 accumulation):
  *   out[i][:] = [mask[i]] * ( resid[i][:] + gelu_erf( x[i][:]·W1ᵀ + bias1 )·W2ᵀ + bias2 )
  * Replaces: feedforward.py:33-40 (Linear -> GELU -> Linear; W1 [inner][dim], W2 [dim][inner] as nn.Linear stores them)
@@ -147,20 +135,6 @@ int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_
                       const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
                       ispk_stream_t stream);
 
-/* ispk_ffn_bf16 that ALSO emits the LayerNorm of its result for the next Linear:
- *   ln_out[i][:] = [mask[i]] * ( (out[i][:] - mean_i) * rstd_i * ln_gamma + ln_beta )       two-pass fp32 statistics
- * Replaces: the block above plus normalization.py:20-27 as applied by the NEXT layer (transformer.py:79) or by the
- * stack's final norm (:205-206): the separate LayerNorm launch and its re-read of the residual stream disappear.
- * W2 must be the packed image (ispk_ffn_pack_w2_bf16); no first-Linear bias.  ln_flags: bit 0 = multiply ln_out by the
- * row mask, bit 1 = ln_out is bf16 (else fp32); ln_ld: leading stride of ln_out.
- * bit 2 = statistics only: ln_out is float [rows][2] = (mean_i, rstd_i), ln_gamma / ln_beta / ln_ld unused - the
- * consumer applies the LayerNorm while it stages its operand (ispk_gemm_bf16_lnin). */
-int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed,
-                         const float* bias2, const float* resid, int64_t ldr, const uint8_t* mask, float* out, int64_t ldo,
-                         int32_t rows, int32_t dim, int32_t inner, uint32_t flags, const float* ln_gamma,
-                         const float* ln_beta, float ln_eps, void* ln_out, int64_t ln_ld, uint32_t ln_flags,
-                         ispk_stream_t stream);
-
 /* The pre-norm feed-forward block of a transformer layer in one kernel, LayerNorm included:
  *   out[i][:] = [mask[i]] * ( x[i][:] + gelu_erf( LN(x[i][:])·W1ᵀ )·W2ᵀ + bias2 ),   LN = (x - mean_i) * rstd_i * gamma + beta
  * Replaces: transformer.py:101-110 (feed_forward_norm -> feed_forward -> residual add -> mask) = normalization.py:20-27 +
@@ -169,7 +143,7 @@ int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16_t* W1, int
  * itself (two-pass fp32, fixed summation order).  The reference also multiplies LN(x) by the row mask (:102); with the
  * same mask applied to the output (flags: ISPK_EP_MASK_OUT / ISPK_EP_MASK_ACC) that product cannot reach any kept value
  * and is skipped.  W2 packed (ispk_ffn_pack_w2_bf16), no first-Linear bias.  row_stats (optional): float [rows][2] =
- * (mean, rstd with stats_eps) of the OUTPUT rows for ispk_gemm_bf16_lnin, as ispk_ffn_bf16_ln(ln_flags bit 2). */
+ * (mean, rstd with stats_eps) of the OUTPUT rows, for ispk_gemm_bf16_lnin to apply the next LayerNorm while it stages them. */
 int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta, float norm_eps,
                               const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed, const float* bias2,
                               const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner,
@@ -204,30 +178,12 @@ int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const float* norm_ga
                                int32_t rows, int32_t dim, int32_t inner, uint32_t flags, float* row_stats, float stats_eps,
                                ispk_stream_t stream);
 
-/* The second half of a pre-norm transformer layer in one kernel - attention output projection, residual, mask,
- * feed_forward_norm, feed-forward, residual, mask:
- *   x1[i][:]  = x[i][:] + mask[i] * ( attn_out[i][:]·Woᵀ )                                  attention.py:168-172, transformer.py:91
- *   out[i][:] = mask[i] * ( x1[i][:] + gelu_erf( LN(x1[i][:])·W1ᵀ )·W2ᵀ )                   transformer.py:101-110
- * Replaces: ispk_gemm_bf16 (to_out + residual + mask) followed by ispk_ffn_bf16_prenorm - one launch less per layer, and
- * x1 is written once and read once (as the epilogue's residual) instead of written once and read twice.  Parity-tested
- * but NOT what the module mirror calls by default: measured on MI355X it is slower than the two launches (150 vs
- * 32 + 114 us at 32,768 rows; the projection prologue is a plain loop).  attn_out bf16
- * [rows][dim] (heads x 64 == dim), Wo bf16 [dim][dim] contiguous (nn.Linear layout), x fp32; x1: fp32 [rows][dim] buffer
- * the kernel fills (it IS the layer's intermediate activation); mask required; no biases (the reference's attention and
- * feed-forward Linears have none, attention.py:63-86, feedforward.py:27-36 with bias=False recipes); W2 packed.
- * row_stats optional as in ispk_ffn_bf16_prenorm. */
-int32_t ispk_attn_out_ffn_bf16(const uint16_t* attn_out, int64_t ldao, const uint16_t* Wo, const float* x, int64_t ldx,
-                               const float* norm_gamma, const float* norm_beta, float norm_eps, const uint16_t* W1,
-                               int64_t ldw1, const uint16_t* W2_packed, const uint8_t* mask, float* x1, int64_t ldx1,
-                               float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, float* row_stats,
-                               float stats_eps, ispk_stream_t stream);
-
 /* Linear whose input is LayerNorm(x), with the row statistics supplied by the kernel that produced x:
  *   C[i][n] = epilogue( sum_k bf16( (x[i][k] - mean_i) * rstd_i * ln_gamma[k] + ln_beta[k] ) * W[n][k] )
  * Replaces: normalization.py:20-27 + the Linear that follows it (transformer.py:79-80, attention.py:63-64: attention_norm
  * -> to_q / to_kv) on the bf16 path - the separate LayerNorm launch, its re-read of the fp32 residual stream and the
  * bf16 copy it writes disappear.  x fp32 [M][K] (the residual stream), row_stats float [M][2] = (mean, rstd) from
- * ispk_ffn_bf16_ln(ln_flags bit 2) / ispk_ffn_bf16_prenorm, or NULL: the kernel computes the statistics itself (its waves
+ * ispk_ffn_bf16_prenorm / ispk_ffn_bf16_prenorm2, or NULL: the kernel computes the statistics itself (its waves
  * own whole rows; two-pass fp32 with ln_eps, fixed summation order) - then any LayerNorm -> Linear pair qualifies
  * (transformer.py:79-80 of a stack's first layer, :101-105 + feedforward.py:33 on the unfused path).
  * K 256 or 384; flags / bias / resid / mask / C as ispk_gemm_bf16 (row-major outputs). */

@@ -1750,16 +1750,26 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
 #else
 #define ISPK_FFN_STAMPED() (void)stamp
 #endif
-#define ISPK_FFN_KC(KC_)                                                   \
+    // Variants that measured slower than what the module mirror calls (projection prologue `pj`; LayerNorm epilogue without the
+    // pre-norm prologue) are compiled into the experiments build only (libispk_exp.so); the product ABI does not reach them.
+#ifdef ISPK_EXPERIMENTS
+#define ISPK_FFN_KC_EXP(KC_)                                               \
     do {                                                                   \
         if (pj && ln) ISPK_FFN_GO_PJ(KC_, true);                           \
         if (pj) ISPK_FFN_GO_PJ(KC_, false);                                \
+        if (!lx && ln && hot) ISPK_FFN_GO_LN(KC_, kHot);                   \
+        if (!lx && ln) ISPK_FFN_GO_LN(KC_, kEpDyn);                        \
+    } while (0)
+#else
+#define ISPK_FFN_KC_EXP(KC_) ISPK_REQUIRE(!pj && (lx || !ln), ISPK_E_UNSUPPORTED, "ffn: variant of the experiments build only")
+#endif
+#define ISPK_FFN_KC(KC_)                                                   \
+    do {                                                                   \
+        ISPK_FFN_KC_EXP(KC_);                                              \
         if (lx && ln && hot) ISPK_FFN_GO_LX(KC_, kHot, true);              \
         if (lx && ln) ISPK_FFN_GO_LX(KC_, kEpDyn, true);                   \
         if (lx && hot) ISPK_FFN_GO_LX(KC_, kHot, false);                   \
         if (lx) ISPK_FFN_GO_LX(KC_, kEpDyn, false);                        \
-        if (ln && hot) ISPK_FFN_GO_LN(KC_, kHot);                          \
-        if (ln) ISPK_FFN_GO_LN(KC_, kEpDyn);                               \
         ISPK_FFN_STAMPED();                                                \
         if (!bias1 && packed && hot) ISPK_FFN_GO(KC_, false, true, kHot, false);  \
         if (!bias1 && packed) ISPK_FFN_GO(KC_, false, true, kEpDyn, false);  \
@@ -1769,6 +1779,7 @@ int32_t ffn_launch(const void* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
     } while (0)
     if (D == 384) ISPK_FFN_KC(6); else ISPK_FFN_KC(4);
 #undef ISPK_FFN_KC
+#undef ISPK_FFN_KC_EXP
 #undef ISPK_FFN_STAMPED
 #undef ISPK_FFN_GO_PJ
 #undef ISPK_FFN_GO_LX
@@ -1785,6 +1796,7 @@ extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t*
     return ffn_launch(x, ldx, W1, ldw1, bias1, W2, ldw2, bias2, resid, ldr, mask, out, ldo, rows, D, F, flags, nullptr, stream);
 }
 
+#ifdef ISPK_EXPERIMENTS   // measured slower than the default path: experiments build only, not in include/ispk.h
 extern "C" int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
                                     const uint16_t* W2_packed, const float* bias2, const float* resid, int64_t ldr,
                                     const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F,
@@ -1794,7 +1806,9 @@ extern "C" int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16
     return ffn_launch(x, ldx, W1, ldw1, nullptr, W2_packed, 0, bias2, resid, ldr, mask, out, ldo, rows, D, F, flags, &ln,
                       stream);
 }
+#endif
 
+#ifdef ISPK_EXPERIMENTS   // measured slower than the default path: experiments build only, not in include/ispk.h
 extern "C" int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc,
                                      const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M,
                                      int32_t N, int32_t K, uint32_t flags, const float* ln_gamma, const float* ln_beta,
@@ -1814,6 +1828,7 @@ extern "C" int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint1
     if (M >= 128 * 160) return N == 384 ? launch_wide<6, 4, true>(p, s) : launch_wide<4, 4, true>(p, s);
     return N == 384 ? launch_wide<6, 2, true>(p, s) : launch_wide<4, 2, true>(p, s);
 }
+#endif
 
 extern "C" int32_t ispk_gemm_bf16_lnin(const float* x, int64_t ldx, const float* row_stats, const float* ln_gamma,
                                        const float* ln_beta, float ln_eps, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
@@ -1848,6 +1863,7 @@ extern "C" int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const floa
                       row_stats ? &ln : nullptr, stream, &lx);
 }
 
+#ifdef ISPK_EXPERIMENTS   // measured slower than the default path: experiments build only, not in include/ispk.h
 extern "C" int32_t ispk_attn_out_ffn_bf16(const uint16_t* attn_out, int64_t ldao, const uint16_t* Wo, const float* x,
                                           int64_t ldx, const float* norm_gamma, const float* norm_beta, float norm_eps,
                                           const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed, const uint8_t* mask,
@@ -1862,3 +1878,4 @@ extern "C" int32_t ispk_attn_out_ffn_bf16(const uint16_t* attn_out, int64_t ldao
     return ffn_launch(x1, ldx1, W1, ldw1, nullptr, W2_packed, 0, nullptr, x1, ldx1, mask, out, ldo, rows, D, F,
                       ISPK_EP_MASK_OUT, row_stats ? &ln : nullptr, stream, &lx, &pj);
 }
+#endif

@@ -91,15 +91,14 @@ class Attention(nn.Module, Constructor):
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 cache: Optional[AttentionIntermediates] = None,
                 shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None,
-                residual: Optional[Tensor] = None, prenorm: Optional[tuple] = None, defer_out: bool = False):
+                residual: Optional[Tensor] = None, prenorm: Optional[tuple] = None):
         """x [B,N,dim] (fp32, or bf16 when compute_dtype is bf16); mask [B,N] bool, True = valid, a length mask.
         `key_len` (int64 [B]) may be passed to skip recomputing mask.sum(1); `residual` (fp32 [B,N,dim]) fuses
         `residual + mask * to_out(...)` into the output GEMM.  Returns (out, AttentionIntermediates,
         AttentionSharedIntermediates) like the reference; `rel_pos_bias` is None because no bias tensor exists.
         `prenorm` = (row_stats | None, weight, bias, eps): x is the fp32 input of the LayerNorm that precedes this block
         and the q/kv GEMM applies that LayerNorm while staging x (bf16 path; statistics from the producing kernel, or
-        computed by the GEMM's own waves when None).  `defer_out`: return the heads' output [B,N,H*64] (bf16) instead of
-        to_out(...) - the caller fuses the projection, residual and mask into the feed-forward kernel."""
+        computed by the GEMM's own waves when None)."""
         if context is not None or context_mask is not None or attention_mask is not None or cache is not None:
             raise NotImplementedError("cross-attention, explicit attention masks and KV caches are not on the "
                                       "acoustic-model forward path and are not built")
@@ -116,8 +115,7 @@ class Attention(nn.Module, Constructor):
                 xs = runtime.split_f16(x.float().contiguous())
             qkv = runtime.gemm_split(xs, wqkv)
             o = runtime.alibi_mqa_attention_split(qkv, self.heads, slopes, key_len)
-            out = o if defer_out else runtime.gemm_split(o, wo, resid=residual, mask=mask,
-                                                         flags=runtime.EP_MASK_ACC if mask is not None else 0)
+            out = runtime.gemm_split(o, wo, resid=residual, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
             hq = self.heads * 64
             inter = AttentionIntermediates(queries=qkv[..., :hq].view(b, n, self.heads, 64).transpose(1, 2),
                                            keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])
@@ -130,11 +128,8 @@ class Attention(nn.Module, Constructor):
                 x = runtime.cast_bf16(x) if dt == torch.bfloat16 else x.float()
             qkv = runtime.gemm(x, wqkv)                                        # [B,N,H*64+128]
         o = runtime.alibi_mqa_attention(qkv, self.heads, slopes, key_len)      # [B,N,H*64]
-        if defer_out:   # the caller applies to_out itself (fused with what follows: runtime.attn_out_ffn)
-            out = o
-        else:
-            flags = runtime.EP_MASK_ACC if mask is not None else 0
-            out = runtime.gemm(o, wo, resid=residual, mask=mask, flags=flags, out_dtype=torch.float32)
+        flags = runtime.EP_MASK_ACC if mask is not None else 0
+        out = runtime.gemm(o, wo, resid=residual, mask=mask, flags=flags, out_dtype=torch.float32)
         hq = self.heads * 64
         inter = AttentionIntermediates(queries=qkv[..., :hq].view(b, n, self.heads, 64).transpose(1, 2),
                                        keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])

@@ -71,28 +71,6 @@ class FeedForward(nn.Module, Constructor):
         return self._cache.get("w2c", (self.net[3].weight,),
                                lambda: runtime.ffn_chunk_w2(self._staged(torch.bfloat16)[1]))
 
-    def fused_with_norm_ok(self, x: Tensor) -> bool:
-        """Can `forward_with_norm` emit the next LayerNorm from the fused kernel's epilogue for this input?"""
-        rows = x.numel() // x.shape[-1]
-        return (self.compute_dtype == torch.bfloat16 and self.act_flag == runtime.EP_GELU and x.shape[-1] in (256, 384)
-                and rows >= self.fused_min_rows and self.net[0].bias is None
-                and not (self.training and self.dropout_p > 0))
-
-    def forward_with_norm(self, x: Tensor, next_norm: tuple, *, residual: Optional[Tensor] = None,
-                          mask: Optional[Tensor] = None):
-        """(y, LN_next(y)): the fused FFN kernel with the LayerNorm that consumes its output in its epilogue
-        (`next_norm` = (weight, bias, eps, apply_mask, dtype)).  Only when `fused_with_norm_ok(x)`."""
-        w1, _ = self._staged(torch.bfloat16)
-        if x.dtype != torch.bfloat16:
-            x = runtime.cast_bf16(x)
-        nw, nb, neps, nmask, ndtype = next_norm
-        if ndtype == "stats":   # only the rows' (mean, rstd): the consumer GEMM normalises in its prologue
-            return runtime.ffn_fused_stats(x, w1, self._packed_w2(), resid=residual, mask=mask, bias2=self.net[3].bias,
-                                           flags=runtime.EP_MASK_OUT if mask is not None else 0, ln_eps=neps)
-        return runtime.ffn_fused_ln(x, w1, self._packed_w2(), nw, nb, resid=residual, mask=mask, bias2=self.net[3].bias,
-                                    flags=runtime.EP_MASK_OUT if mask is not None else 0, ln_mask=nmask, ln_dtype=ndtype,
-                                    ln_eps=neps)
-
     def prenorm_ok(self, x: Tensor, norm) -> bool:
         """Can `forward_prenorm` run the block (norm -> feed-forward -> residual) as one kernel for this input?"""
         rows = x.numel() // x.shape[-1]
@@ -145,16 +123,6 @@ class FeedForward(nn.Module, Constructor):
                                    ln_eps=norm.eps)
         return runtime.gemm(hidden, w2, bias=self.net[3].bias, resid=x, mask=mask,
                             flags=runtime.EP_MASK_OUT if mask is not None else 0, out_dtype=torch.float32)
-
-    def forward_attn_out_prenorm(self, o: Tensor, wo: Tensor, x: Tensor, norm, *, mask: Tensor,
-                                 next_norm: Optional[tuple] = None):
-        """The layer's second half in one kernel (ispk_attn_out_ffn_bf16): x1 = x + mask * to_out(o);
-        y = mask * (x1 + feed_forward(norm(x1))).  Returns (y, stats | None)."""
-        w1, _ = self._staged(torch.bfloat16)
-        want = next_norm is not None and next_norm[4] == "stats"
-        res = runtime.attn_out_ffn(o, wo, x, norm.weight, norm.bias, w1, self._packed_w2(), mask, norm_eps=norm.eps,
-                                   want_stats=want, stats_eps=next_norm[2] if want else 1e-5)
-        return (res[0], res[2]) if want else (res[0], None)
 
     def forward_prenorm(self, x: Tensor, norm, *, mask: Optional[Tensor] = None, next_norm: Optional[tuple] = None):
         """y = [mask] * (x + feed_forward(norm(x))) in one kernel (ispk_ffn_bf16_prenorm), x fp32; with `next_norm` =

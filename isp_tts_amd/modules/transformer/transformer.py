@@ -53,10 +53,6 @@ class TransformerLayer(nn.Module, Constructor):
     # Path switches are plain class attributes (set them on the class or on an instance; nothing reads the environment).
     # LayerNorm applied by the consuming GEMM's own waves (ispk_gemm_bf16_lnin with row_stats = NULL), decoder-sized batches:
     lnin_self = True
-    # to_out + residual + mask inside the feed-forward kernel (ispk_attn_out_ffn_bf16): parity-tested, OFF - its plain
-    # projection prologue takes 35 us against the 32-us out-projection GEMM it replaces (150 vs 146 us for the pair,
-    # 2.21-2.34 vs 2.09 ms per step: the longer lock-step kernel overlaps worse with the second batch in flight)
-    fuse_out_proj = False
 
     def __init__(self, dim: int = 384, attention=None, feed_forward=None, pre_norm: bool = True,
                  adaptive_norm: bool = False, condition_dim: Optional[int] = None):
@@ -102,30 +98,17 @@ class TransformerLayer(nn.Module, Constructor):
                and attention_mask is None and x.shape[-1] in (256, 384) and self.attention_norm.weight is not None
                and self.attention_norm.bias is not None and self.lnin_self
                and x.numel() // x.shape[-1] >= self.lnin_self_min_rows)
-        # to_out + residual + mask fused into the feed-forward kernel (one launch for the layer's second half)?
-        ffw = self.feed_forward
-        fuse_out = (cdt == torch.bfloat16 and mask is not None and ada is None and context is None
-                    and attention_mask is None and (next_norm is None or next_norm[4] == "stats")
-                    and self.attention.heads * 64 == x.shape[-1] and ffw.net[3].bias is None
-                    and ffw.prenorm_ok(x, self.feed_forward_norm)
-                    and self.fuse_out_proj)
         if cdt == torch.bfloat16 and (handed or own):
             # attention_norm inside the q/kv GEMM, applied while it stages x: with the row statistics the previous layer's
             # feed-forward kernel handed over, or (first layer of a stack) computed by the GEMM's own waves
             an = self.attention_norm
-            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x, defer_out=fuse_out,
+            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x,
                                                prenorm=(normed if handed else None, an.weight, an.bias, an.eps))
         else:
             h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
             x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
-                                               attention_mask=attention_mask, key_len=key_len, residual=x,
-                                               defer_out=fuse_out)
+                                               attention_mask=attention_mask, key_len=key_len, residual=x)
         hn = None
-        if fuse_out:   # here `x1` is the heads' output before to_out
-            wo = self.attention._staged(torch.bfloat16)[1]
-            y, hn = ffw.forward_attn_out_prenorm(x1, wo, x, self.feed_forward_norm, mask=mask, next_norm=next_norm)
-            return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
-                                          shared_intermediates=shared, next_normed=hn)
         if (ada is None and (next_norm is None or next_norm[4] == "stats")
                 and self.feed_forward.prenorm_ok(x1, self.feed_forward_norm)):
             # feed_forward_norm inside the fused feed-forward kernel (its waves own whole rows); the `* mask` of :102
@@ -148,10 +131,7 @@ class TransformerLayer(nn.Module, Constructor):
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                           shared_intermediates=shared, next_normed=None)
         h2 = self.feed_forward_norm(x1, adaptive_condition, row_mask=mask, out_dtype=cdt, **kw2)
-        if next_norm is not None and self.feed_forward.fused_with_norm_ok(h2):
-            y, hn = self.feed_forward.forward_with_norm(h2, next_norm, residual=x1, mask=mask)
-        else:
-            y = self.feed_forward(h2, residual=x1, mask=mask)
+        y = self.feed_forward(h2, residual=x1, mask=mask)
         return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                       shared_intermediates=shared, next_normed=hn)
 
@@ -193,32 +173,6 @@ class TransformerLayer(nn.Module, Constructor):
                                        keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])
         return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                       shared_intermediates=AttentionSharedIntermediates(rel_pos_bias=None), next_normed=None)
-
-    def forward_fused(self, x: Tensor, h: Tensor, mask: Optional[Tensor], key_len: Optional[Tensor], next_norm: tuple):
-        """bf16 path with LayerNorms fused into the producing GEMMs (5 launches per layer instead of 7):
-            qkv = h · [Wq;Wkv]ᵀ ; o = attention(qkv)
-            x1, h2 = gemm_ln(o · Woᵀ : x + mask*(.),  LN = feed_forward_norm, * mask)       transformer.py:91-102
-            f = gelu(h2 · W1ᵀ)
-            y, hn = gemm_ln(f · W2ᵀ : mask*(x1 + .),  LN = next_norm)                        :105-110, next :79 / :205
-        `h` = attention_norm(x) in bf16 (from the previous layer's epilogue); `next_norm` = (weight, bias, apply_mask,
-        dtype) of the norm that consumes this layer's output.  Returns (y, hn, AttentionIntermediates)."""
-        att, ff = self.attention, self.feed_forward
-        wqkv, wo, slopes = att._staged(torch.bfloat16)
-        w1, w2 = ff._staged(torch.bfloat16)
-        b, n, _ = x.shape
-        qkv = runtime.gemm(h, wqkv)
-        o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
-        x1, h2 = runtime.gemm_ln(o, wo, self.feed_forward_norm.weight, self.feed_forward_norm.bias, resid=x, mask=mask,
-                                 flags=runtime.EP_MASK_ACC if mask is not None else 0, ln_mask=True,
-                                 ln_eps=self.feed_forward_norm.eps)
-        f = runtime.gemm(h2, w1, bias=ff.net[0].bias, flags=ff.act_flag)
-        nw, nb, nmask, ndtype = next_norm
-        y, hn = runtime.gemm_ln(f, w2, nw, nb, resid=x1, mask=mask, bias=ff.net[3].bias,
-                                flags=runtime.EP_MASK_OUT if mask is not None else 0, ln_mask=nmask, ln_dtype=ndtype)
-        hq = att.heads * 64
-        inter = AttentionIntermediates(queries=qkv[..., :hq].view(b, n, att.heads, 64).transpose(1, 2),
-                                       keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])
-        return y, hn, inter
 
 
 class TransformerOutput(NamedTuple):
@@ -273,29 +227,11 @@ class Transformer(nn.Module, Constructor):
                  for i in range(len(norms))]
         return [(parts[2 * li], parts[2 * li + 1]) for li in range(len(self.layers))]
 
-    # Fusing each LayerNorm into the epilogue of the GEMM that produces its input (ispk_gemm_bf16_ln) is implemented and
-    # parity-tested but OFF by default: measured on MI355X at the benchmark shape it is 3 % SLOWER (4.27 vs 4.15 ms/step).
-    # The wide kernel runs one round of 256 workgroups that all reach their epilogue together, so the extra HBM phase
-    # (residual in, fp32 + bf16 rows out) overlaps with no MFMA work, and its 64-row variant under-fills the chip on the
-    # 6,400-row encoder.  Kept for the next round (needs an epilogue that overlaps with the following tile's K loop).
-    fuse_layernorm = False
-    # LayerNorm of a layer's output in the epilogue of its fused feed-forward kernel (ispk_ffn_bf16_ln: each wave of that
-    # kernel owns whole rows, so the statistics need no extra pass).  Parity-tested, opt-in: at the benchmark shape the
-    # kernel gets 13 us slower per layer (its 256 workgroups reach the epilogue together, nothing overlaps the extra
-    # work) while the removed LayerNorm launch saved 17 us - 2.94 vs 2.98 ms per step, within run-to-run noise.
-    chain_layernorm = False
-    # Variant of the above that moves only the STATISTICS: the fused feed-forward kernel writes (mean, rstd) per row and the
+    # The LayerNorm that consumes a layer's output moves only its STATISTICS: the fused feed-forward kernel writes (mean, rstd) per row and the
     # next layer's q/kv GEMM (ispk_gemm_bf16_lnin) normalises while it stages its fp32 input - no normalised copy in HBM.
     # ON: the feed-forward kernel is unchanged in time (106.6 us), q/kv goes 21.8 -> 26.6 us and the 15.0-us LayerNorm
     # launch disappears: 2.636 -> 2.587 ms per step with one batch in flight, 2.162 -> 2.147 with two.
     stats_layernorm = True
-
-    def _fusable(self, context, context_mask, attention_mask) -> bool:
-        att = self.layers[0].attention
-        return (self.fuse_layernorm and att.compute_dtype == torch.bfloat16 and not self.adaptive_norm and context is None
-                and context_mask is None and attention_mask is None and self.dim in (256, 384)
-                and all(not (l.training and (l.attention.attend.dropout > 0 or l.feed_forward.dropout_p > 0))
-                        for l in self.layers) and self.norm.eps == 1e-5)
 
     def set_compute_dtype(self, dtype: torch.dtype):
         """fp32 (exact-fp32 MFMAs), bf16 (throughput path) or fp16 = the split-fp16 path: fp32-grade products as three fp16
@@ -323,40 +259,20 @@ class Transformer(nn.Module, Constructor):
         if mask is not None and key_len is None:
             key_len = mask.sum(dim=1)
         intermediates = []
-        if self._fusable(context, context_mask, attention_mask):
-            # bf16 path: every LayerNorm except the first rides in the epilogue of the GEMM that produces its input
-            out = out.float().contiguous()
-            h = runtime.layernorm(out, self.layers[0].attention_norm.weight, self.layers[0].attention_norm.bias,
-                                  eps=self.layers[0].attention_norm.eps, out_dtype=torch.bfloat16)
-            for li, layer in enumerate(self.layers):
-                if li + 1 < len(self.layers):
-                    nn_ = self.layers[li + 1].attention_norm
-                    nxt = (nn_.weight, nn_.bias, False, torch.bfloat16)
-                else:
-                    nxt = (self.norm.weight, self.norm.bias, mask is not None, out_dtype)
-                out, h, inter = layer.forward_fused(out, h, mask, key_len, nxt)
-                if return_intermediates:
-                    intermediates.append(TransformerLayerIntermediates(attention=inter))
-            return TransformerOutput(out=h, intermediates=intermediates)
         ada = self._ada_all(adaptive_condition) if (self.adaptive_norm and adaptive_condition is not None) else None
-        # bf16, plain LayerNorm: a layer's fused feed-forward kernel also emits the LayerNorm that consumes its output
-        # (the next layer's attention_norm, or the final norm) when the batch is large enough for that kernel
-        # (`chain_layernorm`: opt-in - measured neutral with one and with two batches in flight)
-        chain = (self.chain_layernorm and not self.adaptive_norm
-                 and self.layers[0].attention.compute_dtype == torch.bfloat16)
+        # bf16, plain LayerNorm: a layer's fused feed-forward kernel also emits the row statistics of the LayerNorm that
+        # consumes its output (the next layer's attention_norm), which that layer's q/kv GEMM applies while it stages x
         cdt = self.layers[0].attention.compute_dtype
-        stats = (not chain and self.stats_layernorm and not self.adaptive_norm
+        stats = (self.stats_layernorm and not self.adaptive_norm
                  and cdt == torch.bfloat16 and context is None and attention_mask is None)
-        chain = chain or stats
+        chain = stats
         normed = None
         for li, layer in enumerate(self.layers):
             nxt = None
             if chain:
                 if li + 1 < len(self.layers):
                     nn_ = self.layers[li + 1].attention_norm
-                    nxt = (nn_.weight, nn_.bias, nn_.eps, False, "stats" if stats else cdt)
-                elif not stats:
-                    nxt = (self.norm.weight, self.norm.bias, self.norm.eps, mask is not None, out_dtype)
+                    nxt = (nn_.weight, nn_.bias, nn_.eps, False, "stats")
                 if nxt is not None and (nxt[0] is None or nxt[1] is None):
                     nxt = None
             res = layer(out, mask=mask, context=context, context_mask=context_mask, attention_mask=attention_mask,

@@ -34,19 +34,13 @@ SIGNATURES = {
     "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_gemm_bf16_last_variant": [],
     "ispk_gemm_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
-    "ispk_gemm_bf16_ln": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64, _U32,
-                          _P],
     "ispk_ffn_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_ffn_pack_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
-    "ispk_ffn_bf16_ln": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32, _P, _I64,
-                         _U32, _P],
     "ispk_ffn_bf16_prenorm": [_P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
     "ispk_ffn_chunk_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
     "ispk_ffn_bf16_prenorm2_split": [_P, _I64, _P, _P, _F32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_ffn_combine_ln_f32": [_P, _I64, _P, _I64, _I32, _P, _P, _I64, _P, _P, _F32, _I32, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_ffn_bf16_prenorm2": [_P, _I64, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
-    "ispk_attn_out_ffn_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32,
-                               _P, _F32, _P],
     "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _F32, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -307,32 +301,6 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Optional[Te
     return out
 
 
-def gemm_ln(a: Tensor, w: Tensor, ln_weight: Tensor, ln_bias: Tensor, resid: Optional[Tensor] = None,
-            mask: Optional[Tensor] = None, flags: int = 0, bias: Optional[Tensor] = None, ln_mask: bool = False,
-            ln_dtype: torch.dtype = torch.bfloat16, ln_eps: float = 1e-5):
-    """ispk_gemm_bf16_ln: (C fp32 [..., N], LN(C) [..., N] in ln_dtype) from bf16 a[..., K] @ w[N, K]^T."""
-    _dev(a, w, ln_weight, ln_bias, resid, mask, bias)
-    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
-    a2 = _rows2d(a)
-    M, K = a2.shape
-    N = w.shape[0]
-    out = torch.empty((*a.shape[:-1], N), dtype=torch.float32, device=a.device)
-    ln_out = torch.empty((*a.shape[:-1], N), dtype=ln_dtype, device=a.device)
-    r2 = _rows2d(resid) if resid is not None else None
-    if r2 is not None and r2.dtype == torch.bfloat16:
-        flags |= EP_RESID_BF16
-    if mask is not None:
-        mask = mask.reshape(-1).contiguous()
-    lnf = (1 if (ln_mask and mask is not None) else 0) | (2 if ln_dtype == torch.bfloat16 else 0)
-    nb = a2.numel() * 2 + w.numel() * 2 + out.numel() * 4 + ln_out.numel() * ln_out.element_size() + \
-        (r2.numel() * r2.element_size() if r2 is not None else 0)
-    _launch(f"gemm_bf16_wide_kernel<{N // 64},{4 if M >= 20480 else 2},ln>", 2.0 * M * N * K, float(nb),
-            lib().ispk_gemm_bf16_ln, a2.data_ptr(), a2.stride(0), w.data_ptr(), w.stride(0), out.data_ptr(), N, _ptr(bias),
-            _ptr(r2), r2.stride(0) if r2 is not None else 0, _ptr(mask), M, N, K, flags, ln_weight.data_ptr(),
-            ln_bias.data_ptr(), ln_eps, ln_out.data_ptr(), N, lnf, _stream())
-    return out, ln_out
-
-
 def ffn_pack_w2(w2: Tensor) -> Tensor:
     """ispk_ffn_pack_w2_bf16: W2 bf16 [D, inner] -> packed [inner/32, D, 32] (one-time weight staging for ffn_fused)."""
     _dev(w2)
@@ -368,54 +336,6 @@ def ffn_fused(x: Tensor, w1: Tensor, w2: Tensor, resid: Optional[Tensor] = None,
             w1.data_ptr(), w1.stride(0), _ptr(bias1), w2.data_ptr(), 0 if packed else w2.stride(0), _ptr(bias2), _ptr(r2),
             r2.stride(0) if r2 is not None else 0, _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, _stream())
     return out
-
-
-def ffn_fused_ln(x: Tensor, w1: Tensor, w2p: Tensor, ln_weight: Tensor, ln_bias: Tensor, resid: Optional[Tensor] = None,
-                 mask: Optional[Tensor] = None, bias2: Optional[Tensor] = None, flags: int = 0, ln_mask: bool = False,
-                 ln_dtype: torch.dtype = torch.bfloat16, ln_eps: float = 1e-5):
-    """ispk_ffn_bf16_ln: (out fp32 [..., D], LN(out) [..., D] in ln_dtype); w2p = the packed image from `ffn_pack_w2`."""
-    _dev(x, w1, w2p, ln_weight, ln_bias, resid, mask, bias2)
-    assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2p.dtype == torch.bfloat16
-    x2 = _rows2d(x)
-    R, D = x2.shape
-    Fi = w1.shape[0]
-    assert w1.shape == (Fi, D) and w1.stride(1) == 1 and w2p.shape == (Fi // 32, D, 32) and w2p.is_contiguous()
-    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
-    ln_out = torch.empty((*x.shape[:-1], D), dtype=ln_dtype, device=x.device)
-    r2 = _rows2d(resid) if resid is not None else None
-    if mask is not None:
-        mask = mask.reshape(-1).contiguous()
-    lnf = (1 if (ln_mask and mask is not None) else 0) | (2 if ln_dtype == torch.bfloat16 else 0)
-    nb = x2.numel() * 2 + (w1.numel() + w2p.numel()) * 2 + out.numel() * 4 + ln_out.numel() * ln_out.element_size() + \
-        (r2.numel() * 4 if r2 is not None else 0)
-    _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_ln, x2.data_ptr(), x2.stride(0),
-            w1.data_ptr(), w1.stride(0), w2p.data_ptr(), _ptr(bias2), _ptr(r2), r2.stride(0) if r2 is not None else 0,
-            _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, ln_weight.data_ptr(), ln_bias.data_ptr(), ln_eps,
-            ln_out.data_ptr(), D, lnf, _stream())
-    return out, ln_out
-
-
-def ffn_fused_stats(x: Tensor, w1: Tensor, w2p: Tensor, resid: Optional[Tensor] = None, mask: Optional[Tensor] = None,
-                    bias2: Optional[Tensor] = None, flags: int = 0, ln_eps: float = 1e-5):
-    """ispk_ffn_bf16_ln with ln_flags bit 2: (out fp32 [..., D], row statistics fp32 [rows, 2] = (mean, rstd) of out) -
-    the LayerNorm itself is applied by the consumer (`gemm_lnin`)."""
-    _dev(x, w1, w2p, resid, mask, bias2)
-    assert x.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16 and w2p.dtype == torch.bfloat16
-    x2 = _rows2d(x)
-    R, D = x2.shape
-    Fi = w1.shape[0]
-    assert w1.shape == (Fi, D) and w1.stride(1) == 1 and w2p.shape == (Fi // 32, D, 32) and w2p.is_contiguous()
-    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
-    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device)
-    r2 = _rows2d(resid) if resid is not None else None
-    if mask is not None:
-        mask = mask.reshape(-1).contiguous()
-    nb = x2.numel() * 2 + (w1.numel() + w2p.numel()) * 2 + out.numel() * 4 + stats.numel() * 4 + \
-        (r2.numel() * 4 if r2 is not None else 0)
-    _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_ln, x2.data_ptr(), x2.stride(0),
-            w1.data_ptr(), w1.stride(0), w2p.data_ptr(), _ptr(bias2), _ptr(r2), r2.stride(0) if r2 is not None else 0,
-            _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, 0, 0, ln_eps, stats.data_ptr(), 0, 4, _stream())
-    return out, stats
 
 
 def ffn_prenorm(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2p: Tensor, mask: Optional[Tensor] = None,
@@ -504,34 +424,11 @@ def ffn_prenorm2_split(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Te
     return y, ln
 
 
-def attn_out_ffn(o: Tensor, wo: Tensor, x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2p: Tensor,
-                 mask: Tensor, norm_eps: float = 1e-5, want_stats: bool = False, stats_eps: float = 1e-5):
-    """ispk_attn_out_ffn_bf16: x1 = x + mask * (o @ wo^T); out = mask * (x1 + gelu(LN(x1) @ w1^T) @ w2^T) in one launch.
-    o bf16 [..., D] (attention output before to_out), x fp32 [..., D].  Returns (out, x1[, stats])."""
-    _dev(o, wo, x, norm_weight, norm_bias, w1, w2p, mask)
-    assert o.dtype == torch.bfloat16 and wo.dtype == torch.bfloat16 and x.dtype == torch.float32
-    o2, x2 = _rows2d(o), _rows2d(x)
-    R, D = x2.shape
-    Fi = w1.shape[0]
-    assert o2.shape == (R, D) and wo.shape == (D, D) and wo.is_contiguous() and w1.shape == (Fi, D) and w1.stride(1) == 1
-    assert w2p.shape == (Fi // 32, D, 32) and w2p.is_contiguous()
-    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
-    x1 = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
-    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device) if want_stats else None
-    mask = mask.reshape(-1).contiguous()
-    nb = o2.numel() * 2 + x2.numel() * 4 + x1.numel() * 8 + out.numel() * 4 + (wo.numel() + w1.numel() + w2p.numel()) * 2
-    _launch(f"ffn_bf16_kernel<{D // 64}>", 4.0 * R * D * Fi + 2.0 * R * D * D, float(nb), lib().ispk_attn_out_ffn_bf16,
-            o2.data_ptr(), o2.stride(0), wo.data_ptr(), x2.data_ptr(), x2.stride(0), norm_weight.data_ptr(),
-            norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w1.stride(0), w2p.data_ptr(), mask.data_ptr(), x1.data_ptr(), D,
-            out.data_ptr(), D, R, D, Fi, _ptr(stats), stats_eps, _stream())
-    return (out, x1, stats) if want_stats else (out, x1)
-
-
 def gemm_lnin(x: Tensor, stats: Optional[Tensor], ln_weight: Tensor, ln_bias: Tensor, w: Tensor,
               bias: Optional[Tensor] = None, mask: Optional[Tensor] = None, flags: int = 0,
               out_dtype: torch.dtype = torch.bfloat16, ln_eps: float = 1e-5) -> Tensor:
     """ispk_gemm_bf16_lnin: C[..., N] = epilogue(bf16(LayerNorm(x)) @ w[N, K]^T) with x fp32 [..., K]; the rows'
-    (mean, rstd) come from `stats` (written by `ffn_fused_stats` / `ffn_prenorm`) or, with stats None, are computed by
+    (mean, rstd) come from `stats` (written by `ffn_prenorm` / `ffn_prenorm2`) or, with stats None, are computed by
     the kernel itself."""
     _dev(x, stats, ln_weight, ln_bias, w, bias, mask)
     assert x.dtype == torch.float32 and w.dtype == torch.bfloat16

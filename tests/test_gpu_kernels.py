@@ -349,29 +349,6 @@ def test_attention_bf16(B, N, H, lens):
     assert err < 1.5e-2, err
 
 
-@pytest.mark.parametrize("R,D,Fi,ln_dtype", [(777, 384, 1536, torch.bfloat16), (16500, 384, 1536, torch.bfloat16),
-                                             (300, 256, 1024, torch.float32)])
-def test_fused_ffn_with_layernorm_epilogue(R, D, Fi, ln_dtype):
-    """ispk_ffn_bf16_ln: `out` is bit-identical to ispk_ffn_bf16's, and ln_out equals the LayerNorm kernel applied to it
-    (both two-pass fp32; only the reduction tree differs), including the row mask on ln_out."""
-    x = _bf(synth._normal(f"t/ffnln/x{R}", (R, D)))
-    w1, w2 = _bf(synth._normal(f"t/ffnln/w1{D}", (Fi, D), D ** -0.5)), _bf(synth._normal(f"t/ffnln/w2{D}", (D, Fi), Fi ** -0.5))
-    resid = synth._normal("t/ffnln/r", (R, D), 1.0, 0.3)
-    g, b = synth._normal("t/ffnln/g", (D,), 0.1, 1.0), synth._normal("t/ffnln/b", (D,), 0.1)
-    mask = torch.arange(R) % 7 != 3
-    d = lambda t: t.to(DEV)  # noqa: E731
-    w2p = runtime.ffn_pack_w2(d(w2))
-    base = runtime.ffn_fused(d(x), d(w1), w2p, resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT)
-    for ln_mask in (False, True):
-        out, ln = runtime.ffn_fused_ln(d(x), d(w1), w2p, d(g), d(b), resid=d(resid), mask=d(mask),
-                                       flags=runtime.EP_MASK_OUT, ln_mask=ln_mask, ln_dtype=ln_dtype)
-        assert torch.equal(out, base)
-        ref = runtime.layernorm(base, d(g), d(b), row_mask=d(mask) if ln_mask else None, out_dtype=ln_dtype)
-        assert ln.dtype == ln_dtype
-        tol = 2 ** -6 if ln_dtype == torch.bfloat16 else 2e-5     # bf16: one ulp at |value| <= 4
-        assert (ln.float() - ref.float()).abs().max().item() <= tol
-
-
 @pytest.mark.parametrize("R,D,N", [(5000, 384, 512), (777, 256, 384), (128 * 130, 384, 512), (31, 384, 192)])
 def test_linear_with_layernorm_prologue(R, D, N):
     """ispk_gemm_bf16_lnin == LayerNorm kernel (bf16 out) followed by ispk_gemm_bf16, given the rows' (mean, rstd):
@@ -406,29 +383,6 @@ def test_linear_with_layernorm_prologue(R, D, N):
     assert (f32.double() - ref64).abs().max().item() <= 0.08
 
 
-def test_fused_ffn_row_statistics_feed_the_next_linear():
-    """ispk_ffn_bf16_ln(ln_flags bit 2): `out` bit-identical to ispk_ffn_bf16, statistics = (mean, rstd) of `out`;
-    chained into ispk_gemm_bf16_lnin it reproduces FFN -> LayerNorm -> Linear."""
-    R, D, Fi, N = 128 * 9 + 17, 384, 1536, 512
-    x = _bf(synth._normal("t/ffnst/x", (R, D)))
-    w1, w2 = _bf(synth._normal("t/ffnst/w1", (Fi, D), D ** -0.5)), _bf(synth._normal("t/ffnst/w2", (D, Fi), Fi ** -0.5))
-    resid = synth._normal("t/ffnst/r", (R, D), 1.0, 0.3)
-    g, b = synth._normal("t/ffnst/g", (D,), 0.1, 1.0), synth._normal("t/ffnst/b", (D,), 0.1)
-    w = _bf(synth._normal("t/ffnst/w", (N, D), D ** -0.5))
-    mask = torch.arange(R) % 7 != 3
-    d = lambda t: t.to(DEV)  # noqa: E731
-    w2p = runtime.ffn_pack_w2(d(w2))
-    base = runtime.ffn_fused(d(x), d(w1), w2p, resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT)
-    out, stats = runtime.ffn_fused_stats(d(x), d(w1), w2p, resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT)
-    assert torch.equal(out, base) and stats.shape == (R, 2)
-    o64 = base.double().cpu()
-    assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
-    rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
-    assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
-    qkv = runtime.gemm_lnin(out, stats, d(g), d(b), d(w)).cpu()
-    ref = runtime.gemm(runtime.layernorm(base, d(g), d(b), out_dtype=torch.bfloat16), d(w)).cpu()
-    err = (qkv.float() - ref.float()).abs()
-    assert err.max().item() <= 2 ** -5 and err.pow(2).mean().sqrt().item() <= 2e-3
 
 
 @pytest.mark.parametrize("R,Fi,masked", [(128 * 9 + 17, 1536, True), (128 * 3, 1536, False), (70, 64, True), (128 * 40, 1536, True)])
@@ -541,32 +495,6 @@ def test_fused_ffn_with_layernorm_prologue(R, D, Fi, masked):
     assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("R,D,Fi", [(128 * 9 + 17, 384, 1536), (300, 256, 1024)])
-def test_attention_output_projection_fused_into_the_feed_forward(R, D, Fi):
-    """ispk_attn_out_ffn_bf16 == ispk_gemm_bf16 (to_out + residual + mask) followed by ispk_ffn_bf16_prenorm: x1 is the
-    same MFMA reduction in the same order (exact or an ulp apart), the block output differs by bf16 flips of the
-    normalised operand only; the statistics describe the output rows; masked rows: x1 = x, out = 0."""
-    o = _bf(synth._normal(f"t/pj/o{R}", (R, D)))
-    wo = _bf(synth._normal(f"t/pj/wo{D}", (D, D), D ** -0.5))
-    x = synth._normal(f"t/pj/x{R}", (R, D), 1.5, 0.4)
-    w1, w2 = _bf(synth._normal(f"t/pj/w1{D}", (Fi, D), D ** -0.5)), _bf(synth._normal(f"t/pj/w2{D}", (D, Fi), Fi ** -0.5))
-    g, b = synth._normal("t/pj/g", (D,), 0.1, 1.0), synth._normal("t/pj/b", (D,), 0.1)
-    mask = torch.arange(R) % 7 != 3
-    d = lambda t: t.to(DEV)  # noqa: E731
-    w2p = runtime.ffn_pack_w2(d(w2))
-    x1_ref = runtime.gemm(d(o), d(wo), resid=d(x), mask=d(mask), flags=runtime.EP_MASK_ACC, out_dtype=torch.float32)
-    ref = runtime.ffn_prenorm(x1_ref, d(g), d(b), d(w1), w2p, mask=d(mask), flags=runtime.EP_MASK_OUT)
-    out, x1, stats = runtime.attn_out_ffn(d(o), d(wo), d(x), d(g), d(b), d(w1), w2p, d(mask), want_stats=True)
-    out_b, x1_b = runtime.attn_out_ffn(d(o), d(wo), d(x), d(g), d(b), d(w1), w2p, d(mask))
-    assert torch.equal(out, out_b) and torch.equal(x1, x1_b)
-    assert (x1 - x1_ref).abs().max().item() <= 2e-6
-    assert torch.equal(x1.cpu()[~mask], x[~mask]) and out.cpu()[~mask].abs().max().item() == 0.0
-    err = (out - ref).abs()
-    assert err.max().item() <= 2e-2 and err.pow(2).mean().sqrt().item() <= 1e-3
-    o64 = out.double().cpu()
-    assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
-    rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
-    assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
 
 
 def test_attention_bf16_several_query_tiles_per_workgroup():
@@ -799,38 +727,8 @@ def test_soft_average_targets():
     assert (got - want).abs().max() < 2e-6
 
 
-@pytest.mark.parametrize("M,N,K", [(21000, 384, 1536), (6400, 384, 384), (2100, 256, 1024)])
-def test_gemm_bf16_with_fused_layernorm(M, N, K):
-    """ispk_gemm_bf16_ln: C = mask*(resid + A·Wᵀ) in fp32 and LN(C)*mask in bf16 from one kernel."""
-    a, w = _bf(synth._normal(f"t/gln/a{M}", (M, K))), _bf(synth._normal(f"t/gln/w{N}x{K}", (N, K), K ** -0.5))
-    resid = synth._normal("t/gln/r", (M, N))
-    g, b = synth._normal("t/gln/g", (N,), 0.1, 1.0), synth._normal("t/gln/b", (N,), 0.1)
-    mask = torch.arange(M) % 7 != 3
-    d = lambda t: t.to(DEV)  # noqa: E731
-    out, ln = runtime.gemm_ln(d(a), d(w), d(g), d(b), resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_OUT, ln_mask=True)
-    ref = _gemm_ref(a, w, resid=resid, mask=mask, mask_out=True)
-    assert (out.cpu().double() - ref).abs().max() < 3e-5
-    ln_ref = F.layer_norm(ref, (N,), g.double(), b.double(), 1e-5) * mask[:, None]
-    assert ln.dtype == torch.bfloat16
-    assert ((ln.cpu().double() - ln_ref).abs() <= ln_ref.abs() * 2 ** -8 + 2e-5).all()
-    out32, ln32 = runtime.gemm_ln(d(a), d(w), d(g), d(b), resid=d(resid), ln_dtype=torch.float32)
-    ref2 = _gemm_ref(a, w, resid=resid)
-    assert (ln32.cpu().double() - F.layer_norm(ref2, (N,), g.double(), b.double(), 1e-5)).abs().max() < 3e-5
 
 
-def test_transformer_with_fused_layernorm_matches_unfused(gpu_model):
-    x = synth._normal("t/fln/x", (3, 100, 384)).to(DEV)
-    mask = (torch.arange(100)[None] < torch.tensor([100, 61, 9])[:, None]).to(DEV)
-    enc = gpu_model.encoder
-    try:
-        enc.set_compute_dtype(torch.bfloat16)
-        base = enc(x, mask=mask).out
-        enc.fuse_layernorm = True
-        fused = enc(x, mask=mask).out
-    finally:
-        enc.fuse_layernorm = False
-        enc.set_compute_dtype(torch.float32)
-    assert (fused - base).abs().max() < 3e-2 and (fused - base).pow(2).mean().sqrt() < 4e-3
 
 
 @pytest.mark.parametrize("R,D,Fi", [(777, 384, 1536), (16500, 384, 1536), (300, 256, 1024)])

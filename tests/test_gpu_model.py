@@ -501,30 +501,6 @@ def test_bf16_fused_ffn_matches_two_gemm_path_at_full_size(gpu_model):
     assert (fused * ~mask[..., None]).abs().max() == 0
 
 
-def test_bf16_chained_layernorm_matches_separate_layernorm_at_full_size(gpu_model):
-    """Decoder stack at the benchmark shape with every LayerNorm after a feed-forward emitted by the fused FFN kernel's
-    epilogue (`Transformer.chain_layernorm`, opt-in) against the same stack with separate LayerNorm launches: the
-    same fp32 two-pass statistics on the same values, so only 1-ulp bf16 roundings of the normalised rows differ (an ulp
-    is 2^-7 at |value| in [1, 2)); through 6 layers they stay a fraction of an ulp in RMS."""
-    x = synth._normal("t/chain/x", (64, 512, 384)).to(DEV)
-    lens = torch.full((64,), 512, device=DEV)
-    lens[2::5] = 211
-    mask = torch.arange(512, device=DEV)[None] < lens[:, None]
-    dec = gpu_model.decoder
-    try:
-        dec.set_compute_dtype(torch.bfloat16)
-        dec.stats_layernorm = False
-        plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
-        del dec.stats_layernorm
-        dec.chain_layernorm = True
-        chained = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
-    finally:
-        dec.chain_layernorm = False
-        dec.set_compute_dtype(torch.float32)
-    assert chained.dtype == torch.bfloat16
-    diff = (chained.float() - plain.float()).abs()
-    assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
-    assert (chained.float() * ~mask[..., None]).abs().max() == 0
 
 
 def test_bf16_layernorm_statistics_handoff_matches_separate_layernorm_at_full_size(gpu_model, monkeypatch):
@@ -574,24 +550,6 @@ def test_bf16_prenorm_feed_forward_matches_separate_layernorm_at_full_size(gpu_m
     assert (fused.float() * ~mask[..., None]).abs().max() == 0
 
 
-def test_bf16_fused_output_projection_matches_separate_launches_at_full_size(gpu_model, monkeypatch):
-    """Decoder stack at the benchmark shape with to_out + residual + mask inside the feed-forward kernel
-    (ispk_attn_out_ffn_bf16, opt-in) against out-projection GEMM + pre-norm feed-forward kernel (the default)."""
-    x = synth._normal("t/chain/x", (64, 512, 384)).to(DEV)
-    lens = torch.full((64,), 512, device=DEV)
-    lens[2::5] = 211
-    mask = torch.arange(512, device=DEV)[None] < lens[:, None]
-    dec = gpu_model.decoder
-    try:
-        dec.set_compute_dtype(torch.bfloat16)
-        plain = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
-        monkeypatch.setattr(TransformerLayer, "fuse_out_proj", True)   # opt-in (measured slower than the two launches)
-        fused = dec(x, mask=mask, key_len=lens, out_dtype=torch.bfloat16).out
-    finally:
-        dec.set_compute_dtype(torch.float32)
-    diff = (fused.float() - plain.float()).abs()
-    assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
-    assert (fused.float() * ~mask[..., None]).abs().max() == 0
 
 
 def test_bf16_encoder_with_layernorms_inside_the_gemms_matches_separate_layernorms(gpu_model, monkeypatch):

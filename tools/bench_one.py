@@ -47,8 +47,6 @@ cases.update({
     "layernorm 384 bf16 out": (lambda: runtime.layernorm(resid, gam, bet, out_dtype=dt), 0.0),
     "ffn_prenorm (fp32 x, own LN)": (lambda: runtime.ffn_prenorm(resid, gam, bet, w1, w2p, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),
     "ffn_prenorm + stats": (lambda: runtime.ffn_prenorm(resid, gam, bet, w1, w2p, mask=mask, flags=runtime.EP_MASK_OUT, want_stats=True), 4.0 * R * 384 * 1536),
-    "attn_out_ffn (proj+LN+ffn+stats)": (lambda: runtime.attn_out_ffn(x, wo, resid, gam, bet, w1, w2p, mask, want_stats=True), 4.0 * R * 384 * 1536 + 2.0 * R * 384 * 384),
-    "ffn_fused + stats": (lambda: runtime.ffn_fused_stats(x, w1, w2p, resid=resid, mask=mask, flags=runtime.EP_MASK_OUT), 4.0 * R * 384 * 1536),
 })
 only = sys.argv[1:]
 graphs = {}

@@ -56,9 +56,10 @@ def parse(argv=None):
     ap.add_argument("--dtype", choices=["f32", "bf16", "split"], default="bf16",
                     help="bf16 = BASELINE config 3 (throughput path); f32 = the 1e-4 parity path on exact-fp32 MFMAs; "
                          "split = the 1e-4 parity path on split-fp16 products (three fp16 MFMAs per fp32-grade product)")
-    ap.add_argument("--alignment", choices=["auto", "f32"], default="auto",
+    ap.add_argument("--alignment", choices=["auto", "f32", "split"], default="auto",
                     help="precision of the chain upstream of MAS (text encoder + aligner front-end): auto = --dtype; "
-                         "f32 = fp32 whatever --dtype is (MAS paths identical to the fp32 path)")
+                         "f32 = fp32 whatever --dtype is (MAS paths identical to the fp32 path); split = split-fp16 products "
+                         "(fp32-grade logits at a third of the fp32 chain's cost)")
     ap.add_argument("--in-flight", type=int, default=1,
                     help="batches in flight per GPU for the headline value (graph instances replayed round-robin on their "
                          "own streams); the 2-in-flight figure is always reported as an extra")
@@ -264,7 +265,7 @@ def worker(args) -> int:
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
     cdt = {"f32": torch.float32, "bf16": torch.bfloat16, "split": torch.float16}[args.dtype]
-    align_dt = torch.float32 if args.alignment == "f32" else None
+    align_dt = {"f32": torch.float32, "split": torch.float16}.get(args.alignment)
     model.set_compute_dtype(cdt, alignment_dtype=align_dt)
 
     L, M = args.text_len, args.mel_len
@@ -557,6 +558,21 @@ def worker(args) -> int:
                     "note": "bf16 decoder / adaptor with the text encoder in fp32 as well: everything upstream of MAS is the "
                             "fp32 path's arithmetic, so alignments and durations are bit-identical to the fp32 path's"}, paths
 
+        def split_chain_line():
+            """bf16 decoder / adaptor with the chain upstream of MAS on split-fp16 products."""
+            if args.dtype != "bf16" or args.alignment != "auto":
+                return None
+            model.set_compute_dtype(torch.bfloat16, alignment_dtype=torch.float16)
+            try:
+                g = GraphedForward(model, *fwd_args(d))
+                sec = timed_graph(g, 10)
+                paths = g.out.aligner_output.attn_hard.clone()
+            finally:
+                model.set_compute_dtype(cdt, alignment_dtype=align_dt)
+            return {"value": round(B * M / sec, 1), "unit": "mel-frames/s", "ms_per_step": round(sec * 1e3, 3), "steps": 10,
+                    "note": "bf16 decoder / adaptor; text encoder + aligner front-end on split-fp16 products (fp32-grade logits: "
+                            "the MAS paths of the parity path at a fraction of the exact-fp32 chain's cost)"}, paths
+
         def f32_line():
             model.set_compute_dtype(torch.float32)
             try:
@@ -620,6 +636,17 @@ def worker(args) -> int:
                     res["mas_paths_identical_to_fp32_path"] = f"{int(same.sum())}/{B}"
                 return res
             extra("fp32_alignment_chain", run_chain)
+
+            def run_split_chain():
+                r = split_chain_line()
+                if r is None:
+                    return None
+                res, pc = r
+                if "p32" in state:
+                    same = (pc == state["p32"]).flatten(1).all(1)
+                    res["mas_paths_identical_to_fp32_path"] = f"{int(same.sum())}/{B}"
+                return res
+            extra("split_fp16_alignment_chain", run_split_chain)
 
             def accuracy():
                 """the headline path's outputs against the fp32 path of the same build on the same batch"""

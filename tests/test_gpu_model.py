@@ -286,6 +286,24 @@ def test_headline_config_bf16_with_fp32_alignment_chain_has_the_fp32_paths(gpu_m
     assert err.max().item() < BF16_MEL_TOL
 
 
+def test_headline_config_bf16_with_split_fp16_alignment_chain_has_the_oracle_paths(gpu_model, headline_case):
+    """`set_compute_dtype(bf16, alignment_dtype=torch.float16)`: the chain upstream of MAS (text encoder, aligner front-end)
+    on split-fp16 products - fp32-grade logits at a third of the exact-fp32 chain's cost - under the bf16 decoder / adaptor:
+    all 64 hard alignments and durations equal the ORACLE's, mel within the bf16 bound."""
+    inp, ref = headline_case
+    try:
+        gpu_model.set_compute_dtype(torch.bfloat16, alignment_dtype=torch.float16)
+        out = _run_headline(gpu_model, inp)
+    finally:
+        gpu_model.set_compute_dtype(torch.float32)
+    same = _identical_paths(out.aligner_output.attn_hard, ref.aligner.attn_hard)
+    err = (out.mel.cpu() - ref.mel).abs().max().item()
+    print(f"B=64 bf16 + split-fp16 alignment chain: {same}/64 alignments identical to the oracle's, mel L-inf {err:.3e}")
+    assert same == 64 and torch.equal(out.aligner_output.attn_hard_duration.cpu(), ref.aligner.attn_hard_duration)
+    assert _maxdiff(out.aligner_output.attn_logits, ref.aligner.attn_logits) < 5e-4
+    assert err < BF16_MEL_TOL
+
+
 @pytest.mark.parametrize("which", ["longest", "shortest"])
 def test_config4_shapes_against_the_oracle(gpu_model, state_dict, which):
     """BASELINE config 4 shapes (B=256, 128..1024 frames, up to 200 tokens, sharded over 8 ranks): the micro-batch rank 0
@@ -317,6 +335,16 @@ def test_config4_shapes_against_the_oracle(gpu_model, state_dict, which):
     hard = gpu_model.aligner.binarize_attention_parallel(ref.aligner.attn_logits.to(DEV), mb["text_len"].to(DEV),
                                                          mb["mel_len"].to(DEV))
     assert torch.equal(hard.cpu(), ref.aligner.attn_hard)
+    # the parity-grade fast path (split-fp16 products) on the same micro-batch: the 1e-4 bar and the oracle's alignments
+    try:
+        gpu_model.set_compute_dtype(torch.float16)
+        outs = _run_headline(gpu_model, mb)
+    finally:
+        gpu_model.set_compute_dtype(torch.float32)
+    ds = _maxdiff(outs.mel[:, :, :mx], ref.mel)
+    same = _identical_paths(outs.aligner_output.attn_hard[:, :mx, :lx], ref.aligner.attn_hard)
+    print(f"config 4 ({which}) split-fp16: mel L-inf vs oracle = {ds:.3e}, {same}/{len(idx)} alignments identical to the oracle's")
+    assert ds < MEL_TOL and same == len(idx) and torch.equal(outs.adaptor_output.dec_lengths.cpu(), ref.adaptor.dec_lengths)
     try:
         gpu_model.set_compute_dtype(torch.bfloat16)
         out16 = _run_headline(gpu_model, mb)

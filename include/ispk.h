@@ -242,8 +242,9 @@ int32_t ispk_alibi_mqa_attn_bf16_tiles(const uint16_t* q, int64_t ldq, const uin
  * kernel 5 / padding 2 over such a buffer is ONE ispk_gemm_f32 call over overlapping rows (lda = C, K = 5*C,
  * M = B*(T+4) - 4, weight [O][5*C] = conv.weight.permute(0,2,1)); output row b*(T+4)+t is frame t.
  *
- * Both kernels read fp32 and write fp32, or bf16 when out_bf16 != 0 (the bf16 throughput path then runs the conv GEMMs
- * on ispk_gemm_bf16 with fp32 outputs, so statistics and scores stay fp32).
+ * Both kernels read fp32 and write fp32 (out_bf16 == 0), bf16 (1: the bf16 throughput path then runs the conv GEMMs on
+ * ispk_gemm_bf16 with fp32 outputs, so statistics and scores stay fp32) or split fp16 planes (2: hi plane at `out`, lo plane
+ * B*(T+4)*C elements behind - the operand format of ispk_gemm_split_f16, the parity-grade fast path).
  * ispk_pad_rows_f32        out[b][t+2][c] = t < len[b] ? x[b*sb + t*st + c*sc] : 0, pad rows zero
  *                          (x*mask of alignment.py:75 plus the layout change; strides in elements, so a channel-first
  *                           mel [B][C][T] is read with st = 1, sc = T).
@@ -344,6 +345,10 @@ int32_t ispk_length_regulate_f32(const float* alignment, const float* dur_f32, c
 int32_t ispk_length_regulate_split_bf16(const float* alignment, const float* dur_f32, const int64_t* dur_i64, const int64_t* enc_len,
                                  const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
                                  int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream);
+/* ... and for the split-fp16 parity path: the same three products over fp16 terms (22 significant bits per operand: fp32-grade). */
+int32_t ispk_length_regulate_split_f16(const float* alignment, const float* dur_f32, const int64_t* dur_i64, const int64_t* enc_len,
+                                const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
+                                int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Training step (BASELINE config 5): fp32 kernels with the recipes' dropout; under AMP the Linear GEMMs and

@@ -100,11 +100,11 @@ class ConvAttention(nn.Module, Constructor):
         _, wq = self._staged()
         gelu, dt = runtime.EP_GELU, self.compute_dtype
         if dt == torch.float16:   # split-fp16 path: conv operands as hi / lo planes, conv outputs and statistics fp32
-            q = runtime.split_f16(runtime.pad_rows(queries.float(), query_len, channel_first=True))
+            q = runtime.pad_rows(queries.float(), query_len, channel_first=True, out_dtype=dt)       # split planes out
             for i in (0, 1):
                 q = runtime.conv5_padded_split(q, wq[i], gelu)
-                q = runtime.split_f16(runtime.masked_instnorm(q, self.query_proj[i].norm.weight, self.query_proj[i].norm.bias,
-                                                              query_len))
+                q = runtime.masked_instnorm(q, self.query_proj[i].norm.weight, self.query_proj[i].norm.bias, query_len,
+                                            out_dtype=dt)
             return runtime.conv5_padded_split(q, wq[2])
         q = runtime.pad_rows(queries.float(), query_len, channel_first=True, out_dtype=dt)
         q = runtime.conv5_padded(q, wq[0], gelu)
@@ -126,9 +126,9 @@ class ConvAttention(nn.Module, Constructor):
         max_q, max_k = queries.shape[2], keys.shape[2]
         gelu, dt = runtime.EP_GELU, self.compute_dtype   # bf16 path: bf16 conv operands, fp32 conv outputs / statistics
         if dt == torch.float16:
-            k = runtime.split_f16(runtime.pad_rows(keys.float(), key_len, channel_first=True))
+            k = runtime.pad_rows(keys.float(), key_len, channel_first=True, out_dtype=dt)
             k = runtime.conv5_padded_split(k, wk[0], gelu)
-            k = runtime.split_f16(runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len))
+            k = runtime.masked_instnorm(k, self.key_proj[0].norm.weight, self.key_proj[0].norm.bias, key_len, out_dtype=dt)
             k = runtime.conv5_padded_split(k, wk[1])
             q = q_proj if q_proj is not None else self.project_queries(queries, query_len)
             return runtime.aligner_scores(q, k, key_len, query_len, max_q, max_k)

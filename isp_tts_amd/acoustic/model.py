@@ -80,7 +80,10 @@ class AcousticModel(nn.Module, Constructor):
         self.temporal_adaptor.predictor.transformer.set_compute_dtype(dtype)
         self.temporal_adaptor.embedding.transformer.set_compute_dtype(dtype)
         self.aligner.attention.compute_dtype = chain
-        self.temporal_adaptor.length_regulator.split_bf16 = dtype == torch.bfloat16    # three bf16 MFMAs per product (2^-16)
+        # the regulator's products: exact fp32 MFMAs (fp32 path), three bf16 MFMAs (bf16 path: 2^-16), three fp16 MFMAs over
+        # 22-bit operands (split-fp16 path: fp32-grade)
+        self.temporal_adaptor.length_regulator.split_bf16 = (True if dtype == torch.bfloat16 else
+                                                             "f16" if dtype == torch.float16 else False)
         self.compute_dtype = dtype
         return self
 

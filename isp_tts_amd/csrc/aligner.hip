@@ -24,11 +24,22 @@ namespace {
 template <typename T_> __device__ __forceinline__ void put(T_* p, float v);
 template <> __device__ __forceinline__ void put<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void put<uint16_t>(uint16_t* p, float v) { *p = f32_to_bf16(v); }
+// split fp16 planes (csrc/split.hip): hi = fp16(v) at p, lo = fp16(v - hi) `plane` elements behind; OutT = _Float16
+__device__ __forceinline__ void put_split(_Float16* p, float v, int64_t plane) {
+    v = __builtin_amdgcn_fmed3f(v, -65504.0f, 65504.0f);
+    const _Float16 hi = (_Float16)v;
+    p[0] = hi;
+    p[plane] = (_Float16)(v - (float)hi);
+}
+template <typename OutT> __device__ __forceinline__ void put_any(OutT* p, float v, int64_t plane) {
+    if constexpr (std::is_same<OutT, _Float16>::value) put_split(p, v, plane);
+    else put<OutT>(p, v);
+}
 
 template <typename OutT>
 __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ x, int64_t sb, int64_t st, int64_t sc,
                                                        const int64_t* __restrict__ len, OutT* __restrict__ out, int T,
-                                                       int C, int64_t total) {
+                                                       int C, int64_t total, int64_t plane) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
     const int c = (int)(idx % C);
@@ -37,7 +48,7 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
     const int t = tp - 2;
     float v = 0.f;
     if (t >= 0 && t < T && t < (int)len[b]) v = x[b * sb + t * st + c * sc];
-    put<OutT>(out + idx, v);
+    put_any<OutT>(out + idx, v, plane);
 }
 
 // Channel-first input ([B][C][T], time contiguous: the collator's mel layout): a 32 x 32 tile transposed through LDS so
@@ -46,7 +57,7 @@ __global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__
 template <typename OutT>
 __global__ __launch_bounds__(256) void pad_rows_cf_kernel(const float* __restrict__ x, int64_t sb, int64_t sc,
                                                           const int64_t* __restrict__ len, OutT* __restrict__ out, int T,
-                                                          int C) {
+                                                          int C, int64_t plane) {
     __shared__ float tile[32][33];
     const int tx = threadIdx.x, ty = threadIdx.y, b = blockIdx.z;
     const int tp0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -61,7 +72,7 @@ __global__ __launch_bounds__(256) void pad_rows_cf_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int tp = tp0 + ty + 8 * k, c = c0 + tx;
-        if (tp < T + 4 && c < C) put<OutT>(out + ((int64_t)b * (T + 4) + tp) * C + c, tile[tx][ty + 8 * k]);
+        if (tp < T + 4 && c < C) put_any<OutT>(out + ((int64_t)b * (T + 4) + tp) * C + c, tile[tx][ty + 8 * k], plane);
     }
 }
 
@@ -74,7 +85,7 @@ template <typename OutT>
 __global__ __launch_bounds__(1024) void masked_instnorm_kernel(const float* __restrict__ y, const float* __restrict__ w,
                                                                const float* __restrict__ bias,
                                                                const int64_t* __restrict__ len, OutT* __restrict__ out,
-                                                               int T, int C, float eps) {
+                                                               int T, int C, float eps, int64_t plane) {
     __shared__ float red[kTL][64];
     const int cl = threadIdx.x & 63, tl = threadIdx.x >> 6;
     const int b = blockIdx.y, c = blockIdx.x * 64 + cl;
@@ -137,7 +148,7 @@ __global__ __launch_bounds__(1024) void masked_instnorm_kernel(const float* __re
         const int tc = t < 0 ? 0 : (t < n ? t : n - 1);          // clamped (always in-bounds) load, selected below
         const float raw = yb[(int64_t)tc * C + c];
         const float v = (t >= 0 && t < n) ? (raw - mean) * rstd * g + be : 0.f;
-        put<OutT>(ob + (int64_t)tp * C + c, v);
+        put_any<OutT>(ob + (int64_t)tp * C + c, v, plane);
     }
 }
 
@@ -582,22 +593,29 @@ extern "C" int32_t ispk_pad_rows_f32(const float* x, int64_t stride_b, int64_t s
     const int64_t total = (int64_t)B * (T + 4) * C;
     dim3 grid((unsigned)((total + 255) / 256));
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    ISPK_REQUIRE(out_bf16 >= 0 && out_bf16 <= 2, ISPK_E_UNSUPPORTED, "pad_rows: output mode %d (0 fp32, 1 bf16, 2 split fp16 planes)", out_bf16);
     if (stride_t == 1 && stride_c > 1 && B <= 65535) {   // channel-first: transposing tile kernel
         dim3 gcf((T + 4 + 31) / 32, (C + 31) / 32, B), bcf(32, 8);
-        if (out_bf16)
+        if (out_bf16 == 2)
+            hipLaunchKernelGGL(pad_rows_cf_kernel<_Float16>, gcf, bcf, 0, s, x, stride_b, stride_c, len,
+                               static_cast<_Float16*>(out), T, C, total);
+        else if (out_bf16)
             hipLaunchKernelGGL(pad_rows_cf_kernel<uint16_t>, gcf, bcf, 0, s, x, stride_b, stride_c, len,
-                               static_cast<uint16_t*>(out), T, C);
+                               static_cast<uint16_t*>(out), T, C, (int64_t)0);
         else
             hipLaunchKernelGGL(pad_rows_cf_kernel<float>, gcf, bcf, 0, s, x, stride_b, stride_c, len,
-                               static_cast<float*>(out), T, C);
+                               static_cast<float*>(out), T, C, (int64_t)0);
         return ispk_launch_status();
     }
-    if (out_bf16)
+    if (out_bf16 == 2)
+        hipLaunchKernelGGL(pad_rows_kernel<_Float16>, grid, dim3(256), 0, s, x, stride_b, stride_t, stride_c, len,
+                           static_cast<_Float16*>(out), T, C, total, total);
+    else if (out_bf16)
         hipLaunchKernelGGL(pad_rows_kernel<uint16_t>, grid, dim3(256), 0, s, x, stride_b, stride_t, stride_c, len,
-                           static_cast<uint16_t*>(out), T, C, total);
+                           static_cast<uint16_t*>(out), T, C, total, (int64_t)0);
     else
         hipLaunchKernelGGL(pad_rows_kernel<float>, grid, dim3(256), 0, s, x, stride_b, stride_t, stride_c, len,
-                           static_cast<float*>(out), T, C, total);
+                           static_cast<float*>(out), T, C, total, (int64_t)0);
     return ispk_launch_status();
 }
 
@@ -610,12 +628,16 @@ extern "C" int32_t ispk_masked_instnorm_f32(const float* y, const float* weight,
     if (B == 0) return 0;
     dim3 grid((C + 63) / 64, B);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    if (out_bf16)
+    ISPK_REQUIRE(out_bf16 >= 0 && out_bf16 <= 2, ISPK_E_UNSUPPORTED, "masked_instnorm: output mode %d (0 fp32, 1 bf16, 2 split fp16 planes)", out_bf16);
+    if (out_bf16 == 2)
+        hipLaunchKernelGGL(masked_instnorm_kernel<_Float16>, grid, dim3(1024), 0, s, y, weight, bias, len,
+                           static_cast<_Float16*>(out), T, C, eps, (int64_t)B * (T + 4) * C);
+    else if (out_bf16)
         hipLaunchKernelGGL(masked_instnorm_kernel<uint16_t>, grid, dim3(1024), 0, s, y, weight, bias, len,
-                           static_cast<uint16_t*>(out), T, C, eps);
+                           static_cast<uint16_t*>(out), T, C, eps, (int64_t)0);
     else
         hipLaunchKernelGGL(masked_instnorm_kernel<float>, grid, dim3(1024), 0, s, y, weight, bias, len,
-                           static_cast<float*>(out), T, C, eps);
+                           static_cast<float*>(out), T, C, eps, (int64_t)0);
     return ispk_launch_status();
 }
 

@@ -80,27 +80,49 @@ constexpr int kLrRows = 64, kLrChunk = 16, kLrAld = kLrChunk + 1;
 // is below 2^-16 of the product) instead of eight v_mfma_f32_32x32x2_f32: 18 MFMAs of 32 cycles per 16-token chunk and wave
 // against 48 of 64 cycles, at ~2^-16 relative error per product - three decimal digits finer than the bf16 GEMMs the result
 // feeds.  The fp32 parity path keeps the exact fp32 MFMAs.
+// kSplit == 2 (ispk_length_regulate_split_f16, the split-fp16 parity path): the same three products over fp16 terms - 22
+// significant bits per operand, fp32-grade results (csrc/split.hip) - on v_mfma_f32_32x32x16_f16.
 typedef uint32_t lr_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 lr_f16x8 __attribute__((ext_vector_type(8)));
+template <int kSplit>
 __device__ __forceinline__ void lr_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
     typedef float f2 __attribute__((ext_vector_type(2)));
     union { lr_u32x4 u; bf16x8 f; } h, l;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         f2 a;
         a.x = v[2 * e]; a.y = v[2 * e + 1];
-        const uint32_t ph = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2));
-        f2 r;
-        r.x = a.x - __builtin_bit_cast(float, ph << 16);
-        r.y = a.y - __builtin_bit_cast(float, ph & 0xffff0000u);
-        h.u[e] = ph;
-        l.u[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf2));
+        if constexpr (kSplit == 2) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            a.x = __builtin_amdgcn_fmed3f(a.x, -65504.0f, 65504.0f);
+            a.y = __builtin_amdgcn_fmed3f(a.y, -65504.0f, 65504.0f);
+            h2 ph, pl;
+            ph.x = (_Float16)a.x; ph.y = (_Float16)a.y;
+            pl.x = (_Float16)(a.x - (float)ph.x); pl.y = (_Float16)(a.y - (float)ph.y);
+            h.u[e] = __builtin_bit_cast(uint32_t, ph);
+            l.u[e] = __builtin_bit_cast(uint32_t, pl);
+        } else {
+            typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+            const uint32_t ph = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, bf2));
+            f2 r;
+            r.x = a.x - __builtin_bit_cast(float, ph << 16);
+            r.y = a.y - __builtin_bit_cast(float, ph & 0xffff0000u);
+            h.u[e] = ph;
+            l.u[e] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf2));
+        }
     }
     hi = h.f;
     lo = l.f;
 }
+template <int kSplit>
+__device__ __forceinline__ f32x16 lr_mfma(const bf16x8& a, const bf16x8& b, const f32x16& c) {
+    if constexpr (kSplit == 2)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(lr_f16x8, a), __builtin_bit_cast(lr_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
 
-template <int NT, bool kSplit = false>   // D = 128 * NT: a wave owns NT 32-feature tiles
+template <int NT, int kSplit = 0>   // D = 128 * NT: a wave owns NT 32-feature tiles; kSplit: 0 exact fp32, 1 bf16 terms, 2 fp16 terms
 __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __restrict__ align, const float* __restrict__ dur_f,
                                                               const int64_t* __restrict__ dur_i,
                                                               const int64_t* __restrict__ enc_len,
@@ -206,7 +228,7 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
         __syncthreads();
         if (t0 + kLrChunk < L) fetch(t0 + kLrChunk);
         const int r = lane & 31, kh = lane >> 5;
-        if constexpr (kSplit) {
+        if constexpr (kSplit != 0) {
             // lane half kh takes tokens 8 kh .. 8 kh + 7 of the chunk in both operands
             bf16x8 ah[2], al[2];
 #pragma unroll
@@ -214,7 +236,7 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
                 float av[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) av[e] = As[(32 * rt + r) * kLrAld + 8 * kh + e];
-                lr_split8(av, ah[rt], al[rt]);
+                lr_split8<kSplit>(av, ah[rt], al[rt]);
             }
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
@@ -222,12 +244,12 @@ __global__ __launch_bounds__(256) void length_regulate_kernel(const float* __res
 #pragma unroll
                 for (int e = 0; e < 8; ++e) bv[e] = Xs[(8 * kh + e) * D + wave * (32 * NT) + ct * 32 + r];
                 bf16x8 bh, bl;
-                lr_split8(bv, bh, bl);
+                lr_split8<kSplit>(bv, bh, bl);
 #pragma unroll
                 for (int rt = 0; rt < 2; ++rt) {
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], bh, acc[rt][ct], 0, 0, 0);
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bl, acc[rt][ct], 0, 0, 0);
-                    acc[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], bh, acc[rt][ct], 0, 0, 0);
+                    acc[rt][ct] = lr_mfma<kSplit>(al[rt], bh, acc[rt][ct]);
+                    acc[rt][ct] = lr_mfma<kSplit>(ah[rt], bl, acc[rt][ct]);
+                    acc[rt][ct] = lr_mfma<kSplit>(ah[rt], bh, acc[rt][ct]);
                 }
             }
             continue;
@@ -288,7 +310,7 @@ extern "C" int32_t ispk_time_embedding_f32(const float* t, int32_t n, const floa
 static int32_t length_regulate_launch(const float* alignment, const float* dur_f32, const int64_t* dur_i64, const int64_t* enc_len,
                                       const float* x, int64_t ldx, float* out, int64_t* dec_len, uint8_t* dec_mask, int32_t B,
                                       int32_t M, int32_t L, int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream,
-                                      bool split) {
+                                      int split) {
     ISPK_REQUIRE(x && out && dec_len, ISPK_E_NULL, "length_regulate: null pointer");
     ISPK_REQUIRE((dur_f32 != nullptr) != (dur_i64 != nullptr), ISPK_E_NULL,
                  "length_regulate: exactly one of dur_f32 / dur_i64 must be given");
@@ -310,8 +332,8 @@ static int32_t length_regulate_launch(const float* alignment, const float* dur_f
         hipLaunchKernelGGL((length_regulate_kernel<NT_, SP_>), grid, dim3(256), lds, s, alignment, dur_f32, dur_i64, enc_len, x, \
                            ldx, out, dec_len, dec_mask, M, L, max_len, dur_cols);                                      \
     } while (0)
-    if (D == 384) { if (split) ISPK_LR(3, true); else ISPK_LR(3, false); }
-    else { if (split) ISPK_LR(2, true); else ISPK_LR(2, false); }
+    if (D == 384) { if (split == 2) ISPK_LR(3, 2); else if (split) ISPK_LR(3, 1); else ISPK_LR(3, 0); }
+    else { if (split == 2) ISPK_LR(2, 2); else if (split) ISPK_LR(2, 1); else ISPK_LR(2, 0); }
 #undef ISPK_LR
     return ispk_launch_status();
 }
@@ -321,7 +343,7 @@ extern "C" int32_t ispk_length_regulate_f32(const float* alignment, const float*
                                             int64_t* dec_len, uint8_t* dec_mask, int32_t B, int32_t M, int32_t L, int32_t D,
                                             int32_t max_len, int32_t dur_cols, ispk_stream_t stream) {
     return length_regulate_launch(alignment, dur_f32, dur_i64, enc_len, x, ldx, out, dec_len, dec_mask, B, M, L, D, max_len, dur_cols,
-                                  stream, false);
+                                  stream, 0);
 }
 
 extern "C" int32_t ispk_length_regulate_split_bf16(const float* alignment, const float* dur_f32, const int64_t* dur_i64,
@@ -329,5 +351,13 @@ extern "C" int32_t ispk_length_regulate_split_bf16(const float* alignment, const
                                                    int64_t* dec_len, uint8_t* dec_mask, int32_t B, int32_t M, int32_t L,
                                                    int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream) {
     return length_regulate_launch(alignment, dur_f32, dur_i64, enc_len, x, ldx, out, dec_len, dec_mask, B, M, L, D, max_len, dur_cols,
-                                  stream, true);
+                                  stream, 1);
+}
+
+extern "C" int32_t ispk_length_regulate_split_f16(const float* alignment, const float* dur_f32, const int64_t* dur_i64,
+                                                  const int64_t* enc_len, const float* x, int64_t ldx, float* out,
+                                                  int64_t* dec_len, uint8_t* dec_mask, int32_t B, int32_t M, int32_t L,
+                                                  int32_t D, int32_t max_len, int32_t dur_cols, ispk_stream_t stream) {
+    return length_regulate_launch(alignment, dur_f32, dur_i64, enc_len, x, ldx, out, dec_len, dec_mask, B, M, L, D, max_len, dur_cols,
+                                  stream, 2);
 }

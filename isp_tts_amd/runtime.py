@@ -61,6 +61,7 @@ SIGNATURES = {
     "ispk_time_embedding_f32": [_P, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P],
     "ispk_length_regulate_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "ispk_length_regulate_split_bf16": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
+    "ispk_length_regulate_split_f16": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "ispk_pad_rows_f32": [_P, _I64, _I64, _I64, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_masked_instnorm_f32": [_P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _F32, _P],
     "ispk_aligner_scores_f32": [_P, _I64, _P, _I64, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
@@ -696,9 +697,10 @@ def pad_rows(x: Tensor, lengths: Tensor, channel_first: bool = False, out_dtype:
         B, T, C = x.shape
         sb, st, sc = x.stride()
     lengths = lengths.to(torch.int64).contiguous()
-    out = torch.empty((B, T + 4, C), dtype=out_dtype, device=x.device)
+    split = out_dtype == torch.float16      # split fp16 planes [2, B, T+4, C] (hi, lo): the split-fp16 GEMMs' operand format
+    out = torch.empty((2, B, T + 4, C) if split else (B, T + 4, C), dtype=out_dtype, device=x.device)
     _launch("pad_rows_kernel", 0.0, 8.0 * B * T * C, lib().ispk_pad_rows_f32, x.data_ptr(), sb, st, sc,
-            lengths.data_ptr(), out.data_ptr(), int(out_dtype == torch.bfloat16), B, T, C, _stream())
+            lengths.data_ptr(), out.data_ptr(), 2 if split else int(out_dtype == torch.bfloat16), B, T, C, _stream())
     return out
 
 
@@ -727,10 +729,11 @@ def masked_instnorm(y: Tensor, weight: Tensor, bias: Tensor, lengths: Tensor, ep
     """ispk_masked_instnorm_f32: conv output [B,T+4,C] (row t = frame t) -> normalised, masked, re-padded [B,T+4,C]."""
     _dev(y, weight, bias, lengths)
     B, TP, C = y.shape
-    out = torch.empty(y.shape, dtype=out_dtype, device=y.device)
+    split = out_dtype == torch.float16      # split fp16 planes [2, B, T+4, C]
+    out = torch.empty((2, *y.shape) if split else y.shape, dtype=out_dtype, device=y.device)
     lengths = lengths.to(torch.int64).contiguous()
     _launch("masked_instnorm_kernel", 0.0, 16.0 * B * TP * C, lib().ispk_masked_instnorm_f32, y.data_ptr(),
-            weight.data_ptr(), bias.data_ptr(), lengths.data_ptr(), out.data_ptr(), int(out_dtype == torch.bfloat16), B,
+            weight.data_ptr(), bias.data_ptr(), lengths.data_ptr(), out.data_ptr(), 2 if split else int(out_dtype == torch.bfloat16), B,
             TP - 4, C, eps, _stream())
     return out
 
@@ -860,10 +863,11 @@ def time_embedding(t: Tensor, inv_freq: Tensor, freq_scale: Tensor, w0: Tensor, 
 
 
 def length_regulate(x: Tensor, durations: Tensor, alignment: Optional[Tensor], frames: int, max_len: int = -1,
-                    enc_len: Optional[Tensor] = None, want_mask: bool = True, split_bf16: bool = False):
+                    enc_len: Optional[Tensor] = None, want_mask: bool = True, split_bf16=False):
     """ispk_length_regulate_f32 -> (out fp32 [B, frames, D], dec_len int64 [B], dec_mask bool [B, frames] | None).
     alignment fp32 [B, frames, L] (forward), or None: the soft path generated from the fp32 `durations` (infer).
-    `split_bf16`: ispk_length_regulate_split_bf16 (the bf16 compute path: three bf16 MFMAs per product, ~2^-16 relative)."""
+    `split_bf16`: True = ispk_length_regulate_split_bf16 (the bf16 compute path: three bf16 MFMAs per product, ~2^-16
+    relative); "f16" = ispk_length_regulate_split_f16 (the split-fp16 parity path: fp16 terms, fp32-grade)."""
     _dev(x, durations, alignment, enc_len)
     assert x.dtype == torch.float32 and x.ndim == 3
     if x.stride(2) != 1 or x.stride(0) != x.shape[1] * x.stride(1):
@@ -887,8 +891,10 @@ def length_regulate(x: Tensor, durations: Tensor, alignment: Optional[Tensor], f
     dec_len = torch.empty((B,), dtype=torch.int64, device=x.device)
     mask = torch.empty((B, frames), dtype=torch.bool, device=x.device) if want_mask else None
     nb = 4.0 * B * (frames * D + L * D + (frames * L if alignment is not None else 0))
-    _launch("length_regulate_kernel<bf16x3>" if split_bf16 else "length_regulate_kernel", 2.0 * B * frames * L * D, nb,
-            lib().ispk_length_regulate_split_bf16 if split_bf16 else lib().ispk_length_regulate_f32, _ptr(alignment),
+    fn = (lib().ispk_length_regulate_split_f16 if split_bf16 == "f16" else
+          lib().ispk_length_regulate_split_bf16 if split_bf16 else lib().ispk_length_regulate_f32)
+    _launch("length_regulate_kernel<split_f16>" if split_bf16 == "f16" else "length_regulate_kernel<bf16x3>" if split_bf16
+            else "length_regulate_kernel", 2.0 * B * frames * L * D, nb, fn, _ptr(alignment),
             _ptr(dur_f), _ptr(dur_i), _ptr(enc_len), x.data_ptr(), x.stride(1), out.data_ptr(), dec_len.data_ptr(),
             _ptr(mask), B, frames, L, D, max_len, dur_cols, _stream())
     return out, dec_len, mask

@@ -629,6 +629,24 @@ def test_length_regulate_split_bf16(B, M, L, D):
     assert torch.equal(d_s, d_f) and (o_s - o_f).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("B,M,L,D", [(3, 512, 100, 384), (2, 301, 37, 256)])
+def test_length_regulate_split_f16(B, M, L, D):
+    """ispk_length_regulate_split_f16 (the split-fp16 parity path): three fp16 MFMAs per product over 22-bit operands - held to
+    the exact-fp32 kernel's own bound against float64 (2e-5), same lengths and mask, and the in-kernel soft path."""
+    x = synth._normal(f"t/lrs/x{M}", (B, L, D))
+    a = torch.softmax(synth._normal(f"t/lrs/a{M}", (B, M, L), 3.0), dim=-1)
+    dur = torch.full((B, 1), M, dtype=torch.int64)
+    out, dec, mask = runtime.length_regulate(x.to(DEV), dur.to(DEV), a.to(DEV), M, max_len=M, split_bf16="f16")
+    ref = torch.bmm(a.double(), x.double())
+    assert (out.cpu().double() - ref).abs().max().item() < 2e-5
+    out32, dec32, mask32 = runtime.length_regulate(x.to(DEV), dur.to(DEV), a.to(DEV), M, max_len=M)
+    assert torch.equal(dec, dec32) and torch.equal(mask, mask32)
+    durf = synth._normal(f"t/lrs/d{M}", (B, L)).abs() * (1.8 * M / L)
+    o_s, d_s, _ = runtime.length_regulate(x.to(DEV), durf.to(DEV), None, M, split_bf16="f16")
+    o_f, d_f, _ = runtime.length_regulate(x.to(DEV), durf.to(DEV), None, M)
+    assert torch.equal(d_s, d_f) and (o_s - o_f).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("B,L,M,D", [(3, 100, 512, 384), (2, 37, 300, 384), (1, 50, 130, 256)])
 def test_length_regulate_from_a_soft_path(B, L, M, D):
     """ispk_length_regulate_f32 (infer mode): the soft path generated inside the kernel from fractional durations vs

@@ -69,6 +69,84 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
     *reinterpret_cast<uint2*>(lo + (int64_t)r * ldy + c) = l;
 }
 
+// The epilogue of the split GEMMs: a wave's RT x TN accumulator tiles (rows m0 + (wm RT + rt) 32 .., features nb0 + (wn TN + t)
+// 32 ..) through the wave's private LDS patches - fp32 rows (+ bias, GELU / SiLU, masks, fp32 residual), split planes, or the
+// transposed [batch][feature][frame] store of to_mel.
+template <int TN, int RT>
+__device__ __forceinline__ void split_store_tiles(const GemmParams& p, char* smem_raw, f32x16 (&acc)[RT][TN], int m0, int nb0,
+                                                  int wm, int wn, int wave, int lane) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int mw = m0 + (wm * RT + rt) * 32;    // first row of this wave's tile rt
+        const int m = mw + l31;
+        const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+        if (p.flags & ISPK_EP_ROWS_T) {
+            // rows are [batch][T] frames, T = cpb; output feature n of frame (b, t) goes to C[b][n][t] (to_mel + transpose)
+            float* cbp = nullptr;
+            if (m < p.M) {
+                const int bb = m / p.cpb;
+                cbp = static_cast<float*>(p.C) + (int64_t)bb * p.bstride + (m - bb * p.cpb);
+            }
+            const float mo = (p.flags & ISPK_EP_MASK_OUT) ? mk : 1.0f;
+#pragma unroll
+            for (int t = 0; t < TN; ++t) store_rows_t(p, cbp, nb0 + (wn * TN + t) * 32, acc[rt][t], mo, h);
+        } else if (p.flags & ISPK_EP_OUT_SPLIT) {
+            // split-plane output: two adjacent 32-feature tiles per pass through a pair of wave-private LDS patches
+            char* stage = smem_raw + wave * (2 * kStageBytes);
+            static_assert(TN % 2 == 0 || TN == 3, "tile pairing");
+            uint16_t* Chi = static_cast<uint16_t*>(p.C);
+#pragma unroll
+            for (int t = 0; t < TN; t += 2) {
+                const bool pair = t + 1 < TN;
+                const int n0 = nb0 + (wn * TN + t) * 32;
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    if (tt == 1 && !pair) break;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[rt][t + tt < TN ? t + tt : t][4 * g + e];
+                        const int n = n0 + tt * 32 + 8 * g + 4 * h;
+                        pre_stage(p, n < p.N ? n : 0, v, mk);
+                        if (p.flags & ISPK_EP_MASK_OUT) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] *= mk;
+                        }
+                        uint2 oh, ol;
+                        split_pair(v[0], v[1], oh.x, ol.x);
+                        split_pair(v[2], v[3], oh.y, ol.y);
+                        *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = oh;
+                        *reinterpret_cast<uint2*>(stage + kStageBytes + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = ol;
+                    }
+                }
+                const int c = lane & 7, n = n0 + 8 * c;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 8 * i + (lane >> 3), mr = mw + r;
+                    const uint4 vh = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
+                    const uint4 vl = *reinterpret_cast<const uint4*>(stage + kStageBytes + r * kStageRow + c * 16);
+                    if (mr < p.M && n < p.N && (pair || c < 4)) {
+                        *reinterpret_cast<uint4*>(Chi + (int64_t)mr * p.ldc + n) = vh;
+                        *reinterpret_cast<uint4*>(Chi + p.c_plane + (int64_t)mr * p.ldc + n) = vl;
+                    }
+                }
+            }
+        } else {
+            char* stage = smem_raw + wave * kStageBytes;
+            float mo4[4];
+            mask_rows(p, mw, lane, mo4);
+            float4 rres[TN][4];
+#pragma unroll
+            for (int t = 0; t < TN; ++t) resid_prefetch(p, mw, nb0 + (wn * TN + t) * 32, lane, rres[t]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t)
+                store_rows_f32(p, stage, mw, nb0 + (wn * TN + t) * 32, acc[rt][t], mk, lane, nullptr, rres[t], mo4);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Linear on split planes
 // C = epilogue(A · Wᵀ) with A [M][K] and W [N][K] given as split planes.  Skeleton of gemm_bf16_wide_kernel (gemm.hip): one
 // workgroup = 32 WM RT activation rows x 64 TN output features on WM x 2 waves, a wave holds RT 32-row tiles x TN 32-feature
@@ -84,6 +162,9 @@ __global__ __launch_bounds__(256) void split_f16_kernel(const float* __restrict_
 //     fragment reads (every wave re-reading them) are co-critical with the MFMAs at 128 x 256 blocks (measured:
 //     tools/ablate_split.py), hence RT = 2: 256 x 256 blocks with 64 x 128 wave tiles halve the fill per product and take
 //     the reads from 0.83 to 0.5 per MFMA;
+//     (Tried and dropped, tools measured: a 16-deep-chunk variant with 128 x 256 tiles and TWO workgroups per CU, so that one's
+//     epilogue would run under the other's MFMAs - 72 / 63 / 183 / 201 us against 56 / 47 / 180 / 150 for q/kv, out, FFN1,
+//     FFN2 at 32,768 rows: its LDS rows hold 32-byte pieces of each plane, and LDS-DMA from 32-byte pieces runs at half rate.)
 //   * XCD-aware block order: workgroups are dealt to the 8 XCDs round-robin in launch order, so workgroup `lin` serves row
 //     block 8 (seq / NCB) + lin % 8, column block seq % NCB with seq = lin / 8: the column blocks of one row block run
 //     back to back on ONE XCD and find the X rows in that XCD's L2 after the first fetch.
@@ -242,75 +323,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
     __syncthreads();   // the epilogue's transposition patches alias the ring
     if constexpr (AB == 7) { st_b = __builtin_readcyclecounter(); st_t[5] = st_b - st_0; st_a = st_b; }
 
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int mw = m0 + (wm * RT + rt) * 32;    // first row of this wave's tile rt
-        const int m = mw + l31;
-        const float mk = (p.mask && m < p.M) ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
-        if (p.flags & ISPK_EP_ROWS_T) {
-            // rows are [batch][T] frames, T = cpb; output feature n of frame (b, t) goes to C[b][n][t] (to_mel + transpose)
-            float* cbp = nullptr;
-            if (m < p.M) {
-                const int bb = m / p.cpb;
-                cbp = static_cast<float*>(p.C) + (int64_t)bb * p.bstride + (m - bb * p.cpb);
-            }
-            const float mo = (p.flags & ISPK_EP_MASK_OUT) ? mk : 1.0f;
-#pragma unroll
-            for (int t = 0; t < TN; ++t) store_rows_t(p, cbp, nb0 + (wn * TN + t) * 32, acc[rt][t], mo, h);
-        } else if (p.flags & ISPK_EP_OUT_SPLIT) {
-            // split-plane output: two adjacent 32-feature tiles per pass through a pair of wave-private LDS patches
-            char* stage = smem_raw + wave * (2 * kStageBytes);
-            static_assert(TN % 2 == 0 || TN == 3, "tile pairing");
-            uint16_t* Chi = static_cast<uint16_t*>(p.C);
-#pragma unroll
-            for (int t = 0; t < TN; t += 2) {
-                const bool pair = t + 1 < TN;
-                const int n0 = nb0 + (wn * TN + t) * 32;
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) {
-                    if (tt == 1 && !pair) break;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[rt][t + tt < TN ? t + tt : t][4 * g + e];
-                        const int n = n0 + tt * 32 + 8 * g + 4 * h;
-                        pre_stage(p, n < p.N ? n : 0, v, mk);
-                        if (p.flags & ISPK_EP_MASK_OUT) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] *= mk;
-                        }
-                        uint2 oh, ol;
-                        split_pair(v[0], v[1], oh.x, ol.x);
-                        split_pair(v[2], v[3], oh.y, ol.y);
-                        *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = oh;
-                        *reinterpret_cast<uint2*>(stage + kStageBytes + l31 * kStageRow + (tt * 32 + 8 * g + 4 * h) * 2) = ol;
-                    }
-                }
-                const int c = lane & 7, n = n0 + 8 * c;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int r = 8 * i + (lane >> 3), mr = mw + r;
-                    const uint4 vh = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
-                    const uint4 vl = *reinterpret_cast<const uint4*>(stage + kStageBytes + r * kStageRow + c * 16);
-                    if (mr < p.M && n < p.N && (pair || c < 4)) {
-                        *reinterpret_cast<uint4*>(Chi + (int64_t)mr * p.ldc + n) = vh;
-                        *reinterpret_cast<uint4*>(Chi + p.c_plane + (int64_t)mr * p.ldc + n) = vl;
-                    }
-                }
-            }
-        } else {
-            char* stage = smem_raw + wave * kStageBytes;
-            float mo4[4];
-            mask_rows(p, mw, lane, mo4);
-            float4 rres[TN][4];
-#pragma unroll
-            for (int t = 0; t < TN; ++t) resid_prefetch(p, mw, nb0 + (wn * TN + t) * 32, lane, rres[t]);
-#pragma unroll
-            for (int t = 0; t < TN; ++t)
-                store_rows_f32(p, stage, mw, nb0 + (wn * TN + t) * 32, acc[rt][t], mk, lane, nullptr, rres[t], mo4);
-        }
-    }
+    split_store_tiles<TN, RT>(p, smem_raw, acc, m0, nb0, wm, wn, wave, lane);
     if constexpr (AB == 7) {   // [workgroup][wave][8]: wait+barrier, reads ks0, mfma ks0, wait ks1, mfma ks1, main loop total, epilogue, start
         if (lane == 0 && p.ln_out) {
             uint64_t* o = static_cast<uint64_t*>(p.ln_out) + ((int64_t)blockIdx.x * NWV + wave) * 8;

@@ -229,6 +229,11 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
             const int rr = (wave * IPL + j) * 8 + (lane >> 3) - (isx ? 0 : BM);
             const int k = kt * 32 + ((((lane & 7) ^ ((rr >> 1) & 7)) & 3) << 3);
             const uint16_t* src = k < p.K ? (isx ? A : W) + src_off[j] + kt * 32 : g_zero16;
+            if constexpr (AB == 9) {   // probe (WRONG data): the same bytes as whole 128-B lines - 8 lanes of a row contiguous
+                const int r = (wave * IPL + j) * 8 + (lane >> 3);
+                const int rowi = isx ? (m0 + r < p.M ? m0 + r : p.M - 1) : (nb0 + rr < p.N ? nb0 + rr : p.N - 1);
+                src = (isx ? A + (int64_t)rowi * p.lda : W + (int64_t)rowi * p.ldw) + kt * 64 + (((lane & 7) ^ ((rr >> 1) & 7)) << 3);
+            }
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(slot + j * 1024), 16, 0, 0);
         }
@@ -267,7 +272,7 @@ __global__ __launch_bounds__(WM * 128) void gemm_split_f16_kernel(GemmParams p, 
         asm volatile("" ::: "memory");
         if constexpr (AB == 7) { st_b = __builtin_readcyclecounter(); st_t[0] += st_b - st_a; st_a = st_b; }
         const uint32_t sl = lds_addr(smem_raw) + (uint32_t)((kt % S) * kSlot);
-        if constexpr (AB == 3) {                 // probe: operand traffic only
+        if constexpr (AB == 3 || AB == 9) {      // probe: operand traffic only
             if (kt + S - 1 < nk) issue(kt + S - 1);
             continue;
         }
@@ -426,6 +431,7 @@ extern "C" int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a
             if (ab == 6) return launch_split<TN_, WM_, RT_, 6>(p, s);                    \
             if (ab == 7) return launch_split<TN_, WM_, RT_, 7>(p, s);                    \
             if (ab == 8) return launch_split<TN_, WM_, RT_, 8>(p, s);                    \
+            if (ab == 9) return launch_split<TN_, WM_, RT_, 9>(p, s);                    \
         }
         ISPK_AB_CASE(441, 4, 4, 1) ISPK_AB_CASE(442, 4, 4, 2) ISPK_AB_CASE(341, 3, 4, 1) ISPK_AB_CASE(342, 3, 4, 2)
 #undef ISPK_AB_CASE

@@ -5,7 +5,7 @@ feed-forward kernels' SQ counter summary.  usage: collect_profiles.py <tag>   e.
 import glob, os, shutil, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst, tag = os.path.join(root, "gpurun_out", "refresh"), os.path.join(root, "profiles"), sys.argv[1]
-for dt in ("bf16", "f32", "train"):
+for dt in ("bf16", "f32", "split", "train"):
     f = max(glob.glob(f"{src}/trace_{dt}/**/*kernel_stats.csv", recursive=True), key=os.path.getmtime)   # newest run
     shutil.copy(f, f"{dst}/{tag}_{dt}_kernel_stats.csv")
 for name, to in (("bench.json", f"{tag}_bench.json"), ("bench_force_dist.json", f"{tag}_bench_force_dist.json"),

@@ -14,6 +14,8 @@ echo "trace bf16 rc=$?"
 python3 $R/tools/timeline.py "$O/trace_bf16" > "$O/timeline_bf16.txt" 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_f32" -- python3 $B --steps 10 --warmup 2 --dtype f32 > "$O/trace_f32.log" 2>&1
 echo "trace f32 rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_split" -- python3 $B --steps 10 --warmup 2 --dtype split > "$O/trace_split.log" 2>&1
+echo "trace split rc=$?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/trace_train" -- python3 $R/bench.py --no-kernel-events --no-cpu-baseline --extras train_step --steps 8 --warmup 2 > "$O/trace_train.log" 2>&1
 echo "trace train rc=$?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$O/pmc_fetch" -- python3 $B --steps 2 --warmup 1 --no-graph > "$O/pmc_fetch.log" 2>&1

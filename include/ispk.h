@@ -541,7 +541,7 @@ int32_t ispk_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, 
  *                           planes (c_plane; no residual), or ISPK_EP_ROWS_T (cols_per_batch = T, batch_stride): rows are
  *                           [batch][T] frames and C[b][n][t] is written (Linear + transpose(1, 2) of model.py:167-168; bias
  *                           + MASK_OUT only).  K % 8 == 0, N % 4 == 0.
- * ispk_gemm_split_f16_tile  which tile ispk_gemm_split_f16 uses for (M, N, K): TN * 10 + WM = 64 TN features x 32 WM rows.
+ * ispk_gemm_split_f16_tile  which tile ispk_gemm_split_f16 uses for (M, N, K): TN * 100 + WM * 10 + RT = 64 TN features x 32 WM RT rows.
  * ispk_layernorm_f32_split  ispk_layernorm_f32 with the result written as split planes (y_hi, lo y_plane behind).
  * ispk_alibi_mqa_attn_split_f16   ispk_alibi_mqa_attn_f32 on split terms: q / k / v fp32 as there (K / V are split once per
  *                           workgroup while staged, Q and the probabilities in registers); out fp32 [B][N][H*64] (o_plane

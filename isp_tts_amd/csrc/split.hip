@@ -368,20 +368,41 @@ extern "C" int32_t ispk_split_f16(const float* x, int64_t ldx, uint16_t* hi, uin
     return ispk_launch_status();
 }
 
-// Tile choice (TN * 100 + WM * 10 + RT = 64 TN features x 32 WM RT rows): the widest feature block that divides N into
-// whole blocks; 256-row blocks (RT = 2) while they still give every CU a workgroup, then 128-row, else 64-row blocks.
+// Tile choice (TN * 100 + WM * 10 + RT = 64 TN features x 32 WM RT rows) by a small cost model fitted to sweeps of the
+// nine variants over the 18 GEMM shapes of the B = 64 forward (tools/sweep_split_shapes.py): weighted by launches per
+// forward its picks cost 2.79 ms where the per-shape best tiles cost 2.76 and the former divisibility rule 2.99.
+// Per workgroup: a fixed start-up, K / 32 chunks that cost max(MFMA time, LDS-DMA time of the slot) plus a barrier, and the
+// epilogue's share of the HBM write burst; the launch runs ~ workgroups / resident slots rounds of that - a ragged last
+// round costs 0.4 + 0.6 of its fill, its workgroups having the chip to themselves - and is bounded below by the
+// L2 -> LDS traffic of the whole grid.
 extern "C" int32_t ispk_gemm_split_f16_tile(int32_t M, int32_t N, int32_t K) {
-    (void)K;
     if (const char* e = ispk_knob("ISPK_SPLIT_TILE")) return atoi(e);  // experiments only
-    int tn;
-    if (N % 256 == 0) tn = 4;
-    else if (N % 192 == 0) tn = 3;
-    else if (N > 128 && N % 128 != 0 && N <= 192) tn = 3;
-    else tn = 2;
-    const int64_t ncb = (N + 64 * tn - 1) / (64 * tn);
-    if ((int64_t)((M + 255) / 256) * ncb >= 240) return tn * 100 + 42;
-    if ((int64_t)((M + 127) / 128) * ncb >= 200) return tn * 100 + 41;
-    return tn * 100 + 21;
+    static const int kTiles[9] = {221, 241, 242, 321, 341, 342, 421, 441, 442};
+    const double nk = (double)((K + 31) / 32);
+    int best = 221;
+    double best_us = 1e30;
+    for (int tile : kTiles) {
+        const int tn = tile / 100, wm = tile / 10 % 10, rt = tile % 10;
+        if (64 * tn > (N + 63) / 64 * 64 + 64) continue;               // more than one idle 64-feature group per block
+        const double bm = 32.0 * wm * rt, bn = 64.0 * tn;
+        const double wgs = (double)((M + (int)bm - 1) / (int)bm) * (double)((N + (int)bn - 1) / (int)bn);
+        const double slot = (bm + bn) * 128.0;
+        const int ring = slot <= 24 * 1024 ? 3 : (4 * slot <= 128 * 1024 ? 4 : (3 * slot <= 152 * 1024 ? 3 : 2));
+        const double occ = ring * slot <= 80 * 1024 ? 2.0 : 1.0;       // workgroups per CU by LDS
+        const double eff = tile == 442 ? 0.6 : 0.7;                    // 256 x 256: 128 accumulator registers, fewer loads in flight
+        const double mfma_us = bm * bn * 32.0 * 6.0 / 9.77e6 / eff, dma_us = slot / 40e3;
+        const double chunk_us = (mfma_us > dma_us ? mfma_us : dma_us) * (occ > 1.0 ? 1.3 : 1.0) + 0.25;
+        const double cap = 256.0 * occ;
+        const double epi_us = (wgs < cap ? wgs : cap) * bm * bn * 4.0 / 4.5e6 + 1.0;
+        const double wg_us = 3.0 + nk * chunk_us + epi_us;
+        const double full = (double)(int64_t)(wgs / cap), frac = wgs / cap - full;
+        double rounds = full + (frac > 0.0 ? 0.4 + 0.6 * frac : 0.0);
+        if (full == 0.0) rounds = 1.0;
+        const double traffic_us = wgs * (bm + bn) * (double)K * 4.0 / 9e6;
+        const double us = rounds * wg_us > traffic_us ? rounds * wg_us : traffic_us;
+        if (us < best_us) best_us = us, best = tile;
+    }
+    return best;
 }
 
 extern "C" int32_t ispk_gemm_split_f16(const uint16_t* A, int64_t lda, int64_t a_plane, const uint16_t* W, int64_t ldw,

@@ -25,7 +25,11 @@ def time_it(fn, rounds=5, inner=10):
 
 shapes = {"key conv0": (6656, 768, 1920), "key conv1": (6656, 128, 768), "query conv0": (33020, 160, 400), "query conv1": (33020, 80, 800),
           "query conv2": (33020, 128, 80), "pred ffn1": (6400, 1024, 256), "pred ffn2": (6400, 256, 1024), "emb out": (6400, 384, 256),
-          "pred qkv": (6400, 384, 256), "to_mel": (32768, 80, 384)}
+          "pred qkv": (6400, 384, 256), "to_mel": (32768, 80, 384),
+          "enc qkv": (6400, 512, 384), "enc out": (6400, 384, 384), "enc ffn1": (6400, 1536, 384), "enc ffn2": (6400, 384, 1536),
+          "dec qkv": (32768, 512, 384), "dec out": (32768, 384, 384), "dec ffn1": (32768, 1536, 384), "dec ffn2": (32768, 384, 1536)}
+if len(sys.argv) > 1:
+    shapes = {k: v for k, v in shapes.items() if any(a in k for a in sys.argv[1:])}
 for name, (M, N, K) in shapes.items():
     a = runtime.split_f16(synth._normal(f"sw/a/{K}", (M, K)).to(dev))
     w = runtime.split_f16(synth._normal(f"sw/w/{N}/{K}", (N, K), K ** -0.5).to(dev))

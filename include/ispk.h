@@ -363,7 +363,7 @@ int32_t ispk_length_regulate_split_f16(const float* alignment, const float* dur_
  *                              A and B 16-byte aligned; ldb < N2 is allowed (overlapping rows: the windows of a padded
  *                              convolution input, for the convolution's weight gradient).
  * ispk_gemm_tn_bf16            the same product, operands rounded to bf16 in flight (autocast's weight gradient), fp32 sums.
- * ispk_alibi_mqa_attn_train_amp / ispk_alibi_mqa_attn_bwd_amp   the attention pair below on bf16 MFMAs (the step under autocast).
+ * ispk_alibi_mqa_attn_train_bf16 / ispk_alibi_mqa_attn_bwd_bf16   the attention pair below on bf16 tensors (the step under autocast).
  * ispk_layernorm_bwd_f32       backward of modules/transformer/normalization.py:20-31 followed by `* mask` (transformer.py:102):
  *                              dx (=) or (+=, add_to_dx) rstd (g - mean(g) - xhat mean(g xhat)), g = dy mask gamma;
  *                              dgamma = sum_rows dy mask xhat, dbeta = sum_rows dy mask (either may be NULL; both NULL needs no
@@ -477,16 +477,18 @@ int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const floa
                                     const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
                                     float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
                                     const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
-/* The same two entries with every product on bf16 MFMAs (operands rounded to bf16 in registers, fp32 accumulation and
- * statistics): the attention of a step under autocast (recipes/default.yaml:56; SDPA and its backward then see bf16 q / k / v).
- * Forward and backward must be used as a pair (the row statistics of one are the other's). */
-int32_t ispk_alibi_mqa_attn_train_amp(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len, float* o,
-                                      int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H, float dropout_p, uint64_t seed,
-                                      ispk_stream_t stream);
-int32_t ispk_alibi_mqa_attn_bwd_amp(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
-                                    const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
-                                    float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
-                                    const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream);
+/* The attention of a step under autocast (recipes/default.yaml:56: SDPA and its backward see bf16 q / k / v / dO and return
+ * bf16): qkv / o / d_o / dqkv are bf16 (uint16 bit patterns) in the layouts of the fp32 pair, products on bf16 MFMAs with
+ * fp32 accumulation and statistics, K / V (forward, dQ) and the heads' Q / dO tiles (dK / dV) staged once per workgroup in
+ * LDS (csrc/attention_train.hip).  lse fp32 [B][H][N] is written by the forward and read by the backward: use them as a pair,
+ * with the same dropout_p and seed.  workspace: B H N + 2 H B ceil(N / 64) floats.  H <= 6, ld_qkv and ld_o multiples of 8. */
+int32_t ispk_alibi_mqa_attn_train_bf16(const uint16_t* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len,
+                                       uint16_t* o, int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H, float dropout_p,
+                                       uint64_t seed, ispk_stream_t stream);
+int32_t ispk_alibi_mqa_attn_bwd_bf16(const uint16_t* qkv, int64_t ld_qkv, const uint16_t* o, const uint16_t* d_o, int64_t ld_o,
+                                     const float* slopes, const int64_t* key_len, const float* lse, uint16_t* dqkv,
+                                     float* dlogslopes, float* workspace, int64_t workspace_floats, int32_t B, int32_t N,
+                                     int32_t H, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_target, const int64_t* mel_len, float* ratio, float* loss,
                           float* grad, float grad_out, int32_t B, int32_t C, int32_t T, ispk_stream_t stream);
 int32_t ispk_aligner_scores_bwd_f32(const float* attn_logits, const float* attn_soft, const float* d_soft, const float* d_logits,

@@ -10,6 +10,7 @@
 //   ispk_alibi_mqa_attn_bwd_f32 attend.py:49-122 + embeddings.py:51-82 backward: dQ per head, dK / dV summed over the heads
 //                               that share them, d log-slope
 #include "common.h"
+#include "dropout.h"
 
 namespace {
 
@@ -18,27 +19,6 @@ __device__ __forceinline__ f32x16 mfma2(float a, float b, f32x16 c) { return __b
 // Row of the 32x32 fp32 accumulator tile that register r of lane l holds (the column is l % 32); also the order in which
 // a lane half walks the reduction index when an accumulator is fed back as an MFMA operand (step t <-> register t).
 __device__ __forceinline__ int acc_row(int r, int hf) { return 8 * (r >> 2) + 4 * hf + (r & 3); }
-
-// Dropout masks are a pure function of (seed, element index): forward and backward evaluate the same function instead of
-// storing a mask.  One 32-bit multiply-xorshift round over (index ^ seed word), see drop_hash; an element is KEPT when the hash is
-// >= p * 2^32.  (The reference draws torch's Philox stream: same distribution, another sequence - masks are tested for
-// their rate and forward / backward consistency, gradients against autograd with the exported mask.)
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {   // "lowbias32": two multiply-xorshift rounds, 32-bit arithmetic only
-    x ^= x >> 16;
-    x *= 0x7feb352du;
-    x ^= x >> 15;
-    x *= 0x846ca68bu;
-    x ^= x >> 16;
-    return x;
-}
-__device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t idx) {
-    // ONE round over (index ^ low seed word), the high word folded in after it: 7 VALU instructions per element (a second
-    // round: 14; a 64-bit finaliser: ~30).  `seed` here is the launcher's splitmix64 of the caller's seed (mix_seed below),
-    // so consecutive caller seeds - one per layer - give unrelated words: two layers' masks are the same hash values at
-    // indices a random 32-bit XOR apart, not shifted copies of each other.  The element index enters modulo 2^32.
-    return mix32(idx ^ (uint32_t)seed) ^ (uint32_t)(seed >> 32);
-}
-__device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t idx, uint32_t thresh) { return drop_hash(seed, idx) >= thresh; }
 
 // ------------------------------------------------------------------------------------------------ transpose
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
@@ -629,87 +609,23 @@ __device__ __forceinline__ f32x16 dot_frags(const Frag& a, const Frag& b) {
     return acc;
 }
 
-// bf16-operand mode (kB16: the step under autocast, recipes/default.yaml:56 - SDPA and its backward take bf16 q / k / v / dO):
-// the same kernels with every product on v_mfma_f32_32x32x16_bf16, 16 x the fp32 MFMA rate.  A 32-float Frag becomes four
-// 8-element operands: k-slot e of step s of lane half hf is the Frag's element 8 s + e - ANY assignment of the head
-// dimensions to k-slots is right as long as both operands of a product use the same one, and both come from load_frag.
-// Where an accumulator tile (P, dS) is the B operand, step u takes its registers 8u .. 8u+7 (reduction rows
-// acc_row(8u + e, hf)) and the A operand gathers the same rows.  Values are rounded to bf16 (RNE) in registers.
-struct Frag16 { bf16x8 s[4]; };
-__device__ __forceinline__ uint32_t bw_pack2(float lo, float hi) {
-    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
-    typedef float f2 __attribute__((ext_vector_type(2)));
-    f2 v;
-    v.x = lo; v.y = hi;
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
-}
-__device__ __forceinline__ bf16x8 bw_pack8(const float* v) {
-    union { uint32_t u[4]; bf16x8 f; } r;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) r.u[e] = bw_pack2(v[2 * e], v[2 * e + 1]);
-    return r.f;
-}
-__device__ __forceinline__ Frag16 to_frag16(const Frag& f) {
-    Frag16 r;
-#pragma unroll
-    for (int st = 0; st < 4; ++st) r.s[st] = bw_pack8(f.v + 8 * st);
-    return r;
-}
-__device__ __forceinline__ f32x16 dot_frags16(const Frag16& a, const Frag16& b) {
-    f32x16 acc = zero16();
-#pragma unroll
-    for (int st = 0; st < 4; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.s[st], b.s[st], acc, 0, 0, 0);
-    return acc;
-}
 // acc[mt] += sum over the 32 reduction rows of rowsrc[row][c + 32 mt] * w[t]   (w: an accumulator tile, t <-> acc_row(t, hf))
-template <bool kB16>
 __device__ __forceinline__ void acc_operand_update(f32x16 (&acc)[2], const float* __restrict__ rowsrc, int64_t ld, int row0, int nrows,
                                                    int c, int hf, const float (&w)[16]) {
-    if constexpr (kB16) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            float a0[8], a1[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int row = row0 + acc_row(8 * u + e, hf);
-                const bool ok = row < nrows;
-                const float* r = rowsrc + (int64_t)(ok ? row : 0) * ld;
-                a0[e] = ok ? r[c] : 0.f;
-                a1[e] = ok ? r[32 + c] : 0.f;
-            }
-            const bf16x8 b = bw_pack8(w + 8 * u);
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_pack8(a0), b, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw_pack8(a1), b, acc[1], 0, 0, 0);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const int row = row0 + acc_row(t, hf);
-            const bool ok = row < nrows;
-            const float* r = rowsrc + (int64_t)(ok ? row : 0) * ld;
-            const float a0 = ok ? r[c] : 0.f, a1 = ok ? r[32 + c] : 0.f;
-            acc[0] = mfma2(a0, w[t], acc[0]);
-            acc[1] = mfma2(a1, w[t], acc[1]);
-        }
+    for (int t = 0; t < 16; ++t) {
+        const int row = row0 + acc_row(t, hf);
+        const bool ok = row < nrows;
+        const float* r = rowsrc + (int64_t)(ok ? row : 0) * ld;
+        const float a0 = ok ? r[c] : 0.f, a1 = ok ? r[32 + c] : 0.f;
+        acc[0] = mfma2(a0, w[t], acc[0]);
+        acc[1] = mfma2(a1, w[t], acc[1]);
     }
 }
-// exp for the probabilities: libm in the fp32 kernels; v_exp_f32 (1 ulp) where P is rounded to bf16 right after
-template <bool kB16>
-__device__ __forceinline__ float prob_exp(float x) {
-    if constexpr (kB16) return __builtin_amdgcn_exp2f(x * 1.4426950408889634f);
-    else return expf(x);
-}
-// S or dP of one 32 x 32 tile: fp32 MFMAs over the Frags, or bf16 MFMAs over their rounded copies
-template <bool kB16>
-__device__ __forceinline__ f32x16 tile_dot(const Frag& a, const Frag& b, const Frag16& b16) {
-    if constexpr (kB16) return dot_frags16(to_frag16(a), b16);
-    else return dot_frags(a, b);
-}
-
 // dQ kernel: one wave per (query tile of 32, head, batch item), transposed orientation S^T[key][query] (query on the lane).
 // Pass 1: row maxima / sums -> LSE (kept, and written for the dK/dV kernel together with delta).  Pass 2: P, dP, dS,
 // dQ^T += K^T dS^T, slope partial.
-template <bool kDrop, bool kB16>
+template <bool kDrop>
 __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ o,
                                                          const float* __restrict__ dout, int64_t ldo,
                                                          const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
@@ -729,8 +645,6 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
     const float slope = slopes[h];
     const Frag qf = load_frag(qb + h * 64, ld, i, N, hf);
     const Frag dof = load_frag(dob, ldo, i, N, hf);
-    Frag16 qf16, dof16;
-    if constexpr (kB16) { qf16 = to_frag16(qf); dof16 = to_frag16(dof); }
     float dl = 0.f;
     {
         const Frag of = load_frag(ob, ldo, i, N, hf);
@@ -744,7 +658,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
     float mx = -INFINITY, sum = 0.f;
     for (int kt = 0; kt < (lse_in ? 0 : kt_end); ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
-        const f32x16 s = tile_dot<kB16>(kf, qf, qf16);
+        const f32x16 s = dot_frags(kf, qf);
         float sv[16], tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -755,7 +669,7 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
         const float nm = fmaxf(mx, tmax);
         float part = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : prob_exp<kB16>(sv[r] - nm);
+        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : expf(sv[r] - nm);
         sum = (mx == -INFINITY ? 0.f : sum * expf(mx - nm)) + part;
         mx = nm;
     }
@@ -778,22 +692,22 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
     float gs = 0.f;
     for (int kt = 0; kt < kt_end; ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
-        const f32x16 s = tile_dot<kB16>(kf, qf, qf16);
+        const f32x16 s = dot_frags(kf, qf);
         const Frag vf = load_frag(vb, ld, kt * 32 + c, N, hf);
-        const f32x16 dp = tile_dot<kB16>(vf, dof, dof16);
+        const f32x16 dp = dot_frags(vf, dof);
         float ds[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = kt * 32 + acc_row(r, hf);
             const float dist = fabsf((float)(i - j));
-            const float p = (j < klen && i < N) ? prob_exp<kB16>(s[r] * scale - slope * dist - L) : 0.f;
+            const float p = (j < klen && i < N) ? expf(s[r] * scale - slope * dist - L) : 0.f;
             float dpr = dp[r];
             if constexpr (kDrop) dpr = drop_keep(seed, row_idx + (uint32_t)j, thresh) ? dpr * inv_keep : 0.f;   // through the dropout
             ds[r] = p * (dpr - dl);
             gs -= ds[r] * dist;
         }
         // dQ^T[d][i] += sum_j K[j][d] dS^T[j][i]: A = K^T, its reduction index j walked in accumulator-row order
-        acc_operand_update<kB16>(dq, kb, ld, kt * 32, N, c, hf, ds);
+        acc_operand_update(dq, kb, ld, kt * 32, N, c, hf, ds);
     }
     if (i < N) {
         float* dst = dqkv + ((int64_t)b * N + i) * ld + h * 64;
@@ -812,7 +726,6 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
 // Training forward (attention dropout, attend.py:118 / SDPA dropout_p): the dQ kernel's skeleton - pass 1 row statistics
 // (kept for the backward), pass 2 P, dropout, O^T[d][i] += sum_j V[j][d] Pdrop^T[j][i] with the accumulator fed back as the
 // operand.  fp32, one wave per (32 queries, head, batch item).
-template <bool kB16>
 __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restrict__ qkv, int64_t ld,
                                                             const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
                                                             float* __restrict__ o, int64_t ldo, float* __restrict__ lse, int N, int H,
@@ -825,14 +738,12 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
     const float* vb = kb + 64;
     const float slope = slopes[h];
     const Frag qf = load_frag(qb + h * 64, ld, i, N, hf);
-    Frag16 qf16;
-    if constexpr (kB16) qf16 = to_frag16(qf);
     const int kt_end = (klen + 31) / 32;
     const uint32_t row_idx = (((uint32_t)b * H + h) * N + (uint32_t)(i < N ? i : 0)) * (uint32_t)N;
     float mx = -INFINITY, sum = 0.f;
     for (int kt = 0; kt < kt_end; ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
-        const f32x16 s = tile_dot<kB16>(kf, qf, qf16);
+        const f32x16 s = dot_frags(kf, qf);
         float sv[16], tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -843,7 +754,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
         const float nm = fmaxf(mx, tmax);
         float part = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : prob_exp<kB16>(sv[r] - nm);
+        for (int r = 0; r < 16; ++r) part += sv[r] == -INFINITY ? 0.f : expf(sv[r] - nm);
         sum = (mx == -INFINITY ? 0.f : sum * expf(mx - nm)) + part;
         mx = nm;
     }
@@ -859,16 +770,16 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
     f32x16 ot[2] = {zero16(), zero16()};
     for (int kt = 0; kt < kt_end; ++kt) {
         const Frag kf = load_frag(kb, ld, kt * 32 + c, N, hf);
-        const f32x16 s = tile_dot<kB16>(kf, qf, qf16);
+        const f32x16 s = dot_frags(kf, qf);
         float pd[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = kt * 32 + acc_row(r, hf);
-            float p = (j < klen && i < N) ? prob_exp<kB16>(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
+            float p = (j < klen && i < N) ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
             if (thresh) p = drop_keep(seed, row_idx + (uint32_t)j, thresh) ? p * inv_keep : 0.f;
             pd[r] = p;
         }
-        acc_operand_update<kB16>(ot, vb, ld, kt * 32, N, c, hf, pd);
+        acc_operand_update(ot, vb, ld, kt * 32, N, c, hf, pd);
     }
     if (i < N) {
         float* dst = o + ((int64_t)b * N + i) * ldo + h * 64;
@@ -884,7 +795,7 @@ __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restr
 // dK / dV kernel: one workgroup per (key tile of 32, batch item), one wave per head; a wave loops over the query tiles
 // (S[query][key], key on the lane) with its head's sums in registers, then the H waves add their tiles into one LDS tile in
 // head order (barrier between heads): no atomics, a fixed summation order, one write per element.
-template <bool kDrop, bool kB16>
+template <bool kDrop>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, int64_t ld, const float* __restrict__ dout,
                                                             int64_t ldo, const float* __restrict__ slopes,
                                                             const int64_t* __restrict__ key_len, const float* __restrict__ lse,
@@ -901,8 +812,6 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
     if (kt * 32 < klen) {
         const Frag kf = load_frag(kb, ld, j, N, hf);
         const Frag vf = load_frag(vb, ld, j, N, hf);
-        Frag16 kf16, vf16;
-        if constexpr (kB16) { kf16 = to_frag16(kf); vf16 = to_frag16(vf); }
         const int qt_end = (N + 31) / 32;
         const float slope = slopes[h];
         const float* qh = qb + h * 64;
@@ -911,16 +820,16 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
         const float* dh = delta + ((int64_t)b * H + h) * N;
         for (int qt = 0; qt < qt_end; ++qt) {
             const Frag qf = load_frag(qh, ld, qt * 32 + c, N, hf);
-            const f32x16 s = tile_dot<kB16>(qf, kf, kf16);
+            const f32x16 s = dot_frags(qf, kf);
             const Frag dof = load_frag(doh, ldo, qt * 32 + c, N, hf);
-            const f32x16 dp = tile_dot<kB16>(dof, vf, vf16);
+            const f32x16 dp = dot_frags(dof, vf);
             float p[16], ds[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = qt * 32 + acc_row(r, hf);
                 const bool ok = i < N && j < klen;
                 const float L = i < N ? lh[i] : 0.f, dl = i < N ? dh[i] : 0.f;
-                p[r] = ok ? prob_exp<kB16>(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
+                p[r] = ok ? expf(s[r] * scale - slope * fabsf((float)(i - j)) - L) : 0.f;
                 if constexpr (kDrop) {
                     const bool keep = drop_keep(seed, (((uint32_t)b * H + h) * N + (uint32_t)(i < N ? i : 0)) * (uint32_t)N + (uint32_t)j, thresh);
                     ds[r] = p[r] * ((keep ? dp[r] * inv_keep : 0.f) - dl);
@@ -929,8 +838,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                     ds[r] = p[r] * (dp[r] - dl);
                 }
             }
-            acc_operand_update<kB16>(dv, doh, ldo, qt * 32, N, c, hf, p);
-            acc_operand_update<kB16>(dk, qh, ld, qt * 32, N, c, hf, ds);
+            acc_operand_update(dv, doh, ldo, qt * 32, N, c, hf, p);
+            acc_operand_update(dk, qh, ld, qt * 32, N, c, hf, ds);
         }
     }
     for (int hh = 0; hh < H; ++hh) {          // heads add in index order
@@ -1108,18 +1017,6 @@ extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const flo
     return ispk_launch_status();
 }
 
-static inline uint64_t mix_seed(uint64_t z) {   // splitmix64 finaliser: the kernels' two seed words from the caller's seed
-    z += 0x9e3779b97f4a7c15ull;
-    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
-    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
-    return z ^ (z >> 31);
-}
-static inline uint32_t drop_thresh(float p) {   // keep when hash >= thresh; 0 = dropout off
-    if (!(p > 0.f)) return 0u;
-    const double t = (double)p * 4294967296.0;
-    return t >= 4294967295.0 ? 4294967295u : (t < 1.0 ? 1u : (uint32_t)t);
-}
-
 extern "C" int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, float dropout_p, uint64_t seed,
                                      ispk_stream_t stream) {
     ISPK_REQUIRE(da && u && du, -1, "ispk_gelu_bwd_f32: null pointer");
@@ -1174,19 +1071,15 @@ extern "C" int32_t ispk_dropout_mask_u8(uint8_t* out, int64_t n, float dropout_p
 
 static int32_t attn_train_launch(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len, float* o, int64_t ld_o,
                                  float* lse, int32_t B, int32_t N, int32_t H, float dropout_p, uint64_t seed, hipStream_t s,
-                                 bool bf16_operands, const char* who) {
+                                 const char* who) {
     ISPK_REQUIRE(qkv && slopes && o && lse, -1, "%s: null pointer", who);
     ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 8 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
                      ld_o % 4 == 0 && B <= 65535, -2, "%s: bad shape B=%d N=%d H=%d", who, B, N, H);
     ISPK_REQUIRE(ispk_aligned(qkv, 16) && ispk_aligned(o, 16), -3, "%s: arrays must be 16-byte aligned", who);
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -4, "%s: dropout_p must be in [0, 1)", who);
     const dim3 grid((N + 31) / 32, H, B);
-    if (bf16_operands)
-        hipLaunchKernelGGL(attn_train_fwd_kernel<true>, grid, dim3(64), 0, s, qkv, ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f,
-                           drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
-    else
-        hipLaunchKernelGGL(attn_train_fwd_kernel<false>, grid, dim3(64), 0, s, qkv, ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f,
-                           drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
+    hipLaunchKernelGGL(attn_train_fwd_kernel, grid, dim3(64), 0, s, qkv, ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f,
+                       drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
     return ispk_launch_status();
 }
 
@@ -1194,31 +1087,26 @@ extern "C" int32_t ispk_alibi_mqa_attn_train_f32(const float* qkv, int64_t ld_qk
                                                  float* o, int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H,
                                                  float dropout_p, uint64_t seed, ispk_stream_t stream) {
     return attn_train_launch(qkv, ld_qkv, slopes, key_len, o, ld_o, lse, B, N, H, dropout_p, seed,
-                             reinterpret_cast<hipStream_t>(stream), false, "ispk_alibi_mqa_attn_train_f32");
+                             reinterpret_cast<hipStream_t>(stream), "ispk_alibi_mqa_attn_train_f32");
 }
 
-extern "C" int32_t ispk_alibi_mqa_attn_train_amp(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len,
-                                                 float* o, int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H,
-                                                 float dropout_p, uint64_t seed, ispk_stream_t stream) {
-    return attn_train_launch(qkv, ld_qkv, slopes, key_len, o, ld_o, lse, B, N, H, dropout_p, seed,
-                             reinterpret_cast<hipStream_t>(stream), true, "ispk_alibi_mqa_attn_train_amp");
-}
-
-template <bool kDrop, bool kB16>
+template <bool kDrop>
 static void attn_bwd_kernels(hipStream_t s, int tiles, const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
                              const float* slopes, const int64_t* key_len, float* dqkv, float* lse, float* delta, float* spart, int B,
                              int N, int H, const float* lse_in, uint32_t thresh, float inv_keep, uint64_t seed) {
     const float scale = 0.125f;
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<kDrop, kB16>), dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len,
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<kDrop>), dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len,
                        dqkv, lse, delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<kDrop, kB16>), dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len,
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<kDrop>), dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len,
                        lse, delta, dqkv, N, H, scale, thresh, inv_keep, seed);
 }
 
-static int32_t attn_bwd_launch(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o, const float* slopes,
-                               const int64_t* key_len, float* dqkv, float* dlogslopes, float* workspace, int64_t workspace_floats,
-                               int32_t B, int32_t N, int32_t H, const float* lse_in, float dropout_p, uint64_t seed, hipStream_t s,
-                               bool bf16_operands, const char* who) {
+extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
+                                               const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
+                                               float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
+                                               const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream) {
+    const char* who = "ispk_alibi_mqa_attn_bwd_f32";
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     ISPK_REQUIRE(qkv && o && d_o && slopes && dqkv && workspace, -1, "%s: null pointer", who);
     ISPK_REQUIRE(B >= 1 && N >= 1 && H >= 1 && H <= 8 && ld_qkv >= H * 64 + 128 && ld_o >= H * 64 && ld_qkv % 4 == 0 &&
                      ld_o % 4 == 0, -2, "%s: bad shape B=%d N=%d H=%d", who, B, N, H);
@@ -1231,28 +1119,13 @@ static int32_t attn_bwd_launch(const float* qkv, int64_t ld_qkv, const float* o,
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -5, "%s: dropout_p must be in [0, 1)", who);
     const uint32_t thresh = drop_thresh(dropout_p);
     const float inv_keep = 1.0f / (1.0f - dropout_p);
-#define ISPK_BWD(D_, B16_) attn_bwd_kernels<D_, B16_>(s, tiles, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse, delta, spart, B, N, \
-                                                     H, lse_in, thresh, inv_keep, mix_seed(seed))
-    if (thresh) { if (bf16_operands) ISPK_BWD(true, true); else ISPK_BWD(true, false); }
-    else { if (bf16_operands) ISPK_BWD(false, true); else ISPK_BWD(false, false); }
-#undef ISPK_BWD
+    if (thresh)
+        attn_bwd_kernels<true>(s, tiles, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse, delta, spart, B, N, H, lse_in, thresh,
+                               inv_keep, mix_seed(seed));
+    else
+        attn_bwd_kernels<false>(s, tiles, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, lse, delta, spart, B, N, H, lse_in, thresh,
+                                inv_keep, mix_seed(seed));
     if (dlogslopes)
         hipLaunchKernelGGL(slope_reduce_kernel, dim3(1), dim3(64 * H), 0, s, spart, B * tiles, slopes, dlogslopes, H);
     return ispk_launch_status();
-}
-
-extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
-                                               const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
-                                               float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
-                                               const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream) {
-    return attn_bwd_launch(qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, dlogslopes, workspace, workspace_floats, B, N, H, lse_in,
-                           dropout_p, seed, reinterpret_cast<hipStream_t>(stream), false, "ispk_alibi_mqa_attn_bwd_f32");
-}
-
-extern "C" int32_t ispk_alibi_mqa_attn_bwd_amp(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,
-                                               const float* slopes, const int64_t* key_len, float* dqkv, float* dlogslopes,
-                                               float* workspace, int64_t workspace_floats, int32_t B, int32_t N, int32_t H,
-                                               const float* lse_in, float dropout_p, uint64_t seed, ispk_stream_t stream) {
-    return attn_bwd_launch(qkv, ld_qkv, o, d_o, ld_o, slopes, key_len, dqkv, dlogslopes, workspace, workspace_floats, B, N, H, lse_in,
-                           dropout_p, seed, reinterpret_cast<hipStream_t>(stream), true, "ispk_alibi_mqa_attn_bwd_amp");
 }

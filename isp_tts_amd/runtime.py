@@ -80,8 +80,8 @@ SIGNATURES = {
     "ispk_dropout_mask_u8": [_P, _I64, _F32, _U64, _P],
     "ispk_alibi_mqa_attn_train_f32": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
     "ispk_alibi_mqa_attn_bwd_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
-    "ispk_alibi_mqa_attn_train_amp": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
-    "ispk_alibi_mqa_attn_bwd_amp": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _P, _F32, _U64, _P],
+    "ispk_alibi_mqa_attn_train_bf16": [_P, _I64, _P, _P, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
+    "ispk_alibi_mqa_attn_bwd_bf16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _U64, _P],
     "ispk_mel_loss_f32": [_P, _P, _P, _P, _P, _P, _F32, _I32, _I32, _I32, _P],
     "ispk_aligner_scores_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _F32, _P],
     "ispk_masked_instnorm_bwd_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _F32, _P],
@@ -1072,21 +1072,23 @@ def dropout_mask(n: int, dropout_p: float, seed: int, device) -> Tensor:
     return out
 
 
-def alibi_mqa_attention_train(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor], dropout_p: float, seed: int,
-                              bf16: bool = False):
-    """ispk_alibi_mqa_attn_train_f32 -> (o fp32 [B, N, heads*64], lse fp32 [B, heads, N]): attention with dropped
-    probabilities, row statistics kept for the backward.  `bf16`: ispk_alibi_mqa_attn_train_amp (bf16 MFMA operands)."""
+def alibi_mqa_attention_train(qkv: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor], dropout_p: float, seed: int):
+    """-> (o [B, N, heads*64] in qkv's dtype, lse fp32 [B, heads, N]): attention with dropped probabilities, row statistics
+    kept for the backward.  fp32 qkv: ispk_alibi_mqa_attn_train_f32.  bf16 qkv (the step under autocast):
+    ispk_alibi_mqa_attn_train_bf16 - bf16 MFMAs, K / V staged in LDS, bf16 o."""
     _dev(qkv, slopes, key_len)
     B, N, W = qkv.shape
-    assert W == heads * 64 + 128 and qkv.dtype == torch.float32 and qkv.is_contiguous()
+    b16 = qkv.dtype == torch.bfloat16
+    assert W == heads * 64 + 128 and qkv.dtype in (torch.float32, torch.bfloat16) and qkv.is_contiguous()
     slopes = slopes.to(torch.float32).contiguous()
     if key_len is not None:
         key_len = key_len.to(torch.int64).contiguous()
-    o = torch.empty((B, N, heads * 64), dtype=torch.float32, device=qkv.device)
+    o = torch.empty((B, N, heads * 64), dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty((B, heads, N), dtype=torch.float32, device=qkv.device)
-    _launch("attn_train_fwd_kernel<bf16>" if bf16 else "attn_train_fwd_kernel", 6.0 * B * heads * N * N * 64, 4.0 * (qkv.numel() + o.numel()),
-            lib().ispk_alibi_mqa_attn_train_amp if bf16 else lib().ispk_alibi_mqa_attn_train_f32, qkv.data_ptr(), W, slopes.data_ptr(), _ptr(key_len), o.data_ptr(), heads * 64,
-            lse.data_ptr(), B, N, heads, dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    _launch("attn_train_fwd_bf16_kernel" if b16 else "attn_train_fwd_kernel", 4.0 * B * heads * N * N * 64,
+            float(qkv.element_size()) * (qkv.numel() + o.numel()),
+            lib().ispk_alibi_mqa_attn_train_bf16 if b16 else lib().ispk_alibi_mqa_attn_train_f32, qkv.data_ptr(), W, slopes.data_ptr(),
+            _ptr(key_len), o.data_ptr(), heads * 64, lse.data_ptr(), B, N, heads, dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return o, lse
 
 
@@ -1105,24 +1107,33 @@ def gelu_bwd(da: Tensor, u: Tensor, out: Optional[Tensor] = None, dropout_p: flo
 
 
 def alibi_mqa_attention_bwd(qkv: Tensor, o: Tensor, d_o: Tensor, heads: int, slopes: Tensor, key_len: Optional[Tensor],
-                            lse: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0, bf16: bool = False):
-    """ispk_alibi_mqa_attn_bwd_f32 -> (dqkv fp32 like qkv, dlogslopes fp32 [heads]).  `lse` (from the training forward)
-    saves the statistics pass; dropout_p / seed must be the forward's.  `bf16`: ispk_alibi_mqa_attn_bwd_amp (bf16 MFMA
-    operands; pairs with the bf16 training forward)."""
+                            lse: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0):
+    """-> (dqkv like qkv, dlogslopes fp32 [heads]).  fp32 tensors: ispk_alibi_mqa_attn_bwd_f32 (`lse` from the training
+    forward saves the statistics pass).  bf16 tensors (the step under autocast): ispk_alibi_mqa_attn_bwd_bf16, `lse` required.
+    dropout_p / seed must be the forward's."""
     _dev(qkv, o, d_o, slopes, key_len, lse)
     B, N, W = qkv.shape
-    assert W == heads * 64 + 128 and qkv.dtype == torch.float32 and qkv.is_contiguous()
-    assert o.shape == (B, N, heads * 64) and d_o.shape == o.shape and o.dtype == torch.float32 and d_o.dtype == torch.float32
+    b16 = qkv.dtype == torch.bfloat16
+    assert W == heads * 64 + 128 and qkv.dtype in (torch.float32, torch.bfloat16) and qkv.is_contiguous()
+    assert o.shape == (B, N, heads * 64) and d_o.shape == o.shape and o.dtype == qkv.dtype and d_o.dtype == qkv.dtype
     o, d_o = o.contiguous(), d_o.contiguous()
     slopes = slopes.to(torch.float32).contiguous()
     if key_len is not None:
         key_len = key_len.to(torch.int64).contiguous()
     dqkv = torch.empty_like(qkv)
     dls = torch.empty((heads,), dtype=torch.float32, device=qkv.device)
+    if b16:
+        assert lse is not None and lse.dtype == torch.float32 and lse.shape == (B, heads, N) and lse.is_contiguous()
+        ws = workspace(qkv.device, B * heads * N + 2 * heads * B * ((N + 63) // 64))
+        _launch("attn_bwd_bf16_kernels", 10.0 * B * heads * N * N * 64, 2.0 * (2 * qkv.numel() + 2 * o.numel()),
+                lib().ispk_alibi_mqa_attn_bwd_bf16, qkv.data_ptr(), W, o.data_ptr(), d_o.data_ptr(), heads * 64, slopes.data_ptr(),
+                _ptr(key_len), lse.data_ptr(), dqkv.data_ptr(), dls.data_ptr(), ws.data_ptr(), ws.numel(), B, N, heads, dropout_p,
+                seed & 0xFFFFFFFFFFFFFFFF, _stream())
+        return dqkv, dls
     tiles = (N + 31) // 32
     ws = workspace(qkv.device, 2 * B * heads * N + heads * B * tiles)
-    _launch("attn_bwd_kernels<bf16>" if bf16 else "attn_bwd_kernels", 10.0 * B * heads * N * N * 64, 4.0 * (2 * qkv.numel() + 2 * o.numel()),
-            lib().ispk_alibi_mqa_attn_bwd_amp if bf16 else lib().ispk_alibi_mqa_attn_bwd_f32, qkv.data_ptr(), W, o.data_ptr(), d_o.data_ptr(), heads * 64, slopes.data_ptr(),
+    _launch("attn_bwd_kernels", 10.0 * B * heads * N * N * 64, 4.0 * (2 * qkv.numel() + 2 * o.numel()),
+            lib().ispk_alibi_mqa_attn_bwd_f32, qkv.data_ptr(), W, o.data_ptr(), d_o.data_ptr(), heads * 64, slopes.data_ptr(),
             _ptr(key_len), dqkv.data_ptr(), dls.data_ptr(), ws.data_ptr(), ws.numel(), B, N, heads, _ptr(lse), dropout_p,
             seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return dqkv, dls

@@ -20,7 +20,7 @@ from torch import Tensor
 
 from .. import runtime
 from ..modules.transformer.transformer import Transformer
-from .stack import _mm_cast
+from .stack import _mm
 
 
 class TimeEmbeddingFunction(torch.autograd.Function):
@@ -161,21 +161,22 @@ class AdaptiveStackFunction(torch.autograd.Function):
             w116, w216 = ff._staged(torch.bfloat16) if amp else (None, None)
             s1, t1 = ss[:, (4 * li) * D:(4 * li + 1) * D], ss[:, (4 * li + 1) * D:(4 * li + 2) * D]
             s2, t2 = ss[:, (4 * li + 2) * D:(4 * li + 3) * D], ss[:, (4 * li + 3) * D:(4 * li + 4) * D]
-            h = runtime.layernorm(out, None, None, s1, t1, L, None, layer.attention_norm.eps)
-            qkv = _mm_cast(h, wqkv, wqkv16)
+            adt = torch.bfloat16 if amp else torch.float32        # dtype of the tensors that are GEMM / attention operands only
+            h = runtime.layernorm(out, None, None, s1, t1, L, None, layer.attention_norm.eps, out_dtype=adt)
+            qkv = _mm(h, wqkv, wqkv16, out_dtype=adt)
             p_att = float(att.attend.dropout) if layer.training else 0.0
             p_ff = float(ff.dropout_p) if layer.training else 0.0
             seed_att, seed_ff = base_seed + 2 * li, base_seed + 2 * li + 1
             lse = None
             if p_att > 0 or amp:
-                o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att, bf16=amp)
+                o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att)
             else:
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
-            x1 = _mm_cast(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
-            h2 = runtime.layernorm(x1, None, None, s2, t2, L, mask, layer.feed_forward_norm.eps)
-            u = _mm_cast(h2, w1, w116)
-            a = runtime.gelu(u, p_ff, seed_ff)
-            y = _mm_cast(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
+            x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
+            h2 = runtime.layernorm(x1, None, None, s2, t2, L, mask, layer.feed_forward_norm.eps, out_dtype=adt)
+            u = _mm(h2, w1, w116)
+            a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)
+            y = _mm(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
             tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
         final = runtime.layernorm(out, tr.norm.weight, tr.norm.bias, row_mask=mask, eps=tr.norm.eps)
@@ -206,19 +207,22 @@ class AdaptiveStackFunction(torch.autograd.Function):
             w1_t16, w2_t16 = ff._cache.get("t16", (ff.net[0].weight, ff.net[3].weight),
                                            lambda: t16(w1_t, w2_t)) if amp else (None, None)
             c = 4 * li * D
-            dw2 = runtime.gemm_tn(dy, a, row_mask=mask, bf16=amp)
-            da = _mm_cast(dy, w2_t, w2_t16, mask=mask, flags=mflag)
+            gdt = torch.bfloat16 if amp else torch.float32        # as in stack.py: GEMM-only tensors live in bf16 under AMP
+            dyg = runtime.cast_bf16(dy) if amp else dy
+            dw2 = runtime.gemm_tn(dyg, a, row_mask=mask, bf16=amp)
+            da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)
             du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
             dw1 = runtime.gemm_tn(du, h2, bf16=amp)
-            dh2 = _mm_cast(du, w1_t, w1_t16)
+            dh2 = _mm(du, w1_t, w1_t16)
             dx1 = runtime.adaln_bwd(x1, dh2, ss[:, c + 2 * D:c + 3 * D], mask, dy, True, d_ss[:, c + 2 * D:c + 3 * D],
                                     d_ss[:, c + 3 * D:c + 4 * D], layer.feed_forward_norm.eps)
-            dwo = runtime.gemm_tn(dx1, o, row_mask=mask, bf16=amp)
-            d_o = _mm_cast(dx1, wo_t, wo_t16, mask=mask, flags=mflag)
+            dx1g = runtime.cast_bf16(dx1) if amp else dx1
+            dwo = runtime.gemm_tn(dx1g, o, row_mask=mask, bf16=amp)
+            d_o = _mm(dx1g, wo_t, wo_t16, out_dtype=gdt, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
-                                                        seed=seed_att, bf16=amp)
+                                                        seed=seed_att)
             dwqkv = runtime.gemm_tn(dqkv, h, bf16=amp)
-            dh = _mm_cast(dqkv, wqkv_t, wqkv_t16)
+            dh = _mm(dqkv, wqkv_t, wqkv_t16)
             dy = runtime.adaln_bwd(xin, dh, ss[:, c:c + D], None, dx1, True, d_ss[:, c:c + D], d_ss[:, c + D:c + 2 * D],
                                    layer.attention_norm.eps)
             hq = att.heads * 64

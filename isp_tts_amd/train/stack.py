@@ -16,7 +16,7 @@ masks them, and every step below keeps zero rows zero):
     dx1 = dy + LN2'(x1, m dh2)                    dWo = (m dx1)^T o      do  = (m dx1) Wo
     dqkv, dlogslopes = attention'(qkv, o, do)     dWqkv = dqkv^T h       dh  = dqkv Wqkv
     dx  = dx1 + LN1'(x, dh)
-Saved per layer: x, h, qkv, o, x1, h2, u, a (fp32): 0.72 GB per decoder layer at 64 x 512 frames - 4.3 GB per stack, small
+Saved per layer: x, x1, u (fp32) and h, qkv, o, h2, a (bf16 under AMP): ~0.5 GB per decoder layer at 64 x 512 frames, small
 beside 288 GB of HBM, so nothing is recomputed except the LayerNorm / softmax statistics.
 """
 from __future__ import annotations
@@ -62,14 +62,6 @@ def _mm(a: Tensor, w32: Tensor, w16: Optional[Tensor], out_dtype: torch.dtype = 
     return runtime.gemm(a, w16, out_dtype=out_dtype, **kw)
 
 
-def _mm_cast(a32: Tensor, w32: Tensor, w16: Optional[Tensor], **kw) -> Tensor:
-    """`_mm` for an fp32 activation that no producer hands over in bf16 (the 6,400-row adaptive-norm stack of the flow
-    predictor): under AMP one cast launch in front of the GEMM."""
-    if w16 is None:
-        return runtime.gemm(a32, w32, **kw)
-    return runtime.gemm(runtime.cast_bf16(a32), w16, out_dtype=torch.float32, **kw)
-
-
 def _deliver(param: Tensor, producer, *args, **kw):
     """A parameter's gradient.  When the parameter's .grad is a preallocated buffer of an optimizer arena
     (`FlatParameters` marks it `_ispk_grad_arena`), the producing kernel writes - or adds, if something has been delivered
@@ -109,23 +101,22 @@ class TransformerStackFunction(torch.autograd.Function):
             w116, w216 = ff._staged(torch.bfloat16) if amp else (None, None)
             adt = torch.bfloat16 if amp else torch.float32        # dtype of the tensors that are GEMM operands only
             h = runtime.layernorm(out, an.weight, an.bias, eps=an.eps, out_dtype=adt)
-            qkv = _mm(h, wqkv, wqkv16)
+            qkv = _mm(h, wqkv, wqkv16, out_dtype=adt)        # AMP: bf16 q / k / v, as SDPA sees them under autocast
             p_att = float(att.attend.dropout) if layer.training else 0.0
             p_ff = float(ff.dropout_p) if layer.training else 0.0
             seed_att, seed_ff = base_seed + 2 * li, base_seed + 2 * li + 1
             lse = None
             if p_att > 0 or amp:   # dropped attention probabilities (attend.py:118); the rows' log-sum-exp is kept for the
                 # backward.  Under AMP forward and backward both take bf16 operands (and must share the statistics)
-                o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att, bf16=amp)
+                o, lse = runtime.alibi_mqa_attention_train(qkv, att.heads, slopes, key_len, p_att, seed_att)
             else:
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
-            og = runtime.cast_bf16(o) if amp else o            # the out-projection's operand AND the one of its weight gradient
-            x1 = _mm(og, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
+            x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
             h2 = runtime.layernorm(x1, fn.weight, fn.bias, row_mask=mask, eps=fn.eps, out_dtype=adt)
             u = _mm(h2, w1, w116)
             a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)        # GELU, then nn.Dropout (feedforward.py:35)
             y = _mm(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
-            tape.append((out, h, qkv, o, og, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
+            tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
         final = runtime.layernorm(out, tr.norm.weight, tr.norm.bias, row_mask=mask, eps=tr.norm.eps)
         ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last, ctx.amp = tr, mask, key_len, tape, out, amp
@@ -138,8 +129,7 @@ class TransformerStackFunction(torch.autograd.Function):
         grads: list = []
         dy, dgf, dbf = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask,
                                              eps=tr.norm.eps)
-        for layer, (xin, h, qkv, o, og, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff) in zip(reversed(tr.layers),
-                                                                                                   reversed(ctx.tape)):
+        for layer, (xin, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff) in zip(reversed(tr.layers), reversed(ctx.tape)):
             att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
             wqkv, wo, slopes = att._staged(torch.float32)
             w1, w2 = ff._staged(torch.float32)
@@ -154,7 +144,8 @@ class TransformerStackFunction(torch.autograd.Function):
                                            lambda: t16(w1_t, w2_t)) if amp else (None, None)
             gdt = torch.bfloat16 if amp else torch.float32
             # Under AMP every tensor that is ONLY a GEMM operand lives in bf16 - a (forward), da / du (their producers write
-            # bf16), and ONE bf16 copy each of the fp32 tensors that a dX GEMM and a weight gradient both read (dy, dx1, dqkv).
+            # bf16; q / k / v, the attention output, dO and dqkv: the attention kernels read and write bf16), and ONE bf16 copy each of
+            # the fp32 residual-stream gradients that a dX GEMM and a weight gradient both read (dy, dx1).
             # feed-forward block
             dyg = runtime.cast_bf16(dy) if amp else dy
             dw2 = _deliver(ff.net[3].weight, runtime.gemm_tn, dyg, a, row_mask=mask, bf16=amp)        # [dim, inner]
@@ -165,13 +156,12 @@ class TransformerStackFunction(torch.autograd.Function):
             dx1, dg2, db2 = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps)
             # attention block
             dx1g = runtime.cast_bf16(dx1) if amp else dx1
-            dwo = _deliver(att.to_out.weight, runtime.gemm_tn, dx1g, og, row_mask=mask, bf16=amp)      # [dim, heads*64]
-            d_o = _mm(dx1g, wo_t, wo_t16, mask=mask, flags=mflag)
+            dwo = _deliver(att.to_out.weight, runtime.gemm_tn, dx1g, o, row_mask=mask, bf16=amp)       # [dim, heads*64]
+            d_o = _mm(dx1g, wo_t, wo_t16, out_dtype=gdt, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
-                                                        seed=seed_att, bf16=amp)
-            dqkvg = runtime.cast_bf16(dqkv) if amp else dqkv
-            dwqkv = runtime.gemm_tn(dqkvg, h, bf16=amp)                                     # [heads*64 + 128, dim]
-            dh = _mm(dqkvg, wqkv_t, wqkv_t16)
+                                                        seed=seed_att)                     # AMP: bf16 in, bf16 out
+            dwqkv = runtime.gemm_tn(dqkv, h, bf16=amp)                                      # [heads*64 + 128, dim]
+            dh = _mm(dqkv, wqkv_t, wqkv_t16)
             dy, dg1, db1 = runtime.layernorm_bwd(xin, dh, an.weight, dx=dx1, add_to_dx=True, eps=an.eps)
             hq = att.heads * 64
             ls = att.rel_pos.learned_logslopes

@@ -822,30 +822,37 @@ def test_gemm_tn_bf16_operands(M, N1, N2, masked):
     _close(acc, 2 * want, 2e-5, "gemm_tn bf16 accumulate")
 
 
-@pytest.mark.parametrize("B,N,H,lens,p", [(2, 100, 6, [100, 73], 0.1), (2, 140, 4, None, 0.0), (1, 37, 8, [20], 0.1)])
-def test_attention_training_pair_with_bf16_operands(B, N, H, lens, p):
-    """ispk_alibi_mqa_attn_train_amp / _bwd_amp (the step under autocast): the same kernels with every product on bf16 MFMAs.
-    Checked against the fp32 pair run on the SAME bf16-rounded q / k / v / dO (what remains is the rounding of P and dS to
-    bf16 and the accumulation order: 1e-2 of each tensor's scale), with the same dropout mask (same seed)."""
-    qkv = _rand((B, N, H * 64 + 128), 91).bfloat16().float().to(DEV)
-    d_o = _rand((B, N, H * 64), 92).bfloat16().float().to(DEV)
+@pytest.mark.parametrize("B,N,H,lens,p", [(2, 100, 6, [100, 73], 0.1), (2, 140, 4, None, 0.0), (1, 37, 5, [20], 0.1),
+                                          (9, 512, 6, [512, 300, 1, 64, 65, 449, 512, 33, 480], 0.1), (2, 600, 6, [600, 515], 0.1),
+                                          (1, 530, 2, None, 0.0)])
+def test_attention_training_pair_on_bf16_tensors(B, N, H, lens, p):
+    """ispk_alibi_mqa_attn_train_bf16 / _bwd_bf16 (the step under autocast; csrc/attention_train.hip): bf16 q / k / v / dO in,
+    bf16 o / dqkv out, products on bf16 MFMAs off LDS-staged tiles.  Checked against the fp32 pair run on the SAME bf16-rounded
+    q / k / v / dO (what remains is the rounding of P, dS and the outputs to bf16 and the accumulation order: 1e-2 of each
+    tensor's scale), with the same dropout mask (same seed).  Cases: ragged key lengths incl. 1 and tile edges, more than one
+    XCD group of batch items, N > 512 (two staging rounds of the forward / dQ kernels), H = 2 .. 6."""
+    qkv16 = _rand((B, N, H * 64 + 128), 91).bfloat16().to(DEV)
+    do16 = _rand((B, N, H * 64), 92).bfloat16().to(DEV)
+    qkv, d_o = qkv16.float(), do16.float()
     slopes = (torch.tensor(synth.alibi_default_slopes(H)) * 1.1).to(DEV)
     key_len = None if lens is None else torch.tensor(lens, device=DEV)
     o32, lse32 = runtime.alibi_mqa_attention_train(qkv, H, slopes, key_len, p, 1234)
-    o16, lse16 = runtime.alibi_mqa_attention_train(qkv, H, slopes, key_len, p, 1234, bf16=True)
-    _close(o16, o32, 1e-2, "o")
-    valid = torch.isfinite(lse32)
-    assert torch.equal(valid, torch.isfinite(lse16))
-    _close(lse16[valid], lse32[valid], 1e-5, "lse")
-    dq32, ds32 = runtime.alibi_mqa_attention_bwd(qkv, o32, d_o, H, slopes, key_len, lse=lse32, dropout_p=p, seed=1234)
-    dq16, ds16 = runtime.alibi_mqa_attention_bwd(qkv, o16, d_o, H, slopes, key_len, lse=lse16, dropout_p=p, seed=1234, bf16=True)
+    o16, lse16 = runtime.alibi_mqa_attention_train(qkv16, H, slopes, key_len, p, 1234)
+    assert o16.dtype == torch.bfloat16
+    _close(o16.float(), o32, 1e-2, "o")
+    _close(lse16, lse32, 1e-5, "lse")
+    # the backward's `o` is an INPUT (delta = rowsum(o dO)): both pairs get the bf16 tensor autocast's SDPA hands over - its
+    # rounding moves delta, and through the distance-weighted sum the slope gradient, by more than the kernels differ
+    dq32, ds32 = runtime.alibi_mqa_attention_bwd(qkv, o16.float(), d_o, H, slopes, key_len, lse=lse32, dropout_p=p, seed=1234)
+    dq16, ds16 = runtime.alibi_mqa_attention_bwd(qkv16, o16, do16, H, slopes, key_len, lse=lse16, dropout_p=p, seed=1234)
+    assert dq16.dtype == torch.bfloat16
     hq = H * 64
-    _close(dq16[..., :hq], dq32[..., :hq], 1e-2, "dq")
-    _close(dq16[..., hq:hq + 64], dq32[..., hq:hq + 64], 1e-2, "dk")
-    _close(dq16[..., hq + 64:], dq32[..., hq + 64:], 1e-2, "dv")
+    _close(dq16[..., :hq].float(), dq32[..., :hq], 1e-2, "dq")
+    _close(dq16[..., hq:hq + 64].float(), dq32[..., hq:hq + 64], 1e-2, "dk")
+    _close(dq16[..., hq + 64:].float(), dq32[..., hq + 64:], 1e-2, "dv")
     _close(ds16, ds32, 2e-2, "d log-slope")
-    again, _ = runtime.alibi_mqa_attention_bwd(qkv, o16, d_o, H, slopes, key_len, lse=lse16, dropout_p=p, seed=1234, bf16=True)
-    assert torch.equal(again, dq16)
+    again, ds_again = runtime.alibi_mqa_attention_bwd(qkv16, o16, do16, H, slopes, key_len, lse=lse16, dropout_p=p, seed=1234)
+    assert torch.equal(again, dq16) and torch.equal(ds_again, ds16)          # fixed summation orders: bit-reproducible
 
 
 def test_training_step_against_the_reference_fixture(state_dict):

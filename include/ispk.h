@@ -115,6 +115,11 @@ int32_t ispk_gemm_f32_tile(int32_t M, int32_t N, int32_t K);
 int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, float* C, int64_t ldc, const float* bias,
                       const float* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N, int32_t K,
                       uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);
+/* C[z] = A[z] . W[z]^T for z < batch (fp32, no epilogue): element strides stride_a / stride_w / stride_c between batch items.
+ * The alignment gradient of the length regulator, d A[b] = d out[b] x[b]^T (temporal_adaptor.py:419-421), as ONE launch. */
+int32_t ispk_gemm_f32_batched(const float* A, int64_t lda, int64_t stride_a, const float* W, int64_t ldw, int64_t stride_w,
+                              float* C, int64_t ldc, int64_t stride_c, int32_t batch, int32_t M, int32_t N, int32_t K,
+                              ispk_stream_t stream);
 /* Kernel instance dispatched by this thread's last ispk_gemm_bf16 call (profiler labels): 1000+KC panel<KC>,
  * 2000+10*TN+WM wide<TN,WM>, 3000+10*TM+TN generic<TM,TN>. */
 int32_t ispk_gemm_bf16_last_variant(void);

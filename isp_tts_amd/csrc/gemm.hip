@@ -27,8 +27,14 @@ constexpr int kLdt = 36;  // padded LDS row length in dwords (32 + 4)
 
 
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams p) {
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmParams pin) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
+    GemmParams p = pin;
+    if (gridDim.z > 1) {          // batched: one product per blockIdx.z
+        p.A = static_cast<const float*>(pin.A) + (int64_t)blockIdx.z * pin.za;
+        p.W = static_cast<const float*>(pin.W) + (int64_t)blockIdx.z * pin.zw;
+        p.C = static_cast<float*>(pin.C) + (int64_t)blockIdx.z * pin.zc;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* As = reinterpret_cast<float*>(smem_raw);  // [2][BM][kLdt]
     float* Bs = As + 2 * BM * kLdt;                  // [2][BN][kLdt]
@@ -913,11 +919,11 @@ bool wide_ok(const GemmParams& p) {
 }
 
 template <int TM, int TN>
-int32_t launch_f32(const GemmParams& p, hipStream_t s) {
+int32_t launch_f32(const GemmParams& p, hipStream_t s, int batch = 1) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     constexpr size_t lds = (size_t)2 * (BM + BN) * kLdt * sizeof(float);
     ISPK_RESERVE_LDS((&gemm_f32_kernel<TM, TN>), lds, "gemm");
-    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM);
+    dim3 grid((p.N + BN - 1) / BN, (p.M + BM - 1) / BM, batch);
     hipLaunchKernelGGL((gemm_f32_kernel<TM, TN>), grid, dim3(256), lds, s, p);
     return ispk_launch_status();
 }
@@ -971,6 +977,23 @@ extern "C" int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, in
         case 12: return launch_f32<1, 2>(p, s);
     }
     return launch_f32<1, 1>(p, s);
+}
+
+extern "C" int32_t ispk_gemm_f32_batched(const float* A, int64_t lda, int64_t stride_a, const float* W, int64_t ldw, int64_t stride_w,
+                                         float* C, int64_t ldc, int64_t stride_c, int32_t batch, int32_t M, int32_t N, int32_t K,
+                                         ispk_stream_t stream) {
+    GemmParams p{A, lda, W, ldw, C, ldc, nullptr, nullptr, 0, nullptr, M, N, K, 0u, 0, 0};
+    p.za = stride_a;
+    p.zw = stride_w;
+    p.zc = stride_c;
+    if (int32_t rc = check_common(p, 4)) return rc;
+    ISPK_REQUIRE(batch >= 0 && batch <= 65535 && stride_a % 4 == 0 && stride_w % 4 == 0 && ldc >= N, ISPK_E_SHAPE,
+                 "gemm_f32_batched: batch=%d (<= 65535), operand strides multiples of 4, ldc >= N", batch);
+    if (M == 0 || batch == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t wg128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
+    if (wg128 >= 256) return launch_f32<2, 2>(p, s, batch);
+    return launch_f32<1, 2>(p, s, batch);
 }
 
 // Which kernel instance the last ispk_gemm_bf16 call of THIS thread dispatched (for profilers' labels):

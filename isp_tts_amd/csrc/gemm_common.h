@@ -38,6 +38,8 @@ struct GemmParams {
     int64_t pj_ldx = 0;
     // split-f16 operands (split.hip): element offset of the lo plane from the hi plane for A, W and a split output C
     int64_t a_plane = 0, w_plane = 0, c_plane = 0;
+    // batched fp32 product (ispk_gemm_f32_batched): element strides of A, W and C from one batch item (blockIdx.z) to the next
+    int64_t za = 0, zw = 0, zc = 0;
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int i, int j, float v) {

@@ -32,6 +32,7 @@ SIGNATURES = {
     "ispk_layernorm_f32_bf16": [_P, _I64, _P, _P, _P, _P, _I64, _I32, _P, _P, _I64, _I32, _I32, _F32, _P],
     "ispk_gemm_f32_tile": [_I32, _I32, _I32],
     "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
+    "ispk_gemm_f32_batched": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_gemm_bf16_last_variant": [],
     "ispk_gemm_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_ffn_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P],
@@ -957,6 +958,27 @@ def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Option
     _launch(f"gemm_tn_{'b16_' if in16 else ('bf16_' if bf16 else '')}kernel<{N1}x{N2}>", 2.0 * M * N1 * N2,
             float(a2.element_size()) * (a2.numel() + b2.numel()) + 4.0 * out.numel(), fn, a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), out.data_ptr(), out.stride(0), M,
             N1, N2, _ptr(row_mask), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
+    return out
+
+
+def gemm_batched(a: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """ispk_gemm_f32_batched: C[i] = a[i] @ w[i]^T for a [batch, M, K], w [batch, N, K] (fp32, unit column strides)
+    -> [batch, M, N] (`out`: a view with unit column stride)."""
+    _dev(a, w, out)
+    assert a.dtype == torch.float32 and w.dtype == torch.float32 and a.ndim == 3 and w.ndim == 3
+    assert a.shape[0] == w.shape[0] and a.shape[2] == w.shape[2]
+    if a.stride(2) != 1:
+        a = a.contiguous()
+    if w.stride(2) != 1:
+        w = w.contiguous()
+    batch, M, K = a.shape
+    N = w.shape[1]
+    if out is None:
+        out = torch.empty((batch, M, N), dtype=torch.float32, device=a.device)
+    assert out.shape == (batch, M, N) and out.stride(2) == 1 and out.dtype == torch.float32
+    _launch("gemm_f32_kernel<batched>", 2.0 * batch * M * N * K, 4.0 * (a.numel() + w.numel() + out.numel()),
+            lib().ispk_gemm_f32_batched, a.data_ptr(), a.stride(1), a.stride(0), w.data_ptr(), w.stride(1), w.stride(0),
+            out.data_ptr(), out.stride(1), out.stride(0), batch, M, N, K, _stream())
     return out
 
 

@@ -211,7 +211,7 @@ def mel_decoder_train_forward(model, dec_in: Tensor, dec_mask: Optional[Tensor],
 class LengthRegulateFunction(torch.autograd.Function):
     """out[b] = A[b] x[b] (LengthRegulator, soft branch: temporal_adaptor.py:411-436; forward = `runtime.length_regulate`).
     Backward: d x[b] = A[b]^T d out[b] (one batched transposed product) and, when the alignment carries a gradient (the
-    path by which the mel loss reaches the aligner), d A[b] = d out[b] x[b]^T - one NT GEMM per utterance in this cut."""
+    path by which the mel loss reaches the aligner), d A[b] = d out[b] x[b]^T (one batched NT product)."""
 
     @staticmethod
     def forward(ctx, x: Tensor, alignment: Tensor, durations: Tensor, frames: int):
@@ -225,11 +225,7 @@ class LengthRegulateFunction(torch.autograd.Function):
     def backward(ctx, d_out: Tensor, _dl, _dm):
         alignment, x = ctx.saved_tensors
         d_out = d_out.float().contiguous()
-        d_a = None
-        if ctx.want_da:
-            d_a = torch.empty_like(alignment)
-            for b in range(alignment.shape[0]):
-                runtime.gemm(d_out[b], x[b].contiguous(), out=d_a[b])
+        d_a = runtime.gemm_batched(d_out, x, out=torch.empty_like(alignment)) if ctx.want_da else None
         return runtime.gemm_tn_batched(alignment, d_out), d_a, None, None
 
 

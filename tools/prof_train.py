@@ -45,3 +45,13 @@ nl = sum(v["launches"] for v in summ.values())
 print(f"B={B} amp={amp}: wall {wall * 1e3:.2f} ms/step; libispk launches {nl}, summed kernel time {tot:.2f} ms")
 for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:40]:
     print(f"  {k:48s} x{v['launches']:4d}  {v['total_ms']:7.3f} ms  avg {v['avg_us']:7.1f} us")
+# fp32 GEMMs by shape (algorithmic FLOPs identify the shape)
+by = {}
+for label, flops, nbytes, e0, e1 in prof.records:
+    if label.startswith("gemm_f32") or label.startswith("gemm_tn_kernel"):
+        d = by.setdefault((label, flops, nbytes), [0, 0.0])
+        d[0] += 1
+        d[1] += e0.elapsed_time(e1)
+print("fp32 GEMMs by shape:")
+for (label, flops, nbytes), (n, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:30]:
+    print(f"  {label:28s} {flops / 1e9:8.3f} GFLOP {nbytes / 1e6:8.2f} MB  x{n:3d} {ms:7.3f} ms")

@@ -572,6 +572,33 @@ int32_t ispk_alibi_mqa_attn_split_f16(const float* q, int64_t ldq, const float* 
 int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy, int32_t rows, int32_t cols,
                            ispk_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Data movement of a training step (csrc/util.hip), so that a step issues no PyTorch kernel: what the reference does with
+ * autograd's AccumulateGrad, torch.cat / .to(bfloat16) on weights, zero fills and scalar algebra on the losses
+ * (tts/experiments/trainer.py:538-579, tts/models/acoustic/loss.py:140-182).
+ *
+ * ispk_segments_f32     up to any number of contiguous fp32 segments in one call (32 per launch): mode 0 dst = src (a
+ *                       concatenation), 1 dst += src (gradient delivery into an optimizer arena), 2 dst = bf16(src).
+ * ispk_fill_zero        bytes of zeros (4-byte aligned buffer).
+ * ispk_scale_f32        x *= s_dev[0] * s_host (s_dev NULL: s_host only): a loss gradient times the incoming scalar gradient.
+ * ispk_sum_scalars_f32  out[0] = sum_i weights[i] * terms[i][0] in index order (n <= 8; weights NULL = ones): the total loss.
+ * ispk_exp_pad_f32      dst[i] = exp(src[i]) (i < n), 0 (n <= i < total): ALiBi slopes from learned_logslopes.
+ * ispk_sqrt_scale_f32   dst[i] = sqrt(src[i]) * scale: the clipped group's gradient norm from its square.
+ * ispk_copy2d_f32       rows x cols with leading strides.
+ * ispk_permute021_f32   dst[a][c][b] = src[a][b][c]: Conv1d weights [O][C][k] <-> GEMM weights [O][k][C].
+ * ispk_conv_weight_flip_f32   wf[c][(K-1-k) O + o] = w[o][c][k]: the GEMM weight of a convolution's input gradient. */
+typedef struct { const float* src; void* dst; int64_t n; int32_t mode; } ispk_segment_t;
+int32_t ispk_segments_f32(const ispk_segment_t* segs, int32_t nseg, ispk_stream_t stream);
+int32_t ispk_fill_zero(void* p, int64_t bytes, ispk_stream_t stream);
+int32_t ispk_scale_f32(float* x, int64_t n, const float* s_dev, float s_host, ispk_stream_t stream);
+int32_t ispk_sum_scalars_f32(const float* const* terms, const float* weights, int32_t n, float* out, ispk_stream_t stream);
+int32_t ispk_exp_pad_f32(const float* src, float* dst, int32_t n, int32_t total, ispk_stream_t stream);
+int32_t ispk_sqrt_scale_f32(const float* src, float* dst, int32_t n, float scale, ispk_stream_t stream);
+int32_t ispk_copy2d_f32(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int32_t rows, int32_t cols,
+                        ispk_stream_t stream);
+int32_t ispk_permute021_f32(const float* src, float* dst, int32_t A, int32_t B, int32_t C, ispk_stream_t stream);
+int32_t ispk_conv_weight_flip_f32(const float* w, float* wf, int32_t O, int32_t C, int32_t K, ispk_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

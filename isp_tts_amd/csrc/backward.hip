@@ -177,7 +177,9 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const void* __restric
     B += (int64_t)bz * stride_b;
     if (kMask) mask += (int64_t)bz * M;
     const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
-    const int sr = tid >> 5, sq = (tid & 31) * 4;
+    // staging roles.  fp32 operands: a thread takes 4 columns (one float4) of rows sr + 8 j; bf16 operands: 8 columns (16 bytes,
+    // one whole image chunk) of rows sr + 16 j - 16-byte requests, half as many of them
+    const int sr = IN16 ? tid >> 4 : tid >> 5, sq = IN16 ? (tid & 15) * 8 : (tid & 31) * 4;
     const bool a_ok = n1 + sq < N1, b_ok = n2 + sq < N2;
     f32x16 acc[2][2];
 #pragma unroll
@@ -187,17 +189,27 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const void* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f32x4 ra[IN16 ? 1 : 4], rb[IN16 ? 1 : 4];
-    uint2 qa[IN16 ? 4 : 1], qb[IN16 ? 4 : 1];     // IN16: four bf16 per row piece, as loaded
+    u32x4 qa[IN16 ? 2 : 1], qb[IN16 ? 2 : 1];     // IN16: eight bf16 per row piece, as loaded
     auto fetch = [&](int m0) {
+        if constexpr (IN16) {
+            const u32x4 z = {0u, 0u, 0u, 0u};
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + sr + 8 * j;
-            const bool ok = m < m_end;
-            if constexpr (IN16) {
-                const bool keep = ok && (!kMask || mask[m]);
-                qa[j] = (keep && a_ok) ? *reinterpret_cast<const uint2*>(A + (int64_t)m * lda + n1 + sq) : make_uint2(0u, 0u);
-                qb[j] = (ok && b_ok) ? *reinterpret_cast<const uint2*>(B + (int64_t)m * ldb + n2 + sq) : make_uint2(0u, 0u);
-            } else {
+            for (int j = 0; j < 2; ++j) {
+                const int m = m0 + sr + 16 * j;
+                const bool ok = m < m_end, keep = ok && (!kMask || mask[m]);
+                // (N1, N2 multiples of 4: a chunk that straddles the edge is fetched as its first half)
+                if (keep && n1 + sq + 8 <= N1) qa[j] = *reinterpret_cast<const u32x4*>(A + (int64_t)m * lda + n1 + sq);
+                else if (keep && a_ok) { const uint2 t = *reinterpret_cast<const uint2*>(A + (int64_t)m * lda + n1 + sq); qa[j] = u32x4{t.x, t.y, 0u, 0u}; }
+                else qa[j] = z;
+                if (ok && n2 + sq + 8 <= N2) qb[j] = *reinterpret_cast<const u32x4*>(B + (int64_t)m * ldb + n2 + sq);
+                else if (ok && b_ok) { const uint2 t = *reinterpret_cast<const uint2*>(B + (int64_t)m * ldb + n2 + sq); qb[j] = u32x4{t.x, t.y, 0u, 0u}; }
+                else qb[j] = z;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int m = m0 + sr + 8 * j;
+                const bool ok = m < m_end;
                 float sc = 1.f;
                 if (kMask) sc = (ok && mask[m]) ? 1.f : 0.f;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -214,23 +226,27 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const void* __restric
         v.x = lo; v.y = hi;
         return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf2));
     };
-    auto stash = [&](int buf) {       // float4 (columns sq .. sq+3) -> 8 bytes at chunk sq / 8, half (sq / 4) & 1
+    auto stash = [&](int buf) {       // fp32: float4 (columns sq .. sq+3) -> 8 bytes at chunk sq / 8, half (sq / 4) & 1
         char* sa = ldsb + buf * 2 * kTnImg;
         char* sb = sa + kTnImg;
+        if constexpr (IN16) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int row = sr + 8 * j;
-            const uint32_t off = tn_img_off(row, sq >> 3) + 8 * ((sq >> 2) & 1);
-            uint2 pa, pb;
-            if constexpr (IN16) {
-                pa = qa[j];
-                pb = qb[j];
-            } else {
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t off = tn_img_off(sr + 16 * j, sq >> 3);
+                *reinterpret_cast<u32x4*>(sa + off) = qa[j];
+                *reinterpret_cast<u32x4*>(sb + off) = qb[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = sr + 8 * j;
+                const uint32_t off = tn_img_off(row, sq >> 3) + 8 * ((sq >> 2) & 1);
+                uint2 pa, pb;
                 pa.x = pack2(ra[j][0], ra[j][1]); pa.y = pack2(ra[j][2], ra[j][3]);
                 pb.x = pack2(rb[j][0], rb[j][1]); pb.y = pack2(rb[j][2], rb[j][3]);
+                *reinterpret_cast<uint2*>(sa + off) = pa;
+                *reinterpret_cast<uint2*>(sb + off) = pb;
             }
-            *reinterpret_cast<uint2*>(sa + off) = pa;
-            *reinterpret_cast<uint2*>(sb + off) = pb;
         }
     };
     // transposing reads: 16-lane group (half hf, 16-column block sub) takes the block of 4 rows x 16 columns whose lane
@@ -972,6 +988,7 @@ extern "C" int32_t ispk_gemm_tn_bf16(const float* A, int64_t lda, const float* B
 extern "C" int32_t ispk_gemm_tn_b16(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t M,
                                     int32_t N1, int32_t N2, const uint8_t* row_mask, int32_t accumulate, float* workspace,
                                     int64_t workspace_floats, ispk_stream_t stream) {
+    ISPK_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, -2, "ispk_gemm_tn_b16: lda / ldb must be multiples of 8 (16-byte row pieces)");
     return gemm_tn_launch(A, lda, 0, B, ldb, 0, C, ldc, 0, 1, M, N1, N2, row_mask, accumulate, workspace, workspace_floats,
                           reinterpret_cast<hipStream_t>(stream), "ispk_gemm_tn_b16", true, true);
 }

@@ -79,6 +79,9 @@ class Attention(nn.Module, Constructor):
                 if dtype == torch.float16:   # split fp16 planes [2, N, K] (hi, lo) for the split-fp16 kernels
                     wqkv = runtime.split_f16(torch.cat([self.to_q.weight, self.to_kv.weight], dim=0).float().contiguous())
                     wo = runtime.split_f16(self.to_out.weight.detach().float().contiguous())
+                elif self.to_q.weight.is_cuda:   # libispk launches only: a training step re-stages after every update
+                    wqkv = runtime.cat0([self.to_q.weight, self.to_kv.weight], dtype)
+                    wo = runtime.cast_bf16(self.to_out.weight.detach()) if dtype == torch.bfloat16 else self.to_out.weight.detach()
                 else:
                     wqkv = torch.cat([self.to_q.weight, self.to_kv.weight], dim=0).to(dtype).contiguous()
                     wo = self.to_out.weight.detach().to(dtype).contiguous()

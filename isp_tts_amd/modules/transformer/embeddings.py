@@ -50,6 +50,9 @@ class ALiBiPositionalBias(nn.Module):
 
     def head_slopes(self) -> Tensor:
         """fp32 [total_heads] slopes for the kernel (heads without ALiBi get slope 0, embeddings.py:66-67)."""
+        logs = getattr(self, "learned_logslopes", None)
+        if logs is not None and logs.is_cuda and logs.dtype == torch.float32:     # one libispk launch (exp + zero padding)
+            return runtime.exp_pad(logs, max(self.total_heads, logs.numel()))
         s = self.get_slopes().reshape(-1).to(torch.float32)
         if self.total_heads > s.numel():
             s = torch.cat([s, s.new_zeros(self.total_heads - s.numel())])

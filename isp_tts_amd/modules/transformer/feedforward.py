@@ -58,6 +58,8 @@ class FeedForward(nn.Module, Constructor):
         if dtype == torch.float16:   # split fp16 planes [2, N, K] for the split-fp16 kernels
             return self._cache.get(dtype, ps, lambda: (runtime.split_f16(ps[0].detach().float().contiguous()),
                                                        runtime.split_f16(ps[1].detach().float().contiguous())))
+        if dtype == torch.bfloat16 and ps[0].is_cuda and ps[0].dtype == torch.float32:   # libispk launches (re-staged every training step)
+            return self._cache.get(dtype, ps, lambda: (runtime.cast_bf16(ps[0].detach()), runtime.cast_bf16(ps[1].detach())))
         return self._cache.get(dtype, ps, lambda: (ps[0].detach().to(dtype).contiguous(),
                                                    ps[1].detach().to(dtype).contiguous()))
 

@@ -33,6 +33,15 @@ SIGNATURES = {
     "ispk_gemm_f32_tile": [_I32, _I32, _I32],
     "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_gemm_f32_batched": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P],
+    "ispk_segments_f32": [_P, _I32, _P],
+    "ispk_fill_zero": [_P, _I64, _P],
+    "ispk_scale_f32": [_P, _I64, _P, _F32, _P],
+    "ispk_sum_scalars_f32": [_P, _P, _I32, _P, _P],
+    "ispk_exp_pad_f32": [_P, _P, _I32, _I32, _P],
+    "ispk_sqrt_scale_f32": [_P, _P, _I32, _F32, _P],
+    "ispk_copy2d_f32": [_P, _I64, _P, _I64, _I32, _I32, _P],
+    "ispk_permute021_f32": [_P, _P, _I32, _I32, _I32, _P],
+    "ispk_conv_weight_flip_f32": [_P, _P, _I32, _I32, _I32, _P],
     "ispk_gemm_bf16_last_variant": [],
     "ispk_gemm_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_ffn_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P],
@@ -910,6 +919,157 @@ def cast_bf16(x: Tensor) -> Tensor:
     return y
 
 
+# ------------------------------------------------------------------------------------------------- data movement (csrc/util.hip)
+class _Segment(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("n", ctypes.c_int64), ("mode", ctypes.c_int32)]
+
+
+SEG_COPY, SEG_ADD, SEG_BF16 = 0, 1, 2
+
+
+def segments(items) -> None:
+    """ispk_segments_f32: items = [(src fp32 contiguous, dst contiguous view, mode)], any number, 32 per launch:
+    SEG_COPY dst = src, SEG_ADD dst += src, SEG_BF16 dst(bf16) = src."""
+    if not items:
+        return
+    arr = (_Segment * len(items))()
+    nbytes = 0.0
+    for k, (src, dst, mode) in enumerate(items):
+        _dev(src, dst)
+        assert src.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and src.numel() == dst.numel()
+        assert dst.dtype == (torch.bfloat16 if mode == SEG_BF16 else torch.float32)
+        arr[k].src, arr[k].dst, arr[k].n, arr[k].mode = src.data_ptr(), dst.data_ptr(), src.numel(), mode
+        nbytes += src.numel() * (4.0 + dst.element_size() * (2 if mode == SEG_ADD else 1))
+    _launch("segments_kernel", 0.0, nbytes, lib().ispk_segments_f32, ctypes.cast(arr, ctypes.c_void_p), len(items), _stream())
+
+
+def cat0(tensors, dtype: torch.dtype = torch.float32) -> Tensor:
+    """torch.cat(tensors, 0).to(dtype) of contiguous fp32 tensors as one ispk_segments_f32 launch (weights that change every
+    training step: the fused [to_q; to_kv] image, the adaptive norms' stacked projections)."""
+    srcs = [t.detach() for t in tensors]
+    assert dtype in (torch.float32, torch.bfloat16) and all(t.dtype == torch.float32 and t.is_contiguous() for t in srcs)
+    rows = sum(t.shape[0] for t in srcs)
+    out = torch.empty((rows, *srcs[0].shape[1:]), dtype=dtype, device=srcs[0].device)
+    items, r = [], 0
+    for t in srcs:
+        items.append((t, out[r:r + t.shape[0]], SEG_BF16 if dtype == torch.bfloat16 else SEG_COPY))
+        r += t.shape[0]
+    segments(items)
+    return out
+
+
+def deliver_grads(pairs) -> list:
+    """pairs = [(parameter, gradient | None)] -> the list of gradients to hand to autograd.  A gradient whose parameter's .grad
+    is a buffer of an optimizer arena (`FlatParameters` marks it `_ispk_grad_arena`) is written - or added, if something has
+    been delivered since the arena was zeroed - into it by ONE segments launch for the whole list, and autograd gets None:
+    no AccumulateGrad add per parameter."""
+    out, items = [], []
+    for p, g in pairs:
+        buf = p.grad if g is not None else None
+        if buf is not None and getattr(buf, "_ispk_grad_arena", False) and g.is_cuda:
+            g = g.detach()
+            g = g if g.dtype == torch.float32 and g.is_contiguous() else g.float().contiguous()
+            items.append((g, buf, SEG_ADD if getattr(buf, "_ispk_dirty", False) else SEG_COPY))
+            buf._ispk_dirty = True
+            out.append(None)
+        else:
+            out.append(g)
+    segments(items)
+    return out
+
+
+def zero_(t: Tensor) -> Tensor:
+    """ispk_fill_zero on a contiguous tensor."""
+    _dev(t)
+    assert t.is_contiguous()
+    _launch("fill_zero_kernel", 0.0, float(t.numel() * t.element_size()), lib().ispk_fill_zero, t.data_ptr(),
+            t.numel() * t.element_size(), _stream())
+    return t
+
+
+def zeros(shape, dtype: torch.dtype = torch.float32, device=None) -> Tensor:
+    return zero_(torch.empty(shape, dtype=dtype, device=device))
+
+
+def scale_(x: Tensor, s_dev: Optional[Tensor] = None, s_host: float = 1.0) -> Tensor:
+    """ispk_scale_f32: x *= s_dev[0] * s_host in place (s_dev: a one-element fp32 device tensor or None)."""
+    _dev(x, s_dev)
+    assert x.dtype == torch.float32 and x.is_contiguous() and (s_dev is None or (s_dev.dtype == torch.float32 and s_dev.numel() == 1))
+    _launch("scale_kernel", 0.0, 8.0 * x.numel(), lib().ispk_scale_f32, x.data_ptr(), x.numel(), _ptr(s_dev), float(s_host), _stream())
+    return x
+
+
+def sum_scalars(terms, weights=None) -> Tensor:
+    """ispk_sum_scalars_f32 -> 0-dim fp32: sum_i weights[i] * terms[i] (one-element fp32 device tensors), in index order."""
+    terms = list(terms)
+    _dev(*terms)
+    assert 1 <= len(terms) <= 8 and all(t.dtype == torch.float32 and t.numel() == 1 for t in terms)
+    ptrs = (ctypes.c_void_p * len(terms))(*[t.data_ptr() for t in terms])
+    ws = (ctypes.c_float * len(terms))(*([1.0] * len(terms) if weights is None else [float(w) for w in weights]))
+    out = torch.empty((1,), dtype=torch.float32, device=terms[0].device)
+    _launch("sum_scalars_kernel", 0.0, 0.0, lib().ispk_sum_scalars_f32, ctypes.cast(ptrs, ctypes.c_void_p),
+            ctypes.cast(ws, ctypes.c_void_p), len(terms), out.data_ptr(), _stream())
+    return out.reshape(())
+
+
+def exp_pad(src: Tensor, total: Optional[int] = None) -> Tensor:
+    """ispk_exp_pad_f32: exp(src) (fp32, flattened), zero-padded to `total` elements."""
+    _dev(src)
+    src = src.detach().reshape(-1)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    total = src.numel() if total is None else total
+    out = torch.empty((total,), dtype=torch.float32, device=src.device)
+    _launch("unary_kernel", 0.0, 0.0, lib().ispk_exp_pad_f32, src.data_ptr(), out.data_ptr(), src.numel(), total, _stream())
+    return out
+
+
+def sqrt_scale(src: Tensor, scale: float = 1.0) -> Tensor:
+    """ispk_sqrt_scale_f32: sqrt(src) * scale (fp32)."""
+    _dev(src)
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    out = torch.empty_like(src)
+    _launch("unary_kernel", 0.0, 0.0, lib().ispk_sqrt_scale_f32, src.data_ptr(), out.data_ptr(), src.numel(), float(scale), _stream())
+    return out
+
+
+def copy2d(src: Tensor, dst: Tensor) -> Tensor:
+    """ispk_copy2d_f32: dst[:, :] = src for 2-D fp32 views with unit column stride."""
+    _dev(src, dst)
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.ndim == 2 and src.shape == dst.shape
+    assert src.stride(1) == 1 and dst.stride(1) == 1
+    _launch("copy2d_kernel", 0.0, 8.0 * src.numel(), lib().ispk_copy2d_f32, src.data_ptr(), src.stride(0), dst.data_ptr(),
+            dst.stride(0), src.shape[0], src.shape[1], _stream())
+    return dst
+
+
+def permute021(src: Tensor) -> Tensor:
+    """ispk_permute021_f32: [A, B, C] fp32 contiguous -> contiguous [A, C, B]."""
+    _dev(src)
+    src = src.detach()
+    assert src.dtype == torch.float32 and src.ndim == 3 and src.is_contiguous()
+    A, B, C = src.shape
+    out = torch.empty((A, C, B), dtype=torch.float32, device=src.device)
+    _launch("permute021_kernel", 0.0, 8.0 * src.numel(), lib().ispk_permute021_f32, src.data_ptr(), out.data_ptr(), A, B, C, _stream())
+    return out
+
+
+def conv_weight_flip(w: Tensor) -> Tensor:
+    """ispk_conv_weight_flip_f32: Conv1d weight [O, C, K] -> [C, K * O] with wf[c][(K-1-k) O + o] = w[o][c][k]."""
+    _dev(w)
+    w = w.detach()
+    assert w.dtype == torch.float32 and w.ndim == 3 and w.is_contiguous()
+    O, C, K = w.shape
+    out = torch.empty((C, K * O), dtype=torch.float32, device=w.device)
+    _launch("conv_flip_kernel", 0.0, 8.0 * w.numel(), lib().ispk_conv_weight_flip_f32, w.data_ptr(), out.data_ptr(), O, C, K, _stream())
+    return out
+
+
+def draw_seed() -> int:
+    """A 62-bit seed for one launch group's dropout masks from torch's CPU generator (`torch.manual_seed(s)` reproduces a
+    run): a host-side draw, no device tensor and no device round trip."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
 # ------------------------------------------------------------------------------------------------- training step (row f2)
 def transpose(x: Tensor) -> Tensor:
     """ispk_transpose_f32: y[c, r] = x[r, c] (fp32 matrix; weights for dX = dY . W through the NT GEMM)."""
@@ -1009,8 +1169,8 @@ def aligner_scores_bwd(attn_logits: Tensor, attn_soft: Tensor, d_soft: Optional[
     _dev(attn_logits, attn_soft, d_soft, d_logits, text_len, mel_len)
     B, M, L = attn_logits.shape
     L4, M4 = (L + 3) // 4 * 4, (M + 3) // 4 * 4
-    dS = torch.zeros((B, M, L4), dtype=torch.float32, device=attn_logits.device)
-    dSt = torch.zeros((B, L, M4), dtype=torch.float32, device=attn_logits.device)
+    dS = zeros((B, M, L4), torch.float32, attn_logits.device)
+    dSt = zeros((B, L, M4), torch.float32, attn_logits.device)
     cg = lambda t: None if t is None else t.float().contiguous()       # noqa: E731
     d_soft, d_logits = cg(d_soft), cg(d_logits)
     _launch("aligner_scores_bwd_kernel", 0.0, 4.0 * B * M * L * 6, lib().ispk_aligner_scores_bwd_f32, attn_logits.contiguous().data_ptr(),
@@ -1247,7 +1407,7 @@ def attn_bin_loss(attn_soft: Tensor, attn_hard: Tensor, eps: float = 1e-6, want_
     attn_soft, attn_hard = attn_soft.contiguous(), attn_hard.contiguous()
     B, M, L = attn_soft.shape[0], attn_soft.shape[-2], attn_soft.shape[-1]
     loss = torch.empty((2,), dtype=torch.float32, device=attn_soft.device)
-    grad = torch.zeros_like(attn_soft) if want_grad else None
+    grad = zeros(attn_soft.shape, attn_soft.dtype, attn_soft.device) if want_grad else None
     ws = workspace(attn_soft.device, 2048)
     _launch("bin_loss_kernels", 0.0, 6.0 * attn_soft.numel(), lib().ispk_attn_bin_loss_f32, attn_soft.data_ptr(),
             attn_hard.data_ptr(), eps, ws.data_ptr(), loss.data_ptr(), _ptr(grad), grad_out, B, M, L, _stream())

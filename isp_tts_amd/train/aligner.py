@@ -26,11 +26,16 @@ def _windows(xpad: Tensor, rows: int, taps: int, first_row: int = 0) -> Tensor:
 
 def _w2d(conv_weight: Tensor) -> Tensor:
     """Conv1d weight [O, C, k] -> GEMM weight [O, k * C] (tap-major, as ConvAttention._staged)."""
-    return conv_weight.detach().permute(0, 2, 1).reshape(conv_weight.shape[0], -1).contiguous()
+    w = conv_weight.detach()
+    if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous():
+        return runtime.permute021(w).reshape(w.shape[0], -1)              # a libispk launch (re-done after every update)
+    return w.permute(0, 2, 1).reshape(w.shape[0], -1).contiguous()
 
 
 def _w2d_grad(g: Tensor, conv_weight: Tensor) -> Tensor:
     o, c, k = conv_weight.shape
+    if g.is_cuda and g.dtype == torch.float32 and g.is_contiguous():
+        return runtime.permute021(g.view(o, k, c))
     return g.view(o, k, c).permute(0, 2, 1).contiguous()
 
 
@@ -74,8 +79,8 @@ class ConvAttentionFunction(torch.autograd.Function):
         dS, dSt = runtime.aligner_scores_bwd(logits, soft, d_soft, d_logits, text_len, mel_len, att.scale)
         # d q_enc[b] = dS[b] k_enc[b], d k_enc[b] = dS[b]^T q_enc[b]: batched transposed products straight into zeroed
         # conv-output-space buffers (frame t at row t; the rows past T stay / become zero: the padding columns of dS are zero)
-        dq_buf = torch.zeros((B, M + 4, 128), dtype=torch.float32, device=dev)
-        dk_buf = torch.zeros((B, L + 4, 128), dtype=torch.float32, device=dev)
+        dq_buf = runtime.zeros((B, M + 4, 128), torch.float32, dev)
+        dk_buf = runtime.zeros((B, L + 4, 128), torch.float32, dev)
         runtime.gemm_tn_batched(dSt, k_enc[:, :L], out=dq_buf[:, :dSt.shape[2]])
         runtime.gemm_tn_batched(dS, q_enc[:, :M], out=dk_buf[:, :dS.shape[2]])
 
@@ -98,9 +103,9 @@ class ConvAttentionFunction(torch.autograd.Function):
             if want_dx:
                 # d xpad[r] = sum_k d u[r - k] W_k: the conv GEMM over d u with four zero rows in front and the taps flipped
                 C = xpad.shape[-1]
-                g = torch.zeros((Bc * TP + 4 + 4, O), dtype=torch.float32, device=d_u.device)
-                g[4:4 + Bc * TP].copy_(d_u.reshape(-1, O))
-                wf = block.conv.weight.detach().flip(2).permute(1, 2, 0).reshape(C, 5 * O).contiguous()   # [C][(j, o)] = W[o][c][4 - j]
+                g = runtime.zeros((Bc * TP + 4 + 4, O), torch.float32, d_u.device)
+                runtime.segments([(d_u.reshape(-1, O), g[4:4 + Bc * TP], runtime.SEG_COPY)])
+                wf = runtime.conv_weight_flip(block.conv.weight)          # [C][(j, o)] = W[o][c][4 - j]
                 dx = runtime.gemm(_windows(g, Bc * TP, 5), wf)                       # [B (T+4), C]: padded row space
             return _w2d_grad(dw, block.conv.weight), dnw, dnb, dx
 
@@ -112,14 +117,15 @@ class ConvAttentionFunction(torch.autograd.Function):
         dwq1, dnq1_w, dnq1_b, d_qp1 = block_bwd(d_qp2, y2, u2, qp1, qb1, mel_len, True)
         # d qp1 is in PADDED row space (frame t at row t + 2): shift by two rows into the conv-output convention
         Bq, TPq = qp1.shape[0], qp1.shape[1]
-        shifted = torch.zeros((Bq * TPq + 2, qp1.shape[2]), dtype=torch.float32, device=dev)
-        shifted[:Bq * TPq].copy_(d_qp1)
+        shifted = runtime.zeros((Bq * TPq + 2, qp1.shape[2]), torch.float32, dev)
+        runtime.segments([(d_qp1.reshape(Bq * TPq, -1), shifted[:Bq * TPq], runtime.SEG_COPY)])
         d_n1 = shifted[2:].view(Bq, TPq, -1)
         dwq0, dnq0_w, dnq0_b, _ = block_bwd(d_n1, y1, u1, qp0, qb0, mel_len, False)
         grads = {id(kb0.conv.weight): dwk0, id(kb0.norm.weight): dnk_w, id(kb0.norm.bias): dnk_b, id(kb1.conv.weight): dwk1,
                  id(qb0.conv.weight): dwq0, id(qb0.norm.weight): dnq0_w, id(qb0.norm.bias): dnq0_b,
                  id(qb1.conv.weight): dwq1, id(qb1.norm.weight): dnq1_w, id(qb1.norm.bias): dnq1_b, id(qb2.conv.weight): dwq2}
-        return (None, None, None, None, None, *[grads[id(p)] for p in aligner_parameters(att)])
+        ps = aligner_parameters(att)
+        return (None, None, None, None, None, *runtime.deliver_grads([(p, grads[id(p)]) for p in ps]))
 
 
 def aligner_parameters(att) -> list:

@@ -9,6 +9,45 @@ from torch import Tensor
 from .. import runtime
 
 
+def _times(grad: Tensor, grad_loss: Tensor) -> Tensor:
+    """grad * grad_loss (the scalar that reaches a loss term in backward), in place on the saved gradient, as a libispk launch."""
+    if grad.is_cuda and grad.dtype == torch.float32 and grad.is_contiguous() and grad_loss.dtype == torch.float32:
+        return runtime.scale_(grad, grad_loss.reshape(1))
+    return grad * grad_loss
+
+
+def _weighted(weight: float, loss: Tensor) -> Tensor:
+    return loss if weight == 1.0 else weight * loss
+
+
+class _SumLossesFunction(torch.autograd.Function):
+    """total = sum of scalar loss terms (loss.py:140-182 adds them one by one): one launch; every term gets the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, *terms: Tensor):
+        ctx.n = len(terms)
+        return runtime.sum_scalars([t.reshape(1) for t in terms])
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return (g,) * ctx.n
+
+
+def sum_losses(terms) -> Tensor:
+    """Sum of scalar loss terms (Python numbers - skipped criteria return 0. - are added on the host side of the result)."""
+    tensors = [t for t in terms if isinstance(t, Tensor)]
+    extra = sum(float(t) for t in terms if not isinstance(t, Tensor))
+    if not tensors:
+        return extra
+    if all(t.is_cuda and t.dtype == torch.float32 for t in tensors) and len(tensors) <= 8:
+        total = _SumLossesFunction.apply(*tensors) if len(tensors) > 1 else tensors[0]
+    else:
+        total = tensors[0]
+        for t in tensors[1:]:
+            total = total + t
+    return total if extra == 0.0 else total + extra
+
+
 class _MelLossFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mel_out: Tensor, mel_target: Tensor, mel_len: Tensor):
@@ -20,7 +59,7 @@ class _MelLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss: Tensor):
         (grad,) = ctx.saved_tensors
-        return grad * grad_loss, None, None
+        return _times(grad, grad_loss), None, None
 
 
 class MelLoss(torch.nn.Module):
@@ -34,7 +73,7 @@ class MelLoss(torch.nn.Module):
     def forward(self, mels_out: Tensor, mels_target: Tensor, mel_lengths: Tensor, step=None):
         if step is not None and step < self.skip_steps:
             return 0.
-        return self.weight * _MelLossFunction.apply(mels_out, mels_target, mel_lengths)
+        return _weighted(self.weight, _MelLossFunction.apply(mels_out, mels_target, mel_lengths))
 
 
 class _BinLossFunction(torch.autograd.Function):
@@ -47,7 +86,7 @@ class _BinLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss: Tensor):
         (grad,) = ctx.saved_tensors
-        return grad * grad_loss, None, None
+        return _times(grad, grad_loss), None, None
 
 
 class AttentionBinarizationLoss(torch.nn.Module):
@@ -63,7 +102,7 @@ class AttentionBinarizationLoss(torch.nn.Module):
             return 0.
         soft = soft_attention.reshape(-1, *soft_attention.shape[-2:])
         hard = hard_attention.reshape(-1, *hard_attention.shape[-2:])
-        return self.weight * _BinLossFunction.apply(soft, hard, self.eps)
+        return _weighted(self.weight, _BinLossFunction.apply(soft, hard, self.eps))
 
 
 class _CTCLossFunction(torch.autograd.Function):
@@ -76,7 +115,7 @@ class _CTCLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_loss: Tensor):
         (grad,) = ctx.saved_tensors
-        return grad * grad_loss, None, None, None
+        return _times(grad, grad_loss), None, None, None
 
 
 class AttentionCTCLoss(torch.nn.Module):
@@ -90,7 +129,7 @@ class AttentionCTCLoss(torch.nn.Module):
     def forward(self, attn_logits: Tensor, text_lengths: Tensor, mel_lengths: Tensor, step=None):
         if step is not None and step < self.skip_steps:
             return 0.
-        return self.weight * _CTCLossFunction.apply(attn_logits, text_lengths, mel_lengths, float(self.blank_logprob))
+        return _weighted(self.weight, _CTCLossFunction.apply(attn_logits, text_lengths, mel_lengths, float(self.blank_logprob)))
 
 
 _DEFAULT = object()   # "argument not given" (None means: criterion disabled, as in the reference)
@@ -113,20 +152,20 @@ class AcousticModelLoss(torch.nn.Module):
 
     def forward(self, inputs, outputs, step=None):
         get = (lambda k: inputs[k]) if isinstance(inputs, dict) else (lambda k: getattr(inputs, k))
-        loss, losses = 0., {}
+        terms, losses = [], {}
         mel_loss = self.mel_criterion(outputs.mel, get("mel"), get("mel_len"), step=step)
         losses["model/mel_loss"] = mel_loss
-        loss = loss + mel_loss
+        terms.append(mel_loss)
         if outputs.adaptor_output.losses is not None:
             for key, loss_i in outputs.adaptor_output.losses.items():
                 losses[f"adaptor/{key}"] = loss_i
-                loss = loss + loss_i
+                terms.append(loss_i)
         if self.attention_criterion is not None:
             attn_loss = self.attention_criterion(outputs.aligner_output.attn_logits, get("text_len"), get("mel_len"), step=step)
             losses["aligner/attention_loss"] = attn_loss
-            loss = loss + attn_loss
+            terms.append(attn_loss)
         if self.attention_kl_criterion is not None:
             kl = self.attention_kl_criterion(outputs.aligner_output.attn_soft, outputs.aligner_output.attn_hard, step=step)
             losses["aligner/kl_loss"] = kl
-            loss = loss + kl
-        return loss, losses
+            terms.append(kl)
+        return sum_losses(terms), losses

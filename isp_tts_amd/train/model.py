@@ -15,10 +15,10 @@ import torch
 from torch import Tensor
 
 from .. import runtime
-from .loss import AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
+from .loss import AttentionBinarizationLoss, AttentionCTCLoss, MelLoss, sum_losses
 from .aligner import conv_attention_train
 from .predictor import flow_predictor_loss
-from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction,
+from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction, fork,
                     transformer_train_forward)
 
 
@@ -30,13 +30,15 @@ def acoustic_train_forward(model, text: Tensor, text_len: Tensor, mel: Tensor, m
     aligner is frozen, loss = mel + flow and the two attention terms are values."""
     ad = model.temporal_adaptor
     emb, enc_mask = EmbedTokensFunction.apply(text, model.text_embedding.weight, text_len)
-    enc_out = transformer_train_forward(model.encoder, emb, enc_mask, amp)
+    enc_out = transformer_train_forward(model.encoder, emb, enc_mask, amp, key_len=text_len)
     keys_t = enc_out.detach().transpose(1, 2)          # model.py:139: the aligner sees the DETACHED encoder output
     if train_aligner:
         attn_soft, attn_logits = conv_attention_train(model.aligner.attention, mel, keys_t, mel_len, text_len)
+        attn_soft, attn_soft_kl = fork(attn_soft)     # two consumers: the length regulator and the binarisation loss
     with torch.no_grad():
         if not train_aligner:
             attn_soft, attn_logits = model.aligner.attention(mel, keys_t, mel_len, text_len)
+            attn_soft_kl = attn_soft
         attn_hard, dur = model.aligner.binarize_attention_parallel(attn_logits.detach(), text_len, mel_len, return_duration=True)
         targets = runtime.soft_average(attn_soft.detach(), pitch, energy, dur, text_len)       # [log1p duration, pitch, energy]
     # The averaged pitch / energy enter the embedding stack DETACHED (temporal_adaptor.py:284, :292 `pitch_target.detach()`,
@@ -46,20 +48,23 @@ def acoustic_train_forward(model, text: Tensor, text_len: Tensor, mel: Tensor, m
     b, l = text.shape
     x0 = flow_noise if flow_noise is not None else torch.randn(b, l, 3, device=text.device)
     t = flow_time if flow_time is not None else torch.rand(b, device=text.device)
-    cond = enc_out.detach() if ad.predictor.detach_inputs else enc_out
-    flow_loss = flow_predictor_loss(ad.predictor, cond, targets, enc_mask, x0, t, amp)
+    if ad.predictor.detach_inputs:
+        cond = enc_out.detach()
+    else:
+        enc_out, cond = fork(enc_out)               # two consumers: the embedding module's residual and the flow predictor
+    flow_loss = flow_predictor_loss(ad.predictor, cond, targets, enc_mask, x0, t, amp, key_len=text_len)
     emod = ad.embedding
-    h = transformer_train_forward(emod.transformer, feats[..., 1:3], enc_mask, amp)
+    # pitch / energy columns as a contiguous [B, L, 2] (a strided copy launch, not a .contiguous())
+    pe = runtime.copy2d(feats.reshape(-1, 3)[:, 1:3], torch.empty((b * l, 2), dtype=torch.float32, device=feats.device)).view(b, l, 2)
+    h = transformer_train_forward(emod.transformer, pe, enc_mask, amp, key_len=text_len)
     x = MaskedLinearResidualFunction.apply(h, emod.linear_layer.weight, emod.linear_layer.bias, enc_mask, enc_out)
     dec_in, dec_len, dec_mask = LengthRegulateFunction.apply(x, attn_soft, mel_len.view(-1, 1), mel.shape[2])
-    dec = transformer_train_forward(model.decoder, dec_in, dec_mask, amp)
+    dec = transformer_train_forward(model.decoder, dec_in, dec_mask, amp, key_len=dec_len)
     mel_out = ToMelFunction.apply(dec, model.to_mel.weight, model.to_mel.bias, dec_mask)
     mel_loss = MelLoss()(mel_out, mel, mel_len)
     with torch.set_grad_enabled(train_aligner):
         ctc = AttentionCTCLoss()(attn_logits, text_len, mel_len)
-        kl = AttentionBinarizationLoss()(attn_soft, attn_hard)
+        kl = AttentionBinarizationLoss()(attn_soft_kl, attn_hard)
     losses = {"model/mel_loss": mel_loss, "adaptor/flow_loss": flow_loss, "aligner/attention_loss": ctc, "aligner/kl_loss": kl}
-    total = mel_loss + flow_loss
-    if train_aligner:
-        total = total + ctc + kl
+    total = sum_losses([mel_loss, flow_loss, ctc, kl] if train_aligner else [mel_loss, flow_loss])
     return mel_out, total, losses

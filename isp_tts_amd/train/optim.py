@@ -86,7 +86,10 @@ class FlatParameters:
         p.grad = g
 
     def zero_grad(self) -> None:
-        self.grad.zero_()
+        if self.grad.is_cuda:
+            runtime.zero_(self.grad)
+        else:
+            self.grad.zero_()
         for p, o in zip(self.params, self.offsets):      # someone may have set .grad to None / another tensor
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o or not getattr(p.grad, "_ispk_grad_arena", False):
                 self._attach_grad(p, o)
@@ -128,13 +131,19 @@ class FlatAdamW:
         self.sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._update = update or runtime.adamw          # (hooks: the CPU gloo test drives the exchange with the oracle's math)
         self._sqnorm = sqnorm or runtime.grad_sqnorm
+        self._one = None
         self.check_finite = True      # `step` returns None for a non-finite norm like the reference (:238-239): one host sync
         self._reduce_scatter = self.world > 1 and dist.get_backend(process_group) != "gloo"   # gloo has none
 
     # ------------------------------------------------------------------------------------------------------------ step
     def step(self, loss_value: Optional[Tensor] = None, step_optimizer: bool = True):
         if loss_value is not None:
-            (loss_value / self.grad_accum_steps).backward()
+            if self.grad_accum_steps == 1 and loss_value.is_cuda and loss_value.dtype == torch.float32:
+                if self._one is None or self._one.device != loss_value.device:
+                    self._one = torch.ones((), dtype=torch.float32, device=loss_value.device)
+                loss_value.backward(self._one)          # (no division, no ones_like: the root gradient is a kept tensor)
+            else:
+                (loss_value / self.grad_accum_steps).backward()
         if not step_optimizer:
             return None
         flat, n_dec = self.flat, self.flat.n_decay
@@ -168,7 +177,8 @@ class FlatAdamW:
         flat.zero_grad()
         if not clip:
             return None
-        norm = self.sq.sqrt() / self.world          # norm of the averaged gradients
+        # norm of the averaged gradients
+        norm = runtime.sqrt_scale(self.sq, 1.0 / self.world) if self.sq.is_cuda else self.sq.sqrt() / self.world
         return norm if not self.check_finite or bool(torch.isfinite(norm)) else None
 
     def zero_grad(self, set_to_none: bool = True) -> None:

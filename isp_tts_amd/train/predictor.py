@@ -27,13 +27,14 @@ class TimeEmbeddingFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, t: Tensor, inv_freq: Tensor, freq_scale: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor):
         ctx.save_for_backward(t, inv_freq, freq_scale, w0, b0, w1)
+        ctx.params = (w0, b0, w1, b1)
         return runtime.time_embedding(t, inv_freq, freq_scale, w0.detach(), b0.detach(), w1.detach(), b1.detach())
 
     @staticmethod
     def backward(ctx, d_out: Tensor):
         t, inv_freq, freq_scale, w0, b0, w1 = ctx.saved_tensors
         dw0, db0, dw1, db1 = runtime.time_embedding_bwd(t, inv_freq, freq_scale, w0.detach(), b0.detach(), w1.detach(), d_out)
-        return None, None, None, dw0, db0, dw1, db1
+        return (None, None, None, *runtime.deliver_grads(list(zip(ctx.params, (dw0, db0, dw1, db1)))))
 
 
 def _ada_norms(tr: Transformer) -> list:
@@ -51,12 +52,11 @@ class AdaProjectionFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tr: Transformer, cond: Tensor, *params: Tensor):
         norms = _ada_norms(tr)
-        with torch.no_grad():
-            w_all = torch.cat([torch.cat([n.weight.weight, n.bias.weight]) for n in norms]).contiguous()
-            b_all = torch.cat([torch.cat([n.weight.bias, n.bias.bias]) for n in norms]).contiguous()
+        w_all = runtime.cat0([w for n in norms for w in (n.weight.weight, n.bias.weight)])      # one launch each
+        b_all = runtime.cat0([b for n in norms for b in (n.weight.bias, n.bias.bias)])
         cond = cond.float().contiguous()
         ctx.save_for_backward(cond, w_all)
-        ctx.dim, ctx.n = tr.dim, len(norms)
+        ctx.dim, ctx.n, ctx.params = tr.dim, len(norms), params
         return runtime.linear_small(cond, w_all, b_all)
 
     @staticmethod
@@ -70,7 +70,7 @@ class AdaProjectionFunction(torch.autograd.Function):
         for i in range(ctx.n):
             grads += [dw[(2 * i) * d:(2 * i + 1) * d], db[(2 * i) * d:(2 * i + 1) * d],
                       dw[(2 * i + 1) * d:(2 * i + 2) * d], db[(2 * i + 1) * d:(2 * i + 2) * d]]
-        return (None, d_cond, *grads)
+        return (None, d_cond, *runtime.deliver_grads(list(zip(ctx.params, grads))))
 
 
 class ProjectSplitFunction(torch.autograd.Function):
@@ -82,9 +82,10 @@ class ProjectSplitFunction(torch.autograd.Function):
         k = x_t.shape[-1]
         cond = cond.float().contiguous()
         x_t = x_t.float().contiguous()
-        wc = weight.detach()[:, k:].contiguous()
+        wc = runtime.copy2d(weight.detach()[:, k:], torch.empty((weight.shape[0], weight.shape[1] - k), dtype=torch.float32,
+                                                                device=weight.device))
         ctx.save_for_backward(x_t, cond, wc)
-        ctx.k = k
+        ctx.k, ctx.params = k, (weight, bias)
         cp = runtime.gemm(cond, wc, bias=bias.detach())
         return runtime.linear_small(x_t, weight.detach()[:, :k], None, resid=cp)
 
@@ -95,8 +96,8 @@ class ProjectSplitFunction(torch.autograd.Function):
         k = ctx.k
         dw = torch.empty((wc.shape[0], k + wc.shape[1]), dtype=torch.float32, device=dy.device)
         runtime.gemm_tn(dy, cond, out=dw[:, k:])
-        dw[:, :k].copy_(runtime.smallk_wgrad(dy, x_t))
-        return None, runtime.gemm(dy, runtime.transpose(wc)), dw, runtime.colsum(dy)
+        runtime.copy2d(runtime.smallk_wgrad(dy, x_t), dw[:, :k])
+        return (None, runtime.gemm(dy, runtime.transpose(wc)), *runtime.deliver_grads(list(zip(ctx.params, (dw, runtime.colsum(dy))))))
 
 
 class SmallOutputLinearFunction(torch.autograd.Function):
@@ -106,6 +107,7 @@ class SmallOutputLinearFunction(torch.autograd.Function):
     def forward(ctx, h: Tensor, weight: Tensor, bias: Tensor):
         h = h.float().contiguous()
         ctx.save_for_backward(h, weight)
+        ctx.params = (weight, bias)
         return runtime.linear_small(h, weight.detach(), bias.detach())
 
     @staticmethod
@@ -114,7 +116,7 @@ class SmallOutputLinearFunction(torch.autograd.Function):
         d_raw = d_raw.float().contiguous()
         dh = runtime.linear_small(d_raw, runtime.transpose(weight.detach()), None)     # [rows, 3] x [3 -> dim]
         dw = runtime.transpose(runtime.smallk_wgrad(h, d_raw))                          # ([dim, 3])^T
-        return dh, dw, runtime.colsum(d_raw)
+        return (dh, *runtime.deliver_grads(list(zip(ctx.params, (dw, runtime.colsum(d_raw))))))
 
 
 class FlowLossFunction(torch.autograd.Function):
@@ -130,7 +132,7 @@ class FlowLossFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g: Tensor):
         raw, flow, mask = ctx.saved_tensors
-        return runtime.flow_loss_bwd(raw, flow, mask) * g, None, None, None
+        return runtime.scale_(runtime.flow_loss_bwd(raw, flow, mask), g.reshape(1)), None, None, None
 
 
 def adaptive_stack_parameters(tr: Transformer) -> list:
@@ -147,11 +149,12 @@ class AdaptiveStackFunction(torch.autograd.Function):
     scale / shift rows from `ss` (AdaProjectionFunction) and returning those rows' gradients."""
 
     @staticmethod
-    def forward(ctx, tr: Transformer, x: Tensor, mask: Optional[Tensor], amp: bool, ss: Tensor, *params: Tensor):
+    def forward(ctx, tr: Transformer, x: Tensor, mask: Optional[Tensor], amp: bool, ss: Tensor, ctx_key_len: Optional[Tensor],
+                *params: Tensor):
         x, ss = x.float().contiguous(), ss.float().contiguous()
         B, L, D = x.shape
-        key_len = mask.sum(dim=1) if mask is not None else None
-        base_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        key_len = ctx_key_len if ctx_key_len is not None else (mask.sum(dim=1) if mask is not None else None)
+        base_seed = runtime.draw_seed()
         tape, out = [], x
         for li, layer in enumerate(tr.layers):
             att, ff = layer.attention, layer.feed_forward
@@ -180,7 +183,7 @@ class AdaptiveStackFunction(torch.autograd.Function):
             tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
         final = runtime.layernorm(out, tr.norm.weight, tr.norm.bias, row_mask=mask, eps=tr.norm.eps)
-        ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last, ctx.amp, ctx.ss = tr, mask, key_len, tape, out, amp, ss
+        ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last, ctx.amp, ctx.ss, ctx.params = tr, mask, key_len, tape, out, amp, ss, params
         return final
 
     @staticmethod
@@ -229,11 +232,11 @@ class AdaptiveStackFunction(torch.autograd.Function):
             ls = att.rel_pos.learned_logslopes
             grads = [dwqkv[:hq], dwqkv[hq:], dls[:ls.numel()].view_as(ls), dwo, dw1, dw2] + grads
         ctx.tape = None
-        return (None, dy, None, None, d_ss, *grads, dgf, dbf)
+        return (None, dy, None, None, d_ss, None, *runtime.deliver_grads(list(zip(ctx.params, grads + [dgf, dbf]))))
 
 
 def flow_predictor_loss(pred, cond: Tensor, targets: Tensor, mask: Tensor, noise: Tensor, time_steps: Tensor,
-                        amp: bool = False) -> Tensor:
+                        amp: bool = False, key_len: Optional[Tensor] = None) -> Tensor:
     """The flow loss of `FlowTransformerTemporalModule.forward` (temporal_adaptor.py:105-147) as a differentiable scalar:
     gradients reach every parameter of the predictor `pred` and `cond` (the encoder output; pass it detached for
     `detach_inputs`).  `targets` [B, L, 3] are constants (:112), `noise` / `time_steps` the step's x0 and t."""
@@ -246,6 +249,6 @@ def flow_predictor_loss(pred, cond: Tensor, targets: Tensor, mask: Tensor, noise
                                            te.mlp[2].weight, te.mlp[2].bias)
     ss = AdaProjectionFunction.apply(tr, time_emb, *ada_parameters(tr))
     proj = ProjectSplitFunction.apply(x_t, cond, tr.project_emb.weight, tr.project_emb.bias)
-    out = AdaptiveStackFunction.apply(tr, proj, mask, amp, ss, *adaptive_stack_parameters(tr))
+    out = AdaptiveStackFunction.apply(tr, proj, mask, amp, ss, key_len, *adaptive_stack_parameters(tr))
     raw = SmallOutputLinearFunction.apply(out, pred.linear_layer.weight, pred.linear_layer.bias)
     return FlowLossFunction.apply(raw, flow, noise, mask)

@@ -82,17 +82,18 @@ class TransformerStackFunction(torch.autograd.Function):
     fp32."""
 
     @staticmethod
-    def forward(ctx, tr: Transformer, x: Tensor, mask: Optional[Tensor], amp: bool, *params: Tensor):
+    def forward(ctx, tr: Transformer, x: Tensor, mask: Optional[Tensor], amp: bool, key_len: Optional[Tensor], *params: Tensor):
         _check(tr)
         ctx.want_dx = x.requires_grad          # (asked before the copy below: a tensor made inside forward never requires grad)
         x = x.float().contiguous()
-        key_len = mask.sum(dim=1) if mask is not None else None
+        if key_len is None and mask is not None:        # (the callers that know the lengths pass them: no reduction launch)
+            key_len = mask.sum(dim=1)
         proj = not isinstance(tr.project_emb, torch.nn.Identity)
         if proj:      # transformer.py:170, :189: a Linear from the few input features (the adaptor's pitch / energy pair)
             ctx.proj_in = x
             x = runtime.linear(x, tr.project_emb.weight, tr.project_emb.bias)
         tape, out = [], x
-        base_seed = int(torch.randint(0, 2 ** 62, (1,)).item())      # torch's CPU generator: torch.manual_seed reproduces a run
+        base_seed = runtime.draw_seed()      # a host generator that follows torch's seed: torch.manual_seed reproduces a run
         for li, layer in enumerate(tr.layers):
             att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
             wqkv, wo, slopes = att._staged(torch.float32)
@@ -119,7 +120,7 @@ class TransformerStackFunction(torch.autograd.Function):
             tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
         final = runtime.layernorm(out, tr.norm.weight, tr.norm.bias, row_mask=mask, eps=tr.norm.eps)
-        ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last, ctx.amp = tr, mask, key_len, tape, out, amp
+        ctx.tr, ctx.mask, ctx.key_len, ctx.tape, ctx.last, ctx.amp, ctx.params = tr, mask, key_len, tape, out, amp, params
         return final
 
     @staticmethod
@@ -173,13 +174,39 @@ class TransformerStackFunction(torch.autograd.Function):
             grads = [runtime.smallk_wgrad(dy, ctx.proj_in), runtime.colsum(dy)] + grads
             # d x = dy W (a handful of outputs): only when the features themselves carry a gradient (the soft averages do)
             dy = runtime.linear_small(dy, runtime.transpose(tr.project_emb.weight.detach()), None) if ctx.want_dx else None
-        return (None, dy, None, None, *grads, dgf, dbf)
+        # small gradients (norm weights, slopes, ...) go to the optimizer arena in ONE launch; the big ones were delivered above
+        return (None, dy, None, None, None, *runtime.deliver_grads(list(zip(ctx.params, grads + [dgf, dbf]))))
 
 
-def transformer_train_forward(tr: Transformer, x: Tensor, mask: Optional[Tensor] = None, amp: bool = False) -> Tensor:
+def transformer_train_forward(tr: Transformer, x: Tensor, mask: Optional[Tensor] = None, amp: bool = False,
+                              key_len: Optional[Tensor] = None) -> Tensor:
     """`tr(x, mask).out` as a differentiable node (gradients reach x and every parameter of the stack); `amp` = bf16
     operands for the Linear GEMMs (see TransformerStackFunction)."""
-    return TransformerStackFunction.apply(tr, x, mask, amp, *stack_parameters(tr))
+    return TransformerStackFunction.apply(tr, x, mask, amp, key_len, *stack_parameters(tr))
+
+
+class ForkFunction(torch.autograd.Function):
+    """x -> (x, x) for a tensor with two differentiable consumers: the two gradients are added by libispk launches here, so
+    the autograd engine never has to (its own accumulation is an ATen add)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        ctx.set_materialize_grads(False)
+        return x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g1: Optional[Tensor], g2: Optional[Tensor]):
+        if g1 is None or g2 is None:
+            return g1 if g2 is None else g2
+        g1, g2 = g1.float().contiguous(), g2.float().contiguous()
+        out = torch.empty_like(g1)
+        runtime.segments([(g1, out, runtime.SEG_COPY)])
+        runtime.segments([(g2, out, runtime.SEG_ADD)])
+        return out
+
+
+def fork(x: Tensor):
+    return ForkFunction.apply(x) if x.requires_grad and x.is_cuda else (x, x)
 
 
 class ToMelFunction(torch.autograd.Function):
@@ -190,7 +217,7 @@ class ToMelFunction(torch.autograd.Function):
     def forward(ctx, dec: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor]):
         dec = dec.float().contiguous()
         ctx.save_for_backward(dec, weight)
-        ctx.mask = mask
+        ctx.mask, ctx.params = mask, (weight, bias)
         return runtime.to_mel(dec, weight.detach(), bias.detach(), mask)
 
     @staticmethod
@@ -199,7 +226,7 @@ class ToMelFunction(torch.autograd.Function):
         g = runtime.mel_grad_rows(dmel.float(), ctx.mask)                 # [B, T, 80]
         d_dec = runtime.gemm(g, runtime.transpose(weight.detach()))        # [B, T, dim]
         dw = runtime.gemm_tn(g, dec)                                       # [80, dim]
-        return d_dec, dw, runtime.colsum(g), None
+        return (d_dec, *runtime.deliver_grads(list(zip(ctx.params, (dw, runtime.colsum(g))))), None)
 
 
 def mel_decoder_train_forward(model, dec_in: Tensor, dec_mask: Optional[Tensor], amp: bool = False) -> Tensor:
@@ -216,6 +243,7 @@ class LengthRegulateFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: Tensor, alignment: Tensor, durations: Tensor, frames: int):
         out, dec_len, dec_mask = runtime.length_regulate(x, durations, alignment, frames, max_len=frames)
+        ctx.set_materialize_grads(False)         # (no zero tensors for the two non-differentiable outputs)
         ctx.save_for_backward(alignment, x)
         ctx.want_da = alignment.requires_grad
         ctx.mark_non_differentiable(dec_len, dec_mask)
@@ -237,7 +265,7 @@ class MaskedLinearResidualFunction(torch.autograd.Function):
     def forward(ctx, h: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor], residual: Tensor):
         h = h.float().contiguous()
         ctx.save_for_backward(h, weight)
-        ctx.mask = mask
+        ctx.mask, ctx.params = mask, (weight, bias)
         return runtime.gemm(h, weight.detach(), bias=bias.detach(), mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0,
                             resid=residual)
 
@@ -246,7 +274,8 @@ class MaskedLinearResidualFunction(torch.autograd.Function):
         h, weight = ctx.saved_tensors
         dy, mask = dy.float().contiguous(), ctx.mask
         dh = runtime.gemm(dy, runtime.transpose(weight.detach()), mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
-        return dh, runtime.gemm_tn(dy, h, row_mask=mask), runtime.colsum(dy, mask), None, dy
+        dw, db = runtime.deliver_grads(list(zip(ctx.params, (runtime.gemm_tn(dy, h, row_mask=mask), runtime.colsum(dy, mask)))))
+        return dh, dw, db, None, dy
 
 
 class EmbedTokensFunction(torch.autograd.Function):
@@ -256,15 +285,17 @@ class EmbedTokensFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, text: Tensor, table: Tensor, text_len: Tensor):
         emb, mask = runtime.embed_tokens(text, table.detach(), text_len)
+        ctx.set_materialize_grads(False)
         ctx.save_for_backward(text)
-        ctx.vocab = table.shape[0]
+        ctx.vocab, ctx.table = table.shape[0], table
         ctx.mark_non_differentiable(mask)
         return emb, mask
 
     @staticmethod
     def backward(ctx, d_emb: Tensor, _dm):
         (text,) = ctx.saved_tensors
-        return None, runtime.embedding_bwd(text, d_emb.float().contiguous(), ctx.vocab, padding_idx=0), None
+        (dt,) = runtime.deliver_grads([(ctx.table, runtime.embedding_bwd(text, d_emb.float().contiguous(), ctx.vocab, padding_idx=0))])
+        return None, dt, None
 
 
 def acoustic_mel_train_forward(model, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor, energy: Tensor,

@@ -855,6 +855,57 @@ def test_attention_training_pair_on_bf16_tensors(B, N, H, lens, p):
     assert torch.equal(again, dq16) and torch.equal(ds_again, ds16)          # fixed summation orders: bit-reproducible
 
 
+def test_training_step_issues_no_aten_compute_ops(state_dict):
+    """One AMP training step - forward with dropout, the four losses, backward of every parameter, clip + AdamW, zeroing of the
+    gradient arena, re-staging of the updated weights - is libispk launches only: a TorchDispatchMode sees views and
+    allocations on the device and nothing else (gradient delivery, weight concatenation / casts, zero fills and the scalar
+    algebra on the losses are kernels of csrc/util.hip; the two tensors with two consumers are forked so that the autograd
+    engine adds nothing itself).  Ops on host tensors only (the dropout seeds come from torch's CPU generator) are not GPU work
+    and are ignored."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from torch.utils._pytree import tree_flatten
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    harmless = ("aten.view", "aten.empty", "aten._unsafe_view", "aten.transpose", "aten.slice", "aten.select",
+                "aten.unsqueeze", "aten.expand", "aten.detach", "aten.alias", "aten.t.", "aten.permute", "aten.squeeze",
+                "aten.reshape", "aten.as_strided", "aten.is_", "aten.size", "aten.stride", "aten.lift_fresh",
+                "aten._reshape_alias", "aten.split", "aten.unbind", "aten.sym_", "aten.empty_like", "aten.new_empty",
+                "aten.record_stream", "aten.view_as")
+    seen = []
+
+    class Spy(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            out = func(*args, **(kwargs or {}))
+            name = str(func)
+            if not name.startswith(harmless):
+                tensors = [t for t in tree_flatten((args, kwargs, out))[0] if isinstance(t, torch.Tensor)]
+                if any(t.is_cuda for t in tensors):
+                    seen.append(name)
+            return out
+
+    torch.manual_seed(3)
+    model = AcousticModel.init(AcousticDims().model_config())
+    model.load_state_dict(state_dict, strict=True)
+    model = model.to(DEV).train()
+    d = {k: v.to(DEV) for k, v in synth.make_inputs(4, 60, 200, variable=True, seed=5).items()}
+    opt = train.FlatAdamW(list(model.parameters()), lr=2e-4, weight_decay=1e-2, grad_clip=1.0)
+    opt.check_finite = False           # (the finiteness check of the reference's step is one host read of the norm)
+
+    def step():
+        _, total, losses = train.acoustic_train_forward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
+                                                        flow_noise=d["flow_x0"], flow_time=d["flow_t"], amp=True)
+        return total, opt.step(total)
+
+    for _ in range(2):
+        first, _ = step()
+    torch.cuda.synchronize()
+    with Spy():
+        total, norm = step()
+    torch.cuda.synchronize()
+    assert seen == [], f"PyTorch kernels inside a training step: {sorted(set(seen))}"
+    assert torch.isfinite(total) and torch.isfinite(norm) and float(norm) > 0
+
+
 def test_training_step_against_the_reference_fixture(state_dict):
     """SURVEY row f2 against the REAL reference: `train.acoustic_train_forward` (HIP forward + backward of the whole model,
     train_aligner=True, no dropout) and one `FlatAdamW` step (clip of the decay group + fused AdamW) on the B=2 golden inputs,

@@ -587,6 +587,21 @@ int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy
  * ispk_copy2d_f32       rows x cols with leading strides.
  * ispk_permute021_f32   dst[a][c][b] = src[a][b][c]: Conv1d weights [O][C][k] <-> GEMM weights [O][k][C].
  * ispk_conv_weight_flip_f32   wf[c][(K-1-k) O + o] = w[o][c][k]: the GEMM weight of a convolution's input gradient. */
+/* A captured (HIP-graph) training step freezes its launch arguments; two things must still change from replay to replay:
+ *   ispk_set_dropout_seed_source   while the calling thread has a source (a DEVICE address of one uint64), every dropout
+ *                                  kernel it launches - the GELU / attention forward and backward pairs, the mask export -
+ *                                  folds that word into its seed when it RUNS; the host rewrites the word between replays.
+ *                                  NULL switches it off.  Thread-local, like the error string.
+ *   ispk_adam_args_f32 / ispk_adamw_f32_dev   the AdamW step's scalar factors (bias corrections of step t, lr, decay) as a
+ *                                  40-byte record: computed on the host exactly as ispk_adamw_f32 computes them, copied to the
+ *                                  device by the caller, read by the kernel when it runs. */
+typedef struct { float f[10]; } ispk_adam_args_t;
+int32_t ispk_set_dropout_seed_source(const uint64_t* device_word);
+int32_t ispk_adam_args_f32(float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                           float grad_scale, ispk_adam_args_t* out);
+int32_t ispk_adamw_f32_dev(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay,
+                           const ispk_adam_args_t* args_dev, const float* grad_sqnorm, ispk_stream_t stream);
+
 typedef struct { const float* src; void* dst; int64_t n; int32_t mode; } ispk_segment_t;
 int32_t ispk_segments_f32(const ispk_segment_t* segs, int32_t nseg, ispk_stream_t stream);
 int32_t ispk_fill_zero(void* p, int64_t bytes, ispk_stream_t stream);

@@ -20,3 +20,11 @@ extern "C" int32_t ispk_device_info(char* name, int32_t cap) {
     if (name && cap > 0) snprintf(name, (size_t)cap, "%s", p.gcnArchName);
     return p.multiProcessorCount;
 }
+
+// dropout seed source of this thread (dropout.h)
+static thread_local const uint64_t* g_seed_source = nullptr;
+const uint64_t* ispk_seed_source() { return g_seed_source; }
+extern "C" int32_t ispk_set_dropout_seed_source(const uint64_t* device_word) {
+    g_seed_source = device_word;
+    return 0;
+}

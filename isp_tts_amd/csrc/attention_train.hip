@@ -160,7 +160,9 @@ __global__ __launch_bounds__(MAXT) void attn_train_fwd_bf16_kernel(const uint16_
                                                                    const float* __restrict__ slopes,
                                                                    const int64_t* __restrict__ key_len, uint16_t* __restrict__ o,
                                                                    int64_t ldo, float* __restrict__ lse, int N, int H, int kvrows,
-                                                                   uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                                   uint32_t thresh, float inv_keep, uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* const Kl = smem_raw;
     char* const Vl = smem_raw + (size_t)kvrows * 128;
@@ -250,7 +252,9 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dq_bf16_kernel(const uint16_t* 
                                                                 const int64_t* __restrict__ key_len, const float* __restrict__ lse,
                                                                 uint16_t* __restrict__ dqkv, float* __restrict__ delta,
                                                                 float* __restrict__ slope_part, int N, int H, int kvrows,
-                                                                uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                                uint32_t thresh, float inv_keep, uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     char* const Kl = smem_raw;
     char* const Vl = smem_raw + (size_t)kvrows * 128;
@@ -343,7 +347,9 @@ __global__ __launch_bounds__(MAXT) void attn_bwd_dkv_bf16_kernel(const uint16_t*
                                                                  const float* __restrict__ slopes,
                                                                  const int64_t* __restrict__ key_len, const float* __restrict__ lse,
                                                                  const float* __restrict__ delta, uint16_t* __restrict__ dqkv, int N,
-                                                                 int H, uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                                 int H, uint32_t thresh, float inv_keep, uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = wave % H, khalf = wave / H, l31 = lane & 31, h = lane >> 5;
@@ -529,7 +535,7 @@ extern "C" int32_t ispk_alibi_mqa_attn_train_bf16(const uint16_t* qkv, int64_t l
     do {                                                                                                                        \
         ISPK_RESERVE_LDS((&attn_train_fwd_bf16_kernel<MAXT_, DROP_>), lds, "attn_train_bf16");                                   \
         hipLaunchKernelGGL((attn_train_fwd_bf16_kernel<MAXT_, DROP_>), grid, block, lds, s, qkv, ld_qkv, slopes, key_len, o, ld_o, \
-                           lse, N, H, kvrows, thresh, inv_keep, mix_seed(seed));                                                \
+                           lse, N, H, kvrows, thresh, inv_keep, mix_seed(seed), ispk_seed_source());                                                \
     } while (0)
     if (thresh) ISPK_AT_FWD(768, true); else ISPK_AT_FWD(768, false);
 #undef ISPK_AT_FWD
@@ -567,10 +573,10 @@ extern "C" int32_t ispk_alibi_mqa_attn_bwd_bf16(const uint16_t* qkv, int64_t ld_
     do {                                                                                                                        \
         ISPK_RESERVE_LDS((&attn_bwd_dq_bf16_kernel<MAXT_, DROP_>), lds_q, "attn_bwd_bf16");                                      \
         hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<MAXT_, DROP_>), grid, block, lds_q, s, qkv, ld_qkv, o, d_o, ld_o, slopes,     \
-                           key_len, lse, dqkv, delta, spart, N, H, kvrows, thresh, inv_keep, sd);                               \
+                           key_len, lse, dqkv, delta, spart, N, H, kvrows, thresh, inv_keep, sd, ispk_seed_source());                               \
         ISPK_RESERVE_LDS((&attn_bwd_dkv_bf16_kernel<MAXT_, DROP_>), lds_kv, "attn_bwd_bf16");                                    \
         hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<MAXT_, DROP_>), grid, block, lds_kv, s, qkv, ld_qkv, d_o, ld_o, slopes,      \
-                           key_len, lse, delta, dqkv, N, H, thresh, inv_keep, sd);                                              \
+                           key_len, lse, delta, dqkv, N, H, thresh, inv_keep, sd, ispk_seed_source());                                              \
     } while (0)
     if (thresh) ISPK_AT_BWD(768, true); else ISPK_AT_BWD(768, false);
 #undef ISPK_AT_BWD

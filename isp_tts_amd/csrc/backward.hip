@@ -525,7 +525,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
 template <bool IO16 = false>   // IO16: da and du are bf16 (both are only ever GEMM operands of an AMP step)
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ da, const float* __restrict__ u,
                                                        void* __restrict__ du, int64_t n4, uint32_t thresh, float inv_keep,
-                                                       uint64_t seed) {
+                                                       uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const f32x4 x = reinterpret_cast<const f32x4*>(u)[i];
@@ -559,7 +561,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ 
 // the training forward keeps the pre-activation u (for the line above), so its GELU is a pass of its own: a = gelu(u)
 template <bool OUT16 = false>   // OUT16: a is bf16 (an AMP step keeps the activation its second Linear multiplies in bf16)
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, void* __restrict__ a, int64_t n4,
-                                                       uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                       uint32_t thresh, float inv_keep, uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
     const f32x4 x = reinterpret_cast<const f32x4*>(u)[i];
@@ -580,7 +584,9 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__
     }
 }
 
-__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t thresh, uint64_t seed) {
+__global__ __launch_bounds__(256) void dropout_mask_kernel(uint8_t* __restrict__ out, int64_t n, uint32_t thresh, uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = drop_keep(seed, (uint32_t)i, thresh) ? 1 : 0;
 }
@@ -648,7 +654,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
                                                          float* __restrict__ dqkv, float* __restrict__ lse,
                                                          float* __restrict__ delta, float* __restrict__ slope_part, int N,
                                                          int H, float scale, const float* __restrict__ lse_in, uint32_t thresh,
-                                                         float inv_keep, uint64_t seed) {
+                                                         float inv_keep, uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, l = threadIdx.x, c = l & 31, hf = l >> 5;
     const int ntiles = gridDim.x;
     const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
@@ -745,7 +753,9 @@ __global__ __launch_bounds__(64) void attn_bwd_dq_kernel(const float* __restrict
 __global__ __launch_bounds__(64) void attn_train_fwd_kernel(const float* __restrict__ qkv, int64_t ld,
                                                             const float* __restrict__ slopes, const int64_t* __restrict__ key_len,
                                                             float* __restrict__ o, int64_t ldo, float* __restrict__ lse, int N, int H,
-                                                            float scale, uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                            float scale, uint32_t thresh, float inv_keep, uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z, l = threadIdx.x, c = l & 31, hf = l >> 5;
     const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
     const int i = tile * 32 + c;
@@ -816,7 +826,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                                                             int64_t ldo, const float* __restrict__ slopes,
                                                             const int64_t* __restrict__ key_len, const float* __restrict__ lse,
                                                             const float* __restrict__ delta, float* __restrict__ dqkv, int N,
-                                                            int H, float scale, uint32_t thresh, float inv_keep, uint64_t seed) {
+                                                            int H, float scale, uint32_t thresh, float inv_keep, uint64_t seed,
+        const uint64_t* __restrict__ seed_src) {
+    seed = run_seed(seed, seed_src);
     __shared__ float red[2][2][16][64];     // [dk | dv][M tile][register][lane]
     const int kt = blockIdx.x, b = blockIdx.y, h = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = threadIdx.x & 63, c = l & 31, hf = l >> 5;
     const int klen = key_len ? (int)min((int64_t)N, max((int64_t)0, key_len[b])) : N;
@@ -1042,7 +1054,7 @@ extern "C" int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du,
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_bwd_f32: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_bwd_kernel<false>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
+                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed), ispk_seed_source());
     return ispk_launch_status();
 }
 extern "C" int32_t ispk_gelu_bwd_bf16(const uint16_t* da, const float* u, uint16_t* du, int64_t n, float dropout_p, uint64_t seed,
@@ -1053,7 +1065,7 @@ extern "C" int32_t ispk_gelu_bwd_bf16(const uint16_t* da, const float* u, uint16
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_bwd_bf16: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_bwd_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
+                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed), ispk_seed_source());
     return ispk_launch_status();
 }
 
@@ -1064,7 +1076,7 @@ extern "C" int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, float drop
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_f32: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_fwd_kernel<false>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
+                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed), ispk_seed_source());
     return ispk_launch_status();
 }
 extern "C" int32_t ispk_gelu_f32_bf16(const float* u, uint16_t* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream) {
@@ -1074,7 +1086,7 @@ extern "C" int32_t ispk_gelu_f32_bf16(const float* u, uint16_t* a, int64_t n, fl
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_f32_bf16: dropout_p must be in [0, 1)");
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_fwd_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
+                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed), ispk_seed_source());
     return ispk_launch_status();
 }
 
@@ -1082,7 +1094,7 @@ extern "C" int32_t ispk_dropout_mask_u8(uint8_t* out, int64_t n, float dropout_p
     ISPK_REQUIRE(out && n >= 0 && dropout_p >= 0.f && dropout_p < 1.f, -1, "ispk_dropout_mask_u8: bad arguments");
     if (n == 0) return 0;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
-                       out, n, drop_thresh(dropout_p), mix_seed(seed));
+                       out, n, drop_thresh(dropout_p), mix_seed(seed), ispk_seed_source());
     return ispk_launch_status();
 }
 
@@ -1096,7 +1108,7 @@ static int32_t attn_train_launch(const float* qkv, int64_t ld_qkv, const float* 
     ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -4, "%s: dropout_p must be in [0, 1)", who);
     const dim3 grid((N + 31) / 32, H, B);
     hipLaunchKernelGGL(attn_train_fwd_kernel, grid, dim3(64), 0, s, qkv, ld_qkv, slopes, key_len, o, ld_o, lse, N, H, 0.125f,
-                       drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed));
+                       drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed), ispk_seed_source());
     return ispk_launch_status();
 }
 
@@ -1113,9 +1125,9 @@ static void attn_bwd_kernels(hipStream_t s, int tiles, const float* qkv, int64_t
                              int N, int H, const float* lse_in, uint32_t thresh, float inv_keep, uint64_t seed) {
     const float scale = 0.125f;
     hipLaunchKernelGGL((attn_bwd_dq_kernel<kDrop>), dim3(tiles, H, B), dim3(64), 0, s, qkv, ld_qkv, o, d_o, ld_o, slopes, key_len,
-                       dqkv, lse, delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed);
+                       dqkv, lse, delta, spart, N, H, scale, lse_in, thresh, inv_keep, seed, ispk_seed_source());
     hipLaunchKernelGGL((attn_bwd_dkv_kernel<kDrop>), dim3(tiles, B), dim3(64 * H), 0, s, qkv, ld_qkv, d_o, ld_o, slopes, key_len,
-                       lse, delta, dqkv, N, H, scale, thresh, inv_keep, seed);
+                       lse, delta, dqkv, N, H, scale, thresh, inv_keep, seed, ispk_seed_source());
 }
 
 extern "C" int32_t ispk_alibi_mqa_attn_bwd_f32(const float* qkv, int64_t ld_qkv, const float* o, const float* d_o, int64_t ld_o,

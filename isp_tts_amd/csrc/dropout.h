@@ -25,6 +25,18 @@ __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t idx) {
 }
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t idx, uint32_t thresh) { return drop_hash(seed, idx) >= thresh; }
 
+// Seed source (ispk_set_dropout_seed_source): while this thread has one, every dropout kernel it launches folds the 64-bit
+// word at that DEVICE address into its launch seed when it RUNS - a captured training step then draws fresh masks on every
+// replay (the host rewrites the word between replays) although its launch arguments are frozen.
+const uint64_t* ispk_seed_source();
+__device__ __forceinline__ uint64_t run_seed(uint64_t seed, const uint64_t* __restrict__ src) {
+    if (!src) return seed;
+    uint64_t z = (seed ^ src[0]) + 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
 static inline uint64_t mix_seed(uint64_t z) {   // splitmix64 finaliser: the kernels' two seed words from the caller's seed
     z += 0x9e3779b97f4a7c15ull;
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;

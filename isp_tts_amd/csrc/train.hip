@@ -8,6 +8,8 @@
 // element-wise passes per tensor over ~290 tensors (~3,500 launches).
 #include <math.h>
 
+#include <string.h>
+
 #include "common.h"
 
 namespace {
@@ -74,7 +76,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, int64_t n, int64_t n_decay,
-                                                    const float* __restrict__ sqnorm, AdamArgs a) {
+                                                    const float* __restrict__ sqnorm, AdamArgs a,
+                                                    const AdamArgs* __restrict__ a_dev) {
+    if (a_dev) a = *a_dev;         // ispk_adamw_f32_dev: the step's factors live in device memory (a captured step replays them)
     // clip coefficient of the decay group: clamp(max_norm / (norm + 1e-6), max = 1) on the SCALED gradients (torch
     // clip_grad_norm_).  torch.clamp PROPAGATES a NaN norm (every clipped gradient, and with it the group, turns NaN - the
     // reference's step() then reports grad_norm None, optimizers.py:238-239, but has already stepped); fminf(NaN, 1) would
@@ -754,7 +758,42 @@ extern "C" int32_t ispk_adamw_f32(float* p, const float* g, float* m, float* v, 
     const int64_t n4 = (n + 3) >> 2;
     const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, n_decay,
-                       grad_sqnorm, a);
+                       grad_sqnorm, a, static_cast<const AdamArgs*>(nullptr));
+    return ispk_launch_status();
+}
+
+static_assert(sizeof(AdamArgs) == sizeof(ispk_adam_args_t), "ispk_adam_args_t mirrors AdamArgs");
+
+extern "C" int32_t ispk_adam_args_f32(float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step, float max_norm,
+                                      float grad_scale, ispk_adam_args_t* out) {
+    ISPK_REQUIRE(out && step >= 1, -1, "ispk_adam_args_f32: null output or step < 1");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    AdamArgs a;
+    a.decay_mul = (float)(1.0 - (double)lr * (double)weight_decay);
+    a.one_m_b1 = (float)(1.0 - (double)beta1);
+    a.b2 = beta2;
+    a.one_m_b2 = (float)(1.0 - (double)beta2);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    a.eps = eps;
+    a.max_norm = max_norm;
+    a.grad_scale = grad_scale;
+    memcpy(out, &a, sizeof(a));
+    return 0;
+}
+
+extern "C" int32_t ispk_adamw_f32_dev(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay,
+                                      const ispk_adam_args_t* args_dev, const float* grad_sqnorm, ispk_stream_t stream) {
+    ISPK_REQUIRE(p && g && m && v && args_dev, -1, "ispk_adamw_f32_dev: null pointer");
+    ISPK_REQUIRE(n >= 0 && n_decay >= 0 && n_decay <= n, -2, "ispk_adamw_f32_dev: need 0 <= n_decay <= n");
+    ISPK_REQUIRE(ispk_aligned(p, 16) && ispk_aligned(g, 16) && ispk_aligned(m, 16) && ispk_aligned(v, 16) && ispk_aligned(args_dev, 4), -3,
+                 "ispk_adamw_f32_dev: arenas must be 16-byte aligned");
+    if (n == 0) return 0;
+    const int64_t n4 = (n + 3) >> 2;
+    const int blocks = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(adamw_kernel, dim3(blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, n_decay,
+                       grad_sqnorm, AdamArgs{}, reinterpret_cast<const AdamArgs*>(args_dev));
     return ispk_launch_status();
 }
 

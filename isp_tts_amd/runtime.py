@@ -107,6 +107,9 @@ SIGNATURES = {
     "ispk_embedding_bwd_f32": [_P, _P, _I64, _I32, _I32, _I32, _P, _I64, _P],
     "ispk_grad_sqnorm_f32": [_P, _I64, _P, _P, _P],
     "ispk_adamw_f32": [_P, _P, _P, _P, _I64, _I64, _F32, _F32, _F32, _F32, _F32, _I32, _P, _F32, _F32, _P],
+    "ispk_adamw_f32_dev": [_P, _P, _P, _P, _I64, _I64, _P, _P, _P],
+    "ispk_adam_args_f32": [_F32, _F32, _F32, _F32, _F32, _I32, _F32, _F32, _P],
+    "ispk_set_dropout_seed_source": [_P],
 }
 
 _lib = None
@@ -1481,6 +1484,37 @@ def grad_sqnorm(g: Tensor, out: Optional[Tensor] = None) -> Tensor:
     _launch("sqnorm_kernels", 0.0, 4.0 * g.numel(), lib().ispk_grad_sqnorm_f32, g.data_ptr(), g.numel(), part.data_ptr(),
             out.data_ptr(), _stream())
     return out
+
+
+def set_seed_source(word: Optional[Tensor]) -> None:
+    """ispk_set_dropout_seed_source: while set (a one-element int64 DEVICE tensor the caller keeps alive), every dropout kernel
+    launched from this thread folds that word into its seed when it runs - what lets a captured training step draw fresh
+    masks on every replay.  None switches it off."""
+    if word is not None:
+        _dev(word)
+        assert word.dtype == torch.int64 and word.numel() == 1
+    _check(lib().ispk_set_dropout_seed_source(None if word is None else word.data_ptr()), "set_dropout_seed_source")
+
+
+def adam_args(lr: float, betas: tuple, eps: float, weight_decay: float, step: int, max_norm: float = 1.0,
+              grad_scale: float = 1.0) -> Tensor:
+    """ispk_adam_args_f32 -> the 10 fp32 factors of AdamW step `step` as a pinned host tensor (for a copy to the device
+    record that ispk_adamw_f32_dev reads)."""
+    buf = (ctypes.c_float * 10)()
+    _check(lib().ispk_adam_args_f32(lr, betas[0], betas[1], eps, weight_decay, step, max_norm, grad_scale,
+                                    ctypes.cast(buf, ctypes.c_void_p)), "adam_args")
+    t = torch.tensor(list(buf), dtype=torch.float32)
+    return t.pin_memory() if torch.cuda.is_available() else t
+
+
+def adamw_dev(p: Tensor, g: Tensor, m: Tensor, v: Tensor, n_decay: int, args_dev: Tensor, grad_sqnorm: Optional[Tensor] = None) -> None:
+    """ispk_adamw_f32_dev: `adamw` with the step's factors read from the device record `args_dev` (fp32 [10], adam_args)."""
+    _dev(p, g, m, v, args_dev, grad_sqnorm)
+    for t in (p, g, m, v):
+        assert t.dtype == torch.float32 and t.ndim == 1 and t.is_contiguous() and t.numel() == p.numel()
+    assert args_dev.dtype == torch.float32 and args_dev.numel() == 10 and args_dev.is_contiguous()
+    _launch("adamw_kernel", 0.0, 28.0 * p.numel(), lib().ispk_adamw_f32_dev, p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+            p.numel(), n_decay, args_dev.data_ptr(), _ptr(grad_sqnorm), _stream())
 
 
 def adamw(p: Tensor, g: Tensor, m: Tensor, v: Tensor, n_decay: int, lr: float, betas: tuple, eps: float, weight_decay: float,

@@ -24,5 +24,7 @@ from .predictor import flow_predictor_loss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params
 from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction, TransformerStackFunction, acoustic_mel_train_forward, mel_decoder_train_forward, transformer_train_forward)
 
-__all__ = ["AcousticModelLoss", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "acoustic_train_forward", "flow_predictor_loss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
+from .graph import GraphedTrainStep
+
+__all__ = ["AcousticModelLoss", "GraphedTrainStep", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "acoustic_train_forward", "flow_predictor_loss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
            "group_weight_decayable_params", "mel_decoder_train_forward", "transformer_train_forward"]

@@ -132,6 +132,7 @@ class FlatAdamW:
         self._update = update or runtime.adamw          # (hooks: the CPU gloo test drives the exchange with the oracle's math)
         self._sqnorm = sqnorm or runtime.grad_sqnorm
         self._one = None
+        self.args_dev = None          # a captured step (train/graph.py): the AdamW factors are read from this device record
         self.check_finite = True      # `step` returns None for a non-finite norm like the reference (:238-239): one host sync
         self._reduce_scatter = self.world > 1 and dist.get_backend(process_group) != "gloo"   # gloo has none
 
@@ -166,9 +167,13 @@ class FlatAdamW:
                 self.sq.zero_()
             if self.world > 1:
                 dist.all_reduce(self.sq, op=dist.ReduceOp.SUM, group=self.group)
-        self._update(flat.data[self.lo:self.lo + self.shard], g, self.exp_avg, self.exp_avg_sq, n_dec, self.lr, self.betas,
-                     self.eps, self.weight_decay, self.step_count, self.sq if clip else None,
-                     self.grad_clip if clip else 1.0, 1.0 / self.world)
+        if self.args_dev is not None:
+            runtime.adamw_dev(flat.data[self.lo:self.lo + self.shard], g, self.exp_avg, self.exp_avg_sq, n_dec, self.args_dev,
+                              self.sq if clip else None)
+        else:
+            self._update(flat.data[self.lo:self.lo + self.shard], g, self.exp_avg, self.exp_avg_sq, n_dec, self.lr, self.betas,
+                         self.eps, self.weight_decay, self.step_count, self.sq if clip else None,
+                         self.grad_clip if clip else 1.0, 1.0 / self.world)
         if self.world > 1:
             # (from a copy of the slice: input and output of the collective do not alias)
             self.param_shard.copy_(flat.data[self.lo:self.lo + self.shard])

@@ -906,6 +906,83 @@ def test_training_step_issues_no_aten_compute_ops(state_dict):
     assert torch.isfinite(total) and torch.isfinite(norm) and float(norm) > 0
 
 
+def test_dropout_seed_source_changes_the_masks_at_run_time():
+    """ispk_set_dropout_seed_source: the same launch (same seed argument) draws another mask when the device word changes, the
+    same mask when it does not, and forward / backward stay consistent - what a captured training step relies on."""
+    u = _rand((1000, 256), 31).to(DEV)
+    word = torch.zeros(1, dtype=torch.int64, device=DEV)
+    base = runtime.gelu(u, 0.3, 77)
+    try:
+        runtime.set_seed_source(word)
+        word.fill_(1)
+        a1, a1b = runtime.gelu(u, 0.3, 77), runtime.gelu(u, 0.3, 77)
+        da = torch.ones_like(u)
+        d1 = runtime.gelu_bwd(da, u, dropout_p=0.3, seed=77)
+        word.fill_(2)
+        a2 = runtime.gelu(u, 0.3, 77)
+        qkv = _rand((2, 70, 6 * 64 + 128), 32).bfloat16().to(DEV)
+        slopes = torch.tensor(synth.alibi_default_slopes(6)).to(DEV)
+        o2, _ = runtime.alibi_mqa_attention_train(qkv, 6, slopes, None, 0.2, 5)
+        word.fill_(3)
+        o3, _ = runtime.alibi_mqa_attention_train(qkv, 6, slopes, None, 0.2, 5)
+    finally:
+        runtime.set_seed_source(None)
+    again = runtime.gelu(u, 0.3, 77)
+    assert torch.equal(a1, a1b) and torch.equal(again, base)
+    assert not torch.equal(a1, a2) and not torch.equal(a1, base) and not torch.equal(o2, o3)
+    assert torch.equal(d1 == 0, a1 == 0) or ((d1 == 0) ^ (a1 == 0)).float().mean() < 1e-3     # same mask forward and backward
+    keep = (a2 != 0).float().mean().item()
+    assert abs(keep - 0.7) < 0.02
+
+
+def test_graphed_training_step_replays_match_eager_steps(state_dict):
+    """train.GraphedTrainStep: the whole step (forward, four losses, backward, clip + AdamW, arena zeroing, weight re-staging)
+    as ONE HIP graph.  With dropout off (eval-mode modules) replays must give bit-for-bit the parameters of the same number of
+    eager steps: the graph re-stages its weight images from the arena the optimizer updates in place and reads the AdamW
+    factors of each step from the device record, so nothing captured goes stale.  In train mode the masks change from replay
+    to replay (the seed word), so two replays on the same batch differ."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+
+    def make(train_mode):
+        torch.manual_seed(11)
+        m = AcousticModel.init(AcousticDims().model_config())
+        m.load_state_dict(state_dict, strict=True)
+        m = m.to(DEV)
+        m = m.train() if train_mode else m.eval()
+        o = train.FlatAdamW(list(m.parameters()), lr=2e-4, weight_decay=1e-2, grad_clip=1.0)
+        o.check_finite = False
+        return m, o
+    d = {k: v.to(DEV) for k, v in synth.make_inputs(3, 52, 160, variable=True, seed=9).items()}
+    keys = ("text", "text_len", "mel", "mel_len", "pitch", "energy", "flow_x0", "flow_t")
+    batch = {k: d[k] for k in keys}
+    m_e, o_e = make(False)
+    eager_tot = []
+    for _ in range(5):
+        _, total, _ = train.acoustic_train_forward(m_e, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
+                                                   flow_noise=d["flow_x0"], flow_time=d["flow_t"], amp=True)
+        o_e.step(total)
+        eager_tot.append(float(total))
+    m_g, o_g = make(False)
+    step = train.GraphedTrainStep(m_g, o_g, batch, amp=True, warmup=2)        # two real steps ...
+    graph_tot = []
+    for _ in range(3):                                                         # ... and three replays = five steps
+        total, losses, norm = step(**batch)
+        graph_tot.append(float(total))
+    torch.cuda.synchronize()
+    assert o_g.step_count == 5 and o_e.step_count == 5
+    assert graph_tot == eager_tot[2:], f"losses: graph {graph_tot} vs eager {eager_tot[2:]}"
+    assert torch.equal(o_g.flat.data, o_e.flat.data) and torch.equal(o_g.exp_avg_sq, o_e.exp_avg_sq)
+    assert float(o_g.flat.grad.abs().max()) == 0.0 and torch.isfinite(norm)
+    # train mode: fresh masks per replay
+    m_t, o_t = make(True)
+    o_t.lr = 0.0                                       # (weights fixed: the only thing that changes between replays is the masks)
+    step_t = train.GraphedTrainStep(m_t, o_t, batch, amp=True, warmup=2)
+    t1 = float(step_t(**batch)[0])
+    t2 = float(step_t(**batch)[0])
+    assert t1 != t2 and abs(t1 - t2) < 0.2 * abs(t1)
+
+
 def test_training_step_against_the_reference_fixture(state_dict):
     """SURVEY row f2 against the REAL reference: `train.acoustic_train_forward` (HIP forward + backward of the whole model,
     train_aligner=True, no dropout) and one `FlatAdamW` step (clip of the decay group + fused AdamW) on the B=2 golden inputs,

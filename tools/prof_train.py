@@ -55,3 +55,15 @@ for label, flops, nbytes, e0, e1 in prof.records:
 print("fp32 GEMMs by shape:")
 for (label, flops, nbytes), (n, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:30]:
     print(f"  {label:28s} {flops / 1e9:8.3f} GFLOP {nbytes / 1e6:8.2f} MB  x{n:3d} {ms:7.3f} ms")
+# the same step as one HIP graph
+if amp:
+    batch = {k: d[k] for k in ("text", "text_len", "mel", "mel_len", "pitch", "energy", "flow_x0", "flow_t")}
+    g = train.GraphedTrainStep(model, opt, batch, amp=True, warmup=2)
+    for _ in range(3):
+        g()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        g()
+    torch.cuda.synchronize()
+    print(f"graph replay: {(time.perf_counter() - t0) / 10 * 1e3:.2f} ms/step")

@@ -602,6 +602,12 @@ int32_t ispk_adam_args_f32(float lr, float beta1, float beta2, float eps, float 
 int32_t ispk_adamw_f32_dev(float* p, const float* g, float* m, float* v, int64_t n, int64_t n_decay,
                            const ispk_adam_args_t* args_dev, const float* grad_sqnorm, ispk_stream_t stream);
 
+/* ispk_stage_weights   kernel-ready images of fp32 [rows][cols] parameters, 16 per launch: flags 1 = transposed (dst[c][r]: the
+ *                       W^T rows the NT GEMM wants for dX = dY W), 2 = bf16 output, 4 = exp of the values; dst rows ld_dst
+ *                       elements apart (so that [to_q; to_kv] lands in one fused image).  What the reference does with
+ *                       torch.cat / .t() / autocast's weight casts after every optimizer step. */
+typedef struct { const float* src; void* dst; int32_t rows, cols; int64_t ld_dst; int32_t flags; } ispk_stage_t;
+int32_t ispk_stage_weights(const ispk_stage_t* segs, int32_t nseg, ispk_stream_t stream);
 typedef struct { const float* src; void* dst; int64_t n; int32_t mode; } ispk_segment_t;
 int32_t ispk_segments_f32(const ispk_segment_t* segs, int32_t nseg, ispk_stream_t stream);
 int32_t ispk_fill_zero(void* p, int64_t bytes, ispk_stream_t stream);

@@ -85,7 +85,69 @@ __global__ __launch_bounds__(256) void conv_flip_kernel(const float* __restrict_
     wf[(int64_t)c * K * O + (int64_t)(K - 1 - k) * O + o] = w[i];
 }
 
+// Weight images for the kernels from fp32 parameters, many per launch (a training step re-stages every image after every
+// update): 32 x 32 tiles through LDS; flags 1 = transposed image dst[c][r], 2 = bf16 output, 4 = exp() of the values (ALiBi
+// slopes from their logarithms); dst rows ld_dst elements apart.
+constexpr int kStageMax = 16;
+struct StagePack {
+    const float* src[kStageMax];
+    void* dst[kStageMax];
+    int64_t ld_dst[kStageMax];
+    int32_t rows[kStageMax], cols[kStageMax], flags[kStageMax];
+};
+__global__ __launch_bounds__(256) void stage_kernel(StagePack p) {
+    __shared__ float t[32][33];
+    const int sg = blockIdx.y;
+    const float* __restrict__ src = p.src[sg];
+    const int rows = p.rows[sg], cols = p.cols[sg], flags = p.flags[sg];
+    const int64_t ldd = p.ld_dst[sg];
+    const bool tr = flags & 1, b16 = flags & 2, ex = flags & 4;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int tcols = (cols + 31) / 32, ntiles = ((rows + 31) / 32) * tcols;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int r0 = (tile / tcols) * 32, c0 = (tile % tcols) * 32;
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8)
+            if (r0 + k < rows && c0 + tx < cols) {
+                const float v = src[(int64_t)(r0 + k) * cols + c0 + tx];
+                t[k][tx] = ex ? expf(v) : v;
+            }
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8) {
+            // plain image: element (r0 + k, c0 + tx); transposed image: row c0 + k, column r0 + tx
+            const int sr = tr ? tx : k, sc = tr ? k : tx;
+            if (r0 + sr >= rows || c0 + sc >= cols) continue;
+            const float v = t[sr][sc];
+            const int64_t at = tr ? (int64_t)(c0 + k) * ldd + r0 + tx : (int64_t)(r0 + k) * ldd + c0 + tx;
+            if (b16) static_cast<uint16_t*>(p.dst[sg])[at] = f32_to_bf16(v);
+            else static_cast<float*>(p.dst[sg])[at] = v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int32_t ispk_stage_weights(const ispk_stage_t* segs, int32_t nseg, ispk_stream_t stream) {
+    ISPK_REQUIRE(nseg >= 0 && (nseg == 0 || segs), ISPK_E_NULL, "stage_weights: null table");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    for (int base = 0; base < nseg; base += kStageMax) {
+        StagePack p;
+        const int cnt = nseg - base < kStageMax ? nseg - base : kStageMax;
+        int most = 0;
+        for (int i = 0; i < cnt; ++i) {
+            const ispk_stage_t& g = segs[base + i];
+            const bool tr = g.flags & 1;
+            ISPK_REQUIRE(g.src && g.dst && g.rows >= 1 && g.cols >= 1 && g.ld_dst >= (tr ? g.rows : g.cols) && (g.flags & ~7) == 0, ISPK_E_SHAPE,
+                         "stage_weights: bad segment %d", base + i);
+            p.src[i] = g.src; p.dst[i] = g.dst; p.ld_dst[i] = g.ld_dst; p.rows[i] = g.rows; p.cols[i] = g.cols; p.flags[i] = g.flags;
+            const int tiles = ((g.rows + 31) / 32) * ((g.cols + 31) / 32);
+            most = tiles > most ? tiles : most;
+        }
+        most = most > 128 ? 128 : most;
+        hipLaunchKernelGGL(stage_kernel, dim3(most, cnt), dim3(256), 0, s, p);
+    }
+    return ispk_launch_status();
+}
 
 extern "C" int32_t ispk_segments_f32(const ispk_segment_t* segs, int32_t nseg, ispk_stream_t stream) {
     ISPK_REQUIRE(nseg >= 0 && (nseg == 0 || segs), ISPK_E_NULL, "segments: null table");

@@ -34,6 +34,7 @@ SIGNATURES = {
     "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_gemm_f32_batched": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_segments_f32": [_P, _I32, _P],
+    "ispk_stage_weights": [_P, _I32, _P],
     "ispk_fill_zero": [_P, _I64, _P],
     "ispk_scale_f32": [_P, _I64, _P, _F32, _P],
     "ispk_sum_scalars_f32": [_P, _P, _I32, _P, _P],
@@ -928,6 +929,30 @@ class _Segment(ctypes.Structure):
 
 
 SEG_COPY, SEG_ADD, SEG_BF16 = 0, 1, 2
+
+
+class _Stage(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("ld_dst", ctypes.c_int64), ("flags", ctypes.c_int32)]
+
+
+def stage_weights(items) -> None:
+    """ispk_stage_weights: items = [(src fp32 contiguous [rows, cols], dst 2-D view with unit column stride (fp32 or bf16),
+    transposed: bool, exp: bool)], 16 per launch.  dst is [rows, cols], or [cols, rows] when transposed."""
+    if not items:
+        return
+    arr = (_Stage * len(items))()
+    nbytes = 0.0
+    for k, (src, dst, tr, ex) in enumerate(items):
+        _dev(src, dst)
+        src = src.detach()
+        assert src.dtype == torch.float32 and src.ndim == 2 and src.is_contiguous() and dst.ndim == 2 and dst.stride(1) == 1
+        assert tuple(dst.shape) == ((src.shape[1], src.shape[0]) if tr else tuple(src.shape)) and dst.dtype in (torch.float32, torch.bfloat16)
+        arr[k].src, arr[k].dst, arr[k].rows, arr[k].cols = src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1]
+        arr[k].ld_dst = dst.stride(0)
+        arr[k].flags = (1 if tr else 0) | (2 if dst.dtype == torch.bfloat16 else 0) | (4 if ex else 0)
+        nbytes += src.numel() * (4.0 + dst.element_size())
+    _launch("stage_kernel", 0.0, nbytes, lib().ispk_stage_weights, ctypes.cast(arr, ctypes.c_void_p), len(items), _stream())
 
 
 def segments(items) -> None:

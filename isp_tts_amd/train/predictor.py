@@ -20,6 +20,7 @@ from torch import Tensor
 
 from .. import runtime
 from ..modules.transformer.transformer import Transformer
+from .images import layer_images
 from .stack import _mm
 
 
@@ -155,13 +156,14 @@ class AdaptiveStackFunction(torch.autograd.Function):
         B, L, D = x.shape
         key_len = ctx_key_len if ctx_key_len is not None else (mask.sum(dim=1) if mask is not None else None)
         base_seed = runtime.draw_seed()
+        images = layer_images(tr, amp)
         tape, out = [], x
         for li, layer in enumerate(tr.layers):
             att, ff = layer.attention, layer.feed_forward
-            wqkv, wo, slopes = att._staged(torch.float32)
-            w1, w2 = ff._staged(torch.float32)
-            wqkv16, wo16, _ = att._staged(torch.bfloat16) if amp else (None, None, None)
-            w116, w216 = ff._staged(torch.bfloat16) if amp else (None, None)
+            im = images[li]
+            wqkv, wo, w1, w2 = (None,) * 4 if amp else (im["wqkv"], im["wo"], im["w1"], im["w2"])
+            wqkv16, wo16, w116, w216 = (im["wqkv"], im["wo"], im["w1"], im["w2"]) if amp else (None,) * 4
+            slopes = im["slopes"]
             s1, t1 = ss[:, (4 * li) * D:(4 * li + 1) * D], ss[:, (4 * li + 1) * D:(4 * li + 2) * D]
             s2, t2 = ss[:, (4 * li + 2) * D:(4 * li + 3) * D], ss[:, (4 * li + 3) * D:(4 * li + 4) * D]
             adt = torch.bfloat16 if amp else torch.float32        # dtype of the tensors that are GEMM / attention operands only
@@ -194,21 +196,15 @@ class AdaptiveStackFunction(torch.autograd.Function):
         d_ss = torch.empty_like(ss)
         grads: list = []
         dy, dgf, dbf = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask, eps=tr.norm.eps)
+        images = layer_images(tr, amp)
         for li in reversed(range(len(tr.layers))):
             layer = tr.layers[li]
             xin, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff = ctx.tape[li]
             att, ff = layer.attention, layer.feed_forward
-            wqkv, wo, slopes = att._staged(torch.float32)
-            w1, w2 = ff._staged(torch.float32)
-            wqkv_t, wo_t = att._cache.get("t32", (att.to_q.weight, att.to_kv.weight, att.to_out.weight),
-                                          lambda: (runtime.transpose(wqkv), runtime.transpose(wo)))
-            w1_t, w2_t = ff._cache.get("t32", (ff.net[0].weight, ff.net[3].weight),
-                                       lambda: (runtime.transpose(w1), runtime.transpose(w2)))
-            t16 = lambda *ws: tuple(runtime.cast_bf16(w) for w in ws)                      # noqa: E731
-            wqkv_t16, wo_t16 = att._cache.get("t16", (att.to_q.weight, att.to_kv.weight, att.to_out.weight),
-                                              lambda: t16(wqkv_t, wo_t)) if amp else (None, None)
-            w1_t16, w2_t16 = ff._cache.get("t16", (ff.net[0].weight, ff.net[3].weight),
-                                           lambda: t16(w1_t, w2_t)) if amp else (None, None)
+            im = images[li]
+            slopes = im["slopes"]
+            wqkv_t, wo_t, w1_t, w2_t = (None,) * 4 if amp else (im["wqkv_t"], im["wo_t"], im["w1_t"], im["w2_t"])
+            wqkv_t16, wo_t16, w1_t16, w2_t16 = (im["wqkv_t"], im["wo_t"], im["w1_t"], im["w2_t"]) if amp else (None,) * 4
             c = 4 * li * D
             gdt = torch.bfloat16 if amp else torch.float32        # as in stack.py: GEMM-only tensors live in bf16 under AMP
             dyg = runtime.cast_bf16(dy) if amp else dy

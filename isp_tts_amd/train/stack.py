@@ -28,6 +28,7 @@ from torch import Tensor
 
 from .. import runtime
 from ..modules.transformer.transformer import Transformer
+from .images import layer_images
 
 
 def _check(tr: Transformer) -> None:
@@ -93,13 +94,14 @@ class TransformerStackFunction(torch.autograd.Function):
             ctx.proj_in = x
             x = runtime.linear(x, tr.project_emb.weight, tr.project_emb.bias)
         tape, out = [], x
+        images = layer_images(tr, amp)
         base_seed = runtime.draw_seed()      # a host generator that follows torch's seed: torch.manual_seed reproduces a run
         for li, layer in enumerate(tr.layers):
             att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
-            wqkv, wo, slopes = att._staged(torch.float32)
-            w1, w2 = ff._staged(torch.float32)
-            wqkv16, wo16, _ = att._staged(torch.bfloat16) if amp else (None, None, None)
-            w116, w216 = ff._staged(torch.bfloat16) if amp else (None, None)
+            im = images[li]                     # this step's weight images (train/images.py)
+            wqkv, wo, w1, w2 = (None,) * 4 if amp else (im["wqkv"], im["wo"], im["w1"], im["w2"])
+            wqkv16, wo16, w116, w216 = (im["wqkv"], im["wo"], im["w1"], im["w2"]) if amp else (None,) * 4
+            slopes = im["slopes"]
             adt = torch.bfloat16 if amp else torch.float32        # dtype of the tensors that are GEMM operands only
             h = runtime.layernorm(out, an.weight, an.bias, eps=an.eps, out_dtype=adt)
             qkv = _mm(h, wqkv, wqkv16, out_dtype=adt)        # AMP: bf16 q / k / v, as SDPA sees them under autocast
@@ -130,19 +132,15 @@ class TransformerStackFunction(torch.autograd.Function):
         grads: list = []
         dy, dgf, dbf = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask,
                                              eps=tr.norm.eps)
-        for layer, (xin, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff) in zip(reversed(tr.layers), reversed(ctx.tape)):
+        images = layer_images(tr, amp)         # (the forward's images: same parameter versions)
+        for li in reversed(range(len(tr.layers))):
+            layer = tr.layers[li]
+            xin, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff = ctx.tape[li]
             att, ff, an, fn = layer.attention, layer.feed_forward, layer.attention_norm, layer.feed_forward_norm
-            wqkv, wo, slopes = att._staged(torch.float32)
-            w1, w2 = ff._staged(torch.float32)
-            wqkv_t, wo_t = att._cache.get("t32", (att.to_q.weight, att.to_kv.weight, att.to_out.weight),
-                                          lambda: (runtime.transpose(wqkv), runtime.transpose(wo)))
-            w1_t, w2_t = ff._cache.get("t32", (ff.net[0].weight, ff.net[3].weight),
-                                       lambda: (runtime.transpose(w1), runtime.transpose(w2)))
-            t16 = lambda *ws: tuple(runtime.cast_bf16(w) for w in ws)                      # noqa: E731
-            wqkv_t16, wo_t16 = att._cache.get("t16", (att.to_q.weight, att.to_kv.weight, att.to_out.weight),
-                                              lambda: t16(wqkv_t, wo_t)) if amp else (None, None)
-            w1_t16, w2_t16 = ff._cache.get("t16", (ff.net[0].weight, ff.net[3].weight),
-                                           lambda: t16(w1_t, w2_t)) if amp else (None, None)
+            im = images[li]
+            slopes = im["slopes"]
+            wqkv_t, wo_t, w1_t, w2_t = (None,) * 4 if amp else (im["wqkv_t"], im["wo_t"], im["w1_t"], im["w2_t"])
+            wqkv_t16, wo_t16, w1_t16, w2_t16 = (im["wqkv_t"], im["wo_t"], im["w1_t"], im["w2_t"]) if amp else (None,) * 4
             gdt = torch.bfloat16 if amp else torch.float32
             # Under AMP every tensor that is ONLY a GEMM operand lives in bf16 - a (forward), da / du (their producers write
             # bf16; q / k / v, the attention output, dO and dqkv: the attention kernels read and write bf16), and ONE bf16 copy each of

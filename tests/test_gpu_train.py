@@ -962,7 +962,7 @@ def test_graphed_training_step_replays_match_eager_steps(state_dict):
         _, total, _ = train.acoustic_train_forward(m_e, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"],
                                                    flow_noise=d["flow_x0"], flow_time=d["flow_t"], amp=True)
         o_e.step(total)
-        eager_tot.append(float(total))
+        eager_tot.append(float(total.detach()))
     m_g, o_g = make(False)
     step = train.GraphedTrainStep(m_g, o_g, batch, amp=True, warmup=2)        # two real steps ...
     graph_tot = []

@@ -49,9 +49,9 @@ for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["total_ms"])[:40]:
 by = {}
 for label, flops, nbytes, e0, e1 in prof.records:
     if label.startswith("gemm_f32") or label.startswith("gemm_tn_kernel"):
-        d = by.setdefault((label, flops, nbytes), [0, 0.0])
-        d[0] += 1
-        d[1] += e0.elapsed_time(e1)
+        rec = by.setdefault((label, flops, nbytes), [0, 0.0])
+        rec[0] += 1
+        rec[1] += e0.elapsed_time(e1)
 print("fp32 GEMMs by shape:")
 for (label, flops, nbytes), (n, ms) in sorted(by.items(), key=lambda kv: -kv[1][1])[:30]:
     print(f"  {label:28s} {flops / 1e9:8.3f} GFLOP {nbytes / 1e6:8.2f} MB  x{n:3d} {ms:7.3f} ms")

@@ -44,33 +44,38 @@ class ConvAttentionFunction(torch.autograd.Function):
     detached encoder output, model.py:139) and the mel spectrogram get no gradient."""
 
     @staticmethod
-    def forward(ctx, att, mel: Tensor, keys_t: Tensor, mel_len: Tensor, text_len: Tensor, *params: Tensor):
+    def forward(ctx, att, mel: Tensor, keys_t: Tensor, mel_len: Tensor, text_len: Tensor, amp: bool, *params: Tensor):
+        """`amp`: the five convolutions (and their backward GEMMs) take bf16 operands - autocast covers conv1d in the reference's
+        step (recipes/default.yaml:56) - with fp32 outputs; GELU, the instance norms and the scores stay fp32."""
         kb0, kb1 = att.key_proj
         qb0, qb1, qb2 = att.query_proj
         M, L = mel.shape[2], keys_t.shape[2]
-        wk0, wk1 = _w2d(kb0.conv.weight), _w2d(kb1.conv.weight)
-        wq0, wq1, wq2 = _w2d(qb0.conv.weight), _w2d(qb1.conv.weight), _w2d(qb2.conv.weight)
-        kp0 = runtime.pad_rows(keys_t.float(), text_len, channel_first=True)
+        dt = torch.bfloat16 if amp else torch.float32
+        cw = (lambda w: runtime.cast_bf16(w)) if amp else (lambda w: w)
+        wk0, wk1 = cw(_w2d(kb0.conv.weight)), cw(_w2d(kb1.conv.weight))
+        wq0, wq1, wq2 = cw(_w2d(qb0.conv.weight)), cw(_w2d(qb1.conv.weight)), cw(_w2d(qb2.conv.weight))
+        kp0 = runtime.pad_rows(keys_t.float(), text_len, channel_first=True, out_dtype=dt)
         u0 = runtime.conv5_padded(kp0, wk0)
         y0 = runtime.gelu(u0)
-        kp1 = runtime.masked_instnorm(y0, kb0.norm.weight, kb0.norm.bias, text_len)
+        kp1 = runtime.masked_instnorm(y0, kb0.norm.weight, kb0.norm.bias, text_len, out_dtype=dt)
         k_enc = runtime.conv5_padded(kp1, wk1)
-        qp0 = runtime.pad_rows(mel.float(), mel_len, channel_first=True)
+        qp0 = runtime.pad_rows(mel.float(), mel_len, channel_first=True, out_dtype=dt)
         u1 = runtime.conv5_padded(qp0, wq0)
         y1 = runtime.gelu(u1)
-        qp1 = runtime.masked_instnorm(y1, qb0.norm.weight, qb0.norm.bias, mel_len)
+        qp1 = runtime.masked_instnorm(y1, qb0.norm.weight, qb0.norm.bias, mel_len, out_dtype=dt)
         u2 = runtime.conv5_padded(qp1, wq1)
         y2 = runtime.gelu(u2)
-        qp2 = runtime.masked_instnorm(y2, qb1.norm.weight, qb1.norm.bias, mel_len)
+        qp2 = runtime.masked_instnorm(y2, qb1.norm.weight, qb1.norm.bias, mel_len, out_dtype=dt)
         q_enc = runtime.conv5_padded(qp2, wq2)
         soft, logits = runtime.aligner_scores(q_enc, k_enc, text_len, mel_len, M, L)
-        ctx.att, ctx.M, ctx.L = att, M, L
+        ctx.att, ctx.M, ctx.L, ctx.amp = att, M, L, amp
         ctx.save_for_backward(mel_len, text_len, kp0, u0, y0, kp1, k_enc, qp0, u1, y1, qp1, u2, y2, qp2, q_enc, soft, logits)
         return soft, logits
 
     @staticmethod
     def backward(ctx, d_soft, d_logits):
-        att, M, L = ctx.att, ctx.M, ctx.L
+        att, M, L, amp = ctx.att, ctx.M, ctx.L, ctx.amp
+        cw = (lambda w: runtime.cast_bf16(w)) if amp else (lambda w: w)          # GEMM operands: bf16 under AMP
         (mel_len, text_len, kp0, u0, y0, kp1, k_enc, qp0, u1, y1, qp1, u2, y2, qp2, q_enc, soft, logits) = ctx.saved_tensors
         kb0, kb1 = att.key_proj
         qb0, qb1, qb2 = att.query_proj
@@ -87,9 +92,10 @@ class ConvAttentionFunction(torch.autograd.Function):
         def conv1_bwd(d_buf: Tensor, xpad: Tensor, conv_weight: Tensor):
             """1 x 1 convolution reading frame t at padded row t + 2: -> (d W [O, C, 1], d x in conv-output row space)."""
             rows = d_buf.shape[0] * d_buf.shape[1] - 2
-            dw = runtime.gemm_tn(d_buf.reshape(-1, d_buf.shape[2])[:rows], _windows(xpad, rows, 1, first_row=2))
+            dg = cw(d_buf.reshape(-1, d_buf.shape[2]))
+            dw = runtime.gemm_tn(dg[:rows], _windows(xpad, rows, 1, first_row=2))
             w = _w2d(conv_weight)                                                    # [O, C]
-            dx = runtime.gemm(d_buf.reshape(-1, d_buf.shape[2]), runtime.transpose(w)).view(d_buf.shape[0], d_buf.shape[1], -1)
+            dx = runtime.gemm(dg, cw(runtime.transpose(w)), out_dtype=torch.float32).view(d_buf.shape[0], d_buf.shape[1], -1)
             return _w2d_grad(dw, conv_weight), dx
 
         def block_bwd(d_normed: Tensor, y: Tensor, u: Tensor, xpad: Tensor, block, lengths: Tensor, want_dx: bool):
@@ -98,15 +104,15 @@ class ConvAttentionFunction(torch.autograd.Function):
             d_u = runtime.gelu_bwd(d_y, u, out=d_y)
             Bc, TP, O = d_u.shape
             rows = Bc * TP - 4
-            dw = runtime.gemm_tn(d_u.reshape(-1, O)[:rows], _windows(xpad, rows, 5))
+            dw = runtime.gemm_tn(cw(d_u.reshape(-1, O))[:rows], _windows(xpad, rows, 5))
             dx = None
             if want_dx:
                 # d xpad[r] = sum_k d u[r - k] W_k: the conv GEMM over d u with four zero rows in front and the taps flipped
                 C = xpad.shape[-1]
-                g = runtime.zeros((Bc * TP + 4 + 4, O), torch.float32, d_u.device)
-                runtime.segments([(d_u.reshape(-1, O), g[4:4 + Bc * TP], runtime.SEG_COPY)])
-                wf = runtime.conv_weight_flip(block.conv.weight)          # [C][(j, o)] = W[o][c][4 - j]
-                dx = runtime.gemm(_windows(g, Bc * TP, 5), wf)                       # [B (T+4), C]: padded row space
+                g = runtime.zeros((Bc * TP + 4 + 4, O), torch.bfloat16 if amp else torch.float32, d_u.device)
+                runtime.segments([(d_u.reshape(-1, O), g[4:4 + Bc * TP], runtime.SEG_BF16 if amp else runtime.SEG_COPY)])
+                wf = cw(runtime.conv_weight_flip(block.conv.weight))      # [C][(j, o)] = W[o][c][4 - j]
+                dx = runtime.gemm(_windows(g, Bc * TP, 5), wf, out_dtype=torch.float32)   # [B (T+4), C]: padded row space
             return _w2d_grad(dw, block.conv.weight), dnw, dnb, dx
 
         # key side: conv1 (768 -> 128), then the first block (its input, the detached encoder output, needs no gradient)
@@ -125,7 +131,7 @@ class ConvAttentionFunction(torch.autograd.Function):
                  id(qb0.conv.weight): dwq0, id(qb0.norm.weight): dnq0_w, id(qb0.norm.bias): dnq0_b,
                  id(qb1.conv.weight): dwq1, id(qb1.norm.weight): dnq1_w, id(qb1.norm.bias): dnq1_b, id(qb2.conv.weight): dwq2}
         ps = aligner_parameters(att)
-        return (None, None, None, None, None, *runtime.deliver_grads([(p, grads[id(p)]) for p in ps]))
+        return (None, None, None, None, None, None, *runtime.deliver_grads([(p, grads[id(p)]) for p in ps]))
 
 
 def aligner_parameters(att) -> list:
@@ -135,9 +141,9 @@ def aligner_parameters(att) -> list:
             qb1.conv.weight, qb1.norm.weight, qb1.norm.bias, qb2.conv.weight]
 
 
-def conv_attention_train(att, mel: Tensor, keys_t: Tensor, mel_len: Tensor, text_len: Tensor):
-    """-> (attn_soft, attn_logits), differentiable with respect to the aligner's parameters."""
-    return ConvAttentionFunction.apply(att, mel, keys_t, mel_len, text_len, *aligner_parameters(att))
+def conv_attention_train(att, mel: Tensor, keys_t: Tensor, mel_len: Tensor, text_len: Tensor, amp: bool = False):
+    """-> (attn_soft, attn_logits), differentiable with respect to the aligner's parameters; `amp`: bf16 convolution operands."""
+    return ConvAttentionFunction.apply(att, mel, keys_t, mel_len, text_len, amp, *aligner_parameters(att))
 
 
 class SoftAverageFunction(torch.autograd.Function):

@@ -33,7 +33,7 @@ def acoustic_train_forward(model, text: Tensor, text_len: Tensor, mel: Tensor, m
     enc_out = transformer_train_forward(model.encoder, emb, enc_mask, amp, key_len=text_len)
     keys_t = enc_out.detach().transpose(1, 2)          # model.py:139: the aligner sees the DETACHED encoder output
     if train_aligner:
-        attn_soft, attn_logits = conv_attention_train(model.aligner.attention, mel, keys_t, mel_len, text_len)
+        attn_soft, attn_logits = conv_attention_train(model.aligner.attention, mel, keys_t, mel_len, text_len, amp)
         attn_soft, attn_soft_kl = fork(attn_soft)     # two consumers: the length regulator and the binarisation loss
     with torch.no_grad():
         if not train_aligner:

@@ -466,6 +466,11 @@ int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int
                                const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
                                float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,
                                float eps, ispk_stream_t stream);
+/* ispk_layernorm_bwd_f32 that also writes dx as bf16 rows (an AMP step: the next dX GEMM and weight gradient read that copy) */
+int32_t ispk_layernorm_bwd_dual_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
+                                    const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
+                                    float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,
+                                    float eps, uint16_t* dx_bf16, int64_t ld_dx_bf16, ispk_stream_t stream);
 int32_t ispk_gelu_f32(const float* u, float* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, float dropout_p, uint64_t seed,
                           ispk_stream_t stream);
@@ -474,6 +479,10 @@ int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n,
 int32_t ispk_gelu_f32_bf16(const float* u, uint16_t* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_gelu_bwd_bf16(const uint16_t* da, const float* u, uint16_t* du, int64_t n, float dropout_p, uint64_t seed,
                            ispk_stream_t stream);
+/* ... and with the pre-activation u stored in bf16 too (under autocast the first Linear's output is bf16) */
+int32_t ispk_gelu_bf16(const uint16_t* u, uint16_t* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
+int32_t ispk_gelu_bwd_b16(const uint16_t* da, const uint16_t* u, uint16_t* du, int64_t n, float dropout_p, uint64_t seed,
+                          ispk_stream_t stream);
 int32_t ispk_dropout_mask_u8(uint8_t* out, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream);
 int32_t ispk_alibi_mqa_attn_train_f32(const float* qkv, int64_t ld_qkv, const float* slopes, const int64_t* key_len, float* o,
                                       int64_t ld_o, float* lse, int32_t B, int32_t N, int32_t H, float dropout_p, uint64_t seed,

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                                                                 int64_t lddy, const float* __restrict__ gamma,
                                                                 const uint8_t* __restrict__ mask, float* __restrict__ dx,
                                                                 int64_t lddx, int add_to_dx, float* __restrict__ part, int rows,
-                                                                float eps) {
+                                                                float eps, uint16_t* __restrict__ dx16, int64_t lddx16) {
     constexpr int D = NV4 * 128;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, l = lane & 31, hf = lane >> 5;
     auto hsum = [](float v) {
@@ -479,6 +479,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
                 f32x4 v = (gv[c] - c1 - xv[c] * c2) * rstd;
                 if (add_to_dx) v += old[c];
                 *reinterpret_cast<f32x4*>(dx + (int64_t)row * lddx + 4 * (l + 32 * c)) = v;
+                if (dx16) {      // the same rows as the bf16 operand the next dX GEMM and weight gradient take (an AMP step)
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(dx16 + (int64_t)row * lddx16 + 4 * (l + 32 * c)) = pk;
+                }
             }
         }
     }
@@ -522,15 +528,23 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
 // ------------------------------------------------------------------------------------------------ GELU backward
 // With dropout (feedforward.py:35: Linear -> GELU -> Dropout -> Linear): a = gelu(u) * keep / (1 - p), and backward
 // du = da * keep / (1 - p) * gelu'(u); keep = drop_keep(seed, element index).
-template <bool IO16 = false>   // IO16: da and du are bf16 (both are only ever GEMM operands of an AMP step)
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ da, const float* __restrict__ u,
+template <bool IO16 = false, bool U16 = false>   // IO16: da and du are bf16 (both are only ever GEMM operands of an AMP step);
+// U16: the pre-activation is bf16 too (under autocast the first Linear's output IS bf16)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ da, const void* __restrict__ u,
                                                        void* __restrict__ du, int64_t n4, uint32_t thresh, float inv_keep,
                                                        uint64_t seed,
         const uint64_t* __restrict__ seed_src) {
     seed = run_seed(seed, seed_src);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    const f32x4 x = reinterpret_cast<const f32x4*>(u)[i];
+    f32x4 x;
+    if constexpr (U16) {
+        const uint2 q = reinterpret_cast<const uint2*>(u)[i];
+        x[0] = bf16_to_f32((uint16_t)(q.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(q.x >> 16));
+        x[2] = bf16_to_f32((uint16_t)(q.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(q.y >> 16));
+    } else {
+        x = reinterpret_cast<const f32x4*>(u)[i];
+    }
     f32x4 a;
     if constexpr (IO16) {
         const uint2 q = reinterpret_cast<const uint2*>(da)[i];
@@ -559,14 +573,21 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ 
 }
 
 // the training forward keeps the pre-activation u (for the line above), so its GELU is a pass of its own: a = gelu(u)
-template <bool OUT16 = false>   // OUT16: a is bf16 (an AMP step keeps the activation its second Linear multiplies in bf16)
-__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* __restrict__ u, void* __restrict__ a, int64_t n4,
+template <bool OUT16 = false, bool U16 = false>   // OUT16: a is bf16 (an AMP step keeps the activation its second Linear multiplies in bf16)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const void* __restrict__ u, void* __restrict__ a, int64_t n4,
                                                        uint32_t thresh, float inv_keep, uint64_t seed,
         const uint64_t* __restrict__ seed_src) {
     seed = run_seed(seed, seed_src);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n4) return;
-    const f32x4 x = reinterpret_cast<const f32x4*>(u)[i];
+    f32x4 x;
+    if constexpr (U16) {
+        const uint2 q = reinterpret_cast<const uint2*>(u)[i];
+        x[0] = bf16_to_f32((uint16_t)(q.x & 0xffffu)); x[1] = bf16_to_f32((uint16_t)(q.x >> 16));
+        x[2] = bf16_to_f32((uint16_t)(q.y & 0xffffu)); x[3] = bf16_to_f32((uint16_t)(q.y >> 16));
+    } else {
+        x = reinterpret_cast<const f32x4*>(u)[i];
+    }
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1013,10 +1034,10 @@ extern "C" int32_t ispk_gemm_tn_batched_f32(const float* A, int64_t lda, int64_t
                           workspace_floats, reinterpret_cast<hipStream_t>(stream), "ispk_gemm_tn_batched_f32");
 }
 
-extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
-                                          const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
-                                          float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,
-                                          float eps, ispk_stream_t stream) {
+static int32_t layernorm_bwd_launch(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
+                                    const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma, float* dbeta,
+                                    float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim, float eps,
+                                    ispk_stream_t stream, uint16_t* dx16, int64_t lddx16) {
     ISPK_REQUIRE(x && dy && dx, -1, "ispk_layernorm_bwd_f32: null pointer");
     ISPK_REQUIRE(rows >= 1 && (dim == 256 || dim == 384) && ldx >= dim && lddy >= dim && lddx >= dim, -2,
                  "ispk_layernorm_bwd_f32: rows=%lld dim=%d (dim must be 256 or 384)", (long long)rows, dim);
@@ -1028,12 +1049,14 @@ extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const flo
     float* part = want ? workspace : nullptr;
     const bool vec = ldx % 4 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && ispk_aligned(x, 16) && ispk_aligned(dy, 16) &&
                      ispk_aligned(dx, 16) && (!gamma || ispk_aligned(gamma, 16));
+    ISPK_REQUIRE(!dx16 || (vec && lddx16 % 4 == 0 && lddx16 >= dim && ispk_aligned(dx16, 8)), -4,
+                 "ispk_layernorm_bwd_dual_f32: the bf16 copy needs 16-byte aligned fp32 operands and an 8-byte aligned copy");
     if (vec && dim == 384)
         hipLaunchKernelGGL(layernorm_bwd_vec_kernel<3>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
-                           add_to_dx, part, (int)rows, eps);
+                           add_to_dx, part, (int)rows, eps, dx16, lddx16);
     else if (vec)
         hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
-                           add_to_dx, part, (int)rows, eps);
+                           add_to_dx, part, (int)rows, eps, dx16, lddx16);
     else if (dim == 384)
         hipLaunchKernelGGL(layernorm_bwd_kernel<6>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
                            add_to_dx, part, (int)rows, eps);
@@ -1044,6 +1067,24 @@ extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const flo
         hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * dim + 255) / 256), dim3(256), 0, s, part, blocks, 2 * dim, dgamma,
                            dbeta);
     return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_layernorm_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
+                                          const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
+                                          float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,
+                                          float eps, ispk_stream_t stream) {
+    return layernorm_bwd_launch(x, ldx, dy, lddy, gamma, row_mask, dx, lddx, add_to_dx, dgamma, dbeta, workspace, workspace_floats, rows,
+                                dim, eps, stream, nullptr, 0);
+}
+
+// ... with dx written a second time as bf16 rows (dx_bf16, ld_dx_bf16): the operand of the next dX GEMM / weight gradient
+extern "C" int32_t ispk_layernorm_bwd_dual_f32(const float* x, int64_t ldx, const float* dy, int64_t lddy, const float* gamma,
+                                               const uint8_t* row_mask, float* dx, int64_t lddx, int32_t add_to_dx, float* dgamma,
+                                               float* dbeta, float* workspace, int64_t workspace_floats, int64_t rows, int32_t dim,
+                                               float eps, uint16_t* dx_bf16, int64_t ld_dx_bf16, ispk_stream_t stream) {
+    ISPK_REQUIRE(dx_bf16, -1, "ispk_layernorm_bwd_dual_f32: null bf16 output");
+    return layernorm_bwd_launch(x, ldx, dy, lddy, gamma, row_mask, dx, lddx, add_to_dx, dgamma, dbeta, workspace, workspace_floats, rows,
+                                dim, eps, stream, dx_bf16, ld_dx_bf16);
 }
 
 extern "C" int32_t ispk_gelu_bwd_f32(const float* da, const float* u, float* du, int64_t n, float dropout_p, uint64_t seed,
@@ -1087,6 +1128,29 @@ extern "C" int32_t ispk_gelu_f32_bf16(const float* u, uint16_t* a, int64_t n, fl
     if (n == 0) return 0;
     hipLaunchKernelGGL(gelu_fwd_kernel<true>, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
                        u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed), ispk_seed_source());
+    return ispk_launch_status();
+}
+
+// the pair with the pre-activation stored in bf16 as well (autocast: the first Linear's output is bf16)
+extern "C" int32_t ispk_gelu_bf16(const uint16_t* u, uint16_t* a, int64_t n, float dropout_p, uint64_t seed, ispk_stream_t stream) {
+    ISPK_REQUIRE(u && a, -1, "ispk_gelu_bf16: null pointer");
+    ISPK_REQUIRE(n >= 0 && n % 4 == 0 && ispk_aligned(u, 8) && ispk_aligned(a, 8), -2, "ispk_gelu_bf16: n %% 4, 8-byte aligned arrays");
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_bf16: dropout_p must be in [0, 1)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL((gelu_fwd_kernel<true, true>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       u, a, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed), ispk_seed_source());
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_gelu_bwd_b16(const uint16_t* da, const uint16_t* u, uint16_t* du, int64_t n, float dropout_p, uint64_t seed,
+                                     ispk_stream_t stream) {
+    ISPK_REQUIRE(da && u && du, -1, "ispk_gelu_bwd_b16: null pointer");
+    ISPK_REQUIRE(n >= 0 && n % 4 == 0 && ispk_aligned(da, 8) && ispk_aligned(u, 8) && ispk_aligned(du, 8), -2,
+                 "ispk_gelu_bwd_b16: n %% 4, 8-byte aligned arrays");
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, -3, "ispk_gelu_bwd_b16: dropout_p must be in [0, 1)");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL((gelu_bwd_kernel<true, true>), dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       da, u, du, n / 4, drop_thresh(dropout_p), 1.0f / (1.0f - dropout_p), mix_seed(seed), ispk_seed_source());
     return ispk_launch_status();
 }
 

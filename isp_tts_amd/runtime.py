@@ -83,9 +83,12 @@ SIGNATURES = {
     "ispk_gemm_tn_bf16": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_gemm_tn_b16": [_P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_gelu_f32_bf16": [_P, _P, _I64, _F32, _U64, _P],
+    "ispk_gelu_bf16": [_P, _P, _I64, _F32, _U64, _P],
+    "ispk_gelu_bwd_b16": [_P, _P, _P, _I64, _F32, _U64, _P],
     "ispk_gelu_bwd_bf16": [_P, _P, _P, _I64, _F32, _U64, _P],
     "ispk_gemm_tn_batched_f32": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P, _I32, _P, _I64, _P],
     "ispk_layernorm_bwd_f32": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _I64, _I32, _F32, _P],
+    "ispk_layernorm_bwd_dual_f32": [_P, _I64, _P, _I64, _P, _P, _P, _I64, _I32, _P, _P, _P, _I64, _I64, _I32, _F32, _P, _I64, _P],
     "ispk_gelu_f32": [_P, _P, _I64, _F32, _U64, _P],
     "ispk_gelu_bwd_f32": [_P, _P, _P, _I64, _F32, _U64, _P],
     "ispk_dropout_mask_u8": [_P, _I64, _F32, _U64, _P],
@@ -1235,9 +1238,11 @@ def soft_average_bwd(attn_soft: Tensor, pitch: Tensor, energy: Tensor, d_feats: 
 
 
 def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], row_mask: Optional[Tensor] = None,
-                  dx: Optional[Tensor] = None, add_to_dx: bool = False, want_param_grads: bool = True, eps: float = 1e-5):
+                  dx: Optional[Tensor] = None, add_to_dx: bool = False, want_param_grads: bool = True, eps: float = 1e-5,
+                  bf16_copy: bool = False):
     """ispk_layernorm_bwd_f32 -> (dx, dgamma | None, dbeta | None).  `dx` given + add_to_dx: accumulated in place (the
-    residual branch's gradient is already there)."""
+    residual branch's gradient is already there).  `bf16_copy` (ispk_layernorm_bwd_dual_f32): a fourth result, dx once more
+    as bf16 rows - the operand an AMP step's next dX GEMM and weight gradient take, without a cast launch."""
     _dev(x, dy, gamma, row_mask, dx)
     x2, dy2 = _rows2d(x), _rows2d(dy)
     rows, D = x2.shape
@@ -1255,6 +1260,13 @@ def layernorm_bwd(x: Tensor, dy: Tensor, gamma: Optional[Tensor], row_mask: Opti
         dg = torch.empty((D,), dtype=torch.float32, device=x.device)
         db = torch.empty((D,), dtype=torch.float32, device=x.device)
         ws = workspace(x.device, ((rows + 63) // 64) * 2 * D)
+    if bf16_copy:
+        dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        _launch(f"layernorm_bwd_kernel<{D // 64}>", 0.0, 4.0 * rows * D * (3.5 + int(add_to_dx)), lib().ispk_layernorm_bwd_dual_f32,
+                x2.data_ptr(), x2.stride(0), dy2.data_ptr(), dy2.stride(0), _ptr(gamma), _ptr(row_mask), dx2.data_ptr(),
+                dx2.stride(0), int(add_to_dx), _ptr(dg), _ptr(db), _ptr(ws), ws.numel() if ws is not None else 0, rows, D, eps,
+                dx16.data_ptr(), D, _stream())
+        return dx, dg, db, dx16
     _launch(f"layernorm_bwd_kernel<{D // 64}>", 0.0, 4.0 * rows * D * (3 + int(add_to_dx)), lib().ispk_layernorm_bwd_f32,
             x2.data_ptr(), x2.stride(0), dy2.data_ptr(), dy2.stride(0), _ptr(gamma), _ptr(row_mask), dx2.data_ptr(),
             dx2.stride(0), int(add_to_dx), _ptr(dg), _ptr(db), _ptr(ws), ws.numel() if ws is not None else 0, rows, D, eps,
@@ -1266,10 +1278,14 @@ def gelu(u: Tensor, dropout_p: float = 0.0, seed: int = 0, out_dtype: torch.dtyp
     """ispk_gelu_f32 / ispk_gelu_f32_bf16: exact-erf GELU as its own pass (the training forward keeps u), optionally followed
     by dropout; `out_dtype=torch.bfloat16`: the result as the bf16 operand an AMP step's second Linear takes."""
     _dev(u)
-    assert u.dtype == torch.float32 and u.is_contiguous() and out_dtype in (torch.float32, torch.bfloat16)
+    assert u.dtype in (torch.float32, torch.bfloat16) and u.is_contiguous() and out_dtype in (torch.float32, torch.bfloat16)
+    if u.dtype == torch.bfloat16:      # ispk_gelu_bf16: the pre-activation itself is bf16 (autocast's Linear output)
+        assert out_dtype == torch.bfloat16
+        fn = lib().ispk_gelu_bf16
+    else:
+        fn = lib().ispk_gelu_f32 if out_dtype == torch.float32 else lib().ispk_gelu_f32_bf16
     a = torch.empty(u.shape, dtype=out_dtype, device=u.device)
-    _launch("gelu_fwd_kernel", 0.0, (4.0 + a.element_size()) * u.numel(),
-            lib().ispk_gelu_f32 if out_dtype == torch.float32 else lib().ispk_gelu_f32_bf16, u.data_ptr(), a.data_ptr(), u.numel(),
+    _launch("gelu_fwd_kernel", 0.0, float(u.element_size() + a.element_size()) * u.numel(), fn, u.data_ptr(), a.data_ptr(), u.numel(),
             dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return a
 
@@ -1305,13 +1321,14 @@ def alibi_mqa_attention_train(qkv: Tensor, heads: int, slopes: Tensor, key_len: 
 def gelu_bwd(da: Tensor, u: Tensor, out: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
     """ispk_gelu_bwd_f32: du = da * [keep / (1 - p)] * gelu'(u) (exact erf); `out` may alias `da`."""
     _dev(da, u, out)
-    assert da.dtype in (torch.float32, torch.bfloat16) and u.dtype == torch.float32 and da.is_contiguous() and u.is_contiguous()
-    assert da.shape == u.shape
+    assert da.dtype in (torch.float32, torch.bfloat16) and u.dtype in (torch.float32, torch.bfloat16) and da.is_contiguous() and u.is_contiguous()
+    assert da.shape == u.shape and (u.dtype == torch.float32 or da.dtype == torch.bfloat16)
     if out is None:
         out = torch.empty_like(da)
     assert out.dtype == da.dtype
-    b16 = da.dtype == torch.bfloat16      # ispk_gelu_bwd_bf16: da and du are bf16 GEMM operands of an AMP step
-    _launch("gelu_bwd_kernel", 0.0, (4.0 + 2 * da.element_size()) * da.numel(), lib().ispk_gelu_bwd_bf16 if b16 else lib().ispk_gelu_bwd_f32,
+    b16 = da.dtype == torch.bfloat16      # ispk_gelu_bwd_bf16: da and du are bf16 GEMM operands of an AMP step (_b16: u bf16 too)
+    fn = (lib().ispk_gelu_bwd_b16 if u.dtype == torch.bfloat16 else lib().ispk_gelu_bwd_bf16) if b16 else lib().ispk_gelu_bwd_f32
+    _launch("gelu_bwd_kernel", 0.0, float(u.element_size() + 2 * da.element_size()) * da.numel(), fn,
             da.data_ptr(), u.data_ptr(), out.data_ptr(), da.numel(), dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
     return out
 

@@ -179,7 +179,7 @@ class AdaptiveStackFunction(torch.autograd.Function):
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
             x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
             h2 = runtime.layernorm(x1, None, None, s2, t2, L, mask, layer.feed_forward_norm.eps, out_dtype=adt)
-            u = _mm(h2, w1, w116)
+            u = _mm(h2, w1, w116, out_dtype=adt)       # AMP: the pre-activation is bf16 (autocast's Linear output)
             a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)
             y = _mm(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
             tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))

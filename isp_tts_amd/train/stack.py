@@ -116,7 +116,7 @@ class TransformerStackFunction(torch.autograd.Function):
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
             x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
             h2 = runtime.layernorm(x1, fn.weight, fn.bias, row_mask=mask, eps=fn.eps, out_dtype=adt)
-            u = _mm(h2, w1, w116)
+            u = _mm(h2, w1, w116, out_dtype=adt)       # AMP: the pre-activation is bf16 (autocast's Linear output)
             a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)        # GELU, then nn.Dropout (feedforward.py:35)
             y = _mm(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
             tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
@@ -130,8 +130,10 @@ class TransformerStackFunction(torch.autograd.Function):
         tr, mask, key_len, amp = ctx.tr, ctx.mask, ctx.key_len, ctx.amp
         mflag = runtime.EP_MASK_OUT if mask is not None else 0
         grads: list = []
-        dy, dgf, dbf = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask,
-                                             eps=tr.norm.eps)
+        # (AMP: every LayerNorm backward also leaves its dx as bf16 rows - the operand of the dX GEMM and weight gradient below it)
+        dy, dgf, dbf, *rest = runtime.layernorm_bwd(ctx.last, dfinal.float().contiguous(), tr.norm.weight, row_mask=mask,
+                                                    eps=tr.norm.eps, bf16_copy=amp)
+        dyg = rest[0] if amp else dy
         images = layer_images(tr, amp)         # (the forward's images: same parameter versions)
         for li in reversed(range(len(tr.layers))):
             layer = tr.layers[li]
@@ -146,22 +148,23 @@ class TransformerStackFunction(torch.autograd.Function):
             # bf16; q / k / v, the attention output, dO and dqkv: the attention kernels read and write bf16), and ONE bf16 copy each of
             # the fp32 residual-stream gradients that a dX GEMM and a weight gradient both read (dy, dx1).
             # feed-forward block
-            dyg = runtime.cast_bf16(dy) if amp else dy
             dw2 = _deliver(ff.net[3].weight, runtime.gemm_tn, dyg, a, row_mask=mask, bf16=amp)        # [dim, inner]
             da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)                         # (m dy) W2
             du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
             dw1 = _deliver(ff.net[0].weight, runtime.gemm_tn, du, h2, bf16=amp)                         # [inner, dim]
             dh2 = _mm(du, w1_t, w1_t16)
-            dx1, dg2, db2 = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps)
+            dx1, dg2, db2, *rest = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps,
+                                                         bf16_copy=amp)
             # attention block
-            dx1g = runtime.cast_bf16(dx1) if amp else dx1
+            dx1g = rest[0] if amp else dx1
             dwo = _deliver(att.to_out.weight, runtime.gemm_tn, dx1g, o, row_mask=mask, bf16=amp)       # [dim, heads*64]
             d_o = _mm(dx1g, wo_t, wo_t16, out_dtype=gdt, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
                                                         seed=seed_att)                     # AMP: bf16 in, bf16 out
             dwqkv = runtime.gemm_tn(dqkv, h, bf16=amp)                                      # [heads*64 + 128, dim]
             dh = _mm(dqkv, wqkv_t, wqkv_t16)
-            dy, dg1, db1 = runtime.layernorm_bwd(xin, dh, an.weight, dx=dx1, add_to_dx=True, eps=an.eps)
+            dy, dg1, db1, *rest = runtime.layernorm_bwd(xin, dh, an.weight, dx=dx1, add_to_dx=True, eps=an.eps, bf16_copy=amp)
+            dyg = rest[0] if amp else dy
             hq = att.heads * 64
             ls = att.rel_pos.learned_logslopes
             grads = [dg1, db1, dwqkv[:hq], dwqkv[hq:], dls[:ls.numel()].view_as(ls), dwo, dg2, db2, dw1, dw2] + grads

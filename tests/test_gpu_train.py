@@ -1070,12 +1070,24 @@ def test_gemm_tn_with_operands_stored_in_bf16(M, N1, N2, masked):
 
 
 def test_gelu_bf16_forms_match_the_fp32_forms():
+    """The bf16 forms of the GELU pair (bf16 a / da / du, and the _b16 pair with a bf16 pre-activation too) against the fp32
+    forms on the same values: one bf16 rounding apart (they evaluate erf by the 3e-7 polynomial of common.h and exp on
+    v_exp_f32, the fp32 forms by libm), with the same dropout mask."""
     u = _rand((300, 1536), 311, 2.0).to(DEV)
     da = _rand((300, 1536), 312).to(DEV)
+
+    def one_ulp(got16, want32, what):
+        err = (got16.float() - want32).abs()
+        bound = want32.abs() * 2.0 ** -8 + 1e-6
+        assert bool((err <= bound).all()), f"{what}: {float((err - bound).max()):.3e} over one bf16 rounding"
+        assert torch.equal(got16 == 0, want32.to(torch.bfloat16) == 0) or ((got16 == 0) ^ (want32 == 0)).float().mean() < 1e-3   # (far negative inputs: 0 vs a denormal-sized value)
     for p, seed in ((0.0, 0), (0.1, 1234)):
         a32 = runtime.gelu(u, p, seed)
-        a16 = runtime.gelu(u, p, seed, out_dtype=torch.bfloat16)
-        assert torch.equal(a16, a32.to(torch.bfloat16))
-        du32 = runtime.gelu_bwd(da.to(torch.bfloat16).float(), u, dropout_p=p, seed=seed)
-        du16 = runtime.gelu_bwd(da.to(torch.bfloat16), u, dropout_p=p, seed=seed)
-        assert torch.equal(du16, du32.to(torch.bfloat16))
+        one_ulp(runtime.gelu(u, p, seed, out_dtype=torch.bfloat16), a32, "gelu -> bf16")
+        da16 = da.to(torch.bfloat16)
+        du32 = runtime.gelu_bwd(da16.float(), u, dropout_p=p, seed=seed)
+        one_ulp(runtime.gelu_bwd(da16, u, dropout_p=p, seed=seed), du32, "gelu backward, bf16 da / du")
+        u16 = u.to(torch.bfloat16)                       # the pair with the pre-activation stored in bf16
+        one_ulp(runtime.gelu(u16, p, seed, out_dtype=torch.bfloat16), runtime.gelu(u16.float(), p, seed), "gelu on a bf16 pre-activation")
+        one_ulp(runtime.gelu_bwd(da16, u16, dropout_p=p, seed=seed), runtime.gelu_bwd(da16.float(), u16.float(), dropout_p=p, seed=seed),
+                "gelu backward on a bf16 pre-activation")

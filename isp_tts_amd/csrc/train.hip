@@ -545,55 +545,89 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict_
 }
 
 // Time embedding backward (embeddings.py:131-157 as ispk_time_embedding_f32 computes it: f = [t, sin, cos], h = silu(W0 f + b0),
-// out = W1 h + b1; t itself gets no gradient).  ONE wave: lane j owns hidden unit / output j; the n time values are walked in
-// order, so every sum has a fixed order.  E <= 64, 1 + 2H <= 160.
-__global__ __launch_bounds__(64) void time_embedding_bwd_kernel(const float* __restrict__ t, int n, const float* __restrict__ inv_freq,
-                                                                const float* __restrict__ freq_scale, int H,
-                                                                const float* __restrict__ w0, const float* __restrict__ b0,
-                                                                const float* __restrict__ w1, int E, const float* __restrict__ d_out,
-                                                                float* __restrict__ dw0, float* __restrict__ db0,
-                                                                float* __restrict__ dw1, float* __restrict__ db1) {
+// out = W1 h + b1; t itself gets no gradient).  One workgroup of 1024 threads; the n time values go through LDS in chunks of 64:
+// per chunk the features, pre-activations and their gradients of all its values are computed in parallel, then every thread
+// adds the chunk's terms of the outputs it owns (rows of dW0 / dW1, the bias sums) walking the time values IN ORDER - every
+// sum has a fixed order.  E <= 64, 1 + 2H <= 160.
+constexpr int kTeChunk = 64, kTeOwn = 16;      // outputs per thread: (64 * 160 + 64 * 64 + 128) / 1024 < 16
+__global__ __launch_bounds__(1024) void time_embedding_bwd_kernel(const float* __restrict__ t, int n, const float* __restrict__ inv_freq,
+                                                                  const float* __restrict__ freq_scale, int H,
+                                                                  const float* __restrict__ w0, const float* __restrict__ b0,
+                                                                  const float* __restrict__ w1, int E, const float* __restrict__ d_out,
+                                                                  float* __restrict__ dw0, float* __restrict__ db0,
+                                                                  float* __restrict__ dw1, float* __restrict__ db1) {
 #pragma clang fp contract(off)
-    __shared__ float f[160], h[64], go[64];
-    const int j = threadIdx.x, K0 = 1 + 2 * H;
-    float aw0[160], aw1[64], ab0 = 0.f, ab1 = 0.f;
-    for (int k = 0; k < K0; ++k) aw0[k] = 0.f;
-    for (int k = 0; k < E; ++k) aw1[k] = 0.f;
+    extern __shared__ float te_lds[];
+    const int K0 = 1 + 2 * H, tid = threadIdx.x;
+    float* f = te_lds;                       // [chunk][K0]
+    float* hh = f + kTeChunk * K0;           // [chunk][E]  silu(pre)
+    float* go = hh + kTeChunk * E;           // [chunk][E]  d out
+    float* dp = go + kTeChunk * E;           // [chunk][E]  d pre
+    float* pre = dp + kTeChunk * E;          // [chunk][E]
     const float fs = freq_scale[0];
-    for (int i = 0; i < n; ++i) {
-        const float pos = t[i];
-        if (j == 0) f[0] = pos;
-        for (int k = j; k < H; k += 64) {
-            const float a = pos * fs * inv_freq[k];
-            f[1 + k] = sinf(a);
-            f[1 + H + k] = cosf(a);
-        }
-        if (j < E) go[j] = d_out[(int64_t)i * E + j];
+    const int n_w0 = E * K0, n_w1 = E * E, n_out = n_w0 + n_w1 + 2 * E;      // [dW0 | dW1 | db0 | db1]
+    float acc[kTeOwn];
+#pragma unroll
+    for (int q = 0; q < kTeOwn; ++q) acc[q] = 0.f;
+    for (int i0 = 0; i0 < n; i0 += kTeChunk) {
+        const int cn = n - i0 < kTeChunk ? n - i0 : kTeChunk;
         __syncthreads();
-        float pre = 0.f;
-        if (j < E) {
-            pre = b0[j];
-            for (int k = 0; k < K0; ++k) pre = fmaf(f[k], w0[(int64_t)j * K0 + k], pre);
-            h[j] = pre / (1.0f + expf(-pre));
+        for (int e = tid; e < cn * K0; e += 1024) {
+            const int i = e / K0, k = e - i * K0;
+            const float pos = t[i0 + i];
+            float v = pos;
+            if (k >= 1) {
+                const int kk = k - 1 < H ? k - 1 : k - 1 - H;
+                const float a = pos * fs * inv_freq[kk];
+                v = k - 1 < H ? sinf(a) : cosf(a);
+            }
+            f[e] = v;
+        }
+        for (int e = tid; e < cn * E; e += 1024) go[e] = d_out[(int64_t)(i0 + e / E) * E + e % E];
+        __syncthreads();
+        for (int e = tid; e < cn * E; e += 1024) {
+            const int i = e / E, j = e - i * E;
+            float pr = b0[j];
+            for (int k = 0; k < K0; ++k) pr = fmaf(f[i * K0 + k], w0[(int64_t)j * K0 + k], pr);
+            pre[e] = pr;
+            hh[e] = pr / (1.0f + expf(-pr));
         }
         __syncthreads();
-        if (j < E) {
+        for (int e = tid; e < cn * E; e += 1024) {
+            const int i = e / E, j = e - i * E;
             float dh = 0.f;                                   // d loss / d h_j = sum_k go[k] W1[k][j]
-            for (int k = 0; k < E; ++k) dh = fmaf(go[k], w1[(int64_t)k * E + j], dh);
-            const float sg = 1.0f / (1.0f + expf(-pre));
-            const float dpre = dh * (sg * (1.0f + pre * (1.0f - sg)));      // silu'(pre)
-            for (int k = 0; k < E; ++k) aw1[k] += go[j] * h[k];             // row j of dW1
-            ab1 += go[j];
-            for (int k = 0; k < K0; ++k) aw0[k] += dpre * f[k];             // row j of dW0
-            ab0 += dpre;
+            for (int k = 0; k < E; ++k) dh = fmaf(go[i * E + k], w1[(int64_t)k * E + j], dh);
+            const float pr = pre[e], sg = 1.0f / (1.0f + expf(-pr));
+            dp[e] = dh * (sg * (1.0f + pr * (1.0f - sg)));      // silu'(pre)
         }
         __syncthreads();
+#pragma unroll
+        for (int q = 0; q < kTeOwn; ++q) {
+            const int o = tid + q * 1024;
+            if (o >= n_out) break;
+            float a = acc[q];
+            if (o < n_w0) {                      // dW0[j][k] += d pre[i][j] f[i][k]
+                const int j = o / K0, k = o - j * K0;
+                for (int i = 0; i < cn; ++i) a += dp[i * E + j] * f[i * K0 + k];
+            } else if (o < n_w0 + n_w1) {        // dW1[j][k] += d out[i][j] h[i][k]
+                const int j = (o - n_w0) / E, k = (o - n_w0) - j * E;
+                for (int i = 0; i < cn; ++i) a += go[i * E + j] * hh[i * E + k];
+            } else {
+                const int j = (o - n_w0 - n_w1) % E;
+                const float* src = o < n_w0 + n_w1 + E ? dp : go;
+                for (int i = 0; i < cn; ++i) a += src[i * E + j];
+            }
+            acc[q] = a;
+        }
     }
-    if (j < E) {
-        for (int k = 0; k < K0; ++k) dw0[(int64_t)j * K0 + k] = aw0[k];
-        for (int k = 0; k < E; ++k) dw1[(int64_t)j * E + k] = aw1[k];
-        db0[j] = ab0;
-        db1[j] = ab1;
+#pragma unroll
+    for (int q = 0; q < kTeOwn; ++q) {
+        const int o = tid + q * 1024;
+        if (o >= n_out) break;
+        if (o < n_w0) dw0[o] = acc[q];
+        else if (o < n_w0 + n_w1) dw1[o - n_w0] = acc[q];
+        else if (o < n_w0 + n_w1 + E) db0[o - n_w0 - n_w1] = acc[q];
+        else db1[o - n_w0 - n_w1 - E] = acc[q];
     }
 }
 
@@ -634,8 +668,10 @@ extern "C" int32_t ispk_time_embedding_bwd_f32(const float* t, int32_t n, const 
                  "ispk_time_embedding_bwd_f32: null pointer");
     ISPK_REQUIRE(n >= 1 && half_dim >= 1 && 1 + 2 * half_dim <= 160 && emb_dim >= 1 && emb_dim <= 64, -2,
                  "ispk_time_embedding_bwd_f32: bad shape n=%d half_dim=%d emb_dim=%d", n, half_dim, emb_dim);
-    hipLaunchKernelGGL(time_embedding_bwd_kernel, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), t, n, inv_freq, freq_scale,
-                       half_dim, w0, b0, w1, emb_dim, d_out, dw0, db0, dw1, db1);
+    const size_t lds = (size_t)kTeChunk * ((1 + 2 * half_dim) + 4 * emb_dim) * sizeof(float);        // <= 106 KB
+    ISPK_RESERVE_LDS(time_embedding_bwd_kernel, lds, "ispk_time_embedding_bwd_f32");
+    hipLaunchKernelGGL(time_embedding_bwd_kernel, dim3(1), dim3(1024), lds, reinterpret_cast<hipStream_t>(stream), t, n, inv_freq,
+                       freq_scale, half_dim, w0, b0, w1, emb_dim, d_out, dw0, db0, dw1, db1);
     return ispk_launch_status();
 }
 

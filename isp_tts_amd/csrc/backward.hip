@@ -416,8 +416,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // forward's layernorm_vec_kernel - the scalar kernel above moved 4 bytes per lane per instruction and ran the 32,768-row decoder
 // norms at 2.5 TB/s (200 MB per launch with the accumulate-into-dx form).  Same arithmetic per element; the statistics' and
 // the (d gamma, d beta) partial sums' orders differ from the scalar kernel's (fixed, deterministic).
-template <int NV4>
-__global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+template <int NV4, int NW = 8>   // NW waves per 64-row block: 8 (two blocks per CU = 16 waves keep more loads in flight than 4 did)
+__global__ __launch_bounds__(NW * 64) void layernorm_bwd_vec_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                                 int64_t lddy, const float* __restrict__ gamma,
                                                                 const uint8_t* __restrict__ mask, float* __restrict__ dx,
                                                                 int64_t lddx, int add_to_dx, float* __restrict__ part, int rows,
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
         db[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int row0 = blockIdx.x * 64;
-    for (int rr = wave * 2 + hf; rr < 64; rr += 8) {
+    for (int rr = wave * 2 + hf; rr < 64; rr += 2 * NW) {
         const int row_raw = row0 + rr;
         const bool live = row_raw < rows;                         // (half-waves of the last block: computed on the last row, not stored)
         const int row = live ? row_raw : rows - 1;
@@ -489,18 +489,18 @@ __global__ __launch_bounds__(256) void layernorm_bwd_vec_kernel(const float* __r
         }
     }
     if (!part) return;
-    __shared__ float red[8][2][D];        // [wave * 2 + half][d gamma | d beta][column]
+    __shared__ float red[2 * NW][2][D];   // [wave * 2 + half][d gamma | d beta][column]
 #pragma unroll
     for (int c = 0; c < NV4; ++c) {
         *reinterpret_cast<f32x4*>(&red[wave * 2 + hf][0][4 * (l + 32 * c)]) = dg[c];
         *reinterpret_cast<f32x4*>(&red[wave * 2 + hf][1][4 * (l + 32 * c)]) = db[c];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * D; i += 256) {
+    for (int i = threadIdx.x; i < 2 * D; i += NW * 64) {
         const int w = i / D, col = i % D;
         float t = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t += red[k][w][col];
+        for (int k = 0; k < 2 * NW; ++k) t += red[k][w][col];
         part[(int64_t)blockIdx.x * 2 * D + i] = t;
     }
 }
@@ -1069,10 +1069,10 @@ static int32_t layernorm_bwd_launch(const float* x, int64_t ldx, const float* dy
     ISPK_REQUIRE(!dx16 || (vec && lddx16 % 4 == 0 && lddx16 >= dim && ispk_aligned(dx16, 8)), -4,
                  "ispk_layernorm_bwd_dual_f32: the bf16 copy needs 16-byte aligned fp32 operands and an 8-byte aligned copy");
     if (vec && dim == 384)
-        hipLaunchKernelGGL(layernorm_bwd_vec_kernel<3>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
+        hipLaunchKernelGGL((layernorm_bwd_vec_kernel<3, 8>), dim3(blocks), dim3(512), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
                            add_to_dx, part, (int)rows, eps, dx16, lddx16);
     else if (vec)
-        hipLaunchKernelGGL(layernorm_bwd_vec_kernel<2>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
+        hipLaunchKernelGGL((layernorm_bwd_vec_kernel<2, 8>), dim3(blocks), dim3(512), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,
                            add_to_dx, part, (int)rows, eps, dx16, lddx16);
     else if (dim == 384)
         hipLaunchKernelGGL(layernorm_bwd_kernel<6>, dim3(blocks), dim3(256), 0, s, x, ldx, dy, lddy, gamma, row_mask, dx, lddx,

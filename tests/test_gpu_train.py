@@ -915,6 +915,54 @@ def test_training_step_issues_no_aten_compute_ops(state_dict):
     assert torch.isfinite(total) and torch.isfinite(norm) and float(norm) > 0
 
 
+def test_data_movement_kernels_of_the_training_step():
+    """csrc/util.hip against their torch expressions, bit for bit: segments (copy / add / bf16 cast, more than 32 per call),
+    the weight-image pass (plain, transposed, bf16, exp; column-offset destinations), zero fill of odd byte counts, scale by a
+    device scalar, ordered scalar sum, exp with zero padding, sqrt, strided copy, the two convolution-weight permutations."""
+    g = torch.Generator().manual_seed(5)
+    srcs = [torch.randn(n, generator=g).to(DEV) for n in (1, 7, 384, 5000, 147456) * 8]           # 40 segments
+    base = [torch.randn(t.numel(), generator=g).to(DEV) for t in srcs]
+    dst = [b.clone() for b in base]
+    d16 = [torch.empty(t.numel(), dtype=torch.bfloat16, device=DEV) for t in srcs]
+    runtime.segments([(t, d, runtime.SEG_ADD if k % 2 else runtime.SEG_COPY) for k, (t, d) in enumerate(zip(srcs, dst))])
+    runtime.segments([(t, d, runtime.SEG_BF16) for t, d in zip(srcs, d16)])
+    for k, (t, b, d, h) in enumerate(zip(srcs, base, dst, d16)):
+        assert torch.equal(d, b + t if k % 2 else t) and torch.equal(h, t.to(torch.bfloat16))
+    wq, wkv, w1 = torch.randn(384, 384, generator=g).to(DEV), torch.randn(128, 384, generator=g).to(DEV), torch.randn(1536, 384, generator=g).to(DEV)
+    logs = torch.randn(1, 6, generator=g).to(DEV)
+    cat16 = torch.empty(512, 384, dtype=torch.bfloat16, device=DEV)
+    cat_t = torch.empty(384, 512, dtype=torch.float32, device=DEV)
+    w1_t16 = torch.empty(384, 1536, dtype=torch.bfloat16, device=DEV)
+    sl = torch.empty(1, 6, device=DEV)
+    runtime.stage_weights([(wq, cat16[:384], False, False), (wkv, cat16[384:], False, False), (wq, cat_t[:, :384], True, False),
+                           (wkv, cat_t[:, 384:], True, False), (w1, w1_t16, True, False), (logs, sl, False, True)])
+    assert torch.equal(cat16, torch.cat([wq, wkv]).to(torch.bfloat16)) and torch.equal(cat_t, torch.cat([wq, wkv]).t())
+    assert torch.equal(w1_t16, w1.t().to(torch.bfloat16))
+    assert (sl - logs.exp()).abs().max() < 1e-6 * float(logs.exp().max())
+    assert torch.equal(runtime.cat0([wq, wkv]), torch.cat([wq, wkv])) and torch.equal(runtime.cat0([wq, wkv], torch.bfloat16), cat16)
+    z = torch.full((1003,), 7, dtype=torch.int16, device=DEV)[:1001]          # 2,002 bytes: a 2-byte tail
+    runtime.zero_(z)
+    assert int(z.abs().sum()) == 0
+    x = srcs[3].clone()
+    sc = torch.tensor([0.37], device=DEV)
+    assert torch.equal(runtime.scale_(x, sc, 3.0), srcs[3] * (sc * 3.0))
+    terms = [torch.randn((), generator=g).to(DEV) for _ in range(4)]
+    want = ((terms[0] * 1.0 + terms[1] * 2.0) + terms[2] * 0.5) + terms[3] * 1.0
+    assert torch.equal(runtime.sum_scalars(terms, [1.0, 2.0, 0.5, 1.0]), want)
+    ep = runtime.exp_pad(logs, 8)
+    assert ep.shape == (8,) and float(ep[6:].abs().sum()) == 0 and (ep[:6] - logs.exp().reshape(-1)).abs().max() < 1e-6 * float(ep.max())
+    sq = torch.tensor([9.0, 2.0], device=DEV)
+    assert torch.equal(runtime.sqrt_scale(sq, 0.5), sq.sqrt() * 0.5)
+    wide = torch.randn(50, 387, generator=g).to(DEV)
+    part = torch.zeros(50, 384, device=DEV)
+    assert torch.equal(runtime.copy2d(wide[:, 3:], part), wide[:, 3:])
+    cw = torch.randn(160, 80, 5, generator=g).to(DEV)
+    assert torch.equal(runtime.permute021(cw), cw.permute(0, 2, 1).contiguous())
+    assert torch.equal(runtime.conv_weight_flip(cw), cw.flip(2).permute(1, 2, 0).reshape(80, 5 * 160))
+    a3, b3 = torch.randn(5, 70, 384, generator=g).to(DEV), torch.randn(5, 33, 384, generator=g).to(DEV)
+    _close(runtime.gemm_batched(a3, b3), torch.einsum("bmk,bnk->bmn", a3.double().cpu(), b3.double().cpu()), 2e-6, "batched NT GEMM")
+
+
 def test_dropout_seed_source_changes_the_masks_at_run_time():
     """ispk_set_dropout_seed_source: the same launch (same seed argument) draws another mask when the device word changes, the
     same mask when it does not, and forward / backward stay consistent - what a captured training step relies on."""

@@ -375,6 +375,52 @@ __global__ __launch_bounds__(512) void ctc_alpha_beta_kernel(const float* __rest
         const float v = (s & 1) ? lg[(int64_t)t * L + (s >> 1)] : blank;
         return v - rl[t];
     };
+    if (S <= 256) {
+        // One state per thread.  A step's only global reads - this state's class log-probability and the frame's normaliser -
+        // do not depend on the recursion, so they are fetched FOUR steps ahead into a register ring: the step itself is then
+        // LDS reads, one lse3 and the barrier (the loads' latency used to sit inside every one of the T steps).
+        const int sx = t8;
+        const bool act = sx < S;
+        auto fetch = [&](int step) -> float {
+            if (step >= T || !act) return 0.f;
+            const int t = back ? T - 1 - step : step;
+            return ((sx & 1) ? lg[(int64_t)t * L + (sx >> 1)] : blank) - rl[t];
+        };
+        float q[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q[k] = fetch(k);
+        for (int step0 = 0; step0 < T; step0 += 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int step = step0 + k;
+                if (step < T) {                                   // (workgroup-uniform)
+                    const int t = back ? T - 1 - step : step;
+                    float* cur = tab + (step & 1) * (S_pad + 4) + 2;
+                    const float* prev = tab + ((step & 1) ^ 1) * (S_pad + 4) + 2;
+                    if (act) {
+                        float v;
+                        if (step == 0) {
+                            const bool start = back ? (sx >= S - 2) : (sx <= 1);
+                            v = start ? q[k] : -INFINITY;
+                        } else if (!back) {
+                            const float skip = ((sx & 1) && sx >= 3) ? prev[sx - 2] : -INFINITY;
+                            v = lse3(prev[sx], prev[sx - 1], skip);
+                            v = v == -INFINITY ? v : v + q[k];
+                        } else {
+                            const float nxt = sx + 1 < S ? prev[sx + 1] : -INFINITY;
+                            const float skip = ((sx & 1) && sx + 2 < S) ? prev[sx + 2] : -INFINITY;
+                            v = lse3(prev[sx], nxt, skip);
+                            v = v == -INFINITY ? v : v + q[k];
+                        }
+                        cur[sx] = v;
+                        out[(int64_t)t * S_pad + sx] = v;
+                    }
+                    q[k] = fetch(step + 4);
+                    __syncthreads();
+                }
+            }
+        }
+    } else {
     for (int step = 0; step < T; ++step) {
         const int t = back ? T - 1 - step : step;
         float* cur = tab + (step & 1) * (S_pad + 4) + 2;
@@ -398,6 +444,7 @@ __global__ __launch_bounds__(512) void ctc_alpha_beta_kernel(const float* __rest
             out[(int64_t)t * S_pad + s] = v;
         }
         __syncthreads();
+    }
     }
     if (tid == 0) {
         const float* last = sm + ((T - 1) & 1) * (S_pad + 4) + 2;     // the alpha table's final buffer

@@ -26,7 +26,7 @@ extern "C" {
 
 typedef struct ihipStream_t* ispk_stream_t; /* == hipStream_t */
 
-#define ISPK_ABI_VERSION 1
+#define ISPK_ABI_VERSION 2 /* 2: round 3 - entry points removed (fused variants, _amp attention pair) and added (split fp16, util, graph support) */
 
 #define ISPK_E_NULL (-1)        /* required pointer is NULL */
 #define ISPK_E_SHAPE (-2)       /* size out of the supported range */

@@ -135,8 +135,8 @@ def lib() -> ctypes.CDLL:
             fn = getattr(handle, name)
             fn.argtypes = argtypes
             fn.restype = ctypes.c_char_p if name == "ispk_last_error_string" else ctypes.c_int32
-        if handle.ispk_abi_version() != 1:
-            raise IspkError(f"libispk.so ABI version {handle.ispk_abi_version()} != 1")
+        if handle.ispk_abi_version() != 2:
+            raise IspkError(f"libispk.so ABI version {handle.ispk_abi_version()} != 2 (rebuild: python -m isp_tts_amd.build)")
         _lib = handle
     return _lib
 

@@ -31,7 +31,7 @@ def test_every_header_symbol_is_exported_and_bound():
     handle = ctypes.CDLL(runtime.LIB_PATH)
     for s in syms:
         assert hasattr(handle, s), f"{s} is declared in include/ispk.h but missing from libispk.so"
-    assert runtime.lib().ispk_abi_version() == 1
+    assert runtime.lib().ispk_abi_version() == 2
 
 
 def test_argument_errors_without_gpu():

@@ -319,6 +319,128 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const void* __restric
         }
 }
 
+// The same product for bf16-stored operands WITHOUT a row mask, fills by LDS-DMA (global_load_lds_dwordx4: a wave instruction
+// writes four 256-byte image rows, the XOR applied on the source side).  The register-staged kernel above moves every chunk
+// through ds_write - 64 KB per round of a CU's sixteen waves at the ~79 B / clk the write path sustains (≈830 cycles) next to
+// 128 KB of transposed reads (≈512) against 1,024 cycles of MFMAs: LDS-bound, and bound by its writes.  The DMA needs no
+// registers and no store instructions; a three-stage ring (48 KB, three workgroups per CU) keeps two chunks in flight.
+// Rows past the range and columns past N1 / N2 come from 16 zero bytes (a DMA cannot zero-fill); N1, N2 multiples of 8.
+__device__ __attribute__((aligned(16))) const uint16_t g_tn_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+constexpr int kTnDmaStages = 3;
+__global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B,
+                                                          int64_t ldb, float* __restrict__ part, int M, int N1, int N2,
+                                                          int rows_per_split, int splits, int nz) {
+    extern __shared__ __attribute__((aligned(16))) char ldsb[];      // [stages][A image | B image]
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, c = l & 31, hf = l >> 5;
+    const int tx = (N1 + 127) / 128, ty = (N2 + 127) / 128, T = tx * ty;
+    int zz, tile;
+    {
+        const int lin = blockIdx.x, full = (nz / 8) * 8 * T;
+        if (lin < full) {
+            const int g = lin / (8 * T), r = lin - g * 8 * T;
+            zz = g * 8 + (r & 7);
+            tile = r >> 3;
+        } else {
+            const int t = lin - full;
+            zz = (nz / 8) * 8 + t / T;
+            tile = t % T;
+        }
+    }
+    const int n1 = (tile % tx) * 128, n2 = (tile / tx) * 128, wa = (wave >> 1) * 64, wb = (wave & 1) * 64;
+    const int split = zz % splits;
+    const int m_begin = split * rows_per_split, m_end = min(M, m_begin + rows_per_split);
+    const int nchunks = (m_end - m_begin + kTnRows - 1) / kTnRows;
+    // DMA roles: instruction i of a stage (16 of them, 4 per wave) fills image i >> 3 (A | B), rows 4 (i & 7) .. + 3; lane L
+    // lands at row 4 (i & 7) + (L >> 4), 16-byte position L & 15, which holds logical chunk (L & 15) ^ swizzle(row)
+    const int drow = l >> 4, dpos = l & 15;
+    auto issue = [&](int chunk) {
+        char* stage = ldsb + (chunk % kTnDmaStages) * 2 * kTnImg;
+        const int m0 = m_begin + chunk * kTnRows;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = wave * 4 + j, isb = i >> 3, grp = i & 7, row = 4 * grp + drow, m = m0 + row;
+            const int ch = dpos ^ (((row & 3) << 2) | ((row >> 2) & 3)), col = (isb ? n2 : n1) + 8 * ch;
+            const bool ok = m < m_end && col < (isb ? N2 : N1);
+            const uint16_t* src = ok ? (isb ? B + (int64_t)m * ldb : A + (int64_t)m * lda) + col : g_tn_zero16;
+            char* dst = stage + isb * kTnImg + grp * 1024;                       // wave-uniform; lane L lands at + 16 L
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int sub = (l >> 4) & 1, q = (l & 15) >> 2, pp = l & 3;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)ldsb;
+    uint32_t aoff[2][2][2], boff[2][2][2];      // [step][run][tile]
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int run = 0; run < 2; ++run)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int row = 16 * ks + 8 * hf + 4 * run + q;
+                aoff[ks][run][t] = tn_img_off(row, ((wa + 32 * t) >> 3) + 2 * sub + (pp >> 1)) + 8 * (pp & 1);
+                boff[ks][run][t] = kTnImg + tn_img_off(row, ((wb + 32 * t) >> 3) + 2 * sub + (pp >> 1)) + 8 * (pp & 1);
+            }
+#pragma unroll 1
+    for (int ch = 0; ch < kTnDmaStages - 1 && ch < nchunks; ++ch) issue(ch);
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ++ch) {
+        // chunk ch has landed once only this wave's younger DMAs are outstanding (4 per chunk); the barrier publishes it and
+        // retires the slot chunk ch - 1 was read from, which the next DMA overwrites
+        if (ch + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ch + kTnDmaStages - 1 < nchunks) issue(ch + kTnDmaStages - 1);
+        const uint32_t base = lds0 + (ch % kTnDmaStages) * 2 * kTnImg;
+        tn_u32x2 fa[2][2][2], fb[2][2][2];     // [step][tile][run]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int run = 0; run < 2; ++run) {
+                    tn_read_tr<0>(fa[ks][t][run], base + aoff[ks][run][t]);
+                    tn_read_tr<0>(fb[ks][t][run], base + boff[ks][run][t]);
+                }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            if (ks == 0) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            union { uint32_t u[4]; bf16x8 f; } a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t].u[0] = fa[ks][t][0][0]; a[t].u[1] = fa[ks][t][0][1]; a[t].u[2] = fa[ks][t][1][0]; a[t].u[3] = fa[ks][t][1][1];
+                b[t].u[0] = fb[ks][t][0][0]; b[t].u[1] = fb[ks][t][0][1]; b[t].u[2] = fb[ks][t][1][0]; b[t].u[3] = fb[ks][t][1][1];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].f, b[0].f, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0].f, b[1].f, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].f, b[0].f, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1].f, b[1].f, acc[1][1], 0, 0, 0);
+        }
+    }
+    float* out = part + (int64_t)zz * N1 * N2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n2 + wb + 32 * j + c;
+            if (col >= N2) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n1 + wa + 32 * i + acc_row(r, hf);
+                if (row < N1) out[(int64_t)row * N2 + col] = acc[i][j][r];
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int splits, int64_t n, int cols,
                                                            float* __restrict__ C, int64_t ldc, int accumulate, int64_t stride_c) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -987,7 +1109,11 @@ static int32_t gemm_tn_launch(const void* A, int64_t lda, int64_t stride_a, cons
         constexpr size_t lds16 = 2 * 2 * kTnImg;                  // 32 KB
         const int nz = (int)(splits * batch);
         const dim3 grid(grid3.x * grid3.y * grid3.z);             // 1-D: the kernel orders (row range, tile) itself
-        if (in16) {
+        if (in16 && !row_mask && batch == 1 && N1 % 8 == 0 && N2 % 8 == 0) {
+            constexpr size_t lds_dma = (size_t)kTnDmaStages * 2 * kTnImg;       // 48 KB
+            hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(256), lds_dma, s, static_cast<const uint16_t*>(A), lda,
+                               static_cast<const uint16_t*>(B), ldb, workspace, M, N1, N2, rows_per, (int)splits, nz);
+        } else if (in16) {
             if (row_mask)
                 hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2,
                                    rows_per, row_mask, (int)splits, stride_a, stride_b, nz);

@@ -208,7 +208,8 @@ class AdaptiveStackFunction(torch.autograd.Function):
             c = 4 * li * D
             gdt = torch.bfloat16 if amp else torch.float32        # as in stack.py: GEMM-only tensors live in bf16 under AMP
             dyg = runtime.cast_bf16(dy) if amp else dy
-            dw2 = runtime.gemm_tn(dyg, a, row_mask=mask, bf16=amp)
+            wmask = None if amp else mask          # (padded rows of dy / dx1 are exactly zero: stack.py)
+            dw2 = runtime.gemm_tn(dyg, a, row_mask=wmask, bf16=amp)
             da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)
             du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
             dw1 = runtime.gemm_tn(du, h2, bf16=amp)
@@ -216,7 +217,7 @@ class AdaptiveStackFunction(torch.autograd.Function):
             dx1 = runtime.adaln_bwd(x1, dh2, ss[:, c + 2 * D:c + 3 * D], mask, dy, True, d_ss[:, c + 2 * D:c + 3 * D],
                                     d_ss[:, c + 3 * D:c + 4 * D], layer.feed_forward_norm.eps)
             dx1g = runtime.cast_bf16(dx1) if amp else dx1
-            dwo = runtime.gemm_tn(dx1g, o, row_mask=mask, bf16=amp)
+            dwo = runtime.gemm_tn(dx1g, o, row_mask=wmask, bf16=amp)
             d_o = _mm(dx1g, wo_t, wo_t16, out_dtype=gdt, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
                                                         seed=seed_att)

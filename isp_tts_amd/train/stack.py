@@ -148,7 +148,10 @@ class TransformerStackFunction(torch.autograd.Function):
             # bf16; q / k / v, the attention output, dO and dqkv: the attention kernels read and write bf16), and ONE bf16 copy each of
             # the fp32 residual-stream gradients that a dX GEMM and a weight gradient both read (dy, dx1).
             # feed-forward block
-            dw2 = _deliver(ff.net[3].weight, runtime.gemm_tn, dyg, a, row_mask=mask, bf16=amp)        # [dim, inner]
+            # (rows of padded positions are exactly zero in dy and dx1 - see the module header - so the weight gradients' row mask
+            # changes nothing; the AMP step leaves it out and gets the LDS-DMA kernel, which has no mask path)
+            wmask = None if amp else mask
+            dw2 = _deliver(ff.net[3].weight, runtime.gemm_tn, dyg, a, row_mask=wmask, bf16=amp)       # [dim, inner]
             da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)                         # (m dy) W2
             du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
             dw1 = _deliver(ff.net[0].weight, runtime.gemm_tn, du, h2, bf16=amp)                         # [inner, dim]
@@ -157,7 +160,7 @@ class TransformerStackFunction(torch.autograd.Function):
                                                          bf16_copy=amp)
             # attention block
             dx1g = rest[0] if amp else dx1
-            dwo = _deliver(att.to_out.weight, runtime.gemm_tn, dx1g, o, row_mask=mask, bf16=amp)       # [dim, heads*64]
+            dwo = _deliver(att.to_out.weight, runtime.gemm_tn, dx1g, o, row_mask=wmask, bf16=amp)      # [dim, heads*64]
             d_o = _mm(dx1g, wo_t, wo_t16, out_dtype=gdt, mask=mask, flags=mflag)
             dqkv, dls = runtime.alibi_mqa_attention_bwd(qkv, o, d_o, att.heads, slopes, key_len, lse=lse, dropout_p=p_att,
                                                         seed=seed_att)                     # AMP: bf16 in, bf16 out

@@ -323,10 +323,10 @@ __global__ __launch_bounds__(256) void gemm_tn_bf16_kernel(const void* __restric
 // writes four 256-byte image rows, the XOR applied on the source side).  The register-staged kernel above moves every chunk
 // through ds_write - 64 KB per round of a CU's sixteen waves at the ~79 B / clk the write path sustains (≈830 cycles) next to
 // 128 KB of transposed reads (≈512) against 1,024 cycles of MFMAs: LDS-bound, and bound by its writes.  The DMA needs no
-// registers and no store instructions; a three-stage ring (48 KB, three workgroups per CU) keeps two chunks in flight.
+// registers and no store instructions; a four-stage ring (64 KB, two workgroups per CU) keeps three chunks in flight.
 // Rows past the range and columns past N1 / N2 come from 16 zero bytes (a DMA cannot zero-fill); N1, N2 multiples of 8.
 __device__ __attribute__((aligned(16))) const uint16_t g_tn_zero16[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-constexpr int kTnDmaStages = 3;
+template <int kTnDmaStages>
 __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const uint16_t* __restrict__ A, int64_t lda, const uint16_t* __restrict__ B,
                                                           int64_t ldb, float* __restrict__ part, int M, int N1, int N2,
                                                           int rows_per_split, int splits, int nz) {
@@ -393,7 +393,10 @@ __global__ __launch_bounds__(256) void gemm_tn_dma_kernel(const uint16_t* __rest
     for (int ch = 0; ch < nchunks; ++ch) {
         // chunk ch has landed once only this wave's younger DMAs are outstanding (4 per chunk); the barrier publishes it and
         // retires the slot chunk ch - 1 was read from, which the next DMA overwrites
-        if (ch + 1 < nchunks) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // (stages - 2 younger chunks of this wave may still be in flight)
+        const int young = nchunks - 1 - ch < kTnDmaStages - 2 ? nchunks - 1 - ch : kTnDmaStages - 2;
+        if (young >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (young == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -1094,9 +1097,14 @@ static int32_t gemm_tn_launch(const void* A, int64_t lda, int64_t stride_a, cons
     const int64_t tile = (int64_t)N1 * N2;
     ISPK_REQUIRE(workspace_floats >= tile * batch, -3, "%s: workspace holds %lld floats, one partial per batch item needs %lld",
                  who, (long long)workspace_floats, (long long)(tile * batch));
-    // row ranges: enough workgroups to fill the chip (>= 1024), at least 64 rows each, bounded by the workspace
+    // row ranges: enough workgroups to fill the chip (>= 1024; the LDS-DMA kernel: ONE round of its two workgroups per CU - swept
+    // in tools/sweep_tn.py: more row ranges only add partial sums to write and add up),
+    // at least 64 rows each, bounded by the workspace
+    const bool dma = bf16_operands && in16 && !row_mask && batch == 1 && N1 % 8 == 0 && N2 % 8 == 0;
     const int tiles = ((N1 + 127) / 128) * ((N2 + 127) / 128) * batch;
-    int64_t splits = (1024 + tiles - 1) / tiles;
+    int target = dma ? 512 : 1024;
+    if (const char* e = ispk_knob("ISPK_TN_TARGET")) target = atoi(e);               // experiments only
+    int64_t splits = dma ? (target / tiles > 0 ? target / tiles : 1) : (target + tiles - 1) / tiles;
     splits = splits < (M + 63) / 64 ? splits : (M + 63) / 64;
     splits = splits < workspace_floats / (tile * batch) ? splits : workspace_floats / (tile * batch);
     splits = splits < 1 ? 1 : (splits > 256 ? 256 : splits);
@@ -1109,10 +1117,19 @@ static int32_t gemm_tn_launch(const void* A, int64_t lda, int64_t stride_a, cons
         constexpr size_t lds16 = 2 * 2 * kTnImg;                  // 32 KB
         const int nz = (int)(splits * batch);
         const dim3 grid(grid3.x * grid3.y * grid3.z);             // 1-D: the kernel orders (row range, tile) itself
-        if (in16 && !row_mask && batch == 1 && N1 % 8 == 0 && N2 % 8 == 0) {
-            constexpr size_t lds_dma = (size_t)kTnDmaStages * 2 * kTnImg;       // 48 KB
-            hipLaunchKernelGGL(gemm_tn_dma_kernel, grid, dim3(256), lds_dma, s, static_cast<const uint16_t*>(A), lda,
-                               static_cast<const uint16_t*>(B), ldb, workspace, M, N1, N2, rows_per, (int)splits, nz);
+        if (dma) {
+            int stages = 4;
+            if (const char* e = ispk_knob("ISPK_TN_STAGES")) stages = atoi(e);       // experiments only
+            const size_t lds_dma = (size_t)stages * 2 * kTnImg;                        // 64 KB: two workgroups per CU
+            if (stages == 2)
+                hipLaunchKernelGGL(gemm_tn_dma_kernel<2>, grid, dim3(256), lds_dma, s, static_cast<const uint16_t*>(A), lda,
+                                   static_cast<const uint16_t*>(B), ldb, workspace, M, N1, N2, rows_per, (int)splits, nz);
+            else if (stages == 4)
+                hipLaunchKernelGGL(gemm_tn_dma_kernel<4>, grid, dim3(256), lds_dma, s, static_cast<const uint16_t*>(A), lda,
+                                   static_cast<const uint16_t*>(B), ldb, workspace, M, N1, N2, rows_per, (int)splits, nz);
+            else
+                hipLaunchKernelGGL(gemm_tn_dma_kernel<3>, grid, dim3(256), lds_dma, s, static_cast<const uint16_t*>(A), lda,
+                                   static_cast<const uint16_t*>(B), ldb, workspace, M, N1, N2, rows_per, (int)splits, nz);
         } else if (in16) {
             if (row_mask)
                 hipLaunchKernelGGL((gemm_tn_bf16_kernel<true, true>), grid, dim3(256), lds16, s, A, lda, B, ldb, workspace, M, N1, N2,

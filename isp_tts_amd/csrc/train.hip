@@ -452,6 +452,98 @@ __global__ __launch_bounds__(512) void ctc_alpha_beta_kernel(const float* __rest
     }
 }
 
+// The two recursions for S = 2 U + 1 <= 256 (every recipe: U <= 127 phonemes ... the launcher falls back above that): ONE WAVE
+// per (utterance, direction), four consecutive states per lane in registers, the neighbours' edge states by DPP wave shifts -
+// no LDS, no barrier (the workgroup version above spends a barrier and an LDS round trip per frame: 0.65 us x 512 frames).
+// exp / log on v_exp_f32 / v_log_f32: the log-sum-exp of a step is m + log(sum) with sum in [1, 3], so a step's error is an
+// absolute ~1e-7 however large the accumulated log-probability is.  The frame's three inputs (two class logits of the lane,
+// the row normaliser) are fetched eight frames ahead.
+__device__ __forceinline__ float ctc_shr1(float src) {      // lane l <- lane l - 1; lane 0 <- -inf
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, -INFINITY), __builtin_bit_cast(int, src), 0x138,
+                                                                 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ctc_shl1(float src) {      // lane l <- lane l + 1; lane 63 <- -inf
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, -INFINITY), __builtin_bit_cast(int, src), 0x130,
+                                                                 0xf, 0xf, false));
+}
+__device__ __forceinline__ float ctc_lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    const float k = 1.4426950408889634f;
+    const float sum = __builtin_amdgcn_exp2f((a - m) * k) + __builtin_amdgcn_exp2f((b - m) * k) + __builtin_amdgcn_exp2f((c - m) * k);
+    return m == -INFINITY ? -INFINITY : fmaf(__builtin_amdgcn_logf(sum), 0.6931471805599453f, m);
+}
+constexpr int kCtcAhead = 8;
+__global__ __launch_bounds__(64) void ctc_wave_kernel(const float* __restrict__ logits, const float* __restrict__ row_lse, float blank,
+                                                      const int64_t* __restrict__ text_len, const int64_t* __restrict__ mel_len,
+                                                      float* __restrict__ alpha, float* __restrict__ beta, float* __restrict__ nll,
+                                                      int M, int L, int S_pad) {
+    __shared__ float fin[256];
+    const int b = blockIdx.x, back = blockIdx.y, lane = threadIdx.x, s0 = 4 * lane;
+    const int U = (int)min((int64_t)L, max((int64_t)0, text_len[b])), T = (int)min((int64_t)M, max((int64_t)0, mel_len[b]));
+    const int S = 2 * U + 1;
+    if (T == 0) {
+        if (!back && lane == 0) nll[b] = INFINITY;
+        return;
+    }
+    const float* lg = logits + (int64_t)b * M * L;
+    const float* rl = row_lse + (int64_t)b * M;
+    float* out = (back ? beta : alpha) + (int64_t)b * M * S_pad;
+    const bool c0ok = 2 * lane < L, c1ok = 2 * lane + 1 < L, st_ok = s0 < S_pad;
+    bool act[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) act[k] = s0 + k < S;
+    float x0q[kCtcAhead], x1q[kCtcAhead], rq[kCtcAhead];
+    auto fetch = [&](int step, int slot) {
+        x0q[slot] = x1q[slot] = rq[slot] = 0.f;
+        if (step < T) {
+            const int t = back ? T - 1 - step : step;
+            if (c0ok) x0q[slot] = lg[(int64_t)t * L + 2 * lane];
+            if (c1ok) x1q[slot] = lg[(int64_t)t * L + 2 * lane + 1];
+            rq[slot] = rl[t];
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < kCtcAhead; ++k) fetch(k, k);
+    float a[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int step0 = 0; step0 < T; step0 += kCtcAhead) {
+#pragma unroll
+        for (int k = 0; k < kCtcAhead; ++k) {
+            const int step = step0 + k;
+            if (step < T) {                                   // (wave-uniform)
+                const int t = back ? T - 1 - step : step;
+                const float lpe = blank - rq[k], lp[4] = {lpe, x0q[k] - rq[k], lpe, x1q[k] - rq[k]};
+                float nw[4];
+                if (step == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) nw[q] = (back ? (s0 + q >= S - 2) : (s0 + q <= 1)) ? 0.f : -INFINITY;
+                } else if (!back) {
+                    const float u3 = ctc_shr1(a[3]);          // state s0 - 1 (its skip target s0 + 1 is odd)
+                    nw[0] = ctc_lse3(a[0], u3, -INFINITY);
+                    nw[1] = ctc_lse3(a[1], a[0], u3);         // odd state: skip from s - 2 (lane 0: -inf, as s = 1 < 3 asks)
+                    nw[2] = ctc_lse3(a[2], a[1], -INFINITY);
+                    nw[3] = ctc_lse3(a[3], a[2], a[1]);
+                } else {
+                    const float d0 = ctc_shl1(a[0]), d1 = ctc_shl1(a[1]);     // states s0 + 4, s0 + 5
+                    nw[0] = ctc_lse3(a[0], a[1], -INFINITY);
+                    nw[1] = ctc_lse3(a[1], a[2], a[3]);       // odd state: skip to s + 2
+                    nw[2] = ctc_lse3(a[2], a[3], -INFINITY);
+                    nw[3] = ctc_lse3(a[3], d0, d1);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] = (nw[q] == -INFINITY || !act[q]) ? -INFINITY : nw[q] + lp[q];
+                if (st_ok) *reinterpret_cast<f32x4*>(out + (int64_t)t * S_pad + s0) = f32x4{a[0], a[1], a[2], a[3]};
+                fetch(step + kCtcAhead, k);
+            }
+        }
+    }
+    if (!back) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fin[s0 + q] = a[q];
+        __syncthreads();
+        if (lane == 0) nll[b] = -lse2(fin[S - 1], S >= 2 ? fin[S - 2] : -INFINITY);
+    }
+}
+
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ logits, const float* __restrict__ row_lse,
                                                        float blank, const int64_t* __restrict__ text_len,
                                                        const int64_t* __restrict__ mel_len, const float* __restrict__ alpha,
@@ -734,10 +826,15 @@ extern "C" int32_t ispk_attn_ctc_loss_f32(const float* attn_logits, const int64_
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(ctc_row_lse_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, attn_logits, blank_logprob, rows, L,
                        row_lse);
-    const size_t lds = (size_t)4 * (S_pad + 4) * sizeof(float);
-    ISPK_RESERVE_LDS(ctc_alpha_beta_kernel, lds, "ispk_attn_ctc_loss_f32");
-    hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(B), dim3(512), lds, s, attn_logits, row_lse, blank_logprob, text_len, mel_len,
-                       alpha, beta, nll, M, L, S_pad);
+    if (2 * L + 1 <= 256) {        // (S <= 2 L + 1: every state of the extended target in one wave's registers)
+        hipLaunchKernelGGL(ctc_wave_kernel, dim3(B, 2), dim3(64), 0, s, attn_logits, row_lse, blank_logprob, text_len, mel_len, alpha,
+                           beta, nll, M, L, S_pad);
+    } else {
+        const size_t lds = (size_t)4 * (S_pad + 4) * sizeof(float);
+        ISPK_RESERVE_LDS(ctc_alpha_beta_kernel, lds, "ispk_attn_ctc_loss_f32");
+        hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(B), dim3(512), lds, s, attn_logits, row_lse, blank_logprob, text_len, mel_len,
+                           alpha, beta, nll, M, L, S_pad);
+    }
     hipLaunchKernelGGL(ctc_mean_kernel, dim3(1), dim3(64), 0, s, nll, text_len, B, L, loss);
     if (grad)
         hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, attn_logits, row_lse, blank_logprob,

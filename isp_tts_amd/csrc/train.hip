@@ -610,9 +610,10 @@ __global__ __launch_bounds__(256) void flow_loss_bwd_kernel(const float* __restr
 // AdaptiveLayerNorm backward (normalization.py:37-61): y = xhat * scale_b + shift_b [* mask], xhat = (x - mean) rstd without
 // affine; per utterance b (rows_per_batch rows): dx = rstd (g - mean(g) - xhat mean(g xhat)) with g = dy mask scale_b,
 // d scale_b = sum_rows dy mask xhat, d shift_b = sum_rows dy mask.  One workgroup per utterance, rows over its 4 waves, a
-// fixed-order cross-wave sum: [B][D] outputs with no second stage.  D = 64 * NPL.
-template <int NPL>
-__global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
+// fixed-order cross-wave sum: [B][D] outputs with no second stage.  D = 64 * NPL.  NW = 16 waves: a wave walks its rows one
+// after the other through three shuffle reductions each, so the 100 rows of an utterance want many waves (4 waves: 64 us).
+template <int NPL, int NW = 16>
+__global__ __launch_bounds__(NW * 64) void adaln_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy,
                                                         int64_t lddy, const float* __restrict__ scale, int64_t ld_scale,
                                                         const uint8_t* __restrict__ mask, float* __restrict__ dx, int64_t lddx,
                                                         int add_to_dx, float* __restrict__ dscale, float* __restrict__ dshift,
@@ -626,7 +627,7 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict_
         ds[k] = 0.f;
         dt[k] = 0.f;
     }
-    for (int rr = wave; rr < rows_per_batch; rr += 4) {
+    for (int rr = wave; rr < rows_per_batch; rr += NW) {
         const int64_t row = (int64_t)b * rows_per_batch + rr;
         const float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
         float xv[NPL], gv[NPL];
@@ -670,16 +671,19 @@ __global__ __launch_bounds__(256) void adaln_bwd_kernel(const float* __restrict_
             *d = add_to_dx ? *d + v : v;
         }
     }
-    __shared__ float red[4][2][D];
+    __shared__ float red[NW][2][D];
 #pragma unroll
     for (int k = 0; k < NPL; ++k) {
         red[wave][0][l + 64 * k] = ds[k];
         red[wave][1][l + 64 * k] = dt[k];
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < D; i += 256) {
-        dscale[(int64_t)b * ld_out + i] = (red[0][0][i] + red[1][0][i]) + (red[2][0][i] + red[3][0][i]);
-        dshift[(int64_t)b * ld_out + i] = (red[0][1][i] + red[1][1][i]) + (red[2][1][i] + red[3][1][i]);
+    for (int i = threadIdx.x; i < 2 * D; i += NW * 64) {
+        const int w = i / D, col = i - w * D;
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) v += red[k][w][col];        // in wave order
+        (w ? dshift : dscale)[(int64_t)b * ld_out + col] = v;
     }
 }
 
@@ -791,10 +795,10 @@ extern "C" int32_t ispk_adaln_bwd_f32(const float* x, int64_t ldx, const float* 
                  "ispk_adaln_bwd_f32: bad shape B=%d rows_per_batch=%d dim=%d (dim 256 or 384)", B, rows_per_batch, dim);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dim == 256)
-        hipLaunchKernelGGL(adaln_bwd_kernel<4>, dim3(B), dim3(256), 0, s, x, ldx, dy, lddy, scale, ld_scale, row_mask, dx, lddx,
+        hipLaunchKernelGGL((adaln_bwd_kernel<4, 16>), dim3(B), dim3(1024), 0, s, x, ldx, dy, lddy, scale, ld_scale, row_mask, dx, lddx,
                            add_to_dx, dscale, dshift, ld_out, rows_per_batch, eps);
     else
-        hipLaunchKernelGGL(adaln_bwd_kernel<6>, dim3(B), dim3(256), 0, s, x, ldx, dy, lddy, scale, ld_scale, row_mask, dx, lddx,
+        hipLaunchKernelGGL((adaln_bwd_kernel<6, 16>), dim3(B), dim3(1024), 0, s, x, ldx, dy, lddy, scale, ld_scale, row_mask, dx, lddx,
                            add_to_dx, dscale, dshift, ld_out, rows_per_batch, eps);
     return ispk_launch_status();
 }

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 // utterance over (80, T), divided by max(80 * len_b, 1e-5), mean over the batch.  One workgroup per utterance computes the
 // ratio (fixed-order reduction) and, when grad is asked for, writes d loss / d mel_out = 2 (out - tgt) / (den_b * B) * go
 // (0 on padded frames); a second tiny launch averages the B ratios in index order.
-__global__ __launch_bounds__(256) void mel_loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
+__global__ __launch_bounds__(1024) void mel_loss_kernel(const float* __restrict__ out, const float* __restrict__ tgt,
                                                        const int64_t* __restrict__ mel_len, float* __restrict__ ratio,
                                                        float* __restrict__ grad, float grad_out, int B, int C, int T) {
     const int b = blockIdx.x;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(const float* __restrict__
     const float* t = tgt + (int64_t)b * C * T;
     float* gr = grad ? grad + (int64_t)b * C * T : nullptr;
     float acc = 0.f;
-    for (int i = threadIdx.x; i < C * T; i += 256) {
+    for (int i = threadIdx.x; i < C * T; i += 1024) {
         const int f = i % T;
         const float d = o[i] - t[i];
         const bool valid = f < len;
@@ -137,10 +137,14 @@ __global__ __launch_bounds__(256) void mel_loss_kernel(const float* __restrict__
         if (gr) gr[i] = valid ? d * gmul : 0.f;
     }
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-    __shared__ float wsum[4];
+    __shared__ float wsum[16];
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) ratio[b] = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / den;
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int w = 0; w < 16; ++w) tot += wsum[w];          // in wave order
+        ratio[b] = tot / den;
+    }
 }
 
 __global__ __launch_bounds__(64) void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
@@ -987,7 +991,7 @@ extern "C" int32_t ispk_mel_loss_f32(const float* mel_out, const float* mel_targ
     ISPK_REQUIRE(mel_out && mel_target && mel_len && ratio && loss, -1, "ispk_mel_loss_f32: null pointer");
     ISPK_REQUIRE(B >= 1 && C >= 1 && T >= 1, -2, "ispk_mel_loss_f32: empty batch (B=%d C=%d T=%d)", B, C, T);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(mel_loss_kernel, dim3(B), dim3(256), 0, s, mel_out, mel_target, mel_len, ratio, grad, grad_out, B, C, T);
+    hipLaunchKernelGGL(mel_loss_kernel, dim3(B), dim3(1024), 0, s, mel_out, mel_target, mel_len, ratio, grad, grad_out, B, C, T);
     hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(64), 0, s, ratio, B, loss);
     return ispk_launch_status();
 }

@@ -60,7 +60,7 @@ def acoustic_train_forward(model, text: Tensor, text_len: Tensor, mel: Tensor, m
     x = MaskedLinearResidualFunction.apply(h, emod.linear_layer.weight, emod.linear_layer.bias, enc_mask, enc_out)
     dec_in, dec_len, dec_mask = LengthRegulateFunction.apply(x, attn_soft, mel_len.view(-1, 1), mel.shape[2])
     dec = transformer_train_forward(model.decoder, dec_in, dec_mask, amp, key_len=dec_len)
-    mel_out = ToMelFunction.apply(dec, model.to_mel.weight, model.to_mel.bias, dec_mask)
+    mel_out = ToMelFunction.apply(dec, model.to_mel.weight, model.to_mel.bias, dec_mask, amp)
     mel_loss = MelLoss()(mel_out, mel, mel_len)
     with torch.set_grad_enabled(train_aligner):
         ctc = AttentionCTCLoss()(attn_logits, text_len, mel_len)

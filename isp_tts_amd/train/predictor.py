@@ -66,7 +66,10 @@ class AdaProjectionFunction(torch.autograd.Function):
         d_ss = d_ss.float().contiguous()
         dw = runtime.gemm_tn(d_ss, cond)                              # [2 n D, cond_dim]
         db = runtime.colsum(d_ss)
-        d_cond = runtime.gemm(d_ss, runtime.transpose(w_all))         # [B, cond_dim]
+        # d cond [B, cond_dim] = d_ss w_all: a reduction over the 2 n D stacked outputs with only B x cond_dim results - as a
+        # weight-gradient-shaped product (rows = the reduction index, split over row ranges) instead of one workgroup's K loop
+        d_cond = (runtime.gemm_tn(runtime.transpose(d_ss), w_all) if d_ss.shape[0] % 4 == 0 and w_all.shape[1] % 4 == 0
+                  else runtime.gemm(d_ss, runtime.transpose(w_all)))
         d, grads = ctx.dim, []
         for i in range(ctx.n):
             grads += [dw[(2 * i) * d:(2 * i + 1) * d], db[(2 * i) * d:(2 * i + 1) * d],

@@ -218,19 +218,27 @@ class ToMelFunction(torch.autograd.Function):
     Backward: masked gradient rows, then d dec = g W (NT GEMM on W^T), dW = g^T dec, db = column sums of g."""
 
     @staticmethod
-    def forward(ctx, dec: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor]):
+    def forward(ctx, dec: Tensor, weight: Tensor, bias: Tensor, mask: Optional[Tensor], amp: bool = False):
+        """`amp`: bf16 operands for the three GEMMs (autocast covers this Linear too), fp32 mel and gradients."""
         dec = dec.float().contiguous()
+        w = weight.detach()
+        if amp:
+            dec, w = runtime.cast_bf16(dec), runtime.cast_bf16(w)
         ctx.save_for_backward(dec, weight)
-        ctx.mask, ctx.params = mask, (weight, bias)
-        return runtime.to_mel(dec, weight.detach(), bias.detach(), mask)
+        ctx.mask, ctx.params, ctx.amp = mask, (weight, bias), amp
+        return runtime.to_mel(dec, w, bias.detach(), mask)
 
     @staticmethod
     def backward(ctx, dmel: Tensor):
         dec, weight = ctx.saved_tensors
         g = runtime.mel_grad_rows(dmel.float(), ctx.mask)                 # [B, T, 80]
-        d_dec = runtime.gemm(g, runtime.transpose(weight.detach()))        # [B, T, dim]
+        db = runtime.colsum(g)
+        wt = runtime.transpose(weight.detach())
+        if ctx.amp:
+            g, wt = runtime.cast_bf16(g), runtime.cast_bf16(wt)
+        d_dec = runtime.gemm(g, wt, out_dtype=torch.float32)               # [B, T, dim]
         dw = runtime.gemm_tn(g, dec)                                       # [80, dim]
-        return (d_dec, *runtime.deliver_grads(list(zip(ctx.params, (dw, runtime.colsum(g))))), None)
+        return (d_dec, *runtime.deliver_grads(list(zip(ctx.params, (dw, db)))), None, None)
 
 
 def mel_decoder_train_forward(model, dec_in: Tensor, dec_mask: Optional[Tensor], amp: bool = False) -> Tensor:

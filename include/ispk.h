@@ -103,6 +103,8 @@ int32_t ispk_layernorm_f32_bf16(const float* x, int64_t ldx, const float* gamma,
 #define ISPK_EP_MASK_COL 32u
 #define ISPK_EP_OUT_BF16 64u   /* _bf16 entry only: C is bf16 (default fp32) */
 #define ISPK_EP_RESID_BF16 128u /* _bf16 entry only: resid is bf16 (default fp32) */
+#define ISPK_EP_DUAL_GELU 1024u /* ispk_gemm_bf16_gelu_train only: second output = dropout(gelu(C)) */
+#define ISPK_EP_GELU_BWD 2048u  /* ispk_gemm_bf16_gelu_bwd only: C = (A W^T) gelu'(u) [dropout] */
 #define ISPK_EP_OUT_SPLIT 512u  /* _split_f16 entry only: C is a pair of fp16 planes (hi at C, lo c_plane elements behind) */
 #define ISPK_EP_ROWS_T 256u     /* _bf16 entry, K = 256 / 384, fp32 C, no resid: the M rows are [batch][T] frames with
                                    T = cols_per_batch and C is stored transposed per batch,
@@ -120,6 +122,17 @@ int32_t ispk_gemm_f32(const float* A, int64_t lda, const float* W, int64_t ldw, 
 int32_t ispk_gemm_f32_batched(const float* A, int64_t lda, int64_t stride_a, const float* W, int64_t ldw, int64_t stride_w,
                               float* C, int64_t ldc, int64_t stride_c, int32_t batch, int32_t M, int32_t N, int32_t K,
                               ispk_stream_t stream);
+/* The feed-forward block's first Linear of a TRAINING step under autocast (feedforward.py:33-35: Linear -> GELU -> Dropout)
+ * with both tensors the backward needs from ONE launch: u = A W^T (bf16, the pre-activation) and a = dropout(gelu(u)) (bf16;
+ * the mask of ispk_gelu_bf16 with the same dropout_p / seed: hash(seed, row * N + feature)) - and its mirror in the backward:
+ * du = (dY W2) gelu'(u) [keep / (1 - p)] straight from the GEMM's epilogue (row mask: dY's padded rows).  K = 256 / 384,
+ * N % 8 == 0, contiguous-row bf16 tensors, 16-byte aligned. */
+int32_t ispk_gemm_bf16_gelu_train(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, uint16_t* u, int64_t ldu,
+                                  uint16_t* a, int64_t ld_a, int32_t M, int32_t N, int32_t K, float dropout_p, uint64_t seed,
+                                  ispk_stream_t stream);
+int32_t ispk_gemm_bf16_gelu_bwd(const uint16_t* dY, int64_t lddy, const uint16_t* W2t, int64_t ldw, const uint16_t* u,
+                                int64_t ldu, uint16_t* du, int64_t lddu, const uint8_t* row_mask, int32_t M, int32_t N,
+                                int32_t K, float dropout_p, uint64_t seed, ispk_stream_t stream);
 /* Kernel instance dispatched by this thread's last ispk_gemm_bf16 call (profiler labels): 1000+KC panel<KC>,
  * 2000+10*TN+WM wide<TN,WM>, 3000+10*TM+TN generic<TM,TN>. */
 int32_t ispk_gemm_bf16_last_variant(void);

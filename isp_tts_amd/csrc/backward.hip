@@ -692,26 +692,17 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const void* __restrict__ 
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float cdf, pdf;
+        float dgelu;
         if constexpr (IO16) {
-            // bf16 in and out: erf by Abramowitz-Stegun 7.1.28 (|error| <= 3e-7, common.h) and v_exp_f32 - two orders below the
+            // bf16 in and out: erf by Abramowitz-Stegun 7.1.28 (|error| <= 3e-7) and v_exp_f32 (common.h) - two orders below the
             // rounding of du to bf16, at a third of libm's instructions (the kernel was issue-bound, not bandwidth-bound)
-            const float ax = fabsf(x[k]), z = ax * 0.70710678118654752440f;
-            float q = fmaf(z, 0.0000430638f, 0.0002765672f);
-            q = fmaf(q, z, 0.0001520143f);
-            q = fmaf(q, z, 0.0092705272f);
-            q = fmaf(q, z, 0.0422820123f);
-            q = fmaf(q, z, 0.0705230784f);
-            q = fmaf(q, z, 1.0f);
-            q = q * q; q = q * q; q = q * q; q = q * q;
-            const float erf_abs = 1.0f - __builtin_amdgcn_rcpf(q);                      // erf(|x| / sqrt 2)
-            cdf = 0.5f * (1.f + (x[k] < 0.f ? -erf_abs : erf_abs));
-            pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x[k] * x[k]);
+            dgelu = gelu_grad_fast(x[k]);
         } else {
-            cdf = 0.5f * (1.f + erff(x[k] * 0.70710678118654752440f));
-            pdf = 0.39894228040143267794f * expf(-0.5f * x[k] * x[k]);
+            const float cdf = 0.5f * (1.f + erff(x[k] * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * x[k] * x[k]);
+            dgelu = cdf + x[k] * pdf;
         }
-        float g = a[k] * (cdf + x[k] * pdf);
+        float g = a[k] * dgelu;
         if (thresh) g = drop_keep(seed, (uint32_t)(4 * i + k), thresh) ? g * inv_keep : 0.f;
         o[k] = g;
     }

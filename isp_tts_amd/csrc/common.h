@@ -125,6 +125,22 @@ __device__ __forceinline__ float gelu_as28(float x) {
     const float hx = 0.5f * ax;
     return fmaf(0.5f, x, fmaf(-hx, r, hx));
 }
+// d gelu / dx for bf16 tensors: cdf(x) + x pdf(x) with the 3e-7 erf above and v_exp_f32 (the bf16 GELU backward and the
+// fused da -> du epilogue of the training step evaluate the SAME expression)
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float ax = fabsf(x), z = ax * 0.70710678118654752440f;
+    float q = fmaf(z, 0.0000430638f, 0.0002765672f);
+    q = fmaf(q, z, 0.0001520143f);
+    q = fmaf(q, z, 0.0092705272f);
+    q = fmaf(q, z, 0.0422820123f);
+    q = fmaf(q, z, 0.0705230784f);
+    q = fmaf(q, z, 1.0f);
+    q = q * q; q = q * q; q = q * q; q = q * q;
+    const float erf_abs = 1.0f - __builtin_amdgcn_rcpf(q);                      // erf(|x| / sqrt 2)
+    const float cdf = 0.5f * (1.f + (x < 0.f ? -erf_abs : erf_abs));
+    const float pdf = 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
+    return cdf + x * pdf;
+}
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 constexpr int kWave = 64;

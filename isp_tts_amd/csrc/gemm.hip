@@ -867,6 +867,8 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
     // the model's hot epilogues get branch-free instances (tools/trace_gemms.py lists what a forward launches)
     constexpr int kQkv = ISPK_EP_OUT_BF16, kFfn1 = ISPK_EP_OUT_BF16 | ISPK_EP_GELU, kProj = ISPK_EP_MASK_ACC | kEpResid;
     constexpr int kMelT = ISPK_EP_ROWS_T | ISPK_EP_MASK_OUT | kEpBias;   // to_mel (model.py:167-168)
+    constexpr int kFfn1T = ISPK_EP_OUT_BF16 | ISPK_EP_DUAL_GELU;          // training: u and dropout(gelu(u)) from one launch
+    constexpr int kFfn2B = ISPK_EP_OUT_BF16 | ISPK_EP_GELU_BWD, kFfn2Bm = kFfn2B | ISPK_EP_MASK_OUT;   // training: da -> du
     const int key = p.cpb == -7 ? -2 : ep_key(p);
 #ifdef ISPK_EXPERIMENTS
     if (const char* e = ispk_knob("ISPK_PANEL_STAMP")) {   // experiments only: per-wave phase cycle sums -> uint64[grid*4][6]
@@ -895,6 +897,9 @@ int32_t launch_panel(const GemmParams& p, hipStream_t s) {
 #undef ISPK_PANEL_GO_LN
     }
     if (ispk_knob("ISPK_EP_DYN") == nullptr) {   // (set: experiments, forces the generic epilogue)
+        if (key == kFfn1T) ISPK_PANEL_GO(kFfn1T, false, p);
+        if (key == kFfn2B) ISPK_PANEL_GO(kFfn2B, false, p);
+        if (key == kFfn2Bm) ISPK_PANEL_GO(kFfn2Bm, false, p);
         if (key == kQkv) ISPK_PANEL_GO(kQkv, false, p);
         if (key == kFfn1) ISPK_PANEL_GO(kFfn1, false, p);
         if (key == kProj) ISPK_PANEL_GO(kProj, false, p);
@@ -994,6 +999,45 @@ extern "C" int32_t ispk_gemm_f32_batched(const float* A, int64_t lda, int64_t st
     const int64_t wg128 = (int64_t)((M + 127) / 128) * ((N + 127) / 128) * batch;
     if (wg128 >= 256) return launch_f32<2, 2>(p, s, batch);
     return launch_f32<1, 2>(p, s, batch);
+}
+
+static int32_t gelu_train_common(GemmParams& p, float dropout_p, uint64_t seed, const char* who) {
+    ISPK_REQUIRE(p.A && p.W && p.C && p.aux, ISPK_E_NULL, "%s: null pointer", who);
+    ISPK_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, ISPK_E_SHAPE, "%s: dropout_p must be in [0, 1)", who);
+    if (int32_t rc = check_common(p, 2)) return rc;
+    ISPK_REQUIRE(panel_ok(p) && p.N % 8 == 0 && p.ldc % 8 == 0 && p.ld_aux % 8 == 0 && ispk_aligned(p.C, 16) && ispk_aligned(p.aux, 16) &&
+                     (int64_t)p.M * p.N < ((int64_t)1 << 32),
+                 ISPK_E_UNSUPPORTED, "%s: K = 256 / 384, N %% 8 == 0, 16-byte aligned bf16 rows, M N < 2^32", who);
+    p.drop_thresh = drop_thresh(dropout_p);
+    p.drop_inv_keep = 1.0f / (1.0f - dropout_p);
+    p.drop_seed = mix_seed(seed);
+    p.drop_src = ispk_seed_source();
+    return 0;
+}
+
+extern "C" int32_t ispk_gemm_bf16_gelu_train(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, uint16_t* u, int64_t ldu,
+                                             uint16_t* a, int64_t ld_a, int32_t M, int32_t N, int32_t K, float dropout_p,
+                                             uint64_t seed, ispk_stream_t stream) {
+    GemmParams p{A, lda, W, ldw, u, ldu, nullptr, nullptr, 0, nullptr, M, N, K, ISPK_EP_OUT_BF16 | ISPK_EP_DUAL_GELU, 0, 0};
+    p.aux = a;
+    p.ld_aux = ld_a;
+    if (int32_t rc = gelu_train_common(p, dropout_p, seed, "gemm_bf16_gelu_train")) return rc;
+    if (M == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
+}
+
+extern "C" int32_t ispk_gemm_bf16_gelu_bwd(const uint16_t* dY, int64_t lddy, const uint16_t* W2t, int64_t ldw, const uint16_t* u,
+                                           int64_t ldu, uint16_t* du, int64_t lddu, const uint8_t* row_mask, int32_t M, int32_t N,
+                                           int32_t K, float dropout_p, uint64_t seed, ispk_stream_t stream) {
+    GemmParams p{dY, lddy, W2t, ldw, du, lddu, nullptr, nullptr, 0, row_mask, M, N, K,
+                 ISPK_EP_OUT_BF16 | ISPK_EP_GELU_BWD | (row_mask ? ISPK_EP_MASK_OUT : 0u), 0, 0};
+    p.aux = const_cast<uint16_t*>(u);
+    p.ld_aux = ldu;
+    if (int32_t rc = gelu_train_common(p, dropout_p, seed, "gemm_bf16_gelu_bwd")) return rc;
+    if (M == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    return K == 256 ? launch_panel<4>(p, s) : launch_panel<6>(p, s);
 }
 
 // Which kernel instance the last ispk_gemm_bf16 call of THIS thread dispatched (for profilers' labels):

@@ -1,6 +1,7 @@
 // Shared pieces of the Linear kernels (gemm.hip, split.hip): the launch parameter block and the epilogues.
 #pragma once
 #include "common.h"
+#include "dropout.h"
 
 namespace {
 
@@ -40,6 +41,14 @@ struct GemmParams {
     int64_t a_plane = 0, w_plane = 0, c_plane = 0;
     // batched fp32 product (ispk_gemm_f32_batched): element strides of A, W and C from one batch item (blockIdx.z) to the next
     int64_t za = 0, zw = 0, zc = 0;
+    // training epilogues of the panel kernel (ISPK_EP_DUAL_GELU / ISPK_EP_GELU_BWD): a second bf16 tensor of C's shape and the
+    // dropout of the feed-forward activation (dropout.h: mask = hash(seed, row * N + feature))
+    void* aux = nullptr;
+    int64_t ld_aux = 0;
+    uint64_t drop_seed = 0;
+    const uint64_t* drop_src = nullptr;
+    uint32_t drop_thresh = 0;
+    float drop_inv_keep = 1.f;
 };
 
 __device__ __forceinline__ void epilogue_store(const GemmParams& p, int i, int j, float v) {
@@ -281,13 +290,74 @@ __device__ __forceinline__ void store_rows_bf16(const GemmParams& p, char* stage
             *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (t * 32 + 8 * g + 4 * h) * 2) = o;
         }
     const int c = lane & 7, n = n0 + 8 * c;
+    if (ep_flag<EP>(p, ISPK_EP_GELU_BWD)) {
+        // C = du = da gelu'(u) [keep / (1 - p)] with u (bf16, aux) read in the store layout: the da -> du pass of the
+        // feed-forward backward (gelu_bwd_kernel<true, true>, same expression, same mask) without its own launch
+        const uint64_t seed = run_seed(p.drop_seed, p.drop_src);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3), m = m0 + r;
+            if (m >= p.M || n >= p.N) continue;
+            const uint4 dv = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
+            const uint4 uv = *reinterpret_cast<const uint4*>(static_cast<const uint16_t*>(p.aux) + (int64_t)m * p.ld_aux + n);
+            const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, uw[4] = {uv.x, uv.y, uv.z, uv.w};
+            uint32_t ow[4];
+            const uint32_t idx0 = (uint32_t)m * (uint32_t)p.N + (uint32_t)n;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float g[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float da = bf16_to_f32((uint16_t)(k ? dw[e] >> 16 : dw[e] & 0xffffu));
+                    const float u = bf16_to_f32((uint16_t)(k ? uw[e] >> 16 : uw[e] & 0xffffu));
+                    float v = da * gelu_grad_fast(u);
+                    if (p.drop_thresh) v = drop_keep(seed, idx0 + 2 * e + k, p.drop_thresh) ? v * p.drop_inv_keep : 0.f;
+                    g[k] = v;
+                }
+                ow[e] = pack_bf16x2(g[0], g[1]);
+            }
+            *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.C) + (int64_t)m * p.ldc + n) = uint4{ow[0], ow[1], ow[2], ow[3]};
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int r = 8 * i + (lane >> 3), m = m0 + r;
         const uint4 v = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
         if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.C) + (int64_t)m * p.ldc + n) = v;
     }
+    if (ep_flag<EP>(p, ISPK_EP_DUAL_GELU)) {
+        // second output aux = dropout(gelu(bf16(u))): what gelu_fwd_kernel<true, true> makes of the u just stored (same
+        // expression on the ROUNDED pre-activation, same mask), without re-reading it
+        const uint64_t seed = run_seed(p.drop_seed, p.drop_src);
+        const uint32_t row_idx = (uint32_t)(m0 + l31) * (uint32_t)p.N;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nn = n0 + t * 32 + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float u = bf16_to_f32(f32_to_bf16(t ? acc1[4 * g + e] : acc0[4 * g + e]));
+                    float a = gelu_as28(u);
+                    if (p.drop_thresh) a = drop_keep(seed, row_idx + (uint32_t)(nn + e), p.drop_thresh) ? a * p.drop_inv_keep : 0.f;
+                    v[e] = a;
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(stage + l31 * kStageRow + (t * 32 + 8 * g + 4 * h) * 2) = o;
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3), m = m0 + r;
+            const uint4 v = *reinterpret_cast<const uint4*>(stage + r * kStageRow + c * 16);
+            if (m < p.M && n < p.N) *reinterpret_cast<uint4*>(static_cast<uint16_t*>(p.aux) + (int64_t)m * p.ld_aux + n) = v;
+        }
+    }
 }
+
 
 // ISPK_EP_ROWS_T: the wave's 32 rows are frames t of batch item b = m / T; output feature n goes to C[b][n][t].  In the
 // transposed-compute accumulator the frame sits on the lane, so each register is already a frame-contiguous 128-byte

@@ -33,6 +33,8 @@ SIGNATURES = {
     "ispk_gemm_f32_tile": [_I32, _I32, _I32],
     "ispk_gemm_f32": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
     "ispk_gemm_f32_batched": [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I32, _I32, _I32, _I32, _P],
+    "ispk_gemm_bf16_gelu_train": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _I32, _I32, _I32, _F32, _U64, _P],
+    "ispk_gemm_bf16_gelu_bwd": [_P, _I64, _P, _I64, _P, _I64, _P, _I64, _P, _I32, _I32, _I32, _F32, _U64, _P],
     "ispk_segments_f32": [_P, _I32, _P],
     "ispk_stage_weights": [_P, _I32, _P],
     "ispk_fill_zero": [_P, _I64, _P],
@@ -1150,6 +1152,42 @@ def gemm_tn(a: Tensor, b: Tensor, row_mask: Optional[Tensor] = None, out: Option
             float(a2.element_size()) * (a2.numel() + b2.numel()) + 4.0 * out.numel(), fn, a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), out.data_ptr(), out.stride(0), M,
             N1, N2, _ptr(row_mask), int(accumulate), ws.data_ptr(), ws.numel(), _stream())
     return out
+
+
+def gemm_gelu_train(x: Tensor, w: Tensor, dropout_p: float = 0.0, seed: int = 0):
+    """ispk_gemm_bf16_gelu_train -> (u, a): u = x @ w^T and a = dropout(gelu(u)), both bf16, from ONE launch (the first Linear
+    of a feed-forward block in an AMP training step: `gemm(x, w)` followed by `gelu(u, dropout_p, seed)`, bit for bit).
+    x bf16 [..., K], w bf16 [N, K], K = 256 / 384."""
+    _dev(x, w)
+    x2 = _rows2d(x)
+    M, K = x2.shape
+    N = w.shape[0]
+    assert x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and w.shape[1] == K and w.stride(1) == 1
+    u = torch.empty((*x.shape[:-1], N), dtype=torch.bfloat16, device=x.device)
+    a = torch.empty_like(u)
+    _launch(f"gemm_bf16_panel_kernel<{K // 64},gelu_train>", 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N), lib().ispk_gemm_bf16_gelu_train,
+            x2.data_ptr(), x2.stride(0), w.data_ptr(), w.stride(0), u.data_ptr(), N, a.data_ptr(), N, M, N, K, dropout_p,
+            seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    return u, a
+
+
+def gemm_gelu_bwd(dy: Tensor, w2_t: Tensor, u: Tensor, mask: Optional[Tensor] = None, dropout_p: float = 0.0, seed: int = 0) -> Tensor:
+    """ispk_gemm_bf16_gelu_bwd -> du = (mask dy @ w2_t^T) * gelu'(u) * [keep / (1 - p)] (bf16): the feed-forward backward's
+    `gemm(dy, w2_t, mask=mask, flags=EP_MASK_OUT)` + `gelu_bwd(da, u, dropout_p=, seed=)` as ONE launch, bit for bit.
+    dy bf16 [..., K], w2_t bf16 [N, K] (= W2^T rows), u bf16 [..., N]."""
+    _dev(dy, w2_t, u, mask)
+    d2, u2 = _rows2d(dy), _rows2d(u)
+    M, K = d2.shape
+    N = w2_t.shape[0]
+    assert dy.dtype == torch.bfloat16 and w2_t.dtype == torch.bfloat16 and u.dtype == torch.bfloat16 and u2.shape == (M, N) and u2.is_contiguous()
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+        assert mask.dtype == torch.bool and mask.numel() == M
+    du = torch.empty_like(u)
+    _launch(f"gemm_bf16_panel_kernel<{K // 64},gelu_bwd>", 2.0 * M * N * K, 2.0 * (M * K + N * K + 2 * M * N), lib().ispk_gemm_bf16_gelu_bwd,
+            d2.data_ptr(), d2.stride(0), w2_t.data_ptr(), w2_t.stride(0), u2.data_ptr(), N, du.data_ptr(), N, _ptr(mask), M, N, K,
+            dropout_p, seed & 0xFFFFFFFFFFFFFFFF, _stream())
+    return du
 
 
 def gemm_batched(a: Tensor, w: Tensor, out: Optional[Tensor] = None) -> Tensor:

@@ -182,8 +182,11 @@ class AdaptiveStackFunction(torch.autograd.Function):
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
             x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
             h2 = runtime.layernorm(x1, None, None, s2, t2, L, mask, layer.feed_forward_norm.eps, out_dtype=adt)
-            u = _mm(h2, w1, w116, out_dtype=adt)       # AMP: the pre-activation is bf16 (autocast's Linear output)
-            a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)
+            if amp and h2.shape[-1] in (256, 384):      # one launch: u (bf16, autocast's Linear output) and a = dropout(gelu(u))
+                u, a = runtime.gemm_gelu_train(h2, w116, p_ff, seed_ff)
+            else:
+                u = _mm(h2, w1, w116, out_dtype=adt)
+                a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)
             y = _mm(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
             tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
@@ -213,8 +216,11 @@ class AdaptiveStackFunction(torch.autograd.Function):
             dyg = runtime.cast_bf16(dy) if amp else dy
             wmask = None if amp else mask          # (padded rows of dy / dx1 are exactly zero: stack.py)
             dw2 = runtime.gemm_tn(dyg, a, row_mask=wmask, bf16=amp)
-            da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)
-            du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
+            if amp and dyg.shape[-1] in (256, 384):
+                du = runtime.gemm_gelu_bwd(dyg, w2_t16, u, mask, p_ff, seed_ff)
+            else:
+                da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)
+                du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
             dw1 = runtime.gemm_tn(du, h2, bf16=amp)
             dh2 = _mm(du, w1_t, w1_t16)
             dx1 = runtime.adaln_bwd(x1, dh2, ss[:, c + 2 * D:c + 3 * D], mask, dy, True, d_ss[:, c + 2 * D:c + 3 * D],

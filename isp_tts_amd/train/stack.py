@@ -116,8 +116,11 @@ class TransformerStackFunction(torch.autograd.Function):
                 o = runtime.alibi_mqa_attention(qkv, att.heads, slopes, key_len)
             x1 = _mm(o, wo, wo16, resid=out, mask=mask, flags=runtime.EP_MASK_ACC if mask is not None else 0)
             h2 = runtime.layernorm(x1, fn.weight, fn.bias, row_mask=mask, eps=fn.eps, out_dtype=adt)
-            u = _mm(h2, w1, w116, out_dtype=adt)       # AMP: the pre-activation is bf16 (autocast's Linear output)
-            a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)        # GELU, then nn.Dropout (feedforward.py:35)
+            if amp and h2.shape[-1] in (256, 384):      # one launch: u (bf16, autocast's Linear output) and a = dropout(gelu(u))
+                u, a = runtime.gemm_gelu_train(h2, w116, p_ff, seed_ff)
+            else:
+                u = _mm(h2, w1, w116, out_dtype=adt)
+                a = runtime.gelu(u, p_ff, seed_ff, out_dtype=adt)        # GELU, then nn.Dropout (feedforward.py:35)
             y = _mm(a, w2, w216, resid=x1, mask=mask, flags=runtime.EP_MASK_OUT if mask is not None else 0)
             tape.append((out, h, qkv, o, x1, h2, u, a, lse, p_att, seed_att, p_ff, seed_ff))
             out = y
@@ -152,8 +155,11 @@ class TransformerStackFunction(torch.autograd.Function):
             # changes nothing; the AMP step leaves it out and gets the LDS-DMA kernel, which has no mask path)
             wmask = None if amp else mask
             dw2 = _deliver(ff.net[3].weight, runtime.gemm_tn, dyg, a, row_mask=wmask, bf16=amp)       # [dim, inner]
-            da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)                         # (m dy) W2
-            du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
+            if amp and dyg.shape[-1] in (256, 384):     # (m dy) W2 and the GELU / dropout derivative in the GEMM's epilogue
+                du = runtime.gemm_gelu_bwd(dyg, w2_t16, u, mask, p_ff, seed_ff)
+            else:
+                da = _mm(dyg, w2_t, w2_t16, out_dtype=gdt, mask=mask, flags=mflag)                     # (m dy) W2
+                du = runtime.gelu_bwd(da, u, out=da, dropout_p=p_ff, seed=seed_ff)
             dw1 = _deliver(ff.net[0].weight, runtime.gemm_tn, du, h2, bf16=amp)                         # [inner, dim]
             dh2 = _mm(du, w1_t, w1_t16)
             dx1, dg2, db2, *rest = runtime.layernorm_bwd(x1, dh2, fn.weight, row_mask=mask, dx=dy, add_to_dx=True, eps=fn.eps,

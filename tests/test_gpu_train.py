@@ -963,6 +963,28 @@ def test_data_movement_kernels_of_the_training_step():
     _close(runtime.gemm_batched(a3, b3), torch.einsum("bmk,bnk->bmn", a3.double().cpu(), b3.double().cpu()), 2e-6, "batched NT GEMM")
 
 
+@pytest.mark.parametrize("M,N,K,masked,p", [(1000, 1536, 384, True, 0.1), (6400, 1024, 256, False, 0.3), (333, 1536, 384, True, 0.0)])
+def test_feed_forward_gemms_with_the_gelu_pair_in_their_epilogues(M, N, K, masked, p):
+    """ispk_gemm_bf16_gelu_train / ispk_gemm_bf16_gelu_bwd: the AMP step's first feed-forward Linear with u AND
+    a = dropout(gelu(u)) from one launch, and du = (m dy W2) gelu'(u) [dropout] from the backward GEMM's epilogue - bit for bit
+    what the GEMM followed by the GELU kernel gives (same expressions on the same rounded values, same mask)."""
+    x = _rand((M, K), 61).bfloat16().to(DEV)
+    w1 = _rand((N, K), 62, K ** -0.5).bfloat16().to(DEV)
+    dy = _rand((M, K), 63).bfloat16().to(DEV)
+    w2t = _rand((N, K), 64, N ** -0.5).bfloat16().to(DEV)
+    mask = (torch.arange(M) % 7 != 3).to(DEV) if masked else None
+    u_ref = runtime.gemm(x, w1, out_dtype=torch.bfloat16)
+    a_ref = runtime.gelu(u_ref, p, 99, out_dtype=torch.bfloat16)
+    u, a = runtime.gemm_gelu_train(x, w1, p, 99)
+    assert torch.equal(u, u_ref) and torch.equal(a, a_ref)
+    da = runtime.gemm(dy, w2t, out_dtype=torch.bfloat16, mask=mask, flags=runtime.EP_MASK_OUT if masked else 0)
+    du_ref = runtime.gelu_bwd(da, u_ref, dropout_p=p, seed=99)
+    du = runtime.gemm_gelu_bwd(dy, w2t, u_ref, mask, p, 99)
+    assert torch.equal(du, du_ref)
+    if p > 0:
+        assert abs(float((a == 0).float().mean()) - p) < 0.02
+
+
 def test_dropout_seed_source_changes_the_masks_at_run_time():
     """ispk_set_dropout_seed_source: the same launch (same seed argument) draws another mask when the device word changes, the
     same mask when it does not, and forward / backward stay consistent - what a captured training step relies on."""
@@ -1035,8 +1057,8 @@ def test_graphed_training_step_replays_match_eager_steps(state_dict):
     m_t, o_t = make(True)
     o_t.lr = 0.0                                       # (weights fixed: the only thing that changes between replays is the masks)
     step_t = train.GraphedTrainStep(m_t, o_t, batch, amp=True, warmup=2)
-    t1 = float(step_t(**batch)[0])
-    t2 = float(step_t(**batch)[0])
+    t1 = float(step_t(**batch)[0].detach())
+    t2 = float(step_t(**batch)[0].detach())
     assert t1 != t2 and abs(t1 - t2) < 0.2 * abs(t1)
 
 

@@ -454,6 +454,35 @@ def test_stack_gradients_under_bf16_amp(state_dict):
     assert not torch.equal(o16, o32)
 
 
+def test_amp_weight_gradients_do_not_see_padded_rows(state_dict):
+    """The AMP step computes its weight gradients WITHOUT a row mask (the LDS-DMA kernel has none): that is only right
+    because the rows of padded positions are exactly zero in every gradient tensor that enters a weight gradient.  Proof by
+    invariance: whatever sits in the padded rows of the stack's input and of the incoming output gradient, the gradients of
+    all parameters - and the valid rows of d x - are bit-for-bit the same."""
+    tr = _decoder_stack(state_dict, 2).eval()              # (no dropout: the masks would differ between the runs' seeds)
+    B, N = 3, 70
+    lens = torch.tensor([70, 41, 64])
+    mask = (torch.arange(N)[None, :] < lens[:, None]).to(DEV)
+    x, dout = _rand((B, N, 384), 20).to(DEV), _rand((B, N, 384), 21).to(DEV)
+
+    def run(garbage):
+        xx, dd = x.clone(), dout.clone()
+        xx[~mask] = garbage
+        dd[~mask] = -3.0 * garbage
+        xg = xx.requires_grad_()
+        out = train.transformer_train_forward(tr, xg, mask, amp=True, key_len=lens.to(DEV))
+        out.backward(dd)
+        g = {n: p.grad.clone() for n, p in tr.named_parameters()}
+        tr.zero_grad(set_to_none=True)
+        return out.detach(), xg.grad, g
+    o_a, dx_a, g_a = run(0.0)
+    o_b, dx_b, g_b = run(7.5)
+    assert torch.equal(o_a, o_b) and float(o_a[~mask].abs().max()) == 0.0
+    assert torch.equal(dx_a[mask], dx_b[mask])
+    for n in g_a:
+        assert torch.equal(g_a[n], g_b[n]), n
+
+
 def test_attention_binarization_loss():
     """AttentionBinarizationLoss (loss.py:80-107) on a real MAS output: value and d / d attn_soft against the reference's
     expression under autograd (float64), including cells clamped at eps (zero gradient) and ragged utterances."""

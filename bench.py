@@ -30,6 +30,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -95,9 +96,13 @@ def launch_workers(args) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         cmd = [sys.executable, os.path.abspath(__file__), *sys.argv[1:], "--worker"]
         procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    # Rank 0's stdout is ONE JSON line at the very end, so it cannot fill the pipe while we poll.  Every rank is polled:
-    # the first non-zero exit (a rank that dies before the rendezvous would otherwise leave the others blocked until the
-    # process group's 300-s timeout) takes the siblings down with it.
+    # Rank 0's stdout (the JSON line: tens of KB with the extras, more than a pipe buffer may hold) is drained by a reader
+    # thread while we poll, so rank 0 never blocks in write().  Every rank is polled: the first non-zero exit (a rank that
+    # dies before the rendezvous would otherwise leave the others blocked until the process group's 300-s timeout) takes
+    # the siblings down with it.
+    chunks: list = []
+    reader = threading.Thread(target=lambda: chunks.extend(iter(lambda: procs[0].stdout.read(65536), "")), daemon=True)
+    reader.start()
     rc = 0
     live = list(procs)
     while live and rc == 0:
@@ -115,8 +120,8 @@ def launch_workers(args) -> int:
         except subprocess.TimeoutExpired:
             p.kill()
             p.wait()
-    out = procs[0].stdout.read() if procs[0].stdout is not None else ""
-    sys.stdout.write(out)
+    reader.join(timeout=30)
+    sys.stdout.write("".join(chunks))
     sys.stdout.flush()
     return rc
 
@@ -264,6 +269,7 @@ def worker(args) -> int:
     model = AcousticModel.init(dims.model_config()).eval()
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
+    model.requires_grad_(False)        # an inference deployment (with trainable parameters and gradients enabled `model(...)` is the training forward)
     cdt = {"f32": torch.float32, "bf16": torch.bfloat16, "split": torch.float16}[args.dtype]
     align_dt = {"f32": torch.float32, "split": torch.float16}.get(args.alignment)
     model.set_compute_dtype(cdt, alignment_dtype=align_dt)
@@ -788,7 +794,7 @@ def worker(args) -> int:
                         gstep()
                     fence()
                     elg = time.perf_counter() - t0
-                    opt.args_dev = None
+                    gstep.close()
                     del gstep
                 kern = None
                 if prof is not None:
@@ -803,8 +809,7 @@ def worker(args) -> int:
             finally:
                 model.set_compute_dtype(cdt, alignment_dtype=align_dt)
                 model.eval()
-                for p in model.parameters():
-                    p.requires_grad_(True)
+                model.requires_grad_(False)
             frames = world * B * M
             # forward 2 N K per Linear + attention 4 N^2 64 H; backward = 2 x the Linears' + 2.5 x the attention's
             best = el if elg is None else min(el, elg)

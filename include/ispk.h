@@ -333,6 +333,11 @@ int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow, const flo
  * ispk_embed_tokens_f32     models/acoustic/model.py:131-134: emb[b][l][:] = table[text[b][l]][:] (nn.Embedding lookup, row
  *                           0 = padding row) and mask[b][l] = l < text_len[b] (utils/functions.py:61-65; mask / text_len may
  *                           be NULL).  Ids outside [0, vocab) read row 0 (the host-side F.embedding would raise).
+ * ispk_add_speaker_f32      models/acoustic/model.py:93-97, :205-207 (`infer` of a multi-speaker model): x[b][l][:] +=
+ *                           table[speaker[b * id_stride]][:] in place on the encoder output, EVERY row of the utterance (the
+ *                           reference adds before any re-masking); id_stride 1 = one id per utterance (the collator's
+ *                           [B, 1] field), 0 = one id for the batch (the notebook's `torch.tensor([speaker])`).  Ids outside
+ *                           [0, speakers) are clamped (the host-side F.embedding would raise).
  * ispk_time_embedding_f32   modules/transformer/embeddings.py:131-157 with `with_steps` (temporal_adaptor.py:87-89):
  *                           f = [t, sin(t * freq_scale * inv_freq), cos(..)] (1 + 2*half_dim values),
  *                           out[n][:] = W1 silu(W0 f + b0) + b1; w0 [emb_dim][1 + 2*half_dim], w1 [emb_dim][emb_dim];
@@ -352,6 +357,8 @@ int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow, const flo
 int32_t ispk_embed_tokens_f32(const int64_t* text, const float* table, int64_t ld_table, int32_t vocab,
                               const int64_t* text_len, float* emb, uint8_t* mask, int32_t B, int32_t L, int32_t D,
                               ispk_stream_t stream);
+int32_t ispk_add_speaker_f32(float* x, const float* table, int64_t ld_table, int32_t speakers, const int64_t* speaker,
+                             int32_t id_stride, int32_t B, int32_t L, int32_t D, ispk_stream_t stream);
 int32_t ispk_time_embedding_f32(const float* t, int32_t n, const float* inv_freq, const float* freq_scale, int32_t half_dim,
                                 const float* w0, const float* b0, const float* w1, const float* b1, int32_t emb_dim,
                                 float* out, ispk_stream_t stream);
@@ -610,10 +617,11 @@ int32_t ispk_cast_f32_bf16(const float* x, int64_t ldx, uint16_t* y, int64_t ldy
  * ispk_permute021_f32   dst[a][c][b] = src[a][b][c]: Conv1d weights [O][C][k] <-> GEMM weights [O][k][C].
  * ispk_conv_weight_flip_f32   wf[c][(K-1-k) O + o] = w[o][c][k]: the GEMM weight of a convolution's input gradient. */
 /* A captured (HIP-graph) training step freezes its launch arguments; two things must still change from replay to replay:
- *   ispk_set_dropout_seed_source   while the calling thread has a source (a DEVICE address of one uint64), every dropout
- *                                  kernel it launches - the GELU / attention forward and backward pairs, the mask export -
- *                                  folds that word into its seed when it RUNS; the host rewrites the word between replays.
- *                                  NULL switches it off.  Thread-local, like the error string.
+ *   ispk_set_dropout_seed_source   while the PROCESS has a source (a DEVICE address of one uint64), every dropout
+ *                                  kernel launched from any of its threads - the GELU / attention forward and backward pairs,
+ *                                  the mask export - folds that word into its seed when it RUNS; the host rewrites the word
+ *                                  between replays.  NULL switches it off.  Process-wide on purpose: an autograd engine
+ *                                  launches the backward kernels from a worker thread, and they must draw the forward's masks.
  *   ispk_adam_args_f32 / ispk_adamw_f32_dev   the AdamW step's scalar factors (bias corrections of step t, lr, decay) as a
  *                                  40-byte record: computed on the host exactly as ispk_adamw_f32 computes them, copied to the
  *                                  device by the caller, read by the kernel when it runs. */

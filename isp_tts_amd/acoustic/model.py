@@ -37,16 +37,18 @@ class AcousticModel(nn.Module, Constructor):
     def __init__(self, encoding_map: dict, mel_dim: int, text_dim: int = 384, encoder=None, decoder=None,
                  temporal_adaptor=None, aligner=None, num_speakers: Optional[int] = 0, pitch_mean=None, pitch_std=None):
         super().__init__()
-        if num_speakers:
-            raise NotImplementedError("multi-speaker models are outside the built scope (recipes: num_speakers null; "
-                                      "the reference's own forward is broken for them, model.py:146)")
         self.encoding_map = dict(encoding_map)
         self.mel_dim, self.text_dim = mel_dim, text_dim
         self.text_embedding = nn.Embedding(len(encoding_map), text_dim, padding_idx=0)
         self.encoder = Transformer.init(encoder, emb_dim=text_dim)
         enc_dim = self.encoder.dim
         self.aligner = Aligner.init(aligner, mel_dim=mel_dim, text_dim=enc_dim)
+        # model.py:93-97: multi-speaker models (the authors' published 1,307-speaker checkpoint, notebooks/inference.ipynb)
         self.speaker_embedding = None
+        if (num_speakers or 0) > 0:
+            self.speaker_embedding = nn.Embedding(num_speakers, enc_dim)
+            nn.init.xavier_uniform_(self.speaker_embedding.weight)
+        self.train_amp: Optional[bool] = None     # forward under grad: bf16 AMP (None = follow torch.autocast's state)
         self.temporal_adaptor = FlowTemporalAdaptor.init(temporal_adaptor, encoder_dim=enc_dim)
         self.decoder = Transformer.init(decoder, emb_dim=enc_dim)
         self.to_mel = nn.Linear(self.decoder.dim, mel_dim)
@@ -96,12 +98,34 @@ class AcousticModel(nn.Module, Constructor):
             w = self._cache.get(torch.bfloat16, (w,), lambda: w.detach().to(torch.bfloat16).contiguous())
         return runtime.to_mel(dec_out, w, self.to_mel.bias, dec_mask)
 
-    @torch.no_grad()
     def forward(self, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Optional[Tensor] = None,
                 energy: Optional[Tensor] = None, speaker: Optional[Tensor] = None, sigma: float = 0., steps: int = 1, *,
                 flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None) -> AcousticModelOutput:
         """model.py:116-174.  text int64 [B,L], mel fp32 [B,80,M], pitch/energy fp32 [B,M], lengths int64 [B]
-        (collator.py:36-55).  Padded shapes define the masks' widths (max length = L / M, as collated batches have)."""
+        (collator.py:36-55).  Padded shapes define the masks' widths (max length = L / M, as collated batches have).
+
+        With gradients enabled and a trainable parameter - the reference's training loop, `outputs = model(**inputs)`
+        (experiments/trainer.py:544) - the outputs carry autograd nodes whose backward is HIP kernels
+        (`train.acoustic_train_outputs`): `criterion(inputs=, outputs=)` then `optimizer.step(loss)` train the model as they
+        train the reference.  Under `torch.no_grad()` / with every parameter frozen: the inference kernels (no tape)."""
+        if self.speaker_embedding is not None:
+            # model.py:145-146: the reference's forward reads `self.speaker_encoder`, which no AcousticModel has - a
+            # multi-speaker model cannot be run through `forward` there either (only through `infer`); same error here
+            raise AttributeError(f"'{type(self).__name__}' object has no attribute 'speaker_encoder'")
+        if torch.is_grad_enabled() and text.is_cuda and any(p.requires_grad for p in self.parameters()):
+            from ..train.model import acoustic_train_outputs
+            amp = self.train_amp if self.train_amp is not None else torch.is_autocast_enabled("cuda")
+            train_aligner = any(p.requires_grad for p in self.aligner.parameters())
+            with torch.autocast("cuda", enabled=False):      # (the kernels choose their own operand types: `amp`)
+                return acoustic_train_outputs(self, text, text_len, mel, mel_len, pitch, energy, flow_noise, flow_time, amp=amp,
+                                              train_aligner=train_aligner)
+        with torch.no_grad():
+            return self._forward_values(text, text_len, mel, mel_len, pitch, energy, flow_noise=flow_noise, flow_time=flow_time)
+
+    def _forward_values(self, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Optional[Tensor] = None,
+                        energy: Optional[Tensor] = None, *, flow_noise: Optional[Tensor] = None,
+                        flow_time: Optional[Tensor] = None) -> AcousticModelOutput:
+        """The forward without a tape (inference kernels, `set_compute_dtype`'s precision)."""
         # The aligner's mel-side projections (33,000 frames: large, HBM-bound launches) do not depend on the text encoder
         # (6,400 tokens: small, latency-bound launches), so they run beside it on a second stream; under HIP-graph
         # capture the fork / join become graph edges.
@@ -211,6 +235,8 @@ class AcousticModel(nn.Module, Constructor):
         token_emb, enc_mask = runtime.embed_tokens(input_sequence, self.text_embedding.weight,
                                                    text_lengths if batch_infer else None, want_mask=batch_infer)
         enc_out = self.encoder(token_emb, mask=enc_mask, key_len=text_lengths if batch_infer else None).out
+        if self.speaker_embedding is not None and speaker is not None:      # model.py:205-207
+            enc_out = runtime.add_speaker_(enc_out, self.speaker_embedding.weight, speaker)
         if pitch_normalize:
             if pitch_target is not None:
                 pitch_target = (pitch_target - self.pitch_mean) / self.pitch_std

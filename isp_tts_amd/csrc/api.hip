@@ -1,4 +1,6 @@
 // ABI bookkeeping: version, thread-local error string, device query.
+#include <atomic>
+
 #include "common.h"
 
 char* ispk_err_buf() {
@@ -21,10 +23,12 @@ extern "C" int32_t ispk_device_info(char* name, int32_t cap) {
     return p.multiProcessorCount;
 }
 
-// dropout seed source of this thread (dropout.h)
-static thread_local const uint64_t* g_seed_source = nullptr;
-const uint64_t* ispk_seed_source() { return g_seed_source; }
+// Dropout seed source (dropout.h).  PROCESS-wide, not thread-local: autograd runs the backward nodes of a step on its own
+// per-device worker thread, and the backward kernels must fold in the same word as the forward kernels the calling thread
+// launched (one process drives one GPU, so one source per process is the right scope).
+static std::atomic<const uint64_t*> g_seed_source{nullptr};
+const uint64_t* ispk_seed_source() { return g_seed_source.load(std::memory_order_acquire); }
 extern "C" int32_t ispk_set_dropout_seed_source(const uint64_t* device_word) {
-    g_seed_source = device_word;
+    g_seed_source.store(device_word, std::memory_order_release);
     return 0;
 }

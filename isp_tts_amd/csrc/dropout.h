@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t drop_hash(uint64_t seed, uint32_t idx) {
 }
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t idx, uint32_t thresh) { return drop_hash(seed, idx) >= thresh; }
 
-// Seed source (ispk_set_dropout_seed_source): while this thread has one, every dropout kernel it launches folds the 64-bit
+// Seed source (ispk_set_dropout_seed_source): while the process has one, every dropout kernel launched from any thread folds the 64-bit
 // word at that DEVICE address into its launch seed when it RUNS - a captured training step then draws fresh masks on every
 // replay (the host rewrites the word between replays) although its launch arguments are frozen.
 const uint64_t* ispk_seed_source();

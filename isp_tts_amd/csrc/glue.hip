@@ -28,6 +28,28 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* __rest
     }
 }
 
+// ------------------------------------------------------------------------------------------------ speaker embedding
+// models/acoustic/model.py:205-207 (`infer`): enc_out = enc_out + speaker_embedding(speaker) - nn.Embedding rows broadcast
+// over the text axis.  In place, every row of the utterance (padded ones too: the reference adds before any re-masking).
+// One wave per row; speaker ids at stride `id_stride` (0: one id for the whole batch).  Ids outside [0, speakers) are
+// clamped (the host-side F.embedding would raise).
+__global__ __launch_bounds__(256) void add_speaker_kernel(float* __restrict__ x, const float* __restrict__ table, int64_t ld_table,
+                                                          int speakers, const int64_t* __restrict__ speaker, int id_stride,
+                                                          int rows, int L, int D) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    int64_t id = speaker[(int64_t)(row / L) * id_stride];
+    id = id < 0 ? 0 : (id >= speakers ? speakers - 1 : id);
+    const f32x4* src = reinterpret_cast<const f32x4*>(table + id * ld_table);
+    f32x4* dst = reinterpret_cast<f32x4*>(x + (int64_t)row * D);
+    for (int c = lane; c < D / 4; c += 64) {
+        f32x4 v = dst[c];
+        const f32x4 e = src[c];
+        v[0] += e[0]; v[1] += e[1]; v[2] += e[2]; v[3] += e[3];
+        dst[c] = v;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ time embedding
 // modules/transformer/embeddings.py:131-157 as built at temporal_adaptor.py:87-89 (freq_dim 64, with_steps):
 //   f = [t, sin(t * freq_scale * inv_freq[0..H)), cos(...)]  (1 + 2H values; the reference multiplies in this order)
@@ -292,6 +314,20 @@ extern "C" int32_t ispk_embed_tokens_f32(const int64_t* text, const float* table
     const int rows = B * L;
     hipLaunchKernelGGL(embed_tokens_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), text,
                        table, ld_table, vocab, text_len, emb, mask, rows, L, D);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_add_speaker_f32(float* x, const float* table, int64_t ld_table, int32_t speakers, const int64_t* speaker,
+                                        int32_t id_stride, int32_t B, int32_t L, int32_t D, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && table && speaker, ISPK_E_NULL, "add_speaker: null pointer");
+    ISPK_REQUIRE(B >= 0 && L >= 1 && D >= 4 && speakers >= 1 && (id_stride == 0 || id_stride == 1), ISPK_E_SHAPE,
+                 "add_speaker: bad shape B=%d L=%d D=%d speakers=%d id_stride=%d", B, L, D, speakers, id_stride);
+    ISPK_REQUIRE(D % 4 == 0 && ld_table % 4 == 0 && ld_table >= D && ispk_aligned(table, 16) && ispk_aligned(x, 16),
+                 ISPK_E_ALIGN, "add_speaker: D / ld_table must be multiples of 4 and table / x 16-byte aligned");
+    if (B == 0) return 0;
+    const int rows = B * L;
+    hipLaunchKernelGGL(add_speaker_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, table,
+                       ld_table, speakers, speaker, id_stride, rows, L, D);
     return ispk_launch_status();
 }
 

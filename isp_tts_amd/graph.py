@@ -73,8 +73,9 @@ class GraphedForward(GraphedCall):
 
     def _run(self):
         s = self.static
-        return self.model(s["text"], s["text_len"], s["mel"], s["mel_len"], s["pitch"], s["energy"],
-                          flow_noise=s["flow_noise"], flow_time=s["flow_time"])
+        with torch.no_grad():      # (a replayed forward has no tape; with gradients enabled `model(...)` is the training forward)
+            return self.model(s["text"], s["text_len"], s["mel"], s["mel_len"], s["pitch"], s["energy"],
+                              flow_noise=s["flow_noise"], flow_time=s["flow_time"])
 
     def __call__(self, **inputs: Tensor):
         for k, v in inputs.items():

@@ -71,6 +71,7 @@ SIGNATURES = {
     "ispk_flow_euler_f32": [_P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
     "ispk_infer_features_f32": [_P, _P, _P, _P, _P, _F32, _F32, _F32, _F32, _F32, _P, _P, _I32, _I32, _P],
     "ispk_embed_tokens_f32": [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_add_speaker_f32": [_P, _P, _I64, _I32, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_time_embedding_f32": [_P, _I32, _P, _P, _I32, _P, _P, _P, _P, _I32, _P, _P],
     "ispk_length_regulate_f32": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "ispk_length_regulate_split_bf16": [_P, _P, _P, _P, _P, _I64, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
@@ -868,6 +869,27 @@ def embed_tokens(text: Tensor, table: Tensor, text_len: Optional[Tensor] = None,
     return emb, mask
 
 
+def add_speaker_(x: Tensor, table: Tensor, speaker: Tensor) -> Tensor:
+    """ispk_add_speaker_f32: x [B, L, D] += table[speaker] in place, broadcast over L the way the reference's
+    `enc_out + self.speaker_embedding(speaker)` broadcasts (model.py:205-207): `speaker` int64 [B, 1] (the collator's field,
+    collator.py:59) = one id per utterance, or one element = one id for the whole batch (the notebook's `torch.tensor([id])`)."""
+    _dev(x, table, speaker)
+    assert x.dtype == torch.float32 and x.ndim == 3 and x.is_contiguous() and table.dtype == torch.float32 and table.stride(1) == 1
+    B, L, D = x.shape
+    assert table.shape[1] == D and speaker.dtype == torch.int64
+    if speaker.numel() == 1:
+        stride = 0
+    elif speaker.ndim == 2 and tuple(speaker.shape) == (B, 1):
+        stride = 1
+    else:
+        raise ValueError(f"speaker of shape {tuple(speaker.shape)} does not broadcast against enc_out [B={B}, L, D] "
+                         "(the reference takes [B, 1] ids or a single id)")
+    speaker = speaker.contiguous()
+    _launch("add_speaker_kernel", 0.0, 8.0 * B * L * D, lib().ispk_add_speaker_f32, x.data_ptr(), table.data_ptr(), table.stride(0),
+            table.shape[0], speaker.data_ptr(), stride, B, L, D, _stream())
+    return x
+
+
 def time_embedding(t: Tensor, inv_freq: Tensor, freq_scale: Tensor, w0: Tensor, b0: Tensor, w1: Tensor, b1: Tensor) -> Tensor:
     """ispk_time_embedding_f32: t [...] -> [..., emb_dim] (sinusoid with the raw position, Linear, SiLU, Linear)."""
     _dev(t, inv_freq, freq_scale, w0, b0, w1, b1)
@@ -941,11 +963,16 @@ class _Stage(ctypes.Structure):
                 ("ld_dst", ctypes.c_int64), ("flags", ctypes.c_int32)]
 
 
+stage_calls = 0     # how many staging passes have been launched (train/graph.py checks that a capture recorded one)
+
+
 def stage_weights(items) -> None:
     """ispk_stage_weights: items = [(src fp32 contiguous [rows, cols], dst 2-D view with unit column stride (fp32 or bf16),
     transposed: bool, exp: bool)], 16 per launch.  dst is [rows, cols], or [cols, rows] when transposed."""
+    global stage_calls
     if not items:
         return
+    stage_calls += 1
     arr = (_Stage * len(items))()
     nbytes = 0.0
     for k, (src, dst, tr, ex) in enumerate(items):
@@ -996,12 +1023,22 @@ def deliver_grads(pairs) -> list:
     is a buffer of an optimizer arena (`FlatParameters` marks it `_ispk_grad_arena`) is written - or added, if something has
     been delivered since the arena was zeroed - into it by ONE segments launch for the whole list, and autograd gets None:
     no AccumulateGrad add per parameter."""
-    out, items = [], []
+    out, items, seen = [], [], set()
     for p, g in pairs:
+        if g is not None and not p.requires_grad:
+            # frozen AFTER the arena was built (model.freeze(), row f3): autograd would have dropped this gradient - so do we,
+            # instead of writing it into the arena where AdamW would apply it
+            out.append(None)
+            continue
         buf = p.grad if g is not None else None
         if buf is not None and getattr(buf, "_ispk_grad_arena", False) and g.is_cuda:
             g = g.detach()
             g = g if g.dtype == torch.float32 and g.is_contiguous() else g.float().contiguous()
+            if buf.data_ptr() in seen:
+                # the same parameter twice in one call: two segments of ONE launch writing one buffer would race - flush first
+                segments(items)
+                items, seen = [], set()
+            seen.add(buf.data_ptr())
             items.append((g, buf, SEG_ADD if getattr(buf, "_ispk_dirty", False) else SEG_COPY))
             buf._ispk_dirty = True
             out.append(None)
@@ -1116,6 +1153,11 @@ def transpose(x: Tensor) -> Tensor:
 
 _TN_WORKSPACE_FLOATS = 48 << 20     # 192 MB: up to 64+ row ranges of the largest weight (1536 x 384)
 _workspaces: dict = {}
+
+
+def drop_workspace(key) -> None:
+    """Forget the scratch buffer of one (device index, stream) - a HIP graph's capture stream when the graph is destroyed."""
+    _workspaces.pop(key, None)
 
 
 def workspace(device, floats: int) -> Tensor:
@@ -1568,8 +1610,8 @@ def grad_sqnorm(g: Tensor, out: Optional[Tensor] = None) -> Tensor:
 
 def set_seed_source(word: Optional[Tensor]) -> None:
     """ispk_set_dropout_seed_source: while set (a one-element int64 DEVICE tensor the caller keeps alive), every dropout kernel
-    launched from this thread folds that word into its seed when it runs - what lets a captured training step draw fresh
-    masks on every replay.  None switches it off."""
+    launched by this process - from the calling thread or from autograd's backward worker - folds that word into its seed
+    when it runs: what lets a captured training step draw fresh masks on every replay.  None switches it off."""
     if word is not None:
         _dev(word)
         assert word.dtype == torch.int64 and word.numel() == 1

@@ -138,6 +138,12 @@ def make_state_dict(dims: AcousticDims = AcousticDims(), seed: int = SEED) -> di
     return sd
 
 
+def make_speaker_table(num_speakers: int, dims: AcousticDims = AcousticDims(), seed: int = SEED) -> torch.Tensor:
+    """`speaker_embedding.weight` [num_speakers, encoder dim] of a multi-speaker model (model.py:93-97), O(0.3) entries so that
+    the speaker shift is visible against the O(1) encoder output."""
+    return _normal("speaker_embedding.weight", (num_speakers, dims.text_dim), 0.3, seed=seed).contiguous()
+
+
 def make_lengths(batch: int, text_max: int, mel_max: int, variable: bool, seed: int = SEED):
     """Fixed-length batches (BASELINE configs 2-3) or the variable-length rule of config 4:
     mel_len ~ U{mel_max/8 .. mel_max}, text_len = clamp(round(mel_len / 5.12), 25, text_max) <= mel_len.

@@ -39,9 +39,8 @@ class GraphedTrainStep:
         self.fresh_noise = "flow_x0" not in batch           # (no noise given: the caller wants new noise per step)
         self.seed_dev = torch.zeros(1, dtype=torch.int64, device=dev)
         self.args_dev = torch.zeros(10, dtype=torch.float32, device=dev)
-        opt.check_finite = False                            # (the finiteness check is a host read of the norm)
-        opt.args_dev = self.args_dev
-        runtime.set_seed_source(self.seed_dev)
+        self.graph = None
+        runtime.set_seed_source(self.seed_dev)              # (process-wide: autograd's backward thread sees it too)
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -57,9 +56,16 @@ class GraphedTrainStep:
             gc.disable()
             try:
                 self._push()
+                # Every weight image must be REBUILT inside the capture: a cache hit (no warm-up step, or an eager forward
+                # since the last optimizer step) would record no staging launch and every replay would read capture-time weights.
+                opt.flat.mark_updated()
+                staged = runtime.stage_calls
                 torch.cuda.synchronize()
+                self._capture_stream_key = None
                 with torch.cuda.graph(self.graph):
+                    self._capture_stream_key = (dev.index or 0, torch.cuda.current_stream(dev).cuda_stream)
                     self.out = self._body()
+                assert runtime.stage_calls > staged, "the captured step re-staged no weight image: replays would train on stale weights"
             finally:
                 if gc_was_on:
                     gc.enable()
@@ -67,12 +73,31 @@ class GraphedTrainStep:
         finally:
             runtime.set_seed_source(None)
 
+    def close(self) -> None:
+        """Forget the graph and what the module-global caches still hold of its private pool (weight images staged during the
+        capture, the capture stream's workspace), so that the pool's memory can be returned."""
+        self.graph, self.out = None, None
+        for m in self.model.modules():
+            m.__dict__.pop("_train_images", None)
+        if getattr(self, "_capture_stream_key", None) is not None:
+            runtime.drop_workspace(self._capture_stream_key)
+            self._capture_stream_key = None
+        self.opt.flat.mark_updated()
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.close()
+        except Exception:      # (interpreter shutdown)
+            pass
+
     def _body(self):
         s = self.static
         _, total, losses = acoustic_train_forward(self.model, s["text"], s["text_len"], s["mel"], s["mel_len"], s["pitch"], s["energy"],
                                                   flow_noise=s["flow_x0"], flow_time=s["flow_t"], amp=self.amp,
                                                   train_aligner=self.train_aligner)
-        norm = self.opt.step(total)
+        # (the finiteness check of an eager step is a host read of the norm; the AdamW factors come from the device record)
+        norm = self.opt.step(total, args_dev=self.args_dev, check_finite=False)
         return total, losses, norm
 
     def _push(self) -> None:
@@ -90,6 +115,7 @@ class GraphedTrainStep:
         if self.fresh_noise and "flow_x0" not in batch:
             self.static["flow_x0"].normal_()
             self.static["flow_t"].uniform_()
+        assert self.graph is not None, "GraphedTrainStep was closed"
         self._push()
         self.graph.replay()
         self.opt.step_count += 1

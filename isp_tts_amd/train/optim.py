@@ -132,12 +132,16 @@ class FlatAdamW:
         self._update = update or runtime.adamw          # (hooks: the CPU gloo test drives the exchange with the oracle's math)
         self._sqnorm = sqnorm or runtime.grad_sqnorm
         self._one = None
-        self.args_dev = None          # a captured step (train/graph.py): the AdamW factors are read from this device record
+        self._frozen: dict = {}       # arena index -> (parameter copy, exp_avg copy, exp_avg_sq copy) of tensors frozen after the build
         self.check_finite = True      # `step` returns None for a non-finite norm like the reference (:238-239): one host sync
         self._reduce_scatter = self.world > 1 and dist.get_backend(process_group) != "gloo"   # gloo has none
 
     # ------------------------------------------------------------------------------------------------------------ step
-    def step(self, loss_value: Optional[Tensor] = None, step_optimizer: bool = True):
+    def step(self, loss_value: Optional[Tensor] = None, step_optimizer: bool = True, *, args_dev: Optional[Tensor] = None,
+             check_finite: Optional[bool] = None):
+        """`args_dev` / `check_finite` are per CALL (a captured step, train/graph.py, passes the device record the AdamW factors
+        are read from and skips the host read of the norm); the optimizer object itself never changes mode."""
+        check_finite = self.check_finite if check_finite is None else check_finite
         if loss_value is not None:
             if self.grad_accum_steps == 1 and loss_value.is_cuda and loss_value.dtype == torch.float32:
                 if self._one is None or self._one.device != loss_value.device:
@@ -159,6 +163,7 @@ class FlatAdamW:
             n_dec = min(max(n_dec - self.lo, 0), self.shard)
         else:
             g = flat.grad
+        frozen = self._hold_frozen()
         clip = self.grad_clip is not None
         if clip:
             if n_dec > 0:
@@ -167,8 +172,8 @@ class FlatAdamW:
                 self.sq.zero_()
             if self.world > 1:
                 dist.all_reduce(self.sq, op=dist.ReduceOp.SUM, group=self.group)
-        if self.args_dev is not None:
-            runtime.adamw_dev(flat.data[self.lo:self.lo + self.shard], g, self.exp_avg, self.exp_avg_sq, n_dec, self.args_dev,
+        if args_dev is not None:
+            runtime.adamw_dev(flat.data[self.lo:self.lo + self.shard], g, self.exp_avg, self.exp_avg_sq, n_dec, args_dev,
                               self.sq if clip else None)
         else:
             self._update(flat.data[self.lo:self.lo + self.shard], g, self.exp_avg, self.exp_avg_sq, n_dec, self.lr, self.betas,
@@ -178,16 +183,59 @@ class FlatAdamW:
             # (from a copy of the slice: input and output of the collective do not alias)
             self.param_shard.copy_(flat.data[self.lo:self.lo + self.shard])
             dist.all_gather_into_tensor(flat.data, self.param_shard, group=self.group)
+        if frozen:
+            self._restore_frozen(frozen)
         flat.mark_updated()
         flat.zero_grad()
         if not clip:
             return None
         # norm of the averaged gradients
         norm = runtime.sqrt_scale(self.sq, 1.0 / self.world) if self.sq.is_cuda else self.sq.sqrt() / self.world
-        return norm if not self.check_finite or bool(torch.isfinite(norm)) else None
+        return norm if not check_finite or bool(torch.isfinite(norm)) else None
 
     def zero_grad(self, set_to_none: bool = True) -> None:
         self.flat.zero_grad()
+
+    # ------------------------------------------------- tensors frozen AFTER the arena was built (`model.freeze()`, row f3)
+    def _shard_range(self, i: int):
+        """The part of arena tensor i that lies in this rank's shard, in shard coordinates (None: nothing)."""
+        o, n = self.flat.offsets[i], self.flat.params[i].numel()
+        a, b = max(o, self.lo), min(o + n, self.lo + self.shard)
+        return (a - self.lo, b - self.lo) if a < b else None
+
+    def _hold_frozen(self) -> list:
+        """torch.optim.AdamW skips a tensor whose .grad is None - no decay, no moment update.  A tensor frozen after the arena
+        was built still lies in it (its gradient stays zero: `runtime.deliver_grads` drops what the backward produces), so the
+        flat update would decay it and age its moments: keep a copy from the moment the freeze is seen and put it back after
+        every update.  -> indices of the frozen tensors."""
+        flat = self.flat
+        idx = [i for i, p in enumerate(flat.params) if not p.requires_grad]
+        for i in list(self._frozen):
+            if i not in idx:
+                del self._frozen[i]                      # trainable again
+        for i in idx:
+            if i not in self._frozen:
+                o, n = flat.offsets[i], flat.params[i].numel()
+                r = self._shard_range(i)
+                self._frozen[i] = (flat.data[o:o + n].clone(),
+                                   None if r is None else self.exp_avg[r[0]:r[1]].clone(),
+                                   None if r is None else self.exp_avg_sq[r[0]:r[1]].clone())
+        return idx
+
+    def _restore_frozen(self, idx: list) -> None:
+        flat, items = self.flat, []
+        for i in idx:
+            o, n = flat.offsets[i], flat.params[i].numel()
+            pc, mc, vc = self._frozen[i]
+            items.append((pc, flat.data[o:o + n], runtime.SEG_COPY))
+            r = self._shard_range(i)
+            if r is not None:
+                items += [(mc, self.exp_avg[r[0]:r[1]], runtime.SEG_COPY), (vc, self.exp_avg_sq[r[0]:r[1]], runtime.SEG_COPY)]
+        if flat.data.is_cuda:
+            runtime.segments(items)
+        else:
+            for src, dst, _ in items:
+                dst.copy_(src)
 
     # ------------------------------------------------------------------------------------------------- lr schedule
     def anneal_on_epoch_end(self, *args) -> None:

@@ -124,17 +124,21 @@ class SmallOutputLinearFunction(torch.autograd.Function):
 
 
 class FlowLossFunction(torch.autograd.Function):
-    """The flow-matching loss of temporal_adaptor.py:145-146 on the predictor's raw output (value from `runtime.flow_finish`)."""
+    """The flow-matching loss of temporal_adaptor.py:145-146 on the predictor's raw output (value from `runtime.flow_finish`);
+    also hands out the kernel's other two results - x_pred = (x0 + pred_flow) * mask (:150, a no-grad value in the reference) and
+    the duration estimate clamp(exp(x_pred[..., 0]) - 1, 0) - as non-differentiable outputs."""
 
     @staticmethod
     def forward(ctx, raw: Tensor, flow: Tensor, x0: Tensor, mask: Tensor):
         raw = raw.float().contiguous()
-        _, _, _, loss = runtime.flow_finish(raw, flow, x0, mask)
+        pred, dur, _, loss = runtime.flow_finish(raw, flow, x0, mask)
         ctx.save_for_backward(raw, flow, mask)
-        return loss.reshape(())
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(pred, dur)
+        return loss.reshape(()), pred, dur
 
     @staticmethod
-    def backward(ctx, g: Tensor):
+    def backward(ctx, g: Tensor, _dp=None, _dd=None):
         raw, flow, mask = ctx.saved_tensors
         return runtime.scale_(runtime.flow_loss_bwd(raw, flow, mask), g.reshape(1)), None, None, None
 
@@ -242,10 +246,11 @@ class AdaptiveStackFunction(torch.autograd.Function):
 
 
 def flow_predictor_loss(pred, cond: Tensor, targets: Tensor, mask: Tensor, noise: Tensor, time_steps: Tensor,
-                        amp: bool = False, key_len: Optional[Tensor] = None) -> Tensor:
+                        amp: bool = False, key_len: Optional[Tensor] = None, return_pred: bool = False):
     """The flow loss of `FlowTransformerTemporalModule.forward` (temporal_adaptor.py:105-147) as a differentiable scalar:
     gradients reach every parameter of the predictor `pred` and `cond` (the encoder output; pass it detached for
-    `detach_inputs`).  `targets` [B, L, 3] are constants (:112), `noise` / `time_steps` the step's x0 and t."""
+    `detach_inputs`).  `targets` [B, L, 3] are constants (:112), `noise` / `time_steps` the step's x0 and t.
+    `return_pred`: -> (loss, x_pred [B, L, 3], duration estimate [B, L]) - the module's other (no-grad) outputs (:148-152)."""
     tr = pred.transformer
     if mask.ndim == 3:
         mask = mask[..., 0]
@@ -257,4 +262,5 @@ def flow_predictor_loss(pred, cond: Tensor, targets: Tensor, mask: Tensor, noise
     proj = ProjectSplitFunction.apply(x_t, cond, tr.project_emb.weight, tr.project_emb.bias)
     out = AdaptiveStackFunction.apply(tr, proj, mask, amp, ss, key_len, *adaptive_stack_parameters(tr))
     raw = SmallOutputLinearFunction.apply(out, pred.linear_layer.weight, pred.linear_layer.bias)
-    return FlowLossFunction.apply(raw, flow, noise, mask)
+    loss, x_pred, duration = FlowLossFunction.apply(raw, flow, noise, mask)
+    return (loss, x_pred, duration) if return_pred else loss

@@ -68,6 +68,8 @@ def _deliver(param: Tensor, producer, *args, **kw):
     (`FlatParameters` marks it `_ispk_grad_arena`), the producing kernel writes - or adds, if something has been delivered
     since the arena was zeroed - straight into it and autograd is handed None: no AccumulateGrad launch per parameter
     (206 element-wise ATen adds per step otherwise).  Else the gradient is returned for autograd to place."""
+    if not param.requires_grad:       # frozen after the arena was built: no gradient, and nothing written behind autograd's back
+        return None
     g = param.grad
     if g is not None and getattr(g, "_ispk_grad_arena", False) and producer is runtime.gemm_tn:
         runtime.gemm_tn(*args, out=g, accumulate=getattr(g, "_ispk_dirty", False), **kw)

@@ -262,6 +262,47 @@ def gen_infer(model, sd):
     np.savez_compressed(os.path.join(OUT, "infer.npz"), **out)
 
 
+def gen_infer_speakers(sd):
+    """A 4-speaker model (model.py:93-97): the reference's `infer` with `speaker` ids (:205-207) - a batch of 2 with the
+    collator's [B, 1] field, and one utterance with the notebook's `torch.tensor([id])`.  (The reference's `forward` cannot
+    run such a model: it reads a `speaker_encoder` attribute that does not exist, :145-146.)"""
+    print("infer(steps=4), 4 speakers")
+    dims = AcousticDims()
+    model = AcousticModel.init(DictConfig(dict(dims.model_config(), num_speakers=4))).eval()
+    sd4 = dict(sd)
+    sd4["speaker_embedding.weight"] = synth.make_speaker_table(4, dims)
+    assert set(model.state_dict()) == set(sd4)
+    model.load_state_dict(sd4, strict=True)
+    inp = synth.make_inputs(2, 100, 512)
+    text_len = torch.tensor([100, 73])
+    text = inp["text"] * (torch.arange(100)[None] < text_len[:, None])
+    dur = torch.zeros(2, 100, dtype=torch.int64)
+    for b, (l, m) in enumerate(((100, 512), (73, 390))):
+        base = m // l
+        dur[b, :l] = base
+        dur[b, : m - base * l] += 1
+    x_t = inp["flow_x0"]
+    out = {}
+    speaker = torch.tensor([[3], [1]])
+    with _Noise(x_t):
+        mel_ref, ao = model.infer(text, text_lengths=text_len, duration_target=dur.clone(), steps=4, speaker=speaker)
+    mel_mine, ad = orc.acoustic_infer(sd4, text, text_len, dur, x_t, 4, speaker=speaker)
+    report("infer.mel (B=2, speakers 3, 1)", mel_ref, mel_mine)
+    report("infer.pitch", ao.pitch, ad.pitch)
+    with _Noise(x_t):
+        mel_plain, _ = model.infer(text, text_lengths=text_len, duration_target=dur.clone(), steps=4)
+    print(f"  the speaker rows move the mel by {float((mel_ref - mel_plain).abs().max()):.3f} (max)")
+    out.update(b2_speaker=speaker.numpy(), b2_text_len=text_len.numpy(), b2_dur=dur.numpy(), b2_mel=mel_ref.numpy(),
+               b2_pitch=ao.pitch.numpy(), b2_energy=ao.energy.numpy(), b2_dec_lengths=ao.dec_lengths.numpy())
+    one = torch.tensor([2])
+    with _Noise(x_t[:1]):
+        mel_ref, ao = model.infer(text[:1], duration_target=dur[:1].clone(), steps=4, speaker=one)
+    mel_mine, ad = orc.acoustic_infer(sd4, text[:1], None, dur[:1], x_t[:1], 4, speaker=one)
+    report("infer.mel (B=1, speaker 2)", mel_ref, mel_mine)
+    out.update(b1_speaker=one.numpy(), b1_mel=mel_ref.numpy(), b1_pitch=ao.pitch.numpy())
+    np.savez_compressed(os.path.join(OUT, "infer_speakers.npz"), **out)
+
+
 # --------------------------------------------------------------------------------------------- training step (row f2)
 def _sample(t: torch.Tensor, n: int = 192) -> np.ndarray:
     """A strided sample of a tensor's flattened values: first element, then every ceil(numel / n)-th."""
@@ -379,6 +420,7 @@ if __name__ == "__main__":
     gen_ops(model, sd)
     gen_forward(model, sd)
     gen_infer(model, sd)
+    gen_infer_speakers(sd)
     gen_train(sd)
     for f in sorted(os.listdir(OUT)):
         print(f"{f:28s} {os.path.getsize(os.path.join(OUT, f)) / 1e6:.2f} MB")

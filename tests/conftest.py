@@ -48,4 +48,6 @@ def gpu_model(state_dict):
     assert torch.cuda.is_available(), "gpu tests need a GPU"
     model = AcousticModel.init(AcousticDims().model_config()).eval()
     model.load_state_dict(state_dict, strict=True)
-    return model.to("cuda")
+    # frozen: the inference kernels.  (With trainable parameters and gradients enabled `model(...)` is the training forward -
+    # tests/test_gpu_train.py builds its own models for that.)
+    return model.to("cuda").requires_grad_(False)

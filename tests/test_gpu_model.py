@@ -129,6 +129,41 @@ def test_infer_against_reference_golden(gpu_model):
     assert _maxdiff(melp, g["b2p_mel"]) < 5e-4       # soft path is continuous in the (fp32-noisy) predicted durations
 
 
+def test_multi_speaker_infer_against_reference_golden(state_dict):
+    """Row f3: a multi-speaker model (model.py:93-97; the authors' published checkpoint has 1,307 speakers) through `infer` with
+    speaker ids (:205-207) against outputs of the reference itself (tests/golden/infer_speakers.npz): the collator's [B, 1]
+    field and a single id; fp32, split-fp16 (1e-4) and bf16 (its stated infer bound)."""
+    from isp_tts_amd.acoustic import AcousticModel
+    from isp_tts_amd.config import AcousticDims
+    g = golden("infer_speakers.npz")
+    sd = dict(state_dict)
+    sd["speaker_embedding.weight"] = synth.make_speaker_table(4)
+    model = AcousticModel.init(dict(AcousticDims().model_config(), num_speakers=4)).eval()
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV)
+    inp = synth.make_inputs(2, 100, 512)
+    text_len = torch.tensor(g["b2_text_len"])
+    text = (inp["text"] * (torch.arange(100)[None] < text_len[:, None])).to(DEV)
+    dur = torch.from_numpy(g["b2_dur"]).to(DEV)
+    x_t = inp["flow_x0"].to(DEV)
+    spk2, spk1 = torch.from_numpy(g["b2_speaker"]).to(DEV), torch.from_numpy(g["b1_speaker"]).to(DEV)
+    for dtype, tol in ((torch.float32, MEL_TOL), (torch.float16, MEL_TOL), (torch.bfloat16, 2e-1)):
+        model.set_compute_dtype(dtype)
+        mel, ao = model.infer(text, text_lengths=text_len.to(DEV), duration_target=dur, steps=4, flow_noise=x_t, speaker=spk2)
+        assert _maxdiff(mel, g["b2_mel"]) < tol, dtype
+        assert _maxdiff(ao.pitch, g["b2_pitch"]) < tol and _maxdiff(ao.energy, g["b2_energy"]) < tol
+        assert np.array_equal(ao.dec_lengths.cpu().numpy(), g["b2_dec_lengths"])
+        mel1, _ = model.infer(text[:1], duration_target=dur[:1], steps=4, flow_noise=x_t[:1], speaker=spk1)
+        assert _maxdiff(mel1, g["b1_mel"]) < tol, dtype
+    model.set_compute_dtype(torch.float32)
+    plain, _ = model.infer(text, text_lengths=text_len.to(DEV), duration_target=dur, steps=4, flow_noise=x_t)     # speaker=None: no add
+    assert _maxdiff(plain, g["b2_mel"]) > 0.1
+    with pytest.raises(ValueError):      # [B] ids with B > 1 do not broadcast in the reference either
+        model.infer(text, text_lengths=text_len.to(DEV), duration_target=dur, steps=4, flow_noise=x_t, speaker=torch.tensor([3, 1], device=DEV))
+    with pytest.raises(AttributeError, match="speaker_encoder"):   # model.py:145-146
+        model(text, text_len.to(DEV), inp["mel"].to(DEV), inp["mel_len"].to(DEV), inp["pitch"].to(DEV), inp["energy"].to(DEV), speaker=spk2)
+
+
 def test_forward_matches_oracle_on_other_inputs(gpu_model, state_dict):
     """Different seed, B=3 variable lengths (not in the fixtures): HIP path vs the oracle."""
     inp = synth.make_inputs(3, 60, 200, variable=True, seed=7)

@@ -57,8 +57,19 @@ def test_unsupported_configurations_are_refused_not_approximated():
     with pytest.raises(NotImplementedError):
         TransformerLayer(dim=384, attention={"heads": 6, "one_kv_head": True, "alibi_pos_bias": True},
                          feed_forward={"activation": "gelu"}, pre_norm=False)
-    with pytest.raises(NotImplementedError):
-        AcousticModel.init(dict(AcousticDims().model_config(), num_speakers=4))
+
+
+def test_multi_speaker_model_builds_with_the_reference_key_and_forward_raises_like_the_reference():
+    """model.py:93-97: `num_speakers > 0` adds `speaker_embedding` (an nn.Embedding(num_speakers, encoder.dim), xavier-uniform);
+    :145-146: the reference's `forward` then reads a `speaker_encoder` no AcousticModel has - AttributeError, reproduced; only
+    `infer` (:205-207) serves such a model (GPU test: tests/test_gpu_model.py)."""
+    model = AcousticModel.init(dict(AcousticDims().model_config(), num_speakers=4)).eval()
+    assert tuple(model.state_dict()["speaker_embedding.weight"].shape) == (4, 384)
+    plain = AcousticModel.init(AcousticDims().model_config())
+    assert set(model.state_dict()) - set(plain.state_dict()) == {"speaker_embedding.weight"}
+    inp = synth.make_inputs(1, 16, 32)
+    with pytest.raises(AttributeError, match="speaker_encoder"):
+        model(inp["text"], inp["text_len"], inp["mel"], inp["mel_len"], inp["pitch"], inp["energy"], speaker=torch.zeros(1, 1, dtype=torch.long))
 
 
 def test_no_cpu_fallback_and_no_oracle_in_the_product():

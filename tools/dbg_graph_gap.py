@@ -3,6 +3,8 @@ replays come from?  Prints ms per STEP (one forward of one batch) for each varia
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+
+torch.set_grad_enabled(False)
 from isp_tts_amd import synth
 from isp_tts_amd.acoustic import AcousticModel
 from isp_tts_amd.config import AcousticDims

@@ -216,7 +216,8 @@ def test_linear_small(M, N, K):
 
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,N,H,lens", [(2, 100, 6, [100, 73]), (2, 512, 6, [512, 390]), (3, 37, 4, [37, 1, 20]),
-                                        (2, 64, 6, None), (1, 129, 8, [65]), (2, 1000, 6, [1000, 333])])
+                                        (2, 64, 6, None), (1, 129, 8, [65]), (2, 1000, 6, [1000, 333]),
+                                        (2, 1723, 6, [1723, 911])])      # 1,723 frames: the recipes' data bound (core.yaml:33-47)
 def test_attention_matches_reference_algorithm(B, N, H, lens):
     """Kernel vs the oracle's `attend` (materialised bias + masked_fill(min/2) + SDPA, attend.py:49-122)."""
     q = synth._normal(f"t/at/q{N}", (B, N, H * 64))
@@ -328,7 +329,7 @@ def test_gemm_bf16_epilogues(K):
 
 @pytest.mark.parametrize("B,N,H,lens", [(2, 100, 6, [100, 73]), (2, 512, 6, [512, 390]), (3, 37, 4, [37, 1, 20]),
                                         (2, 64, 6, None), (1, 129, 8, [65]), (2, 700, 6, [700, 531]), (1, 1100, 4, None),
-                                        (2, 300, 2, [300, 129]), (1, 200, 1, None)])
+                                        (2, 300, 2, [300, 129]), (1, 200, 1, None), (2, 1723, 6, [1723, 911])])
 def test_attention_bf16(B, N, H, lens):
     """bf16 Q/K/V and bf16 P (8 mantissa bits), fp32 statistics: compared with float64 attention on the same
     bf16-rounded inputs.  Bar: 1.5e-2 absolute on O(1) outputs (P quantisation 2^-9 relative per weight)."""

@@ -47,6 +47,29 @@ def test_ops_against_reference_goldens(gpu_model, tag, n):
     assert _maxdiff(stack(xd).out[:, ::step], g[f"{tag}_transformer_nomask"]) < OP_TOL
 
 
+def test_decoder_stack_at_the_data_bound_of_1723_frames(gpu_model, state_dict):
+    """The recipes admit utterances up to 1,723 mel frames (recipes/acoustic/core.yaml:33-47): the MelDecoder
+    stack (6 layers, ALiBi distances up to 1,722) on B = 2 ragged rows at that length against the oracle's `transformer` - the
+    exact-fp32 and split-fp16 paths to the per-op bar scaled by the output's size, the bf16 path to its stated bound."""
+    n, lens = 1723, torch.tensor([1723, 1289])
+    x = synth._normal("t/stack1723/x", (2, n, 384))
+    mask = torch.arange(n)[None] < lens[:, None]
+    ref = orc.transformer(state_dict, "decoder", x, mask)
+    scale = float(ref.abs().max())
+    xd, md, ld = x.to(DEV), mask.to(DEV), lens.to(DEV)
+    dec = gpu_model.decoder
+    try:
+        for dtype, tol in ((torch.float32, OP_TOL), (torch.float16, OP_TOL), (torch.bfloat16, 6e-2)):
+            dec.set_compute_dtype(dtype)
+            out = dec(xd, mask=md, key_len=ld).out
+            err = _maxdiff(out, ref)
+            print(f"decoder stack at 1723 frames, {dtype}: L-inf {err:.2e} (|out| <= {scale:.1f})")
+            assert err < tol * max(1.0, scale), (dtype, err)
+            assert float(out[1, 1289:].abs().max()) == 0.0          # padded rows are exactly zero
+    finally:
+        dec.set_compute_dtype(torch.float32)
+
+
 def test_adaptive_norm_stack_against_reference_goldens(gpu_model):
     g = golden("ops.npz")
     n, lens = 100, torch.tensor(g["ada_lens"])

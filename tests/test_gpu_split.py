@@ -121,7 +121,7 @@ def test_layernorm_split_output(D):
 
 
 @pytest.mark.parametrize("B,N,H,ragged", [(2, 100, 6, True), (3, 512, 6, True), (2, 77, 4, False), (1, 1000, 6, False),
-                                         (2, 130, 2, True), (2, 64, 1, False), (2, 200, 8, True)])
+                                         (2, 130, 2, True), (2, 64, 1, False), (2, 200, 8, True), (2, 1723, 6, True)])
 def test_attention_split_against_the_oracle_and_float64(B, N, H, ragged):
     qkv = synth._normal(f"split/attn/{B}/{N}/{H}", (B, N, H * 64 + 128), 1.5)
     slopes = torch.tensor(synth.alibi_default_slopes(H))

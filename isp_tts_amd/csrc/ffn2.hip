@@ -42,6 +42,7 @@ constexpr int kW1Src = kHC * kD * 2;             // 24,576: W1 chunk [32 hidden]
 constexpr int kW2Bytes = kD * kHC * 2;           // 24,576: W2 chunk [384 features][32 hidden] bf16 (24 DMA instructions)
 constexpr int kWbuf = kW1Bytes + kW2Bytes;       // 50,176 per buffer, two buffers
 constexpr int kDmaPerWave = 7;                   // 49 instructions per group over 8 waves: wave w issues q = w, w + 8, ...
+constexpr int kDmaMax = 10;                      // (uneven distributions: up to this many per wave)
 constexpr int kPOff = 2 * kWbuf;                 // P tiles  [2][4 row groups][32 rows][64 B]
 constexpr int kXcOff = kPOff + 2 * 4 * 2048;     // exchange [2][8 waves][2 planes][64 lanes][16 B]
 constexpr int kLds = kXcOff + 2 * 8 * 2048;      // 149,504 B
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // experiment switches (ABL 6 .. 9, 12): MFMA stages WITHOUT raised priority; tanh-form GELU; the DMA group issued by half 0 only
     // (matrix stages at raised priority: adopted - 102.8 -> 101.7 us, same results; ABL 6 = the kernel without it)
-    constexpr bool kPrio = ABL != 6, kTanh = ABL == 7 || ABL == 9, kDmaHalf0 = ABL == 8 || ABL == 9 || ABL == 12;
+    constexpr bool kPrio = ABL != 6 && ABL != 16 && ABL != 17, kStaticPrio = ABL == 16 || ABL == 17, kTanh = ABL == 7 || ABL == 9, kDmaHalf0 = ABL == 8 || ABL == 9 || ABL == 12;
     [[maybe_unused]] unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     [[maybe_unused]] unsigned long long t_prev = 0, t_first = 0;
     auto stamp = [&](int slot) __attribute__((always_inline)) {
@@ -190,10 +191,27 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     // ---- this lane's part of the wave's DMA instructions (q = wave + 8 j of the group's 49): byte offset inside the chunk
     // in memory.  q < 25: the padded W1 image - 16-byte slot t = 64 q + lane is (row t / 49, piece t % 49), piece 48 and rows
     // past 31 are padding; q >= 25: the W2 image, slot -> (row, piece ^ ((row >> 2) & 3)).
-    uint32_t soff[kDmaPerWave];
+    // Distribution of the 49 instructions over the waves.  Even: q = wave + 8 j (6 each, wave 0 a seventh).  Uneven (kH0 per
+    // half-0 wave, the rest to half 1): the two halves run the stages in different orders and half 1 - the younger wave of
+    // each SIMD, which loses every issue arbitration - is the one the barrier waits for; a DMA instruction costs its issuer
+    // 70 - 115 cycles, so half 0 takes more of them.
+    constexpr int kH0 = (ABL == 13 || ABL == 17) ? 8 : ABL == 14 ? 9 : ABL == 15 ? 10 : 0;        // 0 = even
+    constexpr int kH1 = kH0 ? (48 - 4 * kH0) / 4 : 0;                              // 8 -> 4, 9 -> 3, 10 -> 2  (+ q = 48: wave 0)
+    constexpr int kPerWave = kH0 ? kH0 + 1 : kDmaPerWave;
+    auto q_of = [&](int j) __attribute__((always_inline)) -> int {                 // instruction j of this wave; -1 = none
+        if constexpr (kH0 == 0) {
+            const int q = wave + 8 * j;
+            return q < kW1Dma + 24 ? q : -1;
+        } else {
+            if (half == 0) return j < kH0 ? wave + 4 * j : (j == kH0 && wave == 0 ? 48 : -1);
+            return j < kH1 ? 4 * kH0 + (wave - 4) + 4 * j : -1;
+        }
+    };
+    uint32_t soff[kPerWave];
 #pragma unroll
-    for (int j = 0; j < kDmaPerWave; ++j) {
-        const uint32_t q = wave + 8 * j;
+    for (int j = 0; j < kPerWave; ++j) {
+        const int qq = q_of(j);
+        const uint32_t q = qq < 0 ? 0u : (uint32_t)qq;
         if (q < (uint32_t)kW1Dma) {
             const uint32_t t = 64u * q + lane;
             uint32_t r = t / 49u, c = t - r * 49u;
@@ -218,19 +236,21 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     auto dma_begin = [&](int c1, int c2, int buf) __attribute__((always_inline)) {
         dma_o1 = (int64_t)c1 * kW1Src;
         dma_o2 = (int64_t)c2 * kW2Bytes;
-        dma_base = smem + buf * kWbuf + wave * 1024;
+        dma_base = smem + buf * kWbuf;
     };
     auto dma_one = [&](auto jc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value;
-        const int q = wave + 8 * j;               // wave-uniform
-        if (j == kDmaPerWave - 1 && q >= kW1Dma + 24) return;            // only wave 0 has a seventh instruction
-        const char* src = (q < kW1Dma ? W1b + dma_o1 : W2b + dma_o2) + soff[j];
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dma_base + j * 8192), 16, 0, 0);
+        if constexpr (j < kPerWave) {
+            const int q = q_of(j);                    // wave-uniform
+            if (q < 0) return;
+            const char* src = (q < kW1Dma ? W1b + dma_o1 : W2b + dma_o2) + soff[j];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(dma_base + q * 1024), 16, 0, 0);
+        }
     };
     auto issue = [&](int c1, int c2, int buf) __attribute__((always_inline)) {     // a whole group at once
         dma_begin(c1, c2, buf);
-        static_for<0, kDmaPerWave>([&](auto jc) { dma_one(jc); });
+        static_for<0, kPerWave>([&](auto jc) { dma_one(jc); });
     };
     issue(0, 0, 0);   // W1 chunk 0 -> buffer 0 (and a W2 chunk nobody reads), on its way during the LayerNorm (the tile below
                       // does not touch buffer 0)
@@ -457,11 +477,11 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             if (ABL != 5) {        // the whole group right behind the barrier (ABL == 5, experiment: one instruction at a time
                                    // from inside the matrix stages - measured no faster, and hipcc then drops the vmcnt(0)
                                    // in front of the barrier: racy without the explicit wait below)
-                if (dma) static_for<0, kDmaPerWave>([&](auto jc) { dma_one(jc); });
+                if (dma) static_for<0, kPerWave>([&](auto jc) { dma_one(jc); });
                 dma = false;
             }
             if (dma && !p1) static_for<0, 3>([&](auto jc) { dma_one(jc); });
-            if (dma && !p2) static_for<3, kDmaPerWave>([&](auto jc) { dma_one(jc); });
+            if (dma && !p2) static_for<3, kPerWave>([&](auto jc) { dma_one(jc); });
             stamp(2);
             if constexpr (kOrder == 0) {
                 if (p1) prefetch1(it);
@@ -488,8 +508,12 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             }
         }
     };
+    if constexpr (kStaticPrio) {     // experiment: the younger half of every SIMD at raised priority for the whole loop, no per-stage flips
+        if (half == 1) __builtin_amdgcn_s_setprio(1);
+    }
     if (half == 0) main_loop(std::integral_constant<int, 0>{});
     else main_loop(std::integral_constant<int, 1>{});
+    if constexpr (kStaticPrio) __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue: 64 rows per pass through the fp32 tile; then whole rows: + x, mask, statistics, coalesced stores
     const bool mask_acc = p.flags & ISPK_EP_MASK_ACC, mask_out = p.flags & ISPK_EP_MASK_OUT;
@@ -770,6 +794,14 @@ extern "C" int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const flo
             hipLaunchKernelGGL(ffn2_bf16_kernel<12>, grid, dim3(512), kLds, s, p);
             return ispk_launch_status();
         }
+#define ISPK_FFN2_AB(N_)                                                                    \
+        if (atoi(e) == N_) {                                                                \
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<N_>), kLds, "ffn_prenorm2");               \
+            hipLaunchKernelGGL(ffn2_bf16_kernel<N_>, grid, dim3(512), kLds, s, p);          \
+            return ispk_launch_status();                                                    \
+        }
+        ISPK_FFN2_AB(13) ISPK_FFN2_AB(14) ISPK_FFN2_AB(15) ISPK_FFN2_AB(16) ISPK_FFN2_AB(17)
+#undef ISPK_FFN2_AB
         if (atoi(e) == 5) {
             ISPK_RESERVE_LDS((&ffn2_bf16_kernel<5>), kLds, "ffn_prenorm2");
             hipLaunchKernelGGL(ffn2_bf16_kernel<5>, grid, dim3(512), kLds, s, p);

@@ -25,11 +25,42 @@ def ablated(code):
     return run
 
 
+HAVE3 = runtime.LIB_PATH == build.LIB_EXP      # csrc/ffn3.hip (one wave per SIMD) exists in the experiments build only
+
+
+def ffn_prenorm3(x, g, b, w1, w2p, mask=None, flags=0, want_stats=False):
+    """ispk_ffn_bf16_prenorm3 (experiments build; arguments as ispk_ffn_bf16_prenorm2 with ispk_ffn_pack_w2_bf16's W2 image)."""
+    import ctypes
+    fn = runtime.lib().ispk_ffn_bf16_prenorm3
+    P, I64, I32, U32, F32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32, ctypes.c_float
+    fn.argtypes = [P, I64, P, P, F32, P, P, P, P, I64, I32, I32, I32, U32, P, F32, P]
+    fn.restype = I32
+    out = torch.empty_like(x)
+    stats = torch.empty((x.shape[0], 2), dtype=torch.float32, device=x.device) if want_stats else None
+    rc = fn(x.data_ptr(), x.stride(0), g.data_ptr(), b.data_ptr(), 1e-5, w1.data_ptr(), w2p.data_ptr(),
+            None if mask is None else mask.data_ptr(), out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], w1.shape[0], flags,
+            None if stats is None else stats.data_ptr(), 1e-5, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, runtime.lib().ispk_last_error_string()
+    return (out, stats) if want_stats else out
+
+
+def ablated3(code):
+    def run():
+        os.environ["ISPK_FFN3_ABLATE"] = code
+        ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl, want_stats=True)
+        os.environ.pop("ISPK_FFN3_ABLATE")
+    return run
+
+
 variants = {
     "four-wave (ispk_ffn_bf16_prenorm)": lambda: runtime.ffn_prenorm(x, g, b, w1, w2p, mask=mask, flags=fl, want_stats=True),
     "eight-wave (ispk_ffn_bf16_prenorm2)": lambda: runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True),
 }
-if runtime.LIB_PATH == build.LIB_EXP:
+if HAVE3:
+    variants["single wave per SIMD (ispk_ffn_bf16_prenorm3, experiments build)"] = lambda: ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl, want_stats=True)
+    variants["ffn3, no weight DMA in the main loop (compute only)"] = ablated3("1")
+    variants["ffn3, no GELU work in the gaps"] = ablated3("2")
+if runtime.LIB_PATH == build.LIB_EXP and os.environ.get("FFN2_ABL"):
     variants["eight-wave, no weight DMA after group 1 (compute only)"] = ablated("1")
     variants["eight-wave, DMA + barriers only (no products)"] = ablated("2")
     variants["eight-wave, DMA issued one by one inside the matrix stages"] = ablated("5")
@@ -38,6 +69,11 @@ if runtime.LIB_PATH == build.LIB_EXP:
     variants["eight-wave + DMA issued by half 0 only"] = ablated("8")
     variants["eight-wave + all three"] = ablated("9")
     variants["eight-wave + DMA by half 0 (12)"] = ablated("12")
+    variants["eight-wave, DMA split 8/4 between the halves (13)"] = ablated("13")
+    variants["eight-wave, DMA split 9/3 (14)"] = ablated("14")
+    variants["eight-wave, DMA split 10/2 (15)"] = ablated("15")
+    variants["eight-wave, static prio 1 for half 1, no per-stage setprio (16)"] = ablated("16")
+    variants["eight-wave, static prio + DMA split 8/4 (17)"] = ablated("17")
     variants["eight-wave without the finish stage (no GELU / exchange)"] = ablated("10")
     variants["eight-wave, matrix stages without operand reads"] = ablated("11")
 for f in variants.values():
@@ -60,6 +96,20 @@ for k, v in res.items():
     print(f"{k:40s} median {v[len(v)//2]:7.1f} us  min {v[0]:7.1f} us   {flops / v[len(v)//2] / 1e6:7.1f} TF/s  ({flops / v[len(v)//2] / 1e6 / 2500:.3f} of 2.5 PF)")
 
 if runtime.LIB_PATH == build.LIB_EXP:
+    nwg = (R + 127) // 128
+    dbg3 = torch.zeros((nwg * 4, 5), dtype=torch.int64, device=dev)
+    os.environ["ISPK_FFN3_ABLATE"] = "3"
+    os.environ["ISPK_FFN3_STAMP"] = hex(dbg3.data_ptr())
+    for _ in range(3):
+        ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl, want_stats=True)
+    torch.cuda.synchronize()
+    os.environ.pop("ISPK_FFN3_ABLATE"); os.environ.pop("ISPK_FFN3_STAMP")
+    m = dbg3.cpu().double().median(0).values.tolist()
+    print("ffn3 stamps (cycles per wave, median): " + ", ".join(f"{n} {v:.0f}" for n, v in zip(["prologue", "fill", "main loop", "epilogue", "total"], m)))
+    a3 = ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl)
+    a2 = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl)
+    print(f"ffn3 vs ffn2: max diff {(a3 - a2).abs().max().item():.3e}, rms {(a3 - a2).pow(2).mean().sqrt().item():.3e}; two runs equal = {bool(torch.equal(a3, ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl)))}")
+if runtime.LIB_PATH == build.LIB_EXP and os.environ.get("FFN2_ABL"):
     # in-kernel stamps (s_memtime): where a wave's cycles go
     nwg = (R + 127) // 128
     dbg = torch.zeros((nwg * 8, 8), dtype=torch.int64, device=dev)
@@ -76,7 +126,7 @@ if runtime.LIB_PATH == build.LIB_EXP:
 
     # determinism of each build
     os.environ.pop("ISPK_FFN2_STAMP", None)
-    for code in ("0", "5", "8", "9"):
+    for code in ("0", "5", "8", "9", "13", "14", "15"):
         os.environ["ISPK_FFN2_ABLATE"] = code
         a = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl)
         bb = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl)

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     [[maybe_unused]] unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     [[maybe_unused]] unsigned long long t_prev = 0, t_first = 0;
     auto stamp = [&](int slot) __attribute__((always_inline)) {
-        if constexpr (ABL == 3) {
+        if constexpr (ABL == 3 || ABL == 34) {
             __builtin_amdgcn_sched_barrier(0);
             const unsigned long long t = __builtin_readcyclecounter();
             __builtin_amdgcn_sched_barrier(0);
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     // half-0 wave, the rest to half 1): the two halves run the stages in different orders and half 1 - the younger wave of
     // each SIMD, which loses every issue arbitration - is the one the barrier waits for; a DMA instruction costs its issuer
     // 70 - 115 cycles, so half 0 takes more of them.
-    constexpr int kH0 = (ABL == 13 || ABL == 17) ? 8 : ABL == 14 ? 9 : ABL == 15 ? 10 : 0;        // 0 = even
+    constexpr int kH0 = (ABL == 13 || ABL == 17 || ABL == 30 || ABL == 34) ? 8 : (ABL == 14 || ABL == 32) ? 9 : (ABL == 15 || ABL == 33) ? 10 : 0;        // 0 = even
     constexpr int kH1 = kH0 ? (48 - 4 * kH0) / 4 : 0;                              // 8 -> 4, 9 -> 3, 10 -> 2  (+ q = 48: wave 0)
     constexpr int kPerWave = kH0 ? kH0 + 1 : kDmaPerWave;
     auto q_of = [&](int j) __attribute__((always_inline)) -> int {                 // instruction j of this wave; -1 = none
@@ -508,11 +508,73 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             }
         }
     };
+    // ---- TWO-SLOT schedule (experiment ABL 30 - 33).  The loop above pairs three stages per wave (one vector, two matrix), so one
+    // pairing per iteration is matrix beside matrix and two are a 900-cycle vector stage beside a 384-cycle matrix stage: the
+    // matrix pipe idles under the vector stages.  Here an iteration is two slots, a workgroup barrier in front of each; in a
+    // slot one wave of every SIMD runs BOTH products of its chunk back to back (24 MFMAs) while its partner runs its vector
+    // work (finish of the previous chunk + its share of the DMA group), then they swap:
+    //     slot A(k):  half 1: product 1 (chunk k), product 2 (chunk k-2)      half 0: DMA part of group k+1, finish (chunk k-1)
+    //     slot B(k):  half 0: product 1 (chunk k), product 2 (chunk k-2)      half 1: DMA part of group k+1, finish (chunk k-1)
+    // Hand-offs as before (exchange planes and P tiles by chunk parity, weight buffers by iteration parity), each one slot
+    // boundary or more apart.  Half 1 finishes chunk k-1 AFTER it has started chunk k: its own eight partial sums of k-1 are
+    // carried in a second register set.  Half 0's DMA share has two slots to land, half 1's one: half 1 gets the smaller share.
+    constexpr bool kSlot2 = ABL >= 30 && ABL <= 34;
+    if constexpr (kSlot2) {
+        auto dma_mine = [&]() __attribute__((always_inline)) { static_for<0, kPerWave>([&](auto jc) { dma_one(jc); }); };
+        if (half == 0) {
+#pragma unroll 1
+            for (int k = 0; k <= nchunks + 1; ++k) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of group k (issued in slot A(k-1))
+                __syncthreads();                                        // ---- slot A(k)
+                stamp(1);
+                dma_begin(k + 1 < nchunks ? k + 1 : nchunks - 1, k < 1 ? 0 : (k <= nchunks ? k - 1 : nchunks - 1), (k + 1) & 1);
+                if (k <= nchunks) dma_mine();
+                stamp(2);
+                if (k >= 1 && k <= nchunks) finish(k - 1);
+                stamp(3);
+                __syncthreads();                                        // ---- slot B(k)
+                stamp(1);
+                if (k < nchunks) { prefetch1(k); product1(k, false); }
+                stamp(4);
+                if (k >= 2) { prefetch2(k); product2(k, false); }
+                stamp(5);
+            }
+        } else {
+            float keep_prev[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) keep_prev[i] = 0.f;
+#pragma unroll 1
+            for (int k = 0; k <= nchunks + 1; ++k) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of group k (issued in slot B(k-1))
+                __syncthreads();                                        // ---- slot A(k)
+                stamp(1);
+                if (k < nchunks) { prefetch1(k); product1(k, false); }     // (writes keep[])
+                stamp(4);
+                if (k >= 2) { prefetch2(k); product2(k, false); }
+                stamp(5);
+                __syncthreads();                                        // ---- slot B(k)
+                stamp(1);
+                dma_begin(k + 1 < nchunks ? k + 1 : nchunks - 1, k < 1 ? 0 : (k <= nchunks ? k - 1 : nchunks - 1), (k + 1) & 1);
+                if (k <= nchunks) dma_mine();
+                stamp(2);
+                // finish(k - 1) on the partial sums of chunk k-1: swap them in for the duration of the stage
+                float keep_now[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { keep_now[i] = keep[i]; keep[i] = keep_prev[i]; }
+                if (k >= 1 && k <= nchunks) finish(k - 1);
+                stamp(3);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) keep_prev[i] = keep_now[i];
+            }
+        }
+    } else
     if constexpr (kStaticPrio) {     // experiment: the younger half of every SIMD at raised priority for the whole loop, no per-stage flips
         if (half == 1) __builtin_amdgcn_s_setprio(1);
     }
-    if (half == 0) main_loop(std::integral_constant<int, 0>{});
-    else main_loop(std::integral_constant<int, 1>{});
+    if constexpr (!kSlot2) {
+        if (half == 0) main_loop(std::integral_constant<int, 0>{});
+        else main_loop(std::integral_constant<int, 1>{});
+    }
     if constexpr (kStaticPrio) __builtin_amdgcn_s_setprio(0);
 
     // ---- epilogue: 64 rows per pass through the fp32 tile; then whole rows: + x, mask, statistics, coalesced stores
@@ -585,7 +647,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             }
         }
     }
-    if constexpr (ABL == 3) {
+    if constexpr (ABL == 3 || ABL == 34) {
         stamp(6);
         ts[7] = t_prev - t_first;
         if (lane == 0 && p.stamps) {
@@ -800,7 +862,7 @@ extern "C" int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const flo
             hipLaunchKernelGGL(ffn2_bf16_kernel<N_>, grid, dim3(512), kLds, s, p);          \
             return ispk_launch_status();                                                    \
         }
-        ISPK_FFN2_AB(13) ISPK_FFN2_AB(14) ISPK_FFN2_AB(15) ISPK_FFN2_AB(16) ISPK_FFN2_AB(17)
+        ISPK_FFN2_AB(13) ISPK_FFN2_AB(14) ISPK_FFN2_AB(15) ISPK_FFN2_AB(16) ISPK_FFN2_AB(17) ISPK_FFN2_AB(30) ISPK_FFN2_AB(31) ISPK_FFN2_AB(32) ISPK_FFN2_AB(33)
 #undef ISPK_FFN2_AB
         if (atoi(e) == 5) {
             ISPK_RESERVE_LDS((&ffn2_bf16_kernel<5>), kLds, "ffn_prenorm2");
@@ -812,6 +874,13 @@ extern "C" int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const flo
             p.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 16)) : nullptr;
             ISPK_RESERVE_LDS((&ffn2_bf16_kernel<3>), kLds, "ffn_prenorm2");
             hipLaunchKernelGGL(ffn2_bf16_kernel<3>, grid, dim3(512), kLds, s, p);
+            return ispk_launch_status();
+        }
+        if (atoi(e) == 34) {
+            const char* sp = ispk_knob("ISPK_FFN2_STAMP");
+            p.stamps = sp ? reinterpret_cast<unsigned long long*>(strtoull(sp, nullptr, 16)) : nullptr;
+            ISPK_RESERVE_LDS((&ffn2_bf16_kernel<34>), kLds, "ffn_prenorm2");
+            hipLaunchKernelGGL(ffn2_bf16_kernel<34>, grid, dim3(512), kLds, s, p);
             return ispk_launch_status();
         }
     }

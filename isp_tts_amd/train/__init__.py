@@ -16,15 +16,22 @@
   loss.py    MelLoss (models/acoustic/loss.py:22-35), AttentionCTCLoss (:39-77) and AttentionBinarizationLoss (:80-107), value
              and gradient by kernels.
 
-Not tuned yet: the attention backward and the weight-gradient GEMMs run in fp32, launches are eager.
+  graph.py   GraphedTrainStep: the whole step as ONE HIP graph (dropout seed word and AdamW factors read from device memory).
+
+`AcousticModel.forward` itself returns `acoustic_train_outputs` when gradients are enabled, so the reference's loop body
+(`outputs = model(**inputs)`; `loss, losses = criterion(inputs=, outputs=, step=)`; `optimizer.step(loss)`,
+experiments/trainer.py:543-549) drives these kernels unchanged.  Under bf16 AMP (`amp=True` / torch.autocast) the Linear,
+convolution and attention products - forward, dX and weight gradients - run on bf16 MFMAs with LDS-staged attention kernels
+(csrc/attention_train.hip) and LDS-DMA weight-gradient GEMMs; DESIGN.md section 4.10 has the step's timeline (13.5 ms per
+64 x 512-frame step as a graph).
 """
 from .loss import AcousticModelLoss, AttentionBinarizationLoss, AttentionCTCLoss, MelLoss
-from .model import acoustic_train_forward
+from .model import acoustic_train_forward, acoustic_train_outputs
 from .predictor import flow_predictor_loss
 from .optim import FlatAdamW, FlatParameters, group_weight_decayable_params
 from .stack import (EmbedTokensFunction, LengthRegulateFunction, MaskedLinearResidualFunction, ToMelFunction, TransformerStackFunction, acoustic_mel_train_forward, mel_decoder_train_forward, transformer_train_forward)
 
 from .graph import GraphedTrainStep
 
-__all__ = ["AcousticModelLoss", "GraphedTrainStep", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "acoustic_train_forward", "flow_predictor_loss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
+__all__ = ["AcousticModelLoss", "GraphedTrainStep", "EmbedTokensFunction", "MaskedLinearResidualFunction", "acoustic_mel_train_forward", "acoustic_train_forward", "acoustic_train_outputs", "flow_predictor_loss", "AttentionBinarizationLoss", "AttentionCTCLoss", "FlatAdamW", "FlatParameters", "LengthRegulateFunction", "MelLoss", "ToMelFunction", "TransformerStackFunction",
            "group_weight_decayable_params", "mel_decoder_train_forward", "transformer_train_forward"]

@@ -60,6 +60,11 @@ if HAVE3:
     variants["single wave per SIMD (ispk_ffn_bf16_prenorm3, experiments build)"] = lambda: ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl, want_stats=True)
     variants["ffn3, no weight DMA in the main loop (compute only)"] = ablated3("1")
     variants["ffn3, no GELU work in the gaps"] = ablated3("2")
+if HAVE3:
+    variants["eight-wave, TWO-SLOT schedule, DMA 8/4 (30)"] = ablated("30")
+    variants["eight-wave, two-slot, DMA even (31)"] = ablated("31")
+    variants["eight-wave, two-slot, DMA 9/3 (32)"] = ablated("32")
+    variants["eight-wave, two-slot, DMA 10/2 (33)"] = ablated("33")
 if runtime.LIB_PATH == build.LIB_EXP and os.environ.get("FFN2_ABL"):
     variants["eight-wave, no weight DMA after group 1 (compute only)"] = ablated("1")
     variants["eight-wave, DMA + barriers only (no products)"] = ablated("2")
@@ -106,6 +111,28 @@ if runtime.LIB_PATH == build.LIB_EXP:
     os.environ.pop("ISPK_FFN3_ABLATE"); os.environ.pop("ISPK_FFN3_STAMP")
     m = dbg3.cpu().double().median(0).values.tolist()
     print("ffn3 stamps (cycles per wave, median): " + ", ".join(f"{n} {v:.0f}" for n, v in zip(["prologue", "fill", "main loop", "epilogue", "total"], m)))
+    ref0 = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True)
+    for code in ("30", "31", "32", "33"):
+        os.environ["ISPK_FFN2_ABLATE"] = code
+        got = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True)
+        again = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True)
+        os.environ.pop("ISPK_FFN2_ABLATE")
+        torch.cuda.synchronize()
+        print(f"two-slot ({code}) vs the default schedule: out equal = {bool(torch.equal(got[0], ref0[0]))}, stats equal = {bool(torch.equal(got[1], ref0[1]))}, "
+              f"max diff {(got[0] - ref0[0]).abs().max().item():.3e}; two runs equal = {bool(torch.equal(got[0], again[0]))}")
+    dbg = torch.zeros((nwg * 8, 8), dtype=torch.int64, device=dev)
+    for code in ("3", "34"):
+        os.environ["ISPK_FFN2_ABLATE"] = code
+        os.environ["ISPK_FFN2_STAMP"] = hex(dbg.data_ptr())
+        for _ in range(3):
+            runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True)
+        torch.cuda.synchronize()
+        t = dbg.cpu().double().view(nwg, 8, 8)
+        names = ["prologue", "barrier wait", "DMA issue", "finish(+prefetch1)", "product1", "product2(+prefetch2)", "epilogue", "total"]
+        for half in (0, 1):
+            m = t[:, 4 * half:4 * half + 4].reshape(-1, 8).median(0).values
+            print(f"stamps {'default' if code == '3' else 'two-slot'} half {half}: " + ", ".join(f"{n} {v:.0f}" for n, v in zip(names, m.tolist())))
+    os.environ.pop("ISPK_FFN2_ABLATE"); os.environ.pop("ISPK_FFN2_STAMP")
     a3 = ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl)
     a2 = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl)
     print(f"ffn3 vs ffn2: max diff {(a3 - a2).abs().max().item():.3e}, rms {(a3 - a2).pow(2).mean().sqrt().item():.3e}; two runs equal = {bool(torch.equal(a3, ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl)))}")

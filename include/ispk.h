@@ -139,6 +139,15 @@ int32_t ispk_gemm_bf16_last_variant(void);
 int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
                        const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N,
                        int32_t K, uint32_t flags, int32_t cols_per_batch, int64_t batch_stride, ispk_stream_t stream);
+/* Few rows, long reduction (a rank's share under strong scaling: the text-side stacks at 8 - 16 utterances per GPU): the same
+ * product with K cut into `ksplit` slices that run as separate workgroups into fp32 slabs of `workspace` (ksplit * M * N
+ * floats), then one pass adds the slabs in slice order and applies ispk_gemm_bf16's epilogue.  ispk_gemm_bf16_splitk_plan
+ * returns the ksplit to use for a shape (1: call ispk_gemm_bf16).  Same reference sites as ispk_gemm_bf16
+ * (feedforward.py:36 at K = inner, alignment.py:69-83 convolutions as GEMMs). */
+int32_t ispk_gemm_bf16_splitk_plan(int32_t M, int32_t N, int32_t K, uint32_t flags);
+int32_t ispk_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
+                              const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M, int32_t N,
+                              int32_t K, uint32_t flags, float* workspace, int32_t ksplit, ispk_stream_t stream);
 
 /* The whole feed-forward block in one kernel (bf16 operands, fp32 accumulation):
  *   out[i][:] = [mask[i]] * ( resid[i][:] + gelu_erf( x[i][:]·W1ᵀ + bias1 )·W2ᵀ + bias2 )

@@ -121,6 +121,32 @@ __device__ __forceinline__ void gelu8_bf16_grade(float (&v)[8]) {
     for (int i = 0; i < 8; ++i) v[i] = fmaf(0.5f, v[i], q[i]);
 }
 
+// The same, with a hook after every level (experiment ABL 40: the wave's weight-DMA instructions go out between the levels)
+template <typename Hook>
+__device__ __forceinline__ void gelu8_bf16_grade_hooked(float (&v)[8], Hook&& hook) {
+    const float kRs2 = opaque(0.70710678118654752440f), a4 = opaque(0.078108f), a3 = opaque(0.000972f),
+                a2 = opaque(0.230389f), a1 = opaque(0.278393f);
+    float z[8], q[8];
+#define ISPK_LVL(n_, expr_)                          \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) { expr_; } \
+    __builtin_amdgcn_sched_barrier(0);               \
+    hook(std::integral_constant<int, n_>{});         \
+    __builtin_amdgcn_sched_barrier(0);
+    ISPK_LVL(0, z[i] = fabsf(v[i]) * kRs2)
+    ISPK_LVL(1, q[i] = fmaf(z[i], a4, a3))
+    ISPK_LVL(2, q[i] = fmaf(q[i], z[i], a2))
+    ISPK_LVL(3, q[i] = fmaf(q[i], z[i], a1))
+    ISPK_LVL(4, q[i] = fmaf(q[i], z[i], 1.0f))
+    ISPK_LVL(5, q[i] = q[i] * q[i])
+    ISPK_LVL(6, q[i] = q[i] * q[i])
+    ISPK_LVL(7, q[i] = __builtin_amdgcn_rcpf(q[i]))
+    ISPK_LVL(8, z[i] = 0.5f * fabsf(v[i]))
+    ISPK_LVL(9, q[i] = fmaf(-z[i], q[i], z[i]))
+#undef ISPK_LVL
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = fmaf(0.5f, v[i], q[i]);
+}
+
 // Variant: the tanh form, gelu(x) ~ x / (1 + exp(-2 u)), u = sqrt(2/pi) (x + 0.044715 x^3): 7 instructions per value, two
 // of them transcendental; max |error| vs the erf form about 5e-4 (at |x| ~ 2).
 __device__ __forceinline__ void gelu8_tanh_form(float (&v)[8]) {
@@ -243,6 +269,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
         if constexpr (j < kPerWave) {
             const int q = q_of(j);                    // wave-uniform
             if (q < 0) return;
+            if constexpr (ABL == 36) { if (q >= kW1Dma && dma_o1 > kW1Src) return; }      // experiment: half the bytes
             const char* src = (q < kW1Dma ? W1b + dma_o1 : W2b + dma_o2) + soff[j];
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                              (__attribute__((address_space(3))) void*)(dma_base + q * 1024), 16, 0, 0);
@@ -377,7 +404,8 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
         xc[0] = s0;
         xc[64] = s1v;
     };
-    auto finish = [&](int c) __attribute__((always_inline)) {         // chunk c: own + partner's partial sums -> GELU -> bf16 -> P tile
+    constexpr bool kDmaInFinish = ABL == 40;
+    auto finish = [&](int c, bool dma_here = false) __attribute__((always_inline)) {         // chunk c: own + partner's partial sums -> GELU -> bf16 -> P tile
         const f32x4* pc = reinterpret_cast<const f32x4*>(smem + kXcOff + ((c & 1) * 8 + (wave ^ 4)) * 2048 + lane * 16);
         const f32x4 a0 = pc[0], a1 = pc[64];
         float g[8];
@@ -386,7 +414,16 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             g[i] = keep[i] + a0[i];
             g[4 + i] = keep[4 + i] + a1[i];
         }
-        if constexpr (kTanh) gelu8_tanh_form(g); else gelu8_bf16_grade(g);
+        if constexpr (kDmaInFinish) {
+            // this wave's DMA instructions of the iteration's group between the GELU's levels: ~60 cycles apart instead of a burst
+            // of 49 from eight waves at the barrier, which queues on the CU's one address path (stamped: 70 - 115 cycles each)
+            gelu8_bf16_grade_hooked(g, [&](auto lc) {
+                constexpr int lv = decltype(lc)::value;
+                if constexpr (lv < kPerWave) {
+                    if (dma_here) dma_one(std::integral_constant<int, lv>{});
+                }
+            });
+        } else if constexpr (kTanh) gelu8_tanh_form(g); else gelu8_bf16_grade(g);
         char* pt = smem + kPOff + ((c & 1) * 4 + rg) * 2048 + l31 * 64 + 8 * h;
 #pragma unroll
         for (int gq = 0; gq < 2; ++gq) {
@@ -474,6 +511,10 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
                 }
                 dma = false;
             }
+            bool dma_fin = false;
+            if constexpr (kDmaInFinish) {
+                if (dma && fi) { dma_fin = true; dma = false; }      // (pipeline fill: no finish stage yet - the group goes out at the barrier)
+            }
             if (ABL != 5) {        // the whole group right behind the barrier (ABL == 5, experiment: one instruction at a time
                                    // from inside the matrix stages - measured no faster, and hipcc then drops the vmcnt(0)
                                    // in front of the barrier: racy without the explicit wait below)
@@ -485,7 +526,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             stamp(2);
             if constexpr (kOrder == 0) {
                 if (p1) prefetch1(it);
-                if (fi) finish(it - 1);
+                if (fi) finish(it - 1, dma_fin);
                 stamp(3);
                 if (p1) product1(it, dma);
                 stamp(4);
@@ -501,7 +542,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
                 }
                 stamp(5);
                 if (p1) prefetch1(it);
-                if (fi) finish(it - 1);
+                if (fi) finish(it - 1, dma_fin);
                 stamp(3);
                 if (p1) product1(it, dma);
                 stamp(4);
@@ -518,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     // Hand-offs as before (exchange planes and P tiles by chunk parity, weight buffers by iteration parity), each one slot
     // boundary or more apart.  Half 1 finishes chunk k-1 AFTER it has started chunk k: its own eight partial sums of k-1 are
     // carried in a second register set.  Half 0's DMA share has two slots to land, half 1's one: half 1 gets the smaller share.
-    constexpr bool kSlot2 = ABL >= 30 && ABL <= 34;
+    constexpr bool kSlot2 = ABL >= 30 && ABL <= 35;     // (35: two-slot WITHOUT weight DMA after the first groups: compute-bound timing, wrong results)
     if constexpr (kSlot2) {
         auto dma_mine = [&]() __attribute__((always_inline)) { static_for<0, kPerWave>([&](auto jc) { dma_one(jc); }); };
         if (half == 0) {
@@ -528,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
                 __syncthreads();                                        // ---- slot A(k)
                 stamp(1);
                 dma_begin(k + 1 < nchunks ? k + 1 : nchunks - 1, k < 1 ? 0 : (k <= nchunks ? k - 1 : nchunks - 1), (k + 1) & 1);
-                if (k <= nchunks) dma_mine();
+                if (k <= nchunks && (ABL != 35 || k < 2)) dma_mine();
                 stamp(2);
                 if (k >= 1 && k <= nchunks) finish(k - 1);
                 stamp(3);
@@ -555,7 +596,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
                 __syncthreads();                                        // ---- slot B(k)
                 stamp(1);
                 dma_begin(k + 1 < nchunks ? k + 1 : nchunks - 1, k < 1 ? 0 : (k <= nchunks ? k - 1 : nchunks - 1), (k + 1) & 1);
-                if (k <= nchunks) dma_mine();
+                if (k <= nchunks && (ABL != 35 || k < 2)) dma_mine();
                 stamp(2);
                 // finish(k - 1) on the partial sums of chunk k-1: swap them in for the duration of the stage
                 float keep_now[8];
@@ -862,7 +903,7 @@ extern "C" int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const flo
             hipLaunchKernelGGL(ffn2_bf16_kernel<N_>, grid, dim3(512), kLds, s, p);          \
             return ispk_launch_status();                                                    \
         }
-        ISPK_FFN2_AB(13) ISPK_FFN2_AB(14) ISPK_FFN2_AB(15) ISPK_FFN2_AB(16) ISPK_FFN2_AB(17) ISPK_FFN2_AB(30) ISPK_FFN2_AB(31) ISPK_FFN2_AB(32) ISPK_FFN2_AB(33)
+        ISPK_FFN2_AB(13) ISPK_FFN2_AB(14) ISPK_FFN2_AB(15) ISPK_FFN2_AB(16) ISPK_FFN2_AB(17) ISPK_FFN2_AB(30) ISPK_FFN2_AB(31) ISPK_FFN2_AB(32) ISPK_FFN2_AB(33) ISPK_FFN2_AB(35) ISPK_FFN2_AB(36) ISPK_FFN2_AB(40)
 #undef ISPK_FFN2_AB
         if (atoi(e) == 5) {
             ISPK_RESERVE_LDS((&ffn2_bf16_kernel<5>), kLds, "ffn_prenorm2");

@@ -57,7 +57,7 @@ constexpr int kLdT = 388;                        // epilogue: fp32 tile [64 rows
 constexpr int kLds = kXtOff + 128 * kD * 2;      // 148,480 B
 static_assert(2 * kWbuf <= kLds && 64 * kLdT * 4 <= kLds, "LDS carve-up");
 constexpr int kDmaSlots = 13;                    // instructions per wave and group: q = wave + 4 j (wave 0: j = 12 too)
-constexpr int kRing = 4;                         // operand fragments in flight
+constexpr int kRing = 8;                         // operand fragments in flight (4: 2 us slower)
 
 struct Ffn3Params {
     const float* x;

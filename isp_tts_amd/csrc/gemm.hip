@@ -280,7 +280,7 @@ int32_t launch_bf16(const GemmParams& p, hipStream_t s) {
 // (bank half, slot) pairs.  Each wave issues IPL = (BM + BN) / 8 / waves DMAs per chunk and waits for its own with a
 // counted vmcnt; one raw s_barrier per chunk publishes the chunk and retires the slot the next DMA overwrites.
 template <int TN, int WM, bool LN = false>  // WM row-waves (32 rows each) x 2 feature-waves (TN 32-wide tiles each)
-__global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) {
+__global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams pin) {
     constexpr int BM = 32 * WM, BN = 64 * TN, NT = WM * 128, NWV = NT / 64;
     constexpr int kSlot = (BM + BN) * 128;                       // bytes per ring slot: X tile then W tile, 128-B rows
     constexpr int S = 4 * kSlot <= 128 * 1024 ? 4 : (3 * kSlot <= 144 * 1024 ? 3 : 2);
@@ -293,8 +293,11 @@ __global__ __launch_bounds__(WM * 128) void gemm_bf16_wide_kernel(GemmParams p) 
     const int l31 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * BM;
     const int nb0 = blockIdx.y * BN;  // feature offset of this workgroup (grid.y > 1 only for small M)
-    const uint16_t* A = static_cast<const uint16_t*>(p.A);
-    const uint16_t* W = static_cast<const uint16_t*>(p.W);
+    // split-K (ispk_gemm_bf16_splitk: few rows, long K): workgroup z reduces K slice z - both operands advance za = zw = p.K
+    // elements, the raw fp32 partial product goes to slab z of the workspace (zc elements apart); no epilogue flags then
+    const GemmParams p = [&]() { GemmParams q = pin; q.C = static_cast<float*>(pin.C) + (int64_t)blockIdx.z * pin.zc; return q; }();
+    const uint16_t* A = static_cast<const uint16_t*>(p.A) + (int64_t)blockIdx.z * p.za;
+    const uint16_t* W = static_cast<const uint16_t*>(p.W) + (int64_t)blockIdx.z * p.zw;
 
     // this lane's part of DMA instruction j: row (8-row group wave*IPL + j, row lane>>3), LDS slot lane&7
     const uint16_t* src_row[IPL];
@@ -491,6 +494,47 @@ int32_t launch_wide(const GemmParams& p, hipStream_t s) {
     ISPK_RESERVE_LDS((&gemm_bf16_wide_kernel<TN, WM, LN>), lds, "gemm");
     hipLaunchKernelGGL((gemm_bf16_wide_kernel<TN, WM, LN>), dim3((p.M + BM - 1) / BM, (p.N + BN - 1) / BN),
                        dim3(WM * 128), lds, s, p);
+    return ispk_launch_status();
+}
+
+// ---- split-K for the row-block kernel at FEW rows (a rank's share under strong scaling: 8 - 16 utterances).  With a handful of
+// row blocks the K loop of one workgroup IS the kernel - 24 dependent 64-deep steps at ~0.8 us each for 800 x 384 x 1536 - while
+// nine CUs in ten idle.  ksplit workgroups per tile reduce one K slice each into fp32 slabs; gemm_splitk_combine_kernel adds the
+// slabs in slice order (deterministic) and applies the epilogue (bias, activation, masks, residual, output type).
+__global__ __launch_bounds__(256) void gemm_splitk_combine_kernel(GemmParams p, const float* __restrict__ parts, int ksplit) {
+    const int n4 = p.N / 4;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) * 4;
+    const int64_t slab = (int64_t)p.M * p.N;
+    const float4 a = *reinterpret_cast<const float4*>(parts + (int64_t)m * p.N + n);
+    float v[4] = {a.x, a.y, a.z, a.w};
+    for (int z = 1; z < ksplit; ++z) {
+        const float4 b = *reinterpret_cast<const float4*>(parts + z * slab + (int64_t)m * p.N + n);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    const float mk = p.mask ? (p.mask[m] ? 1.0f : 0.0f) : 1.0f;
+    epilogue_vec4(p, m, n, v, mk);
+}
+
+template <int TN, int WM>
+int32_t launch_wide_splitk(const GemmParams& p, hipStream_t s, int ksplit, float* workspace) {
+    constexpr int BM = 32 * WM, BN = 64 * TN;
+    constexpr size_t slot = (size_t)(BM + BN) * 128;
+    constexpr size_t lds_tiles = (4 * slot <= 128 * 1024 ? 4 : (3 * slot <= 144 * 1024 ? 3 : 2)) * slot;
+    constexpr size_t lds_epi = (size_t)WM * 2 * kStageBytes;
+    constexpr size_t lds = lds_tiles > lds_epi ? lds_tiles : lds_epi;
+    GemmParams q = p;
+    q.K = p.K / ksplit;
+    q.za = q.zw = q.K;
+    q.C = workspace; q.ldc = p.N; q.zc = (int64_t)p.M * p.N;
+    q.bias = nullptr; q.resid = nullptr; q.mask = nullptr; q.flags = 0; q.ldr = 0;
+    ISPK_RESERVE_LDS((&gemm_bf16_wide_kernel<TN, WM, false>), lds, "gemm");
+    hipLaunchKernelGGL((gemm_bf16_wide_kernel<TN, WM, false>), dim3((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, ksplit),
+                       dim3(WM * 128), lds, s, q);
+    if (int32_t rc = ispk_launch_status()) return rc;
+    const int64_t total = (int64_t)p.M * (p.N / 4);
+    hipLaunchKernelGGL(gemm_splitk_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, p, workspace, ksplit);
     return ispk_launch_status();
 }
 
@@ -919,7 +963,13 @@ bool panel_ok(const GemmParams& p) {
 bool wide_ok(const GemmParams& p) {
     const bool long_k = (p.K >= 512 || ispk_knob("ISPK_FORCE_WIDE")) && (p.N == 384 || p.N == 256 || p.N % 192 == 0);
     const bool skinny = p.N <= 192 && ispk_knob("ISPK_NO_SKINNY") == nullptr;
-    return (long_k || skinny) && p.M >= 128 * 16 && vec_epilogue_ok(p) && !(p.flags & ISPK_EP_OUT_BF16) &&
+    // (rows: from one 64-row block on.  Below 2,048 rows the generic tile kernel used to take these shapes: with a handful of
+    // workgroups its two-loads-in-flight K loop is pure latency - 800 x 384 x 1536, the text encoder's second feed-forward
+    // Linear at 8 utterances per GPU, took 39 us on 39 workgroups; the row-block kernel's LDS-DMA ring streams the same
+    // reduction several k-steps deep.  ISPK_WIDE_MIN_M: experiments.)
+    const char* mm = ispk_knob("ISPK_WIDE_MIN_M");
+    const int min_m = mm ? atoi(mm) : 64;
+    return (long_k || skinny) && p.M >= min_m && vec_epilogue_ok(p) && !(p.flags & ISPK_EP_OUT_BF16) &&
            ispk_knob("ISPK_NO_WIDE") == nullptr;
 }
 
@@ -1094,6 +1144,42 @@ extern "C" int32_t ispk_gemm_bf16(const uint16_t* A, int64_t lda, const uint16_t
         case 12: return launch_bf16<1, 2>(p, s);
     }
     return launch_bf16<1, 1>(p, s);
+}
+
+// ---- split-K entry points (see launch_wide_splitk)
+static int splitk_choice(int M, int N, int K, uint32_t flags) {
+    if (M >= 2048 || M < 1 || N % 4 != 0 || K % 64 != 0 || K == 256 || K == 384) return 1;     // (K 256 / 384: the panel kernel)
+    if (flags & (ISPK_EP_BIAS_ROW | ISPK_EP_MASK_COL | ISPK_EP_ROWS_T | ISPK_EP_DUAL_GELU | ISPK_EP_GELU_BWD | ISPK_EP_OUT_SPLIT)) return 1;
+    const bool long_k = K >= 512 && (N == 384 || N == 256 || N % 192 == 0);
+    const bool skinny = N <= 192 && K >= 512;
+    if (!long_k && !skinny) return 1;
+    const bool w192 = N <= 192 ? N > 128 : N % 192 == 0;
+    const int bn = w192 ? 192 : 128;
+    const int blocks = ((M + 63) / 64) * ((N + bn - 1) / bn);
+    int best = 1;
+    for (int s : {2, 3, 4, 5, 6, 8, 10, 12})       // slices of >= 3 steps of 64, one round of the chip's 256 CUs at most
+        if (K % (64 * s) == 0 && K / (64 * s) >= 3 && blocks * s <= 256) best = s;
+    return best;
+}
+
+extern "C" int32_t ispk_gemm_bf16_splitk_plan(int32_t M, int32_t N, int32_t K, uint32_t flags) {
+    return splitk_choice(M, N, K, flags);
+}
+
+extern "C" int32_t ispk_gemm_bf16_splitk(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, void* C, int64_t ldc,
+                                         const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M,
+                                         int32_t N, int32_t K, uint32_t flags, float* workspace, int32_t ksplit,
+                                         ispk_stream_t stream) {
+    GemmParams p{A, lda, W, ldw, C, ldc, bias, resid, ldr, mask, M, N, K, flags, 0, 0};
+    if (int32_t rc = check_common(p, 2)) return rc;
+    ISPK_REQUIRE(workspace && ispk_aligned(workspace, 16), ISPK_E_NULL, "gemm_bf16_splitk: workspace (ksplit * M * N floats, 16-byte aligned)");
+    ISPK_REQUIRE(ksplit >= 2 && ksplit <= 12 && K % (64 * ksplit) == 0 && splitk_choice(M, N, K, flags) > 1 && vec_epilogue_ok(p),
+                 ISPK_E_UNSUPPORTED, "gemm_bf16_splitk: M=%d N=%d K=%d ksplit=%d is not a split-K shape (ispk_gemm_bf16_splitk_plan)", M, N, K, ksplit);
+    if (M == 0) return 0;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const bool w192 = N <= 192 ? N > 128 : N % 192 == 0;
+    g_last_bf16_variant = 2000 + (w192 ? 32 : 22);
+    return w192 ? launch_wide_splitk<3, 2>(p, s, ksplit, workspace) : launch_wide_splitk<2, 2>(p, s, ksplit, workspace);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

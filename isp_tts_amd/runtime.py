@@ -47,6 +47,8 @@ SIGNATURES = {
     "ispk_conv_weight_flip_f32": [_P, _P, _I32, _I32, _I32, _P],
     "ispk_gemm_bf16_last_variant": [],
     "ispk_gemm_bf16": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _I32, _I64, _P],
+    "ispk_gemm_bf16_splitk_plan": [_I32, _I32, _I32, _U32],
+    "ispk_gemm_bf16_splitk": [_P, _I64, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P, _I32, _P],
     "ispk_ffn_bf16": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _P, _I64, _P, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_ffn_pack_w2_bf16": [_P, _I64, _I32, _I32, _P, _P],
     "ispk_ffn_bf16_prenorm": [_P, _I64, _P, _P, _F32, _P, _I64, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
@@ -313,6 +315,13 @@ def gemm(a: Tensor, w: Tensor, bias: Optional[Tensor] = None, resid: Optional[Te
         if r2 is not None and r2.dtype == torch.bfloat16:
             flags |= EP_RESID_BF16
         fn = lib().ispk_gemm_bf16
+        ks = lib().ispk_gemm_bf16_splitk_plan(M, N, K, flags) if M < 2048 and K >= 512 else 1
+        if ks > 1:      # few rows, long K: K slices on separate workgroups + one combine pass (ispk_gemm_bf16_splitk)
+            ws = torch.empty((ks * M * N,), dtype=torch.float32, device=a.device)
+            _launch(f"gemm_bf16_splitk<{ks}>", 2.0 * M * N * K, _gemm_bytes(a2, w, out, r2) + 8.0 * ks * M * N, lib().ispk_gemm_bf16_splitk,
+                    a2.data_ptr(), a2.stride(0), w.data_ptr(), w.stride(0), c2.data_ptr(), c2.stride(0), _ptr(bias), _ptr(r2),
+                    r2.stride(0) if r2 is not None else 0, _ptr(mask), M, N, K, flags, ws.data_ptr(), ks, _stream())
+            return out
     else:
         assert out.dtype == torch.float32 and (r2 is None or r2.dtype == torch.float32)
         fn = lib().ispk_gemm_f32

@@ -295,6 +295,7 @@ def _bf(t):
 @pytest.mark.parametrize("M,N,K", [(1000, 384, 384), (32768, 512, 384), (300, 1536, 384), (777, 384, 1536),
                                    (64, 64, 8), (130, 80, 384),
                                    (8200, 384, 1536), (8300, 256, 1024),      # "wide" kernel (long K), ragged M
+                                   (800, 384, 1536), (77, 256, 1024), (130, 768, 1920), (832, 128, 768),   # ... at few rows
                                    (6400, 384, 256), (515, 1024, 256)])       # "panel" kernel with K = 256
 def test_gemm_bf16_shapes(M, N, K):
     """bf16 operands, fp32 accumulation: compared with a float64 product of the SAME bf16-rounded operands, so the only
@@ -306,6 +307,38 @@ def test_gemm_bf16_shapes(M, N, K):
     out16 = runtime.gemm(a.to(DEV), w.to(DEV)).cpu()
     assert out16.dtype == torch.bfloat16
     assert ((out16.double() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-6).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(800, 384, 1536), (77, 256, 1024), (832, 768, 1920), (130, 128, 768), (1600, 384, 1536)])
+def test_gemm_bf16_split_k_for_few_rows(M, N, K):
+    """ispk_gemm_bf16_splitk (few rows, long K: the text-side stacks of a rank under strong scaling): K slices on separate
+    workgroups into fp32 slabs + one ordered combine pass that applies the epilogue - against float64 on the same bf16 operands
+    for every epilogue the model uses with these shapes (GELU + bias, residual with either mask position, bf16 residual, bf16
+    output), deterministic, and the plan: split only below 2,048 rows."""
+    lib = runtime.lib()
+    ks = lib.ispk_gemm_bf16_splitk_plan(M, N, K, 0)
+    assert ks >= 2 and K % (64 * ks) == 0 and lib.ispk_gemm_bf16_splitk_plan(4096, N, K, 0) == 1
+    assert lib.ispk_gemm_bf16_splitk_plan(M, N, 384, 0) == 1          # (K = 256 / 384 is the panel kernel's)
+    a, w = _bf(synth._normal(f"t/sk/a{M}{K}", (M, K))), _bf(synth._normal(f"t/sk/w{N}{K}", (N, K), K ** -0.5))
+    bias, resid = synth._normal("t/sk/b", (N,)), synth._normal(f"t/sk/r{M}{N}", (M, N))
+    mask = torch.arange(M) % 5 != 2
+    d = lambda t: t.to(DEV)  # noqa: E731
+    out = runtime.gemm(d(a), d(w), out_dtype=torch.float32)
+    assert torch.equal(out, runtime.gemm(d(a), d(w), out_dtype=torch.float32))
+    assert (out.cpu().double() - _gemm_ref(a, w)).abs().max() < 2e-5
+    out = runtime.gemm(d(a), d(w), bias=d(bias), flags=runtime.EP_GELU).cpu()
+    ref = _gemm_ref(a, w, bias=bias, act="gelu")
+    assert out.dtype == torch.bfloat16 and ((out.double() - ref).abs() <= ref.abs() * 2 ** -8 + 1e-5).all()
+    out = runtime.gemm(d(a), d(w), resid=d(resid), mask=d(mask), flags=runtime.EP_MASK_ACC, out_dtype=torch.float32).cpu()
+    assert (out.double() - _gemm_ref(a, w, resid=resid, mask=mask, mask_acc=True)).abs().max() < 2e-5
+    out = runtime.gemm(d(a), d(w), resid=d(_bf(resid)), mask=d(mask), flags=runtime.EP_MASK_OUT, out_dtype=torch.float32).cpu()
+    assert (out.double() - _gemm_ref(a, w, resid=_bf(resid), mask=mask, mask_out=True)).abs().max() < 2e-5
+    assert out[~mask].abs().max().item() == 0.0
+    # the C ABI refuses shapes outside the plan instead of serving them some other way
+    ws = torch.empty(2 * M * N, device=DEV)
+    c = torch.empty(M, N, device=DEV)
+    assert lib.ispk_gemm_bf16_splitk(d(a).data_ptr(), K, d(w).data_ptr(), K, c.data_ptr(), N, None, None, 0, None, M, N, K, 0,
+                                     ws.data_ptr(), 7, None) < 0
 
 
 @pytest.mark.parametrize("K", [384, 1536])

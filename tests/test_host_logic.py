@@ -402,6 +402,26 @@ def _train_rank_main(rank, world, port, q):
         sd = opt.state_dict()["optimizer"]["state"]               # sharded moments gathered into torch's layout
         rsd = ref.state_dict()["state"]
         ok &= all(float((sd[i]["exp_avg"] - rsd[i]["exp_avg"]).abs().max()) < 1e-6 for i in range(len(my_p)))
+        # tensors frozen AFTER the optimizer was built (`model.freeze()`): torch's AdamW skips a tensor whose .grad is None - no
+        # decay, no moment update; the flat update must leave value and (sharded) moments alone too.  Frozen here: a decay-group
+        # matrix (its arena range straddles the two ranks' shards) and a no-decay vector.
+        frozen = (2, 3)
+        for i in frozen:
+            my_p[i].requires_grad_(False)
+        for step in range(4, 7):
+            mine = _train_grads(step, rank, my_p)
+            for i, (p, g) in enumerate(zip(my_p, mine)):
+                if i not in frozen:                              # (what the backward delivers: nothing for a frozen tensor)
+                    p.grad.copy_(g)
+            every = [_train_grads(step, r, ref_p) for r in range(world)]
+            for i, p in enumerate(ref_p):
+                p.grad = None if i in frozen else sum(e[i] for e in every) / world
+            n_ref, n_my = torc.reference_step(ref, 1.0), opt.step()
+            ok &= abs(float(n_ref) - float(n_my)) < 1e-5 * float(n_ref)
+            ok &= all(float((a - b).abs().max()) < 1e-6 for a, b in zip(ref_p, my_p))
+        sd, rsd = opt.state_dict()["optimizer"]["state"], ref.state_dict()["state"]
+        ok &= all(float((sd[i]["exp_avg"] - rsd[i]["exp_avg"]).abs().max()) < 1e-6 and
+                  float((sd[i]["exp_avg_sq"] - rsd[i]["exp_avg_sq"]).abs().max()) < 1e-6 for i in range(len(my_p)))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()

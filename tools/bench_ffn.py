@@ -63,6 +63,10 @@ if HAVE3:
 if HAVE3:
     variants["eight-wave, TWO-SLOT schedule, DMA 8/4 (30)"] = ablated("30")
     variants["eight-wave, two-slot, DMA even (31)"] = ablated("31")
+    variants["eight-wave, DMA between the GELU levels of the finish stage (40)"] = ablated("40")
+    variants["eight-wave, two-slot, NO weight DMA after group 1 (35)"] = ablated("35")
+    variants["eight-wave, default schedule, W1 half of the DMA bytes only (36)"] = ablated("36")
+    variants["eight-wave, no weight DMA after group 1 (compute only)"] = ablated("1")
     variants["eight-wave, two-slot, DMA 9/3 (32)"] = ablated("32")
     variants["eight-wave, two-slot, DMA 10/2 (33)"] = ablated("33")
 if runtime.LIB_PATH == build.LIB_EXP and os.environ.get("FFN2_ABL"):
@@ -112,7 +116,7 @@ if runtime.LIB_PATH == build.LIB_EXP:
     m = dbg3.cpu().double().median(0).values.tolist()
     print("ffn3 stamps (cycles per wave, median): " + ", ".join(f"{n} {v:.0f}" for n, v in zip(["prologue", "fill", "main loop", "epilogue", "total"], m)))
     ref0 = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True)
-    for code in ("30", "31", "32", "33"):
+    for code in ("30", "31", "32", "33", "40"):
         os.environ["ISPK_FFN2_ABLATE"] = code
         got = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True)
         again = runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True)

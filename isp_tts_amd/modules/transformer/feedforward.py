@@ -48,9 +48,10 @@ class FeedForward(nn.Module, Constructor):
                                  nn.Dropout(dropout) if dropout > 0. else nn.Identity(),
                                  nn.Linear(inner_dim, dim, bias=bias))
         self.compute_dtype = torch.float32
-        # the fused kernel gives a workgroup 128 rows: below ~256 workgroups it under-fills the chip and the two-GEMM
-        # path (which splits the feature axis as well) is faster
-        self.fused_min_rows = 128 * 128
+        # the fused kernel gives a workgroup 128 rows and the whole inner dimension: with 128 row blocks or fewer (<= 16,384 rows:
+        # half the chip) the split form - several workgroups per row block, each a slice of the inner dimension, + one combine
+        # pass - fills the CUs instead (dim 384); other dims take the two-GEMM path there
+        self.fused_min_rows = 128 * 128 + 1
         self._cache = StagedWeights()
 
     def _staged(self, dtype: torch.dtype):
@@ -86,12 +87,14 @@ class FeedForward(nn.Module, Constructor):
     # row block, partial products combined (+ residual, mask, the consumer's LayerNorm) by a second launch.
     # 22.4 (FFN2) + 19.8 (FFN1) + 7.1 (LayerNorm) + 5.8 (next LayerNorm) us -> measured in DESIGN.md
     split_small = True
+    split_min_rows = 128       # (one row block: at 8 utterances per GPU the text encoder has 800 rows)
+    max_splits = 8             # (16 measured no faster at 800 rows: the combine pass reads every partial)
 
     def split_ok(self, x: Tensor, norm) -> bool:
         rows = x.numel() // x.shape[-1]
         return (self.split_small and self.pair_kernel and isinstance(norm, nn.LayerNorm) and norm.weight is not None
                 and norm.bias is not None and x.dtype == torch.float32 and self.compute_dtype == torch.bfloat16
-                and self.act_flag == runtime.EP_GELU and x.shape[-1] == 384 and 1024 <= rows < self.fused_min_rows
+                and self.act_flag == runtime.EP_GELU and x.shape[-1] == 384 and self.split_min_rows <= rows < self.fused_min_rows
                 and self.net[0].bias is None and self.net[3].bias is None and self.net[0].weight.shape[0] % 64 == 0
                 and not (self.training and self.dropout_p > 0))
 
@@ -102,8 +105,8 @@ class FeedForward(nn.Module, Constructor):
         rows, chunks = x.numel() // x.shape[-1], w1.shape[0] // 32
         blocks = (rows + 127) // 128
         splits = 1
-        for s in (2, 3, 4, 6, 8):       # as many workgroups as fit one round of the 256 CUs, at least 2 chunks each
-            if chunks % s == 0 and chunks // s >= 2 and blocks * s <= 256:
+        for s in (2, 3, 4, 6, 8, 12, 16):       # as many workgroups as fit one round of the 256 CUs, at least 2 chunks each
+            if s <= self.max_splits and chunks % s == 0 and chunks // s >= 2 and blocks * s <= 256:
                 splits = s
         return runtime.ffn_prenorm2_split(x, norm.weight, norm.bias, w1, self._chunked_w2(), mask, splits, next_norm=next_norm,
                                           norm_eps=norm.eps)

@@ -457,7 +457,8 @@ def test_eight_wave_ffn_kernel(R, Fi, masked):
     assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
 
 
-@pytest.mark.parametrize("R,splits,masked", [(6400, 4, True), (128 * 9 + 17, 8, True), (1500, 3, False)])
+@pytest.mark.parametrize("R,splits,masked", [(6400, 4, True), (128 * 9 + 17, 8, True), (1500, 3, False), (800, 16, True), (130, 12, False),
+                                             (16384, 2, True)])
 def test_split_ffn_for_small_batches(R, splits, masked):
     """ispk_ffn_bf16_prenorm2_split + ispk_ffn_combine_ln_f32 (inner dimension split over workgroups, partials added in split
     order with residual and mask, consumer LayerNorm from the same pass) against the unsplit eight-wave kernel - the same

@@ -324,6 +324,15 @@ int32_t ispk_soft_average_f32(const float* attn_soft, const float* pitch, const 
  *                          (fp32 or int64, at most one given) wherever that is >= 0 (:355-362); features [B][L][2] =
  *                          { (pitch_target | pred[..,1]) * pitch_factor + pitch_delta, (energy_target | pred[..,2]) *
  *                          energy_factor + energy_delta } (:366-381) - the embedding stack's input. */
+/* ispk_flow_head_f32    what ends FlowTransformerTemporalModule.forward behind the stack's last layer, in one call: the stack's
+ *                       final LayerNorm with its row mask (transformer.py:205-206) on the raw rows y [B][L][256], linear_layer
+ *                       (256 -> 3, temporal_adaptor.py:98, :131) and ispk_flow_finish_f32's algebra (:133-147) - pred, duration
+ *                       estimate, per-utterance loss ratios and their mean (loss_mean may be NULL).  workspace: 2 * B *
+ *                       ceil(L / 16) floats (per-block partial sums, added in block order: deterministic). */
+int32_t ispk_flow_head_f32(const float* y, int64_t ldy, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                           const float* W, const float* bias, const float* flow, const float* x0, const uint8_t* mask,
+                           float* pred, float* duration, float* loss_ratio, float* loss_mean, float* workspace, int32_t B,
+                           int32_t L, int32_t D, int32_t C, ispk_stream_t stream);
 int32_t ispk_flow_euler_f32(const float* x_t, const float* velocity, float dt, const uint8_t* mask, float* out, int32_t B,
                             int32_t L, int32_t C, ispk_stream_t stream);
 int32_t ispk_infer_features_f32(const float* pred, const float* duration_target_f32, const int64_t* duration_target_i64,

@@ -71,6 +71,7 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
                                             condition_dim=time_embedding_dim)
         self.linear_layer = nn.Linear(self.transformer.dim, output_dim, bias=True)
         self.output_dim, self.sigma, self.detach_inputs = output_dim, sigma, detach_inputs
+        self.fused_head = True          # final norm + linear_layer + flow algebra as `runtime.flow_head` (False: three launches; tests)
         self._cache = StagedWeights()
         self._grids: dict = {}
 
@@ -107,8 +108,17 @@ class FlowTransformerTemporalModule(nn.Module, Constructor):
         time_emb = self.time_embedding(t)
         x_t, flow = runtime.flow_mix(x0, x1, t, self.sigma)                     # :123-126, one launch
         proj = self._project(x_t, self._cond_projection(cond))
-        out = self.transformer(None, mask=mask, adaptive_condition=time_emb, projected=proj,
-                               key_len=key_len if have_mask else None).out
+        tr = self.transformer
+        head = (self.fused_head and tr.dim == 256 and self.output_dim == 3 and tr.norm.weight is not None and tr.norm.bias is not None
+                and self.linear_layer.bias is not None)
+        out = tr(None, mask=mask, adaptive_condition=time_emb, projected=proj, key_len=key_len if have_mask else None,
+                 final_norm=not head).out
+        if head:
+            # the stack's final LayerNorm, linear_layer and the flow-matching algebra in ONE pass per row (two launches, the
+            # second a one-workgroup sum): these are the last kernels of the forward's side branch - they run after the decoder
+            pred, self._duration_estimate, _, loss = runtime.flow_head(out, tr.norm.weight, tr.norm.bias, tr.norm.eps,
+                                                                       self.linear_layer.weight, self.linear_layer.bias, flow, x0, mask)
+            return pred, {"flow_loss": loss}
         raw = runtime.linear_small(out, self.linear_layer.weight, self.linear_layer.bias)
         # pred_flow = raw * m3 ; loss = masked_mean(mse(pred_flow, flow), m3) ; pred = (x0 + pred_flow) * m3 ;
         # duration estimate = clamp(exp(pred[..., 0]) - 1, 0): one launch + the mean over the batch

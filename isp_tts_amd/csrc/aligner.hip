@@ -544,6 +544,116 @@ __global__ __launch_bounds__(1024) void flow_finish_kernel(const float* __restri
 }
 
 
+// ------------------------------------------------------------------------------------------------ the predictor's head in one pass
+// What ends FlowTransformerTemporalModule.forward (temporal_adaptor.py:127-147) after the stack's last layer: the stack's final
+// LayerNorm (transformer.py:205-206, with its row mask), the 256 -> 3 `linear_layer`, and the flow-matching algebra of
+// flow_finish_kernel - three launches that trail the whole forward (they are the LAST kernels of its side branch, after the
+// decoder has finished) as two: flow_head_kernel (one wave per 4 rows: everything per row) leaves per-workgroup partial sums of
+// the masked squared error, flow_head_finalize_kernel adds them in block order per utterance and takes the batch mean in index
+// order (fixed orders: bit-reproducible).  D = 256 (one float4 per lane), C = 3.
+constexpr int kFhRows = 16;      // rows per workgroup: 4 waves x 4 rows
+__device__ __forceinline__ float fh_wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__global__ __launch_bounds__(256) void flow_head_kernel(const float* __restrict__ y, int64_t ldy, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps, const float* __restrict__ W,
+                                                        const float* __restrict__ bias, const float* __restrict__ flow,
+                                                        const float* __restrict__ x0, const uint8_t* __restrict__ mask,
+                                                        float* __restrict__ pred, float* __restrict__ dur,
+                                                        float* __restrict__ part, int L, int nblk) {
+#pragma clang fp contract(off)
+    __shared__ float sp[4][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * lane), b4 = *reinterpret_cast<const f32x4*>(beta + 4 * lane);
+    f32x4 w4[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) w4[c] = *reinterpret_cast<const f32x4*>(W + c * 256 + 4 * lane);
+    const float bc[3] = {bias[0], bias[1], bias[2]};
+    float num = 0.f, den = 0.f;
+    const int l0 = blk * kFhRows + wave * 4;
+    f32x4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int l = l0 + i < L ? l0 + i : L - 1;          // rows past the end: a valid row, never stored
+        v[i] = *reinterpret_cast<const f32x4*>(y + ((int64_t)b * L + l) * ldy + 4 * lane);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int l = l0 + i;
+        const bool live = l < L;
+        const int64_t r = (int64_t)b * L + (live ? l : L - 1);
+        const bool m = mask[r] != 0;
+        const float mean = fh_wave_sum((v[i][0] + v[i][1]) + (v[i][2] + v[i][3])) * (1.0f / 256.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = v[i][e] - mean;
+            q = fmaf(d, d, q);
+        }
+        const float rstd = 1.0f / sqrtf(fh_wave_sum(q) * (1.0f / 256.0f) + eps);
+        float h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h[e] = m ? fmaf((v[i][e] - mean) * rstd, g4[e], b4[e]) : 0.f;      // (LayerNorm's row mask)
+        float raw[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a = fmaf(h[e], w4[c][e], a);
+            raw[c] = fh_wave_sum(a) + bc[c];
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float f = flow[r * 3 + c], x = x0[r * 3 + c];
+                const float pf = m ? raw[c] : 0.f;
+                const float pr = m ? x + pf : 0.f;
+                if (lane == c) pred[r * 3 + c] = pr;
+                if (c == 0 && lane == 0) dur[r] = fmaxf(expf(pr) - 1.0f, 0.f);
+                const float d = pf - f;
+                num += m ? d * d : 0.f;
+                den += m ? 1.0f : 0.f;
+            }
+        }
+    }
+    if (lane == 0) { sp[wave][0] = num; sp[wave][1] = den; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t o = ((int64_t)b * nblk + blk) * 2;
+        part[o] = (sp[0][0] + sp[1][0]) + (sp[2][0] + sp[3][0]);
+        part[o + 1] = (sp[0][1] + sp[1][1]) + (sp[2][1] + sp[3][1]);
+    }
+}
+__global__ __launch_bounds__(1024) void flow_head_finalize_kernel(const float* __restrict__ part, int nblk, float* __restrict__ ratio,
+                                                                  float* __restrict__ loss, int B) {
+    __shared__ float sratio[1024];
+    const int tid = threadIdx.x;
+    float s = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int b = b0 + tid;
+        if (b < B) {
+            float num = 0.f, den = 0.f;
+            for (int k = 0; k < nblk; ++k) {
+                num += part[((int64_t)b * nblk + k) * 2];
+                den += part[((int64_t)b * nblk + k) * 2 + 1];
+            }
+            const float q = num / fmaxf(den, 1e-5f);
+            ratio[b] = q;
+            sratio[tid] = q;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int n = B - b0 < 1024 ? B - b0 : 1024;
+            for (int i = 0; i < n; ++i) s += sratio[i];
+        }
+        __syncthreads();
+    }
+    if (loss && tid == 0) loss[0] = s / (float)B;
+}
+
 // ------------------------------------------------------------------------------------------------ infer: Euler update, features
 // FlowTransformerTemporalModule.infer (temporal_adaptor.py:158-170): x_t <- x_t + velocity * dt per step, `* mask` after the
 // last one.  dt comes from the host (the warped grid depends only on (steps, step_factor): :150-156).
@@ -728,6 +838,26 @@ extern "C" int32_t ispk_flow_finish_f32(const float* pred_raw, const float* flow
     if (B == 0) return 0;
     hipLaunchKernelGGL(flow_finish_kernel, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), pred_raw, flow, x0,
                        mask, pred, duration, loss_ratio, loss_mean, B, L, C);
+    return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_flow_head_f32(const float* y, int64_t ldy, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                                      const float* W, const float* bias, const float* flow, const float* x0, const uint8_t* mask,
+                                      float* pred, float* duration, float* loss_ratio, float* loss_mean, float* workspace,
+                                      int32_t B, int32_t L, int32_t D, int32_t C, ispk_stream_t stream) {
+    ISPK_REQUIRE(y && norm_gamma && norm_beta && W && bias && flow && x0 && mask && pred && duration && loss_ratio && workspace,
+                 ISPK_E_NULL, "flow_head: null pointer");
+    ISPK_REQUIRE(D == 256 && C == 3, ISPK_E_UNSUPPORTED, "flow_head: built for dim 256 -> 3 flow channels (got %d -> %d)", D, C);
+    ISPK_REQUIRE(B >= 0 && L >= 1 && B <= 65535 && ldy >= D && ldy % 4 == 0, ISPK_E_SHAPE, "flow_head: bad shape B=%d L=%d", B, L);
+    ISPK_REQUIRE(ispk_aligned(y, 16) && ispk_aligned(norm_gamma, 16) && ispk_aligned(norm_beta, 16) && ispk_aligned(W, 16), ISPK_E_ALIGN,
+                 "flow_head: y / gamma / beta / W must be 16-byte aligned");
+    if (B == 0) return 0;
+    const int nblk = (L + kFhRows - 1) / kFhRows;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(flow_head_kernel, dim3(nblk, B), dim3(256), 0, s, y, ldy, norm_gamma, norm_beta, norm_eps, W, bias, flow, x0, mask,
+                       pred, duration, workspace, L, nblk);
+    if (int32_t rc = ispk_launch_status()) return rc;
+    hipLaunchKernelGGL(flow_head_finalize_kernel, dim3(1), dim3(1024), 0, s, workspace, nblk, loss_ratio, loss_mean, B);
     return ispk_launch_status();
 }
 

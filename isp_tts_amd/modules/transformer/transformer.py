@@ -246,8 +246,10 @@ class Transformer(nn.Module, Constructor):
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 adaptive_condition: Optional[Tensor] = None, return_intermediates: bool = False, *,
                 key_len: Optional[Tensor] = None, projected: Optional[Tensor] = None,
-                out_dtype: torch.dtype = torch.float32):
-        """`projected` lets a caller that already holds project_emb(x) (e.g. the Euler loop, which re-projects only the
+                out_dtype: torch.dtype = torch.float32, final_norm: bool = True):
+        """`final_norm=False`: `.out` is the last layer's raw output - for a caller whose next kernel applies `self.norm` itself
+        (the flow predictor's head, `runtime.flow_head`).
+        `projected` lets a caller that already holds project_emb(x) (e.g. the Euler loop, which re-projects only the
         3 flow channels per step) skip the projection.  `out_dtype=torch.bfloat16` makes the final LayerNorm emit bf16
         for a bf16 consumer (the decoder's to_mel GEMM on the bf16 path)."""
         if projected is not None:
@@ -281,6 +283,8 @@ class Transformer(nn.Module, Constructor):
             out, normed = res.out, res.next_normed
             if return_intermediates:
                 intermediates.append(res.intermediates)
+        if not final_norm:
+            return TransformerOutput(out=out, intermediates=intermediates)
         if normed is None:
             if out_dtype == torch.float16:   # split fp16 planes [2, B, N, D] for a split-fp16 consumer GEMM
                 normed = runtime.layernorm_split(out, self.norm.weight, self.norm.bias, row_mask=mask, eps=self.norm.eps)

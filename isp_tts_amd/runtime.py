@@ -70,6 +70,7 @@ SIGNATURES = {
     "ispk_alibi_mqa_attn_split_f16": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I64, _I32, _I32, _I32, _P],
     "ispk_flow_mix_f32": [_P, _P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
     "ispk_flow_finish_f32": [_P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _P],
+    "ispk_flow_head_f32": [_P, _I64, _P, _P, _F32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "ispk_flow_euler_f32": [_P, _P, _F32, _P, _P, _I32, _I32, _I32, _P],
     "ispk_infer_features_f32": [_P, _P, _P, _P, _P, _F32, _F32, _F32, _F32, _F32, _P, _P, _I32, _I32, _P],
     "ispk_embed_tokens_f32": [_P, _P, _I64, _I32, _P, _P, _P, _I32, _I32, _I32, _P],
@@ -819,6 +820,27 @@ def flow_finish(pred_raw: Tensor, flow: Tensor, x0: Tensor, mask: Tensor):
     _launch("flow_finish_kernel", 0.0, 20.0 * B * L * C, lib().ispk_flow_finish_f32, pr.data_ptr(), fl.data_ptr(),
             x0c.data_ptr(), mk.data_ptr(), pred.data_ptr(), dur.data_ptr(), ratio.data_ptr(), loss.data_ptr(), B, L, C,
             _stream())
+    return pred, dur, ratio, loss
+
+
+def flow_head(y: Tensor, norm_weight: Tensor, norm_bias: Tensor, norm_eps: float, weight: Tensor, bias: Tensor, flow: Tensor,
+              x0: Tensor, mask: Tensor):
+    """ispk_flow_head_f32: the predictor's final LayerNorm (row-masked) + 256 -> 3 linear_layer + `flow_finish` on the stack's raw
+    output rows y [B, L, 256] -> (pred [B,L,3], duration [B,L], loss_ratio [B], loss 0-d), two launches instead of three."""
+    _dev(y, norm_weight, norm_bias, weight, bias, flow, x0, mask)
+    B, L, D = y.shape
+    C = weight.shape[0]
+    assert y.dtype == torch.float32 and y.stride(2) == 1 and y.stride(0) == L * y.stride(1) and weight.shape == (C, D) and weight.is_contiguous()
+    assert mask.dtype == torch.bool and mask.shape == (B, L)
+    fl, x0c, mk = flow.contiguous(), x0.float().contiguous(), mask.contiguous()
+    pred = torch.empty((B, L, C), dtype=torch.float32, device=y.device)
+    dur = torch.empty((B, L), dtype=torch.float32, device=y.device)
+    ratio = torch.empty((B,), dtype=torch.float32, device=y.device)
+    loss = torch.empty((), dtype=torch.float32, device=y.device)
+    ws = torch.empty((2 * B * ((L + 15) // 16),), dtype=torch.float32, device=y.device)
+    _launch("flow_head_kernels", 0.0, 4.0 * B * L * D, lib().ispk_flow_head_f32, y.data_ptr(), y.stride(1), norm_weight.data_ptr(),
+            norm_bias.data_ptr(), float(norm_eps), weight.data_ptr(), bias.data_ptr(), fl.data_ptr(), x0c.data_ptr(), mk.data_ptr(),
+            pred.data_ptr(), dur.data_ptr(), ratio.data_ptr(), loss.data_ptr(), ws.data_ptr(), B, L, D, C, _stream())
     return pred, dur, ratio, loss
 
 

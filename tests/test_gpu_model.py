@@ -187,6 +187,31 @@ def test_multi_speaker_infer_against_reference_golden(state_dict):
         model(text, text_len.to(DEV), inp["mel"].to(DEV), inp["mel_len"].to(DEV), inp["pitch"].to(DEV), inp["energy"].to(DEV), speaker=spk2)
 
 
+def test_predictor_head_in_one_pass_equals_the_three_launches(gpu_model):
+    """`ispk_flow_head_f32` (final LayerNorm of the predictor's stack + linear_layer + flow-matching algebra per row, block partials
+    added in a fixed order) against the three launches it replaces (LayerNorm, linear_small, flow_finish): same values to fp32
+    summation order, masked positions exactly zero, deterministic; ragged lengths, L not a multiple of the 16-row blocks."""
+    inp = synth.make_inputs(5, 53, 160, variable=True, seed=13)
+    args = [inp[k].to(DEV) for k in ("text", "text_len", "mel", "mel_len", "pitch", "energy")]
+    kw = dict(flow_noise=inp["flow_x0"].to(DEV), flow_time=inp["flow_t"].to(DEV))
+    pred = gpu_model.temporal_adaptor.predictor
+    assert pred.fused_head
+    a = gpu_model(*args, **kw).adaptor_output
+    a2 = gpu_model(*args, **kw).adaptor_output
+    try:
+        pred.fused_head = False
+        b = gpu_model(*args, **kw).adaptor_output
+    finally:
+        pred.fused_head = True
+    for name in ("log_duration", "pitch", "energy", "duration"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert torch.equal(x, getattr(a2, name)), name
+        assert _maxdiff(x, y) < 2e-6 * max(1.0, float(y.abs().max())), name
+    assert abs(float(a.losses["flow_loss"]) - float(b.losses["flow_loss"])) < 2e-6 * float(b.losses["flow_loss"])
+    tmask = (torch.arange(53)[None] < inp["text_len"][:, None]).to(DEV)
+    assert float((a.log_duration * ~tmask).abs().max()) == 0.0 and float((a.pitch * ~tmask).abs().max()) == 0.0
+
+
 def test_forward_matches_oracle_on_other_inputs(gpu_model, state_dict):
     """Different seed, B=3 variable lengths (not in the fixtures): HIP path vs the oracle."""
     inp = synth.make_inputs(3, 60, 200, variable=True, seed=7)

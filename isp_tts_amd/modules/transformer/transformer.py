@@ -109,23 +109,23 @@ class TransformerLayer(nn.Module, Constructor):
             x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
                                                attention_mask=attention_mask, key_len=key_len, residual=x)
         hn = None
-        if (ada is None and (next_norm is None or next_norm[4] == "stats")
-                and self.feed_forward.prenorm_ok(x1, self.feed_forward_norm)):
+        final = next_norm is not None and next_norm[4] != "stats"    # the stack's final norm: only the split path's combine serves it
+        if ada is None and self.feed_forward.prenorm_ok(x1, self.feed_forward_norm):
             # feed_forward_norm inside the fused feed-forward kernel (its waves own whole rows); the `* mask` of :102
             # cannot reach a kept value because the same mask multiplies the block's output (:110)
-            y, hn = self.feed_forward.forward_prenorm(x1, self.feed_forward_norm, mask=mask, next_norm=next_norm)
+            y, hn = self.feed_forward.forward_prenorm(x1, self.feed_forward_norm, mask=mask, next_norm=None if final else next_norm)
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                           shared_intermediates=shared, next_normed=hn)
-        if (ada is None and (next_norm is None or next_norm[4] == "stats" or next_norm[4] == cdt)
+        if (ada is None and (next_norm is None or next_norm[4] == "stats" or next_norm[4] in (cdt, torch.float32))
                 and self.feed_forward.split_ok(x1, self.feed_forward_norm)):
             # small batches: feed_forward_norm + feed-forward split over the inner dimension, then ONE pass that adds the
             # partial products, the residual and the mask and already applies the norm that consumes the result
-            nn_ = None if next_norm is None else (next_norm[0], next_norm[1], next_norm[2], next_norm[3], cdt)
+            nn_ = None if next_norm is None else (next_norm[0], next_norm[1], next_norm[2], next_norm[3],
+                                                  torch.float32 if next_norm[4] == torch.float32 else cdt)
             y, hn = self.feed_forward.forward_prenorm_split(x1, self.feed_forward_norm, mask=mask, next_norm=nn_)
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                           shared_intermediates=shared, next_normed=hn)
-        if (ada is None and (next_norm is None or next_norm[4] == "stats")
-                and self.feed_forward.prenorm_unfused_ok(x1, self.feed_forward_norm)):
+        if ada is None and self.feed_forward.prenorm_unfused_ok(x1, self.feed_forward_norm):
             # small batches (two-GEMM feed-forward): feed_forward_norm inside the first Linear's GEMM
             y = self.feed_forward.forward_prenorm_unfused(x1, self.feed_forward_norm, mask=mask)
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
@@ -275,6 +275,10 @@ class Transformer(nn.Module, Constructor):
                 if li + 1 < len(self.layers):
                     nn_ = self.layers[li + 1].attention_norm
                     nxt = (nn_.weight, nn_.bias, nn_.eps, False, "stats")
+                elif final_norm and out_dtype in (torch.float32, torch.bfloat16):
+                    # last layer: the stack's own final norm (row-masked, transformer.py:205-206) - the split feed-forward's
+                    # combine pass applies it from the same read (small batches); the fused kernel cannot and ignores it
+                    nxt = (self.norm.weight, self.norm.bias, self.norm.eps, mask is not None, out_dtype)
                 if nxt is not None and (nxt[0] is None or nxt[1] is None):
                     nxt = None
             res = layer(out, mask=mask, context=context, context_mask=context_mask, attention_mask=attention_mask,

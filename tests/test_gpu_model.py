@@ -10,7 +10,7 @@ from conftest import crc, golden
 
 pytestmark = pytest.mark.gpu
 
-from isp_tts_amd import synth  # noqa: E402
+from isp_tts_amd import runtime, synth  # noqa: E402
 from isp_tts_amd.modules.transformer import FeedForward, Transformer, TransformerLayer  # noqa: E402
 from oracle import acoustic_oracle as orc  # noqa: E402
 
@@ -689,6 +689,31 @@ def test_bf16_encoder_with_layernorms_inside_the_gemms_matches_separate_layernor
     diff = (fused - plain).abs()
     assert diff.max() < 6e-2 and diff.pow(2).mean().sqrt() < 5e-3
     assert (fused * ~mask[..., None]).abs().max() == 0
+
+
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.bfloat16])
+def test_final_norm_from_the_split_feed_forward_combine_pass(gpu_model, out_dtype):
+    """bf16 path, small batches: the stack's final LayerNorm (transformer.py:205-206, row-masked) comes out of the last layer's
+    combine pass (`ispk_ffn_combine_ln_f32`) instead of a launch of its own - same values as the separate LayerNorm on the same
+    y (one rounding apart for the bf16 form), masked rows exactly zero; with and without a mask."""
+    x = synth._normal("t/finalnorm/x", (16, 100, 384)).to(DEV)
+    lens = torch.full((16,), 100, device=DEV)
+    lens[2::3] = 41
+    mask = torch.arange(100, device=DEV)[None] < lens[:, None]
+    enc = gpu_model.encoder
+    try:
+        enc.set_compute_dtype(torch.bfloat16)
+        for m_, l_ in ((mask, lens), (None, None)):
+            folded = enc(x, mask=m_, key_len=l_, out_dtype=out_dtype).out
+            raw = enc(x, mask=m_, key_len=l_, final_norm=False).out
+            sep = runtime.layernorm(raw, enc.norm.weight, enc.norm.bias, row_mask=m_, eps=enc.norm.eps, out_dtype=out_dtype)
+            assert folded.dtype == out_dtype and folded.shape == sep.shape
+            tol = 2e-5 if out_dtype == torch.float32 else 2.0 ** -7
+            assert (folded.float() - sep.float()).abs().max().item() <= tol * max(1.0, sep.float().abs().max().item())
+            if m_ is not None:
+                assert (folded.float() * ~m_[..., None]).abs().max() == 0
+    finally:
+        enc.set_compute_dtype(torch.float32)
 
 
 def test_config2_encoder_decoder_scope_fp32(gpu_model, state_dict):

@@ -204,6 +204,23 @@ int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const float* norm_ga
                                const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask, float* out, int64_t ldo,
                                int32_t rows, int32_t dim, int32_t inner, uint32_t flags, float* row_stats, float stats_eps,
                                ispk_stream_t stream);
+/* Second half of a pre-norm TransformerLayer in ONE kernel: the attention block's output projection and the feed-forward block,
+ *   x1[i][:]  = x[i][:] + [mask[i] if ISPK_EP_MASK_ACC] * (attn_out[i][:] Wo^T)            attention.py:172-173, transformer.py:91
+ *   out[i][:] = [mask[i] if ISPK_EP_MASK_OUT] * (x1[i][:] + gelu_erf(LN(x1[i][:]) W1^T) W2^T)   transformer.py:97-110
+ * Replaces: `to_out` (attention.py:69, :172) + the residual add (transformer.py:91) + feed_forward_norm + FeedForward + the
+ * second residual add and mask (transformer.py:97-110) - i.e. ispk_gemm_bf16(to_out, residual) followed by
+ * ispk_ffn_bf16_prenorm2 - for decoder-sized batches with heads * 64 = dim = 384.  x1 never reaches memory: the row block's
+ * residual rows are loaded INTO the accumulators of the kernel's second product, the projection is twelve more steps of that
+ * product on top of them (Wo_chunks = ispk_ffn_chunk_w2_bf16(Wo): [384/32][384][32]; attn_out bf16 [rows][384] rows are the
+ * B operands, zeroed for masked rows), the LayerNorm is taken from the accumulators, and the feed-forward block accumulates
+ * onto them - one read of x, one of attn_out, one write of out per row (per layer: 50 + 25 + 50 MB at 32,768 rows instead
+ * of 125 MB for the projection + 170 MB measured for the feed-forward kernel).  Everything else as ispk_ffn_bf16_prenorm2
+ * (W1, W2_chunks, row_stats = (mean, rstd) of the output rows for the next layer's q/kv GEMM). */
+int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                               const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                               const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask, float* out, int64_t ldo,
+                               int32_t rows, int32_t dim, int32_t inner, uint32_t flags, float* row_stats, float stats_eps,
+                               ispk_stream_t stream);
 
 /* Linear whose input is LayerNorm(x), with the row statistics supplied by the kernel that produced x:
  *   C[i][n] = epilogue( sum_k bf16( (x[i][k] - mean_i) * rstd_i * ln_gamma[k] + ln_beta[k] ) * W[n][k] )

@@ -51,6 +51,7 @@ constexpr int kLdT = 388;                        // epilogue: fp32 tile [64 rows
 static_assert(kXtOff + 128 * kD * 2 <= kLds && 64 * kLdT * 4 <= kLds, "LDS carve-up");
 
 constexpr int kSplitMode = 20;   // template argument of the split-inner instance (ispk_ffn_bf16_prenorm2_split)
+constexpr int kProjMode = 50;    // ... of the instance whose prologue is the attention block's output projection (ispk_attn_out_ffn_bf16)
 
 struct Ffn2Params {
     const float* x;
@@ -70,6 +71,9 @@ struct Ffn2Params {
     int chunk_count = 0;          // split mode (blockIdx.y = split): chunks per split; 0 = the whole inner dimension
     int64_t part_stride = 0;      // split mode: floats between the splits' partial outputs
     unsigned long long* stamps = nullptr;   // experiments build, ABL == 3: per-wave phase cycle sums [grid * 8][8]
+    const uint16_t* o = nullptr;  // projection mode: attention output rows [rows][384] bf16 ...
+    int64_t ld_o = 0;
+    const uint16_t* WoC = nullptr;   // ... and to_out's weight as twelve chunks [384 / 32][384][32] (ispk_ffn_chunk_w2_bf16)
 };
 
 // GELU(erf) for values that are rounded to bf16 right away.  erf by Abramowitz-Stegun 7.1.27:
@@ -172,6 +176,17 @@ __device__ __forceinline__ void gelu8_tanh_form(float (&v)[8]) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = v[i] * t[i];
+}
+
+// A global load the compiler's wait insertion does not see, and the counted wait that covers it (the loaded registers are
+// operands of the wait: no use of them can be scheduled in front of it)
+template <int OFF>
+__device__ __forceinline__ void gload_b128_asm(u32x4& dst, const void* ptr) {
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(ptr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_tied(u32x4& a, u32x4& b) {
+    asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "n"(N) : "memory");
 }
 
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
@@ -279,72 +294,8 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
         dma_begin(c1, c2, buf);
         static_for<0, kPerWave>([&](auto jc) { dma_one(jc); });
     };
-    issue(0, 0, 0);   // W1 chunk 0 -> buffer 0 (and a W2 chunk nobody reads), on its way during the LayerNorm (the tile below
-                      // does not touch buffer 0)
-
-    // ---- prologue: LayerNorm of 16 rows per wave (two rows at a time: 32 lanes x 3 float4 cover a row), bf16 into the tile
-    {
-        const int rbase = rg * 32 + half * 16;
-        f32x4 g4[3], b4[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            g4[j] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * (l31 + 32 * j));
-            b4[j] = *reinterpret_cast<const f32x4*>(p.beta + 4 * (l31 + 32 * j));
-        }
-        f32x4 v[8][3];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int r = row0 + rbase + 2 * i + h;
-            r = r < p.rows ? r : p.rows - 1;            // rows past the end: a valid row, never stored
-#pragma unroll
-            for (int j = 0; j < 3; ++j) v[i][j] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)r * p.ldx + 4 * (l31 + 32 * j));
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float s = 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) s += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-            const float mean = s * (1.0f / kD);
-            float q = 0.f;
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float d = v[i][j][e] - mean;
-                    q = fmaf(d, d, q);
-                }
-#pragma unroll
-            for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
-            const float rstd = 1.0f / sqrtf(q * (1.0f / kD) + p.eps);
-            const int rl = rbase + 2 * i + h;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                float y[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = fmaf((v[i][j][e] - mean) * rstd, g4[j][e], b4[j][e]);
-                uint2 pk;
-                pk.x = pack_bf16(y[0], y[1]);
-                pk.y = pack_bf16(y[2], y[3]);
-                const int c16 = (l31 + 32 * j) >> 1;     // 16-byte chunk of the row; this lane owns its half (l31 & 1)
-                *reinterpret_cast<uint2*>(smem + kXtOff + rl * 768 + 16 * (c16 ^ (rl & 15)) + 8 * (l31 & 1)) = pk;
-            }
-        }
-    }
-    __syncthreads();
     bf16x8 xf[12];   // B operands of product 1: LN(x)[row rg*32 + l31][this half's 192 features], k-step ks = 16 features
-#pragma unroll
-    for (int ks = 0; ks < 12; ++ks)
-        xf[ks] = *reinterpret_cast<const bf16x8*>(smem + kXtOff + (rg * 32 + l31) * 768 + 16 * ((24 * half + 2 * ks + h) ^ (l31 & 15)));
-    __syncthreads();   // the tile is dead: buffer 1, the P tiles and the exchange area may be written from here on
-
-    stamp(0);
     f32x16 acc2[6];
-#pragma unroll
-    for (int nt = 0; nt < 6; ++nt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
     float keep[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) keep[i] = 0.f;
@@ -447,8 +398,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             static_for<0, kRing>([&](auto jc) { w2read(jc, b0, b1); });
         }
     };
-    auto product2 = [&](int it, bool dma) __attribute__((always_inline)) {   // acc2 += W2[this half's 192 features][chunk it - 2] · Pᵀ
-        const uint32_t b0 = w2a0 + (it & 1) * kWbuf, b1 = w2a1 + (it & 1) * kWbuf;
+    auto product2_at = [&](uint32_t b0, uint32_t b1, bool dma) __attribute__((always_inline)) {   // (b0 / b1: the W2 image's k-step 0 / 1 addresses)
         if constexpr (kPrio) __builtin_amdgcn_s_setprio(1);
         static_for<0, 12>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
@@ -466,6 +416,196 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
         });
         if constexpr (kPrio) __builtin_amdgcn_s_setprio(0);
     };
+    auto product2 = [&](int it, bool dma) __attribute__((always_inline)) {   // acc2 += W2[this half's 192 features][chunk it - 2] · Pᵀ
+        product2_at(w2a0 + (it & 1) * kWbuf, w2a1 + (it & 1) * kWbuf, dma);
+    };
+
+    // ---- prologue (a lambda: projection mode runs it INSIDE the two branches that select the main loop's stage order - with the
+    // accumulators live across that branch hipcc has to agree on one register assignment for both loop copies and spills 76 VGPRs)
+    constexpr bool proj_mode = ABL == kProjMode;
+    auto prologue = [&]() __attribute__((always_inline)) {
+    if constexpr (proj_mode) {
+        // Projection mode: this row block's residual rows start in the accumulators of product 2 and the attention block's
+        // output projection is twelve more "product 2" steps on top of them (to_out's weight cut into [384][32] chunks like W2,
+        // the attention output rows as B operands straight from global memory into registers):
+        //     x1 = x + [mask] * (o · Woᵀ)                              attention.py:172, transformer.py:91
+        // x1 never exists in memory: its LayerNorm is taken from the accumulators (a row lives in four lanes: l31 and l31 + 32 of
+        // the two waves of a SIMD), and the feed-forward block then accumulates onto it - no residual read in the epilogue.
+        const char* WoB = reinterpret_cast<const char*>(p.WoC);
+        // Chunk buffers of the projection: the W2 areas of both weight buffers and buffer 1's W1 area - three, so that chunk c + 2
+        // is on its way while chunk c is multiplied (a DMA's latency is longer than one 12-MFMA step)
+        constexpr int kPjBuf[3] = {kW1Bytes, kWbuf + kW1Bytes, kWbuf};
+        auto dma_w1_0 = [&](auto jc) __attribute__((always_inline)) {           // this wave's part of W1 chunk 0 -> buffer 0
+            constexpr int j = decltype(jc)::value;
+            const int q = q_of(j);                    // wave-uniform
+            if (q < 0 || q >= kW1Dma) return;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W1b + soff[j]),
+                                             (__attribute__((address_space(3))) void*)(smem + q * 1024), 16, 0, 0);
+        };
+        // ... of a Wo chunk (24 instructions of 1 KB): wave w issues pieces w, w + 8, w + 16 - three each, no branch (straight-line
+        // code lets the compiler count the outstanding loads exactly; behind a wave-uniform branch it waits for all of them)
+        uint32_t swo[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const uint32_t t = 64u * (wave + 8 * j) + lane, r = t >> 2, c = t & 3u;
+            swo[j] = r * 64u + 16u * (c ^ ((r >> 2) & 3u));
+        }
+        auto dma_wo = [&](int c, int boff) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(WoB + c * kW2Bytes + swo[j]),
+                                                 (__attribute__((address_space(3))) void*)(smem + boff + (wave + 8 * j) * 1024), 16, 0, 0);
+        };
+        int rr = row0 + rg * 32 + l31;
+        rr = rr < p.rows ? rr : p.rows - 1;           // rows past the end: a valid row, never stored
+        // attention output, row l31 of the row group, as B operands: the two k-steps of a chunk are requested right behind the
+        // chunk's weight DMA (five vector-memory instructions per wave and chunk: the waits below count them)
+        const uint16_t* orow = p.o + (int64_t)rr * p.ld_o + 8 * h;
+        const uint32_t row_on = (!(p.flags & ISPK_EP_MASK_ACC) || p.mask[rr]) ? 0xffffffffu : 0u;
+        u32x4 af[3][2];
+        auto fetch = [&](auto cc) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            dma_wo(c, kPjBuf[c % 3]);
+            // (asm: hipcc's own wait in front of the first use of a plain load is vmcnt(0) once LDS-DMA instructions are in
+            // flight - it would drain the chunks requested ahead; these are covered by the counted waits below)
+            gload_b128_asm<64 * c>(af[c % 3][0], orow);
+            gload_b128_asm<64 * c + 32>(af[c % 3][1], orow);
+        };
+        static_for<0, kPerWave>([&](auto jc) { dma_w1_0(jc); });      // (its W1 area is not touched before the main loop)
+        {
+            const float* xr = p.x + (int64_t)rr * p.ldx + 192 * half + 4 * h;
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xr + 32 * nt + 8 * gq);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc2[nt][4 * gq + e] = v[e];
+                }
+        }
+        fetch(std::integral_constant<int, 0>{});
+        fetch(std::integral_constant<int, 1>{});
+        static_for<0, 12>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            // chunk c (everything older than the five instructions of chunk c + 1) has landed for this wave ...
+            // (the fragments are operands of the wait so that no use of them can be scheduled in front of it)
+            vm_wait_tied<(c < 11 ? 5 : 0)>(af[c % 3][0], af[c % 3][1]);
+            __builtin_amdgcn_s_barrier();                        // ... and for the others, who are also done with chunk c - 1
+            asm volatile("" ::: "memory");
+            if constexpr (c + 2 < 12) fetch(std::integral_constant<int, c + 2>{});      // into the buffer chunk c - 1 has left
+            pb[0] = __builtin_bit_cast(bf16x8, af[c % 3][0] & row_on);      // (masked rows contribute nothing: attention.py:172)
+            pb[1] = __builtin_bit_cast(bf16x8, af[c % 3][1] & row_on);
+            const uint32_t b0 = w2a0 - kW1Bytes + kPjBuf[c % 3], b1 = w2a1 - kW1Bytes + kPjBuf[c % 3];
+            static_for<0, kRing>([&](auto jc) { w2read(jc, b0, b1); });
+            product2_at(b0, b1, false);
+        });
+        __syncthreads();     // (everyone is done with the last chunks: the sums below and the tile go over their buffers)
+        // LayerNorm of x1 from the accumulators; the partner wave's sums come through buffer 0's W2 area
+        float* sc = reinterpret_cast<float*>(smem + kW1Bytes);
+        float s = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += acc2[nt][r];
+        s += __shfl_xor(s, 32, 64);
+        sc[wave * 64 + lane] = s;
+        __syncthreads();
+        const float mean = (s + sc[(wave ^ 4) * 64 + lane]) * (1.0f / kD);
+        float q = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float d = acc2[nt][r] - mean;
+                q = fmaf(d, d, q);
+            }
+        q += __shfl_xor(q, 32, 64);
+        sc[512 + wave * 64 + lane] = q;
+        __syncthreads();
+        const float rstd = 1.0f / sqrtf((q + sc[512 + (wave ^ 4) * 64 + lane]) * (1.0f / kD) + p.eps);
+        // bf16 rows into the tile (over buffer 1, the P tiles and the exchange area - all idle; not over the sums above)
+        const int rl = rg * 32 + l31;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int f0 = 192 * half + 32 * nt + 8 * gq + 4 * h;
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + f0), b4 = *reinterpret_cast<const f32x4*>(p.beta + f0);
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y[e] = fmaf((acc2[nt][4 * gq + e] - mean) * rstd, g4[e], b4[e]);
+                uint2 pk;
+                pk.x = pack_bf16(y[0], y[1]);
+                pk.y = pack_bf16(y[2], y[3]);
+                *reinterpret_cast<uint2*>(smem + kXtOff + rl * 768 + 16 * ((f0 >> 3) ^ (rl & 15)) + 8 * h) = pk;
+            }
+    } else {
+        issue(0, 0, 0);   // W1 chunk 0 -> buffer 0 (and a W2 chunk nobody reads), on its way during the LayerNorm (the tile below
+                          // does not touch buffer 0)
+
+        // ---- prologue: LayerNorm of 16 rows per wave (two rows at a time: 32 lanes x 3 float4 cover a row), bf16 into the tile
+        {
+            const int rbase = rg * 32 + half * 16;
+            f32x4 g4[3], b4[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                g4[j] = *reinterpret_cast<const f32x4*>(p.gamma + 4 * (l31 + 32 * j));
+                b4[j] = *reinterpret_cast<const f32x4*>(p.beta + 4 * (l31 + 32 * j));
+            }
+            f32x4 v[8][3];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int r = row0 + rbase + 2 * i + h;
+                r = r < p.rows ? r : p.rows - 1;            // rows past the end: a valid row, never stored
+#pragma unroll
+                for (int j = 0; j < 3; ++j) v[i][j] = *reinterpret_cast<const f32x4*>(p.x + (int64_t)r * p.ldx + 4 * (l31 + 32 * j));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) s += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+                const float mean = s * (1.0f / kD);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = v[i][j][e] - mean;
+                        q = fmaf(d, d, q);
+                    }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+                const float rstd = 1.0f / sqrtf(q * (1.0f / kD) + p.eps);
+                const int rl = rbase + 2 * i + h;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    float y[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) y[e] = fmaf((v[i][j][e] - mean) * rstd, g4[j][e], b4[j][e]);
+                    uint2 pk;
+                    pk.x = pack_bf16(y[0], y[1]);
+                    pk.y = pack_bf16(y[2], y[3]);
+                    const int c16 = (l31 + 32 * j) >> 1;     // 16-byte chunk of the row; this lane owns its half (l31 & 1)
+                    *reinterpret_cast<uint2*>(smem + kXtOff + rl * 768 + 16 * (c16 ^ (rl & 15)) + 8 * (l31 & 1)) = pk;
+                }
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 12; ++ks)
+        xf[ks] = *reinterpret_cast<const bf16x8*>(smem + kXtOff + (rg * 32 + l31) * 768 + 16 * ((24 * half + 2 * ks + h) ^ (l31 & 15)));
+    __syncthreads();   // the tile is dead: buffer 1, the P tiles and the exchange area may be written from here on
+    stamp(0);
+    };
+    if constexpr (!proj_mode) prologue();
 
     // ---- main loop.  Iteration `it`: product 1 of chunk it, finish of chunk it-1, product 2 of chunk it-2.
     // Stage order: finish, product 1, product 2 for half 0; product 2, finish, product 1 for half 1 (finish always
@@ -613,8 +753,13 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
         if (half == 1) __builtin_amdgcn_s_setprio(1);
     }
     if constexpr (!kSlot2) {
-        if (half == 0) main_loop(std::integral_constant<int, 0>{});
-        else main_loop(std::integral_constant<int, 1>{});
+        if (half == 0) {
+            if constexpr (proj_mode) prologue();
+            main_loop(std::integral_constant<int, 0>{});
+        } else {
+            if constexpr (proj_mode) prologue();
+            main_loop(std::integral_constant<int, 1>{});
+        }
     }
     if constexpr (kStaticPrio) __builtin_amdgcn_s_setprio(0);
 
@@ -644,14 +789,19 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             const int r = row0 + pass * 64 + rl;
             const bool live = r < p.rows;
             const int rc = live ? r : p.rows - 1;
-            const float mk = (p.mask && (mask_acc || mask_out)) ? (p.mask[rc] ? 1.0f : 0.0f) : 1.0f;
+            const float mk = (p.mask && (mask_acc || mask_out)) ? (p.mask[rc] ? 1.0f : 0.0f) : 1.0f;   // (projection mode: MASK_ACC belongs to the prologue)
             f32x4 y[3];
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int c = 4 * (l31 + 32 * j);
                 f32x4 a = *reinterpret_cast<const f32x4*>(T + rl * kLdT + c);
-                if (!split_mode) {       // (split mode: the raw partial product; residual, mask and sums happen in the combine pass)
+                if constexpr (proj_mode) {      // (the residual has been in the accumulators since the prologue)
+                    if (mask_out) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] *= mk;
+                    }
+                } else if (!split_mode) {       // (split mode: the raw partial product; residual, mask and sums happen in the combine pass)
                     const f32x4 xr = *reinterpret_cast<const f32x4*>(p.x + (int64_t)rc * p.ldx + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -829,6 +979,35 @@ extern "C" int32_t ispk_ffn_combine_ln_f32(const float* x, int64_t ldx, const fl
     else
         hipLaunchKernelGGL(ffn_combine_ln_kernel<float>, grid, dim3(256), 0, s, x, ldx, parts, part_stride, splits, mask, y, ldy,
                            ln_gamma, ln_beta, ln_eps, ln_mask, static_cast<float*>(ln_out), ld_ln, rows);
+    return ispk_launch_status();
+}
+
+// The attention block's output projection + the feed-forward block of a pre-norm layer, one kernel (kProjMode above):
+//     x1 = x + [mask] * (attn_out · Woᵀ);   out = [mask] * (x1 + gelu(LN(x1) · W1ᵀ) · W2ᵀ)     transformer.py:91-110
+extern "C" int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                          const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta,
+                                          float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask,
+                                          float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
+                                          float* row_stats, float stats_eps, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && attn_out && Wo_chunks && norm_gamma && norm_beta && W1 && W2_chunks && out, ISPK_E_NULL,
+                 "attn_out_ffn: null pointer");
+    ISPK_REQUIRE(dim == kD, ISPK_E_UNSUPPORTED, "attn_out_ffn: dim %d (built for 384 = heads * 64)", dim);
+    ISPK_REQUIRE(rows >= 0 && inner >= 64 && inner % 32 == 0, ISPK_E_SHAPE, "attn_out_ffn: bad shape rows=%d inner=%d", rows, inner);
+    ISPK_REQUIRE((flags & ~(ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) == 0, ISPK_E_UNSUPPORTED, "attn_out_ffn: unsupported flags");
+    ISPK_REQUIRE(!((flags & (ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) && !mask), ISPK_E_NULL, "attn_out_ffn: mask flag without mask");
+    ISPK_REQUIRE(ldx % 4 == 0 && ldo % 4 == 0 && ld_attn % 8 == 0 && ldx >= dim && ldo >= dim && ld_attn >= dim &&
+                     ispk_aligned(x, 16) && ispk_aligned(out, 16) && ispk_aligned(attn_out, 16) && ispk_aligned(Wo_chunks, 16) &&
+                     ispk_aligned(W1, 16) && ispk_aligned(W2_chunks, 16) && ispk_aligned(norm_gamma, 16) &&
+                     ispk_aligned(norm_beta, 16) && (!row_stats || ispk_aligned(row_stats, 8)),
+                 ISPK_E_ALIGN, "attn_out_ffn: 16-byte alignment / strides that are multiples of 4 (fp32) and 8 (bf16) required");
+    if (rows == 0) return 0;
+    Ffn2Params p{x, ldx, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, mask, out, ldo, rows, inner, flags, row_stats, stats_eps};
+    p.o = attn_out;
+    p.ld_o = ld_attn;
+    p.WoC = Wo_chunks;
+    ISPK_RESERVE_LDS((&ffn2_bf16_kernel<kProjMode>), kLds, "attn_out_ffn");
+    hipLaunchKernelGGL(ffn2_bf16_kernel<kProjMode>, dim3((rows + 127) / 128), dim3(512), kLds,
+                       reinterpret_cast<hipStream_t>(stream), p);
     return ispk_launch_status();
 }
 

@@ -1949,7 +1949,8 @@ extern "C" int32_t ispk_ffn_bf16(const uint16_t* x, int64_t ldx, const uint16_t*
     return ffn_launch(x, ldx, W1, ldw1, bias1, W2, ldw2, bias2, resid, ldr, mask, out, ldo, rows, D, F, flags, nullptr, stream);
 }
 
-#ifdef ISPK_EXPERIMENTS   // measured slower than the default path: experiments build only, not in include/ispk.h
+#ifdef ISPK_EXPERIMENTS   // round 2, the four-wave kernel writing x1 and re-reading it: measured slower than two launches; experiments
+                          // build only (the product's ispk_attn_out_ffn_bf16 is csrc/ffn2.hip's projection mode: x1 stays in the accumulators)
 extern "C" int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16_t* W1, int64_t ldw1,
                                     const uint16_t* W2_packed, const float* bias2, const float* resid, int64_t ldr,
                                     const uint8_t* mask, float* out, int64_t ldo, int32_t rows, int32_t D, int32_t F,
@@ -1961,7 +1962,8 @@ extern "C" int32_t ispk_ffn_bf16_ln(const uint16_t* x, int64_t ldx, const uint16
 }
 #endif
 
-#ifdef ISPK_EXPERIMENTS   // measured slower than the default path: experiments build only, not in include/ispk.h
+#ifdef ISPK_EXPERIMENTS   // round 2, the four-wave kernel writing x1 and re-reading it: measured slower than two launches; experiments
+                          // build only (the product's ispk_attn_out_ffn_bf16 is csrc/ffn2.hip's projection mode: x1 stays in the accumulators)
 extern "C" int32_t ispk_gemm_bf16_ln(const uint16_t* A, int64_t lda, const uint16_t* W, int64_t ldw, float* C, int64_t ldc,
                                      const float* bias, const void* resid, int64_t ldr, const uint8_t* mask, int32_t M,
                                      int32_t N, int32_t K, uint32_t flags, const float* ln_gamma, const float* ln_beta,
@@ -2016,8 +2018,9 @@ extern "C" int32_t ispk_ffn_bf16_prenorm(const float* x, int64_t ldx, const floa
                       row_stats ? &ln : nullptr, stream, &lx);
 }
 
-#ifdef ISPK_EXPERIMENTS   // measured slower than the default path: experiments build only, not in include/ispk.h
-extern "C" int32_t ispk_attn_out_ffn_bf16(const uint16_t* attn_out, int64_t ldao, const uint16_t* Wo, const float* x,
+#ifdef ISPK_EXPERIMENTS   // round 2, the four-wave kernel writing x1 and re-reading it: measured slower than two launches; experiments
+                          // build only (the product's ispk_attn_out_ffn_bf16 is csrc/ffn2.hip's projection mode: x1 stays in the accumulators)
+extern "C" int32_t ispk_attn_out_ffn_bf16_v1(const uint16_t* attn_out, int64_t ldao, const uint16_t* Wo, const float* x,
                                           int64_t ldx, const float* norm_gamma, const float* norm_beta, float norm_eps,
                                           const uint16_t* W1, int64_t ldw1, const uint16_t* W2_packed, const uint8_t* mask,
                                           float* x1, int64_t ldx1, float* out, int64_t ldo, int32_t rows, int32_t D,

@@ -90,18 +90,25 @@ class Attention(nn.Module, Constructor):
             return wqkv, wo, slopes
         return self._cache.get(dtype, ps, build)
 
+    def _chunked_wo(self) -> Tensor:
+        """to_out's weight as [out_dim / 32][dim][32] chunks (ispk_attn_out_ffn_bf16), staged once per weight version."""
+        return self._cache.get("woc", (self.to_out.weight,),
+                               lambda: runtime.ffn_chunk_w2(self._staged(torch.bfloat16)[1]))
+
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 cache: Optional[AttentionIntermediates] = None,
                 shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None,
-                residual: Optional[Tensor] = None, prenorm: Optional[tuple] = None):
+                residual: Optional[Tensor] = None, prenorm: Optional[tuple] = None, defer_out: bool = False):
         """x [B,N,dim] (fp32, or bf16 when compute_dtype is bf16); mask [B,N] bool, True = valid, a length mask.
         `key_len` (int64 [B]) may be passed to skip recomputing mask.sum(1); `residual` (fp32 [B,N,dim]) fuses
         `residual + mask * to_out(...)` into the output GEMM.  Returns (out, AttentionIntermediates,
         AttentionSharedIntermediates) like the reference; `rel_pos_bias` is None because no bias tensor exists.
         `prenorm` = (row_stats | None, weight, bias, eps): x is the fp32 input of the LayerNorm that precedes this block
         and the q/kv GEMM applies that LayerNorm while staging x (bf16 path; statistics from the producing kernel, or
-        computed by the GEMM's own waves when None)."""
+        computed by the GEMM's own waves when None).  `defer_out` (bf16 path): the first element is the attention output
+        BEFORE `to_out` (bf16 [B,N,heads*64]) - the caller's next kernel applies `to_out`, mask and residual itself
+        (`runtime.attn_out_ffn`)."""
         if context is not None or context_mask is not None or attention_mask is not None or cache is not None:
             raise NotImplementedError("cross-attention, explicit attention masks and KV caches are not on the "
                                       "acoustic-model forward path and are not built")
@@ -131,8 +138,12 @@ class Attention(nn.Module, Constructor):
                 x = runtime.cast_bf16(x) if dt == torch.bfloat16 else x.float()
             qkv = runtime.gemm(x, wqkv)                                        # [B,N,H*64+128]
         o = runtime.alibi_mqa_attention(qkv, self.heads, slopes, key_len)      # [B,N,H*64]
-        flags = runtime.EP_MASK_ACC if mask is not None else 0
-        out = runtime.gemm(o, wo, resid=residual, mask=mask, flags=flags, out_dtype=torch.float32)
+        if defer_out:
+            assert dt == torch.bfloat16
+            out = o
+        else:
+            flags = runtime.EP_MASK_ACC if mask is not None else 0
+            out = runtime.gemm(o, wo, resid=residual, mask=mask, flags=flags, out_dtype=torch.float32)
         hq = self.heads * 64
         inter = AttentionIntermediates(queries=qkv[..., :hq].view(b, n, self.heads, 64).transpose(1, 2),
                                        keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])

@@ -144,6 +144,21 @@ class FeedForward(nn.Module, Constructor):
                                   want_stats=want, stats_eps=next_norm[2] if want else 1e-5)
         return res if want else (res, None)
 
+    def proj_ok(self, x: Tensor, norm) -> bool:
+        """Can `forward_proj_prenorm` run to_out + residual + norm + feed-forward + residual as one kernel (x: the layer's input)?"""
+        return (self.prenorm_ok(x, norm) and self.pair_kernel and x.shape[-1] == 384 and self.net[3].bias is None
+                and self.net[0].weight.shape[0] % 32 == 0 and self.net[0].weight.shape[0] >= 64)
+
+    def forward_proj_prenorm(self, x: Tensor, attn_out: Tensor, woc: Tensor, norm, *, mask: Optional[Tensor] = None,
+                             next_norm: Optional[tuple] = None):
+        """(y, stats | None) with x1 = x + [mask] * to_out(attn_out), y = [mask] * (x1 + feed_forward(norm(x1))) in one kernel
+        (ispk_attn_out_ffn_bf16): x1 exists only in the kernel's accumulators.  `woc` = Attention._chunked_wo()."""
+        w1, _ = self._staged(torch.bfloat16)
+        want = next_norm is not None and next_norm[4] == "stats"
+        res = runtime.attn_out_ffn(x, attn_out, woc, norm.weight, norm.bias, w1, self._chunked_w2(), mask=mask, norm_eps=norm.eps,
+                                   want_stats=want, stats_eps=next_norm[2] if want else 1e-5)
+        return res if want else (res, None)
+
     def forward(self, x: Tensor, *, residual: Optional[Tensor] = None, mask: Optional[Tensor] = None) -> Tensor:
         if self.training and self.dropout_p > 0:
             raise NotImplementedError("feed-forward dropout (training) is outside the forward-path scope")

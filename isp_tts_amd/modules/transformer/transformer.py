@@ -53,6 +53,9 @@ class TransformerLayer(nn.Module, Constructor):
     # Path switches are plain class attributes (set them on the class or on an instance; nothing reads the environment).
     # LayerNorm applied by the consuming GEMM's own waves (ispk_gemm_bf16_lnin with row_stats = NULL), decoder-sized batches:
     lnin_self = True
+    # to_out + residual + feed_forward_norm + feed-forward + residual as ONE kernel (ispk_attn_out_ffn_bf16; x1 never reaches
+    # memory), bf16 path, dim 384 = heads * 64, decoder-sized batches:
+    proj_ffn = True
 
     def __init__(self, dim: int = 384, attention=None, feed_forward=None, pre_norm: bool = True,
                  adaptive_norm: bool = False, condition_dim: Optional[int] = None):
@@ -98,18 +101,25 @@ class TransformerLayer(nn.Module, Constructor):
                and attention_mask is None and x.shape[-1] in (256, 384) and self.attention_norm.weight is not None
                and self.attention_norm.bias is not None and self.lnin_self
                and x.numel() // x.shape[-1] >= self.lnin_self_min_rows)
+        final = next_norm is not None and next_norm[4] != "stats"    # the stack's final norm: only the split path's combine serves it
+        fuse = (cdt == torch.bfloat16 and self.proj_ffn and ada is None and context is None and attention_mask is None
+                and self.attention.out_dim == x.shape[-1] and self.feed_forward.proj_ok(x, self.feed_forward_norm))
         if cdt == torch.bfloat16 and (handed or own):
             # attention_norm inside the q/kv GEMM, applied while it stages x: with the row statistics the previous layer's
             # feed-forward kernel handed over, or (first layer of a stack) computed by the GEMM's own waves
             an = self.attention_norm
-            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x,
+            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x, defer_out=fuse,
                                                prenorm=(normed if handed else None, an.weight, an.bias, an.eps))
         else:
             h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
             x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
-                                               attention_mask=attention_mask, key_len=key_len, residual=x)
+                                               attention_mask=attention_mask, key_len=key_len, residual=x, defer_out=fuse)
         hn = None
-        final = next_norm is not None and next_norm[4] != "stats"    # the stack's final norm: only the split path's combine serves it
+        if fuse:    # (x1 is the attention output before to_out)
+            y, hn = self.feed_forward.forward_proj_prenorm(x, x1, self.attention._chunked_wo(), self.feed_forward_norm, mask=mask,
+                                                           next_norm=None if final else next_norm)
+            return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
+                                          shared_intermediates=shared, next_normed=hn)
         if ada is None and self.feed_forward.prenorm_ok(x1, self.feed_forward_norm):
             # feed_forward_norm inside the fused feed-forward kernel (its waves own whole rows); the `* mask` of :102
             # cannot reach a kept value because the same mask multiplies the block's output (:110)

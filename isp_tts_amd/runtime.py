@@ -56,6 +56,7 @@ SIGNATURES = {
     "ispk_ffn_bf16_prenorm2_split": [_P, _I64, _P, _P, _F32, _P, _P, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_ffn_combine_ln_f32": [_P, _I64, _P, _I64, _I32, _P, _P, _I64, _P, _P, _F32, _I32, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_ffn_bf16_prenorm2": [_P, _I64, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
+    "ispk_attn_out_ffn_bf16": [_P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
     "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _F32, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -420,6 +421,33 @@ def ffn_prenorm2(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, 
     _launch("ffn2_bf16_kernel<0>", 4.0 * R * D * Fi, float(nb), lib().ispk_ffn_bf16_prenorm2, x2.data_ptr(),
             x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w2c.data_ptr(), _ptr(mask),
             out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())
+    return (out, stats) if want_stats else out
+
+
+def attn_out_ffn(x: Tensor, attn_out: Tensor, woc: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2c: Tensor,
+                 mask: Optional[Tensor] = None, norm_eps: float = 1e-5, want_stats: bool = False, stats_eps: float = 1e-5):
+    """ispk_attn_out_ffn_bf16 (dim 384 = heads * 64): the second half of a pre-norm layer in one kernel,
+        x1 = x + [mask] * (attn_out @ Wo^T);  out = [mask] * (x1 + gelu(LN(x1) @ w1^T) @ w2^T)
+    from the fp32 residual rows x and the bf16 attention output; woc = `ffn_chunk_w2(Wo)`, w2c = `ffn_chunk_w2(w2)`.  With
+    `want_stats` also the (mean, rstd) of the output rows, fp32 [rows, 2]."""
+    _dev(x, attn_out, woc, norm_weight, norm_bias, w1, w2c, mask)
+    assert x.dtype == torch.float32 and attn_out.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
+    assert woc.dtype == torch.bfloat16 and w2c.dtype == torch.bfloat16
+    x2, o2 = _rows2d(x), _rows2d(attn_out)
+    R, D = x2.shape
+    Fi = w1.shape[0]
+    assert o2.shape == (R, D) and woc.shape == (D // 32, D, 32) and woc.is_contiguous()
+    assert w1.shape == (Fi, D) and w1.is_contiguous() and w2c.shape == (Fi // 32, D, 32) and w2c.is_contiguous()
+    out = torch.empty((*x.shape[:-1], D), dtype=torch.float32, device=x.device)
+    stats = torch.empty((R, 2), dtype=torch.float32, device=x.device) if want_stats else None
+    flags = 0
+    if mask is not None:
+        mask = mask.reshape(-1).contiguous()
+        flags = EP_MASK_ACC | EP_MASK_OUT
+    nb = x2.numel() * 4 + o2.numel() * 2 + (woc.numel() + w1.numel() + w2c.numel()) * 2 + out.numel() * 4 + (R * 8 if want_stats else 0)
+    _launch("ffn2_bf16_kernel<50>", 4.0 * R * D * Fi + 2.0 * R * D * D, float(nb), lib().ispk_attn_out_ffn_bf16, x2.data_ptr(),
+            x2.stride(0), o2.data_ptr(), o2.stride(0), woc.data_ptr(), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps,
+            w1.data_ptr(), w2c.data_ptr(), _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())
     return (out, stats) if want_stats else out
 
 

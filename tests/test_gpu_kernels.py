@@ -457,6 +457,54 @@ def test_eight_wave_ffn_kernel(R, Fi, masked):
     assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
 
 
+@pytest.mark.parametrize("R,Fi,masked", [(128 * 9 + 17, 1536, True), (128 * 3, 1536, False), (70, 64, True), (128 * 40, 1536, True)])
+def test_projection_and_ffn_kernel(R, Fi, masked):
+    """ispk_attn_out_ffn_bf16 (csrc/ffn2.hip, projection mode): x1 = x + mask * (o Wo^T) in the accumulators, LayerNorm from the
+    accumulators, the feed-forward block on top - against float64 on the un-rounded x1 / LayerNorm, and against the two
+    launches it replaces (to_out GEMM with residual epilogue, then ispk_ffn_bf16_prenorm2): same products in another summation
+    order.  Ragged row counts, masked rows exactly zero (garbage - NaN bit patterns - in the masked rows of the attention
+    output must not leak), output statistics, determinism."""
+    D = 384
+    x = synth._normal(f"t/pj/x{R}", (R, D), 1.5, 0.4)
+    o = _bf(synth._normal(f"t/pj/o{R}", (R, D), 1.0))
+    wo = _bf(synth._normal("t/pj/wo", (D, D), D ** -0.5))
+    w1, w2 = _bf(synth._normal(f"t/pj/w1{Fi}", (Fi, D), D ** -0.5)), _bf(synth._normal(f"t/pj/w2{Fi}", (D, Fi), Fi ** -0.5))
+    g, b = synth._normal("t/pj/g", (D,), 0.1, 1.0), synth._normal("t/pj/b", (D,), 0.1)
+    mask = (torch.arange(R) % 7 != 3) if masked else None
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    woc, w2c = runtime.ffn_chunk_w2(d(wo)), runtime.ffn_chunk_w2(d(w2))
+    o_dev = d(o).clone()
+    if masked:
+        o_dev[~d(mask)] = float("nan")        # what a padded query row may hold
+    out, stats = runtime.attn_out_ffn(d(x), o_dev, woc, d(g), d(b), d(w1), w2c, mask=d(mask), want_stats=True)
+    again = runtime.attn_out_ffn(d(x), o_dev, woc, d(g), d(b), d(w1), w2c, mask=d(mask))
+    assert torch.equal(out, again)
+    out = out.cpu()
+    assert torch.isfinite(out).all()
+    x64 = x.double()
+    pr = o.double() @ wo.double().t()
+    x1 = x64 + (pr * mask[:, None] if masked else pr)
+    hn = (x1 - x1.mean(1, keepdim=True)) / torch.sqrt(x1.var(1, unbiased=False, keepdim=True) + 1e-5) * g.double() + b.double()
+    ref64 = x1 + F.gelu(hn @ w1.double().t()) @ w2.double().t()
+    if masked:
+        ref64 = ref64 * mask[:, None]
+        assert out[~mask].abs().max().item() == 0.0
+    err = (out.double() - ref64).abs()
+    print(f"attn_out_ffn R={R} Fi={Fi}: max err vs float64 = {err.max().item():.3e}, rms = {err.pow(2).mean().sqrt().item():.3e}")
+    assert err.max().item() <= 0.06 and err.pow(2).mean().sqrt().item() <= 6e-3
+    # the two launches it replaces
+    o_clean = d(o) if not masked else torch.where(d(mask)[:, None], d(o), torch.zeros_like(d(o)))
+    x1k = runtime.gemm(o_clean, d(wo), resid=d(x), mask=d(mask), flags=runtime.EP_MASK_ACC if masked else 0, out_dtype=torch.float32)
+    two = runtime.ffn_prenorm2(x1k, d(g), d(b), d(w1), w2c, mask=d(mask), flags=runtime.EP_MASK_OUT if masked else 0).cpu()
+    e2 = (out - two).abs()
+    print(f"   vs to_out GEMM + ffn_prenorm2: max {e2.max().item():.3e}, rms {e2.pow(2).mean().sqrt().item():.3e}")
+    assert e2.max().item() <= 3e-2 and e2.pow(2).mean().sqrt().item() <= 2e-3
+    o64 = out.double()
+    assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
+    rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
+    assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
+
+
 @pytest.mark.parametrize("R,splits,masked", [(6400, 4, True), (128 * 9 + 17, 8, True), (1500, 3, False), (800, 16, True), (130, 12, False),
                                              (16384, 2, True)])
 def test_split_ffn_for_small_batches(R, splits, masked):

@@ -17,6 +17,10 @@ model = model.to("cuda").requires_grad_(False)
 model.set_compute_dtype(torch.bfloat16)
 d = {k: v.to("cuda") for k, v in synth.make_inputs(B, 100, 512).items()}
 obj = model
+if path[0] in ("TransformerLayer", "FeedForward"):      # a class attribute: every layer of every stack
+    from isp_tts_amd.modules.transformer import feedforward, transformer
+    obj = {"TransformerLayer": transformer.TransformerLayer, "FeedForward": feedforward.FeedForward}[path[0]]
+    path = path[1:]
 for n in path[:-1]:
     obj = getattr(obj, n)
 graphs = {}

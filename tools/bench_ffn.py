@@ -56,6 +56,18 @@ variants = {
     "four-wave (ispk_ffn_bf16_prenorm)": lambda: runtime.ffn_prenorm(x, g, b, w1, w2p, mask=mask, flags=fl, want_stats=True),
     "eight-wave (ispk_ffn_bf16_prenorm2)": lambda: runtime.ffn_prenorm2(x, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True),
 }
+o_att = synth._normal("b/ffn/o", (R, D), 1.0).to(dev).to(torch.bfloat16)
+wo = synth._normal("b/ffn/wo", (D, D), D ** -0.5).to(dev).to(torch.bfloat16)
+woc = runtime.ffn_chunk_w2(wo)
+
+
+def two_launches():
+    x1 = runtime.gemm(o_att, wo, resid=x, mask=mask, flags=runtime.EP_MASK_ACC, out_dtype=torch.float32)
+    return runtime.ffn_prenorm2(x1, g, b, w1, w2c, mask=mask, flags=fl, want_stats=True)
+
+
+variants["to_out GEMM (+ residual), then eight-wave: the two launches"] = two_launches
+variants["projection + feed-forward, one kernel (ispk_attn_out_ffn_bf16)"] = lambda: runtime.attn_out_ffn(x, o_att, woc, g, b, w1, w2c, mask=mask, want_stats=True)
 if HAVE3:
     variants["single wave per SIMD (ispk_ffn_bf16_prenorm3, experiments build)"] = lambda: ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl, want_stats=True)
     variants["ffn3, no weight DMA in the main loop (compute only)"] = ablated3("1")

@@ -222,6 +222,21 @@ int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uint16_t* attn
                                int32_t rows, int32_t dim, int32_t inner, uint32_t flags, float* row_stats, float stats_eps,
                                ispk_stream_t stream);
 
+/* The same kernel with the NEXT layer's attention_norm and fused [to_q; to_kv] projection as its epilogue:
+ *   qkv[i][:] = bf16( LN_next(out[i][:]) ) [Wq; Wkv]^T        transformer.py:79-80, attention.py:63-64 of the next TransformerLayer
+ * Replaces, in addition: that layer's ispk_gemm_bf16_lnin launch (its re-read of the fp32 rows and 393 KB of weights per
+ * workgroup) - between two decoder layers the residual stream is written once and read once.  The finished rows are normalised
+ * from the registers that store them (two-pass statistics, next_eps), kept as a bf16 tile in LDS, and multiplied with the weight
+ * streamed as 24 k-step chunks: Wqkv_chunks = ispk_chunk_k16_bf16([Wq; Wkv]): [384/16][512][16].  qkv bf16 [rows][512]
+ * (6 heads x 64 query features, then 64 key and 64 value features), ld_qkv elements between rows.  No row_stats. */
+int32_t ispk_chunk_k16_bf16(const uint16_t* W, int64_t ldw, int32_t N, int32_t K, uint16_t* out, ispk_stream_t stream);
+int32_t ispk_attn_out_ffn_qkv_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                   const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                                   const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask, float* out, int64_t ldo,
+                                   int32_t rows, int32_t dim, int32_t inner, uint32_t flags, const float* next_gamma,
+                                   const float* next_beta, float next_eps, const uint16_t* Wqkv_chunks, uint16_t* qkv,
+                                   int64_t ld_qkv, ispk_stream_t stream);
+
 /* Linear whose input is LayerNorm(x), with the row statistics supplied by the kernel that produced x:
  *   C[i][n] = epilogue( sum_k bf16( (x[i][k] - mean_i) * rstd_i * ln_gamma[k] + ln_beta[k] ) * W[n][k] )
  * Replaces: normalization.py:20-27 + the Linear that follows it (transformer.py:79-80, attention.py:63-64: attention_norm

@@ -52,6 +52,11 @@ static_assert(kXtOff + 128 * kD * 2 <= kLds && 64 * kLdT * 4 <= kLds, "LDS carve
 
 constexpr int kSplitMode = 20;   // template argument of the split-inner instance (ispk_ffn_bf16_prenorm2_split)
 constexpr int kProjMode = 50;    // ... of the instance whose prologue is the attention block's output projection (ispk_attn_out_ffn_bf16)
+constexpr int kProjQkvMode = 51; // ... and whose epilogue is also the NEXT layer's attention_norm + q/kv projection (ispk_attn_out_ffn_qkv_bf16)
+constexpr int kNq = 512;         // q/kv features of that mode: 6 heads x 64 + 128
+constexpr int kQChunk = kNq * 16 * 2;            // one k-step of the q/kv weight: [512 features][16] bf16 = 16 KB (ispk_chunk_k16_bf16)
+constexpr int kX2Off = 32 * 388 * 4;             // that epilogue: fp32 tile of 32 rows at 0, then the bf16 tile of LN_next(out) [128][768 B]
+constexpr int kOutRow = kNq * 2 + 16;            // ... and the q/kv staging tile [128 rows][1024 + 16 B]
 
 struct Ffn2Params {
     const float* x;
@@ -74,7 +79,14 @@ struct Ffn2Params {
     const uint16_t* o = nullptr;  // projection mode: attention output rows [rows][384] bf16 ...
     int64_t ld_o = 0;
     const uint16_t* WoC = nullptr;   // ... and to_out's weight as twelve chunks [384 / 32][384][32] (ispk_ffn_chunk_w2_bf16)
+    const float* gamma2 = nullptr;   // q/kv mode: the next layer's attention_norm ...
+    const float* beta2 = nullptr;
+    float eps2 = 0.f;
+    const uint16_t* WqC = nullptr;   // ... its [to_q; to_kv] weight as 24 k-step chunks [384 / 16][512][16] ...
+    uint16_t* qkv = nullptr;         // ... and the q/kv rows it produces, bf16 [rows][512]
+    int64_t ld_qkv = 0;
 };
+static_assert(kX2Off + 128 * kD * 2 <= kLds && 3 * kQChunk <= kX2Off && 128 * kOutRow <= kLds, "LDS carve-up of the q/kv epilogue");
 
 // GELU(erf) for values that are rounded to bf16 right away.  erf by Abramowitz-Stegun 7.1.27:
 // erf(z) = 1 - (1 + a1 z + a2 z^2 + a3 z^3 + a4 z^4)^-4, z >= 0, |error| <= 5e-4, so |gelu error| <= 2.5e-4 |x| - an eighth of
@@ -422,7 +434,8 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
 
     // ---- prologue (a lambda: projection mode runs it INSIDE the two branches that select the main loop's stage order - with the
     // accumulators live across that branch hipcc has to agree on one register assignment for both loop copies and spills 76 VGPRs)
-    constexpr bool proj_mode = ABL == kProjMode;
+    constexpr bool qkv_mode = ABL == kProjQkvMode;
+    constexpr bool proj_mode = ABL == kProjMode || qkv_mode;
     auto prologue = [&]() __attribute__((always_inline)) {
     if constexpr (proj_mode) {
         // Projection mode: this row block's residual rows start in the accumulators of product 2 and the attention block's
@@ -763,6 +776,150 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     }
     if constexpr (kStaticPrio) __builtin_amdgcn_s_setprio(0);
 
+    // ---- epilogue of the q/kv mode: 32 rows per pass through the fp32 tile (mask, coalesced stores, row statistics as below) and
+    // from the same registers the NEXT layer's attention_norm of the finished rows, bf16, into a second tile - then that
+    // layer's q/kv projection of the 128 rows: wave (rg, half) owns rows 32 rg .. and features 256 half .., the weight streams
+    // through a three-chunk ring in the fp32 tile's place (one k-step = 16 KB per chunk, requested two steps ahead), the rows
+    // leave through a staging tile as whole 1-KB lines.
+    if constexpr (qkv_mode) {
+        const bool mask_out = p.flags & ISPK_EP_MASK_OUT;
+        float* T = reinterpret_cast<float*>(smem);
+#pragma unroll 1
+        for (int pass = 0; pass < 4; ++pass) {
+            __syncthreads();
+            if (rg == pass) {
+                float* trow = T + l31 * kLdT + 192 * half + 4 * h;
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+                    for (int gq = 0; gq < 4; ++gq) {
+                        f32x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc2[nt][4 * gq + e];
+                        *reinterpret_cast<f32x4*>(trow + 32 * nt + 8 * gq) = o;
+                    }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int i = 0; i < 2; ++i) {
+                const int rl = wave * 4 + 2 * i + h;                 // row of the tile
+                const int rb = pass * 32 + rl;                       // row of the block
+                const int r = row0 + rb;
+                const bool live = r < p.rows;
+                const int rc = live ? r : p.rows - 1;
+                const float mk = (p.mask && mask_out) ? (p.mask[rc] ? 1.0f : 0.0f) : 1.0f;
+                f32x4 y[3];
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    f32x4 a = *reinterpret_cast<const f32x4*>(T + rl * kLdT + 4 * (l31 + 32 * j));
+                    if (mask_out) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) a[e] *= mk;
+                    }
+                    y[j] = a;
+                    sum += (a[0] + a[1]) + (a[2] + a[3]);
+                }
+                if (live) {
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(p.out + (int64_t)r * p.ldo + 4 * (l31 + 32 * j)) = y[j];
+                }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                const float mean = sum * (1.0f / kD);
+                float q = 0.f;
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = y[j][e] - mean;
+                        q = fmaf(d, d, q);
+                    }
+#pragma unroll
+                for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+                const float rstd = 1.0f / sqrtf(q * (1.0f / kD) + p.eps2);
+                if (p.stats && live && l31 == 0) {
+                    p.stats[2 * (int64_t)r] = mean;
+                    p.stats[2 * (int64_t)r + 1] = 1.0f / sqrtf(q * (1.0f / kD) + p.stats_eps);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int c = 4 * (l31 + 32 * j);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma2 + c), b4 = *reinterpret_cast<const f32x4*>(p.beta2 + c);
+                    float o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = fmaf((y[j][e] - mean) * rstd, g4[e], b4[e]);
+                    uint2 pk;
+                    pk.x = pack_bf16(o[0], o[1]);
+                    pk.y = pack_bf16(o[2], o[3]);
+                    *reinterpret_cast<uint2*>(smem + kX2Off + rb * 768 + 16 * ((c >> 3) ^ (rb & 15)) + 8 * (l31 & 1)) = pk;
+                }
+            }
+        }
+        __syncthreads();     // the fp32 tile is dead (the ring takes its place), the bf16 tile is complete
+        const char* WqB = reinterpret_cast<const char*>(p.WqC);
+        auto dma_q = [&](int c, int buf) __attribute__((always_inline)) {     // chunk c: 16 pieces of 1 KB, wave w takes w and w + 8
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(WqB + (int64_t)c * kQChunk + (wave + 8 * j) * 1024 + lane * 16),
+                    (__attribute__((address_space(3))) void*)(smem + buf * kQChunk + (wave + 8 * j) * 1024), 16, 0, 0);
+        };
+        dma_q(0, 0);
+        dma_q(1, 1);
+        f32x16 aq[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aq[t][r] = 0.f;
+        const uint32_t xb = lds0 + kX2Off + (rg * 32 + l31) * 768;        // B fragments: + 16 ((2 c + h) ^ (l31 & 15))
+        const uint32_t wa = lds0 + (256 * half + l31) * 32 + 16 * h;       // A fragments: + chunk buffer + 1024 t (lane-linear: conflict-free)
+        bf16x8 bq;
+#pragma unroll 1
+        for (int c = 0, buf = 0; c < 24; ++c) {
+            // chunk c has landed for this wave (at most chunk c + 1's two instructions are younger) ...
+            if (c < 23) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // ... and for the others, who are also done with chunk c - 1
+            asm volatile("" ::: "memory");
+            if (c + 2 < 24) dma_q(c + 2, buf >= 1 ? buf - 1 : 2);      // (buf + 2) % 3: the buffer chunk c - 1 has left
+            const uint32_t a = wa + buf * kQChunk;
+            lds_read_b128_asm<0>(bq, xb + 16 * ((2 * c + h) ^ (l31 & 15)));
+            static_for<0, kRing>([&](auto tc) { lds_read_b128_asm<1024 * decltype(tc)::value>(r2[decltype(tc)::value], a); });
+            if constexpr (kPrio) __builtin_amdgcn_s_setprio(1);
+            static_for<0, 8>([&](auto tc) {
+                constexpr int t = decltype(tc)::value;
+                lds_wait<(7 - t) < kRing - 1 ? (7 - t) : kRing - 1>();
+                __builtin_amdgcn_sched_barrier(0);
+                aq[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(r2[t % kRing], bq, aq[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (t + kRing < 8) lds_read_b128_asm<1024 * (t + kRing)>(r2[t % kRing], a);
+            });
+            if constexpr (kPrio) __builtin_amdgcn_s_setprio(0);
+            buf = buf == 2 ? 0 : buf + 1;
+        }
+        __syncthreads();     // both tiles and the ring are dead: the staging tile goes over them
+        {
+            char* orow = smem + (rg * 32 + l31) * kOutRow + 2 * (256 * half + 4 * h);
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    uint2 pk;
+                    pk.x = pack_bf16(aq[t][4 * gq], aq[t][4 * gq + 1]);
+                    pk.y = pack_bf16(aq[t][4 * gq + 2], aq[t][4 * gq + 3]);
+                    *reinterpret_cast<uint2*>(orow + 2 * (32 * t + 8 * gq)) = pk;
+                }
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int rb = wave * 16 + i, r = row0 + rb;
+            if (r < p.rows)
+                *reinterpret_cast<u32x4*>(p.qkv + (int64_t)r * p.ld_qkv + 8 * lane) =
+                    *reinterpret_cast<const u32x4*>(smem + rb * kOutRow + 16 * lane);
+        }
+        return;
+    }
     // ---- epilogue: 64 rows per pass through the fp32 tile; then whole rows: + x, mask, statistics, coalesced stores
     const bool mask_acc = p.flags & ISPK_EP_MASK_ACC, mask_out = p.flags & ISPK_EP_MASK_OUT;
     float* T = reinterpret_cast<float*>(smem);
@@ -861,7 +1018,31 @@ __global__ __launch_bounds__(256) void ffn_chunk_w2_kernel(const uint16_t* __res
         *reinterpret_cast<const u32x4*>(W2 + (int64_t)d * ldw2 + c * 32 + piece * 8);
 }
 
+// W [N][K] (nn.Linear layout) -> k-step chunks [K / 16][N][16]: chunk c is N rows of 32 bytes - as an LDS image the MFMA A fragments
+// of 32 consecutive rows are one contiguous kilobyte
+__global__ __launch_bounds__(256) void chunk_k16_kernel(const uint16_t* __restrict__ W, int64_t ldw, uint16_t* __restrict__ out,
+                                                        int N, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // one 16-byte piece (8 k-values) per thread
+    const int64_t total = (int64_t)N * K / 8;
+    if (i >= total) return;
+    const int piece = (int)(i & 1);
+    const int64_t rest = i >> 1;
+    const int n = (int)(rest % N), c = (int)(rest / N);
+    *reinterpret_cast<u32x4*>(out + (((int64_t)c * N + n) * 16 + piece * 8)) =
+        *reinterpret_cast<const u32x4*>(W + (int64_t)n * ldw + c * 16 + piece * 8);
+}
+
 }  // namespace
+
+extern "C" int32_t ispk_chunk_k16_bf16(const uint16_t* W, int64_t ldw, int32_t N, int32_t K, uint16_t* out, ispk_stream_t stream) {
+    ISPK_REQUIRE(W && out, ISPK_E_NULL, "chunk_k16: null pointer");
+    ISPK_REQUIRE(N >= 1 && K >= 16 && K % 16 == 0 && ldw >= K, ISPK_E_SHAPE, "chunk_k16: bad shape %d x %d", N, K);
+    ISPK_REQUIRE(ldw % 8 == 0 && ispk_aligned(W, 16) && ispk_aligned(out, 16), ISPK_E_ALIGN, "chunk_k16: 16-byte alignment required");
+    const int64_t total = (int64_t)N * K / 8;
+    hipLaunchKernelGGL(chunk_k16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream),
+                       W, ldw, out, N, K);
+    return ispk_launch_status();
+}
 
 extern "C" int32_t ispk_ffn_chunk_w2_bf16(const uint16_t* W2, int64_t ldw2, int32_t dim, int32_t inner, uint16_t* out,
                                           ispk_stream_t stream) {
@@ -984,11 +1165,13 @@ extern "C" int32_t ispk_ffn_combine_ln_f32(const float* x, int64_t ldx, const fl
 
 // The attention block's output projection + the feed-forward block of a pre-norm layer, one kernel (kProjMode above):
 //     x1 = x + [mask] * (attn_out · Woᵀ);   out = [mask] * (x1 + gelu(LN(x1) · W1ᵀ) · W2ᵀ)     transformer.py:91-110
-extern "C" int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
-                                          const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta,
-                                          float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask,
-                                          float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
-                                          float* row_stats, float stats_eps, ispk_stream_t stream) {
+// and (kProjQkvMode) also the next layer's   qkv = LN_next(out) · [Wq; Wkv]ᵀ                    transformer.py:79-80, attention.py:63-64
+static int32_t attn_out_ffn_launch(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                   const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                                   const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask, float* out, int64_t ldo,
+                                   int32_t rows, int32_t dim, int32_t inner, uint32_t flags, float* row_stats, float stats_eps,
+                                   const float* next_gamma, const float* next_beta, float next_eps, const uint16_t* Wqkv_chunks,
+                                   uint16_t* qkv, int64_t ld_qkv, bool with_qkv, ispk_stream_t stream) {
     ISPK_REQUIRE(x && attn_out && Wo_chunks && norm_gamma && norm_beta && W1 && W2_chunks && out, ISPK_E_NULL,
                  "attn_out_ffn: null pointer");
     ISPK_REQUIRE(dim == kD, ISPK_E_UNSUPPORTED, "attn_out_ffn: dim %d (built for 384 = heads * 64)", dim);
@@ -1000,15 +1183,53 @@ extern "C" int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uin
                      ispk_aligned(W1, 16) && ispk_aligned(W2_chunks, 16) && ispk_aligned(norm_gamma, 16) &&
                      ispk_aligned(norm_beta, 16) && (!row_stats || ispk_aligned(row_stats, 8)),
                  ISPK_E_ALIGN, "attn_out_ffn: 16-byte alignment / strides that are multiples of 4 (fp32) and 8 (bf16) required");
+    if (with_qkv) {
+        ISPK_REQUIRE(next_gamma && next_beta && Wqkv_chunks && qkv, ISPK_E_NULL, "attn_out_ffn_qkv: null pointer");
+        ISPK_REQUIRE(ld_qkv >= kNq && ld_qkv % 8 == 0 && ispk_aligned(qkv, 16) && ispk_aligned(Wqkv_chunks, 16) &&
+                         ispk_aligned(next_gamma, 16) && ispk_aligned(next_beta, 16),
+                     ISPK_E_ALIGN, "attn_out_ffn_qkv: q/kv rows of 512 bf16, 16-byte aligned, row stride a multiple of 8");
+    }
     if (rows == 0) return 0;
     Ffn2Params p{x, ldx, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, mask, out, ldo, rows, inner, flags, row_stats, stats_eps};
     p.o = attn_out;
     p.ld_o = ld_attn;
     p.WoC = Wo_chunks;
-    ISPK_RESERVE_LDS((&ffn2_bf16_kernel<kProjMode>), kLds, "attn_out_ffn");
-    hipLaunchKernelGGL(ffn2_bf16_kernel<kProjMode>, dim3((rows + 127) / 128), dim3(512), kLds,
-                       reinterpret_cast<hipStream_t>(stream), p);
+    const dim3 grid((rows + 127) / 128);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (with_qkv) {
+        p.gamma2 = next_gamma;
+        p.beta2 = next_beta;
+        p.eps2 = next_eps;
+        p.WqC = Wqkv_chunks;
+        p.qkv = qkv;
+        p.ld_qkv = ld_qkv;
+        ISPK_RESERVE_LDS((&ffn2_bf16_kernel<kProjQkvMode>), kLds, "attn_out_ffn_qkv");
+        hipLaunchKernelGGL(ffn2_bf16_kernel<kProjQkvMode>, grid, dim3(512), kLds, s, p);
+    } else {
+        ISPK_RESERVE_LDS((&ffn2_bf16_kernel<kProjMode>), kLds, "attn_out_ffn");
+        hipLaunchKernelGGL(ffn2_bf16_kernel<kProjMode>, grid, dim3(512), kLds, s, p);
+    }
     return ispk_launch_status();
+}
+
+extern "C" int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                          const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta,
+                                          float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask,
+                                          float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
+                                          float* row_stats, float stats_eps, ispk_stream_t stream) {
+    return attn_out_ffn_launch(x, ldx, attn_out, ld_attn, Wo_chunks, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, mask, out, ldo,
+                               rows, dim, inner, flags, row_stats, stats_eps, nullptr, nullptr, 0.f, nullptr, nullptr, 0, false, stream);
+}
+
+extern "C" int32_t ispk_attn_out_ffn_qkv_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                              const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta,
+                                              float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask,
+                                              float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
+                                              const float* next_gamma, const float* next_beta, float next_eps,
+                                              const uint16_t* Wqkv_chunks, uint16_t* qkv, int64_t ld_qkv, ispk_stream_t stream) {
+    return attn_out_ffn_launch(x, ldx, attn_out, ld_attn, Wo_chunks, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, mask, out, ldo,
+                               rows, dim, inner, flags, nullptr, 1e-5f, next_gamma, next_beta, next_eps, Wqkv_chunks, qkv, ld_qkv,
+                               true, stream);
 }
 
 extern "C" int32_t ispk_ffn_bf16_prenorm2(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta,

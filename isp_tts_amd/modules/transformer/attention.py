@@ -95,11 +95,18 @@ class Attention(nn.Module, Constructor):
         return self._cache.get("woc", (self.to_out.weight,),
                                lambda: runtime.ffn_chunk_w2(self._staged(torch.bfloat16)[1]))
 
+    def _chunked_wqkv(self) -> Tensor:
+        """[to_q; to_kv] as k-step chunks [dim / 16][heads * 64 + 128][16] (ispk_attn_out_ffn_qkv_bf16: the PREVIOUS layer's
+        kernel applies this layer's attention_norm and q/kv projection), staged once per weight version."""
+        return self._cache.get("wqc", (self.to_q.weight, self.to_kv.weight),
+                               lambda: runtime.chunk_k16(self._staged(torch.bfloat16)[0]))
+
     def forward(self, x: Tensor, mask: Optional[Tensor] = None, context: Optional[Tensor] = None,
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 cache: Optional[AttentionIntermediates] = None,
                 shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None,
-                residual: Optional[Tensor] = None, prenorm: Optional[tuple] = None, defer_out: bool = False):
+                residual: Optional[Tensor] = None, prenorm: Optional[tuple] = None, defer_out: bool = False,
+                qkv: Optional[Tensor] = None):
         """x [B,N,dim] (fp32, or bf16 when compute_dtype is bf16); mask [B,N] bool, True = valid, a length mask.
         `key_len` (int64 [B]) may be passed to skip recomputing mask.sum(1); `residual` (fp32 [B,N,dim]) fuses
         `residual + mask * to_out(...)` into the output GEMM.  Returns (out, AttentionIntermediates,
@@ -108,7 +115,8 @@ class Attention(nn.Module, Constructor):
         and the q/kv GEMM applies that LayerNorm while staging x (bf16 path; statistics from the producing kernel, or
         computed by the GEMM's own waves when None).  `defer_out` (bf16 path): the first element is the attention output
         BEFORE `to_out` (bf16 [B,N,heads*64]) - the caller's next kernel applies `to_out`, mask and residual itself
-        (`runtime.attn_out_ffn`)."""
+        (`runtime.attn_out_ffn`).  `qkv` (bf16 [B,N,heads*64+128]): the q/kv rows of norm(x), already produced by the previous
+        layer's kernel - no projection here."""
         if context is not None or context_mask is not None or attention_mask is not None or cache is not None:
             raise NotImplementedError("cross-attention, explicit attention masks and KV caches are not on the "
                                       "acoustic-model forward path and are not built")
@@ -130,7 +138,9 @@ class Attention(nn.Module, Constructor):
             inter = AttentionIntermediates(queries=qkv[..., :hq].view(b, n, self.heads, 64).transpose(1, 2),
                                            keys=qkv[..., hq:hq + 64], values=qkv[..., hq + 64:])
             return out, inter, AttentionSharedIntermediates(rel_pos_bias=None)
-        if prenorm is not None:
+        if qkv is not None:
+            assert dt == torch.bfloat16 and qkv.dtype == dt and qkv.shape == (b, n, self.heads * 64 + 128)
+        elif prenorm is not None:
             assert dt == torch.bfloat16 and x.dtype == torch.float32
             qkv = runtime.gemm_lnin(x, prenorm[0], prenorm[1], prenorm[2], wqkv, ln_eps=prenorm[3])
         else:

@@ -33,6 +33,7 @@ class FeedForward(nn.Module, Constructor):
     # path switches: class attributes (override on the class or an instance; nothing reads the environment)
     prenorm_fused = True   # norm -> feed-forward -> residual as one kernel (ispk_ffn_bf16_prenorm) when a caller offers it
     lnin_self = True       # two-GEMM path: feed_forward_norm applied by the first GEMM's own waves (ispk_gemm_bf16_lnin)
+    next_qkv = True        # ispk_attn_out_ffn_qkv_bf16: the next layer's attention_norm + q/kv projection as the kernel's epilogue
     pair_kernel = True     # dim 384: the eight-wave kernel (ispk_ffn_bf16_prenorm2, csrc/ffn2.hip) instead of the four-wave one
 
     def __init__(self, dim: int = 384, inner_dim: int = 1536, dropout: float = 0.0, activation: str = "relu",
@@ -151,10 +152,18 @@ class FeedForward(nn.Module, Constructor):
 
     def forward_proj_prenorm(self, x: Tensor, attn_out: Tensor, woc: Tensor, norm, *, mask: Optional[Tensor] = None,
                              next_norm: Optional[tuple] = None):
-        """(y, stats | None) with x1 = x + [mask] * to_out(attn_out), y = [mask] * (x1 + feed_forward(norm(x1))) in one kernel
-        (ispk_attn_out_ffn_bf16): x1 exists only in the kernel's accumulators.  `woc` = Attention._chunked_wo()."""
+        """(y, stats | qkv | None) with x1 = x + [mask] * to_out(attn_out), y = [mask] * (x1 + feed_forward(norm(x1))) in one
+        kernel (ispk_attn_out_ffn_bf16): x1 exists only in the kernel's accumulators.  `woc` = Attention._chunked_wo().
+        `next_norm` = (weight, bias, eps, _, "stats"[, next layer's Attention]): with the Attention given and 6 heads the second
+        result is that layer's q/kv rows (bf16 [..., 512]) instead of the row statistics."""
         w1, _ = self._staged(torch.bfloat16)
         want = next_norm is not None and next_norm[4] == "stats"
+        nxt_attn = next_norm[5] if want and len(next_norm) > 5 else None
+        if nxt_attn is not None and self.next_qkv and nxt_attn.heads * 64 + 128 == 512 and nxt_attn.dim == x.shape[-1]:
+            # the next layer's attention_norm + q/kv projection from the same kernel: (y, qkv)
+            return runtime.attn_out_ffn(x, attn_out, woc, norm.weight, norm.bias, w1, self._chunked_w2(), mask=mask,
+                                        norm_eps=norm.eps,
+                                        next_qkv=(next_norm[0], next_norm[1], next_norm[2], nxt_attn._chunked_wqkv()))
         res = runtime.attn_out_ffn(x, attn_out, woc, norm.weight, norm.bias, w1, self._chunked_w2(), mask=mask, norm_eps=norm.eps,
                                    want_stats=want, stats_eps=next_norm[2] if want else 1e-5)
         return res if want else (res, None)

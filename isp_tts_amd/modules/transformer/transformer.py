@@ -97,6 +97,8 @@ class TransformerLayer(nn.Module, Constructor):
         kw1 = {"scale_shift": ada[0]} if ada is not None else {}
         kw2 = {"scale_shift": ada[1]} if ada is not None else {}
         handed = normed is not None and normed.dtype == torch.float32 and normed.shape[-1] == 2
+        qkv_in = (normed is not None and cdt == torch.bfloat16 and normed.dtype == torch.bfloat16
+                  and normed.shape[-1] == self.attention.heads * 64 + 128 != x.shape[-1])   # q/kv rows from the previous layer's kernel
         own = (normed is None and ada is None and isinstance(self.attention_norm, nn.LayerNorm) and context is None
                and attention_mask is None and x.shape[-1] in (256, 384) and self.attention_norm.weight is not None
                and self.attention_norm.bias is not None and self.lnin_self
@@ -104,7 +106,9 @@ class TransformerLayer(nn.Module, Constructor):
         final = next_norm is not None and next_norm[4] != "stats"    # the stack's final norm: only the split path's combine serves it
         fuse = (cdt == torch.bfloat16 and self.proj_ffn and ada is None and context is None and attention_mask is None
                 and self.attention.out_dim == x.shape[-1] and self.feed_forward.proj_ok(x, self.feed_forward_norm))
-        if cdt == torch.bfloat16 and (handed or own):
+        if qkv_in:
+            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x, defer_out=fuse, qkv=normed)
+        elif cdt == torch.bfloat16 and (handed or own):
             # attention_norm inside the q/kv GEMM, applied while it stages x: with the row statistics the previous layer's
             # feed-forward kernel handed over, or (first layer of a stack) computed by the GEMM's own waves
             an = self.attention_norm
@@ -284,7 +288,7 @@ class Transformer(nn.Module, Constructor):
             if chain:
                 if li + 1 < len(self.layers):
                     nn_ = self.layers[li + 1].attention_norm
-                    nxt = (nn_.weight, nn_.bias, nn_.eps, False, "stats")
+                    nxt = (nn_.weight, nn_.bias, nn_.eps, False, "stats", self.layers[li + 1].attention)
                 elif final_norm and out_dtype in (torch.float32, torch.bfloat16):
                     # last layer: the stack's own final norm (row-masked, transformer.py:205-206) - the split feed-forward's
                     # combine pass applies it from the same read (small batches); the fused kernel cannot and ignores it

@@ -57,6 +57,9 @@ SIGNATURES = {
     "ispk_ffn_combine_ln_f32": [_P, _I64, _P, _I64, _I32, _P, _P, _I64, _P, _P, _F32, _I32, _P, _I64, _I32, _I32, _I32, _P],
     "ispk_ffn_bf16_prenorm2": [_P, _I64, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
     "ispk_attn_out_ffn_bf16": [_P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _F32, _P],
+    "ispk_attn_out_ffn_qkv_bf16": [_P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32,
+                                   _P, _P, _I64, _P],
+    "ispk_chunk_k16_bf16": [_P, _I64, _I32, _I32, _P, _P],
     "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _F32, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -424,12 +427,26 @@ def ffn_prenorm2(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, 
     return (out, stats) if want_stats else out
 
 
+def chunk_k16(w: Tensor) -> Tensor:
+    """ispk_chunk_k16_bf16: W bf16 [N, K] -> k-step chunks [K/16, N, 16] (weight staging for attn_out_ffn's q/kv epilogue)."""
+    _dev(w)
+    assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.stride(1) == 1
+    N, K = w.shape
+    out = torch.empty((K // 16, N, 16), dtype=torch.bfloat16, device=w.device)
+    _launch("chunk_k16_kernel", 0.0, 4.0 * N * K, lib().ispk_chunk_k16_bf16, w.data_ptr(), w.stride(0), N, K, out.data_ptr(),
+            _stream())
+    return out
+
+
 def attn_out_ffn(x: Tensor, attn_out: Tensor, woc: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2c: Tensor,
-                 mask: Optional[Tensor] = None, norm_eps: float = 1e-5, want_stats: bool = False, stats_eps: float = 1e-5):
+                 mask: Optional[Tensor] = None, norm_eps: float = 1e-5, want_stats: bool = False, stats_eps: float = 1e-5,
+                 next_qkv: Optional[tuple] = None):
     """ispk_attn_out_ffn_bf16 (dim 384 = heads * 64): the second half of a pre-norm layer in one kernel,
         x1 = x + [mask] * (attn_out @ Wo^T);  out = [mask] * (x1 + gelu(LN(x1) @ w1^T) @ w2^T)
     from the fp32 residual rows x and the bf16 attention output; woc = `ffn_chunk_w2(Wo)`, w2c = `ffn_chunk_w2(w2)`.  With
-    `want_stats` also the (mean, rstd) of the output rows, fp32 [rows, 2]."""
+    `want_stats` also the (mean, rstd) of the output rows, fp32 [rows, 2].  With `next_qkv` = (norm weight, norm bias, eps,
+    `chunk_k16([Wq; Wkv])`) of the NEXT layer (ispk_attn_out_ffn_qkv_bf16) also that layer's q/kv rows, bf16 [..., 512]:
+    -> (out, qkv)."""
     _dev(x, attn_out, woc, norm_weight, norm_bias, w1, w2c, mask)
     assert x.dtype == torch.float32 and attn_out.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
     assert woc.dtype == torch.bfloat16 and w2c.dtype == torch.bfloat16
@@ -445,6 +462,17 @@ def attn_out_ffn(x: Tensor, attn_out: Tensor, woc: Tensor, norm_weight: Tensor, 
         mask = mask.reshape(-1).contiguous()
         flags = EP_MASK_ACC | EP_MASK_OUT
     nb = x2.numel() * 4 + o2.numel() * 2 + (woc.numel() + w1.numel() + w2c.numel()) * 2 + out.numel() * 4 + (R * 8 if want_stats else 0)
+    if next_qkv is not None:
+        assert not want_stats
+        ng, nbeta, neps, wqc = next_qkv
+        _dev(ng, nbeta, wqc)
+        assert wqc.dtype == torch.bfloat16 and wqc.shape == (D // 16, 512, 16) and wqc.is_contiguous()
+        qkv = torch.empty((*x.shape[:-1], 512), dtype=torch.bfloat16, device=x.device)
+        _launch("ffn2_bf16_kernel<51>", 4.0 * R * D * Fi + 2.0 * R * D * D + 2.0 * R * D * 512, float(nb + wqc.numel() * 2 + R * 1024),
+                lib().ispk_attn_out_ffn_qkv_bf16, x2.data_ptr(), x2.stride(0), o2.data_ptr(), o2.stride(0), woc.data_ptr(),
+                norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w2c.data_ptr(), _ptr(mask), out.data_ptr(), D,
+                R, D, Fi, flags, ng.data_ptr(), nbeta.data_ptr(), neps, wqc.data_ptr(), qkv.data_ptr(), 512, _stream())
+        return out, qkv
     _launch("ffn2_bf16_kernel<50>", 4.0 * R * D * Fi + 2.0 * R * D * D, float(nb), lib().ispk_attn_out_ffn_bf16, x2.data_ptr(),
             x2.stride(0), o2.data_ptr(), o2.stride(0), woc.data_ptr(), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps,
             w1.data_ptr(), w2c.data_ptr(), _ptr(mask), out.data_ptr(), D, R, D, Fi, flags, _ptr(stats), stats_eps, _stream())

@@ -503,6 +503,21 @@ def test_projection_and_ffn_kernel(R, Fi, masked):
     assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
     rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
     assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
+    # ispk_attn_out_ffn_qkv_bf16: the same rows, and the NEXT layer's attention_norm + q/kv projection from the epilogue
+    wq = _bf(synth._normal("t/pj/wq", (512, D), D ** -0.5))
+    g2, b2 = synth._normal("t/pj/g2", (D,), 0.1, 1.0), synth._normal("t/pj/b2", (D,), 0.1)
+    wqc = runtime.chunk_k16(d(wq))
+    assert torch.equal(wqc.cpu(), wq.view(512, D // 16, 16).permute(1, 0, 2).contiguous())
+    out2, qkv = runtime.attn_out_ffn(d(x), o_dev, woc, d(g), d(b), d(w1), w2c, mask=d(mask), next_qkv=(d(g2), d(b2), 1e-5, wqc))
+    out3, qkv3 = runtime.attn_out_ffn(d(x), o_dev, woc, d(g), d(b), d(w1), w2c, mask=d(mask), next_qkv=(d(g2), d(b2), 1e-5, wqc))
+    assert torch.equal(out2.cpu(), out) and torch.equal(qkv, qkv3) and torch.equal(out2, out3)
+    assert qkv.dtype == torch.bfloat16 and qkv.shape == (R, 512)
+    two_q = runtime.gemm_lnin(out2, None, d(g2), d(b2), d(wq)).cpu().float()       # the launch it replaces
+    eq = (qkv.cpu().float() - two_q).abs()
+    hn2 = (o64 - o64.mean(1, keepdim=True)) * rstd[:, None] * g2.double() + b2.double()
+    e64 = (qkv.cpu().double() - hn2 @ wq.double().t()).abs()
+    print(f"   q/kv epilogue: vs gemm_lnin max {eq.max().item():.3e} rms {eq.pow(2).mean().sqrt().item():.3e}; vs float64 max {e64.max().item():.3e}")
+    assert eq.max().item() <= 2 ** -5 and eq.pow(2).mean().sqrt().item() <= 2e-3 and e64.max().item() <= 0.08
 
 
 @pytest.mark.parametrize("R,splits,masked", [(6400, 4, True), (128 * 9 + 17, 8, True), (1500, 3, False), (800, 16, True), (130, 12, False),

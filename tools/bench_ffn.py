@@ -68,6 +68,17 @@ def two_launches():
 
 variants["to_out GEMM (+ residual), then eight-wave: the two launches"] = two_launches
 variants["projection + feed-forward, one kernel (ispk_attn_out_ffn_bf16)"] = lambda: runtime.attn_out_ffn(x, o_att, woc, g, b, w1, w2c, mask=mask, want_stats=True)
+wq = synth._normal("b/ffn/wq", (512, D), D ** -0.5).to(dev).to(torch.bfloat16)
+wqc = runtime.chunk_k16(wq)
+
+
+def three_launches():
+    y, _ = two_launches()
+    return runtime.gemm_lnin(y, None, g, b, wq)
+
+
+variants["... and the next layer's q/kv GEMM (own statistics): three launches"] = three_launches
+variants["projection + feed-forward + next q/kv, one kernel (ispk_attn_out_ffn_qkv_bf16)"] = lambda: runtime.attn_out_ffn(x, o_att, woc, g, b, w1, w2c, mask=mask, next_qkv=(g, b, 1e-5, wqc))
 if HAVE3:
     variants["single wave per SIMD (ispk_ffn_bf16_prenorm3, experiments build)"] = lambda: ffn_prenorm3(x, g, b, w1, w2p, mask=mask, flags=fl, want_stats=True)
     variants["ffn3, no weight DMA in the main loop (compute only)"] = ablated3("1")

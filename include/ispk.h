@@ -190,6 +190,7 @@ int32_t ispk_ffn_chunk_w2_bf16(const uint16_t* W2, int64_t ldw2, int32_t dim, in
  * (ispk_ffn_bf16_prenorm2_split: parts[s][i][:] = gelu_erf(LN(x[i][:]) W1_s^T) W2_s^T, raw fp32, split s = hidden units
  * [s * inner / splits, (s + 1) * inner / splits)), then ispk_ffn_combine_ln_f32 adds them in split order:
  *   y[i][:] = [mask[i]] * (x[i][:] + sum_s parts[s][i][:])                              transformer.py:105-110
+ *   (x may be NULL: the residual is then inside parts[0], ispk_attn_out_ffn_split_bf16)
  *   ln_out[i][:] = LN(y[i][:]) [* mask[i] if ln_mask]  (optional: the norm that consumes y - next layer's transformer.py:79
  *   or the final :205-206; fp32 or bf16), two-pass statistics.  parts: [splits] blocks at part_stride floats, rows x 384 each. */
 int32_t ispk_ffn_bf16_prenorm2_split(const float* x, int64_t ldx, const float* norm_gamma, const float* norm_beta,
@@ -229,6 +230,16 @@ int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uint16_t* attn
  * from the registers that store them (two-pass statistics, next_eps), kept as a bf16 tile in LDS, and multiplied with the weight
  * streamed as 24 k-step chunks: Wqkv_chunks = ispk_chunk_k16_bf16([Wq; Wkv]): [384/16][512][16].  qkv bf16 [rows][512]
  * (6 heads x 64 query features, then 64 key and 64 value features), ld_qkv elements between rows.  No row_stats. */
+/* The SMALL-batch form (text encoder) of the projection prologue: ispk_ffn_bf16_prenorm2_split whose every split first forms
+ * x1 = x + [mask if ISPK_EP_MASK_ACC] * (attn_out Wo^T) in its accumulators (each needs LN(x1)); split 0's partial product keeps
+ * x1, the others start from zero:  parts[0] = x1 + ffn_0(LN(x1)),  parts[s] = ffn_s(LN(x1)).  ispk_ffn_combine_ln_f32 then runs
+ * with x = NULL (y = [mask] * sum_s parts[s]).  Replaces the to_out GEMM launch of an encoder layer (attention.py:172-173,
+ * transformer.py:91). */
+int32_t ispk_attn_out_ffn_split_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                     const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                                     const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask, uint32_t flags,
+                                     float* parts, int64_t part_stride, int32_t splits, int32_t rows, int32_t dim, int32_t inner,
+                                     ispk_stream_t stream);
 int32_t ispk_chunk_k16_bf16(const uint16_t* W, int64_t ldw, int32_t N, int32_t K, uint16_t* out, ispk_stream_t stream);
 int32_t ispk_attn_out_ffn_qkv_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
                                    const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta, float norm_eps,

@@ -52,6 +52,7 @@ static_assert(kXtOff + 128 * kD * 2 <= kLds && 64 * kLdT * 4 <= kLds, "LDS carve
 
 constexpr int kSplitMode = 20;   // template argument of the split-inner instance (ispk_ffn_bf16_prenorm2_split)
 constexpr int kProjMode = 50;    // ... of the instance whose prologue is the attention block's output projection (ispk_attn_out_ffn_bf16)
+constexpr int kSplitProjMode = 21;   // ... of the split-inner instance with the projection prologue (ispk_attn_out_ffn_split_bf16)
 constexpr int kProjQkvMode = 51; // ... and whose epilogue is also the NEXT layer's attention_norm + q/kv projection (ispk_attn_out_ffn_qkv_bf16)
 constexpr int kNq = 512;         // q/kv features of that mode: 6 heads x 64 + 128
 constexpr int kQChunk = kNq * 16 * 2;            // one k-step of the q/kv weight: [512 features][16] bf16 = 16 KB (ispk_chunk_k16_bf16)
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     // split mode (small batches, ispk_ffn_bf16_prenorm2_split): workgroup (row block, split) walks only its `chunk_count`
     // chunks of the inner dimension and leaves a raw fp32 partial product; both weight images are chunk-contiguous
     // (kHC rows of W1 = kHC * kD * 2 bytes = one W2 chunk), so a split is a pointer offset
-    constexpr bool split_mode = ABL == kSplitMode;      // (its own instance: a distinct kernel name in profiles)
+    constexpr bool split_mode = ABL == kSplitMode || ABL == kSplitProjMode;      // (own instances: distinct kernel names in profiles)
     const int nchunks = split_mode ? p.chunk_count : p.inner / kHC;
     const int64_t wskip = split_mode ? (int64_t)blockIdx.y * p.chunk_count * (kHC * kD * 2) : 0;
     const char* W1b = reinterpret_cast<const char*>(p.W1) + wskip;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
     // ---- prologue (a lambda: projection mode runs it INSIDE the two branches that select the main loop's stage order - with the
     // accumulators live across that branch hipcc has to agree on one register assignment for both loop copies and spills 76 VGPRs)
     constexpr bool qkv_mode = ABL == kProjQkvMode;
-    constexpr bool proj_mode = ABL == kProjMode || qkv_mode;
+    constexpr bool proj_mode = ABL == kProjMode || qkv_mode || ABL == kSplitProjMode;
     auto prologue = [&]() __attribute__((always_inline)) {
     if constexpr (proj_mode) {
         // Projection mode: this row block's residual rows start in the accumulators of product 2 and the attention block's
@@ -552,6 +553,15 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
                 pk.y = pack_bf16(y[2], y[3]);
                 *reinterpret_cast<uint2*>(smem + kXtOff + rl * 768 + 16 * ((f0 >> 3) ^ (rl & 15)) + 8 * h) = pk;
             }
+        if constexpr (split_mode) {
+            // every split needs x1 for its LayerNorm, but only split 0's partial product carries it into the combine pass
+            if (blockIdx.y != 0) {
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[nt][r] = 0.f;
+            }
+        }
     } else {
         issue(0, 0, 0);   // W1 chunk 0 -> buffer 0 (and a W2 chunk nobody reads), on its way during the LayerNorm (the tile below
                           // does not touch buffer 0)
@@ -953,12 +963,15 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
             for (int j = 0; j < 3; ++j) {
                 const int c = 4 * (l31 + 32 * j);
                 f32x4 a = *reinterpret_cast<const f32x4*>(T + rl * kLdT + c);
-                if constexpr (proj_mode) {      // (the residual has been in the accumulators since the prologue)
+                if constexpr (split_mode) {
+                    // the raw partial product; residual, mask and sums happen in the combine pass (projection mode: split 0's
+                    // partial product already contains x1)
+                } else if constexpr (proj_mode) {      // (the residual has been in the accumulators since the prologue)
                     if (mask_out) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) a[e] *= mk;
                     }
-                } else if (!split_mode) {       // (split mode: the raw partial product; residual, mask and sums happen in the combine pass)
+                } else {
                     const f32x4 xr = *reinterpret_cast<const f32x4*>(p.x + (int64_t)rc * p.ldx + c);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -1071,7 +1084,8 @@ __global__ __launch_bounds__(256) void ffn_combine_ln_kernel(const float* __rest
     const float mk = mask ? (mask[row] ? 1.f : 0.f) : 1.f;
     f32x4 v[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const f32x4*>(x + (int64_t)row * ldx + 4 * (l + 32 * j));
+    for (int j = 0; j < 3; ++j)      // (x NULL: the residual is inside part 0 - ispk_attn_out_ffn_split_bf16)
+        v[j] = x ? *reinterpret_cast<const f32x4*>(x + (int64_t)row * ldx + 4 * (l + 32 * j)) : f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = 0; s < splits; ++s) {
         const float* ps = part + (int64_t)s * part_stride + (int64_t)row * kD;
 #pragma unroll
@@ -1140,16 +1154,50 @@ extern "C" int32_t ispk_ffn_bf16_prenorm2_split(const float* x, int64_t ldx, con
     return ispk_launch_status();
 }
 
+// Small batches, with the attention block's output projection as the prologue of EVERY split (each needs LN(x1); split 0's partial
+// product carries x1 itself, so the combine pass runs with x = NULL):  parts[0] = x1 + ffn_0(LN(x1)), parts[s] = ffn_s(LN(x1))
+extern "C" int32_t ispk_attn_out_ffn_split_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                                const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta,
+                                                float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks,
+                                                const uint8_t* mask, uint32_t flags, float* parts, int64_t part_stride,
+                                                int32_t splits, int32_t rows, int32_t dim, int32_t inner, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && attn_out && Wo_chunks && norm_gamma && norm_beta && W1 && W2_chunks && parts, ISPK_E_NULL,
+                 "attn_out_ffn_split: null pointer");
+    ISPK_REQUIRE(dim == kD, ISPK_E_UNSUPPORTED, "attn_out_ffn_split: dim %d (built for 384 = heads * 64)", dim);
+    ISPK_REQUIRE(rows >= 0 && inner >= 32 && inner % 32 == 0 && splits >= 1 && (inner / 32) % splits == 0 &&
+                     (inner / 32) / splits >= 2 && part_stride >= (int64_t)rows * kD,
+                 ISPK_E_SHAPE, "attn_out_ffn_split: bad shape rows=%d inner=%d splits=%d (chunks of 32 must divide evenly, >= 2 each)",
+                 rows, inner, splits);
+    ISPK_REQUIRE((flags & ~ISPK_EP_MASK_ACC) == 0 && !((flags & ISPK_EP_MASK_ACC) && !mask), ISPK_E_UNSUPPORTED,
+                 "attn_out_ffn_split: flags other than MASK_ACC (with a mask) are the combine pass's business");
+    ISPK_REQUIRE(ldx % 4 == 0 && ldx >= dim && ld_attn % 8 == 0 && ld_attn >= dim && part_stride % 4 == 0 && ispk_aligned(x, 16) &&
+                     ispk_aligned(attn_out, 16) && ispk_aligned(Wo_chunks, 16) && ispk_aligned(parts, 16) && ispk_aligned(W1, 16) &&
+                     ispk_aligned(W2_chunks, 16) && ispk_aligned(norm_gamma, 16) && ispk_aligned(norm_beta, 16),
+                 ISPK_E_ALIGN, "attn_out_ffn_split: 16-byte alignment required");
+    if (rows == 0) return 0;
+    Ffn2Params p{x, ldx, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, mask, parts, kD, rows, inner, flags, nullptr, 0.f};
+    p.chunk_count = (inner / 32) / splits;
+    p.part_stride = part_stride;
+    p.o = attn_out;
+    p.ld_o = ld_attn;
+    p.WoC = Wo_chunks;
+    ISPK_RESERVE_LDS((&ffn2_bf16_kernel<kSplitProjMode>), kLds, "attn_out_ffn_split");
+    hipLaunchKernelGGL(ffn2_bf16_kernel<kSplitProjMode>, dim3((rows + 127) / 128, splits), dim3(512), kLds,
+                       reinterpret_cast<hipStream_t>(stream), p);
+    return ispk_launch_status();
+}
+
 extern "C" int32_t ispk_ffn_combine_ln_f32(const float* x, int64_t ldx, const float* parts, int64_t part_stride, int32_t splits,
                                            const uint8_t* mask, float* y, int64_t ldy, const float* ln_gamma,
                                            const float* ln_beta, float ln_eps, int32_t ln_mask, void* ln_out, int64_t ld_ln,
                                            int32_t ln_bf16, int32_t rows, int32_t dim, ispk_stream_t stream) {
-    ISPK_REQUIRE(x && parts && y, ISPK_E_NULL, "ffn_combine_ln: null pointer");
+    ISPK_REQUIRE(parts && y, ISPK_E_NULL, "ffn_combine_ln: null pointer");
+    if (!x) ldx = dim;
     ISPK_REQUIRE(dim == kD && rows >= 0 && splits >= 1 && ldx >= dim && ldy >= dim && ldx % 4 == 0 && ldy % 4 == 0 &&
                      part_stride % 4 == 0, ISPK_E_SHAPE, "ffn_combine_ln: bad shape rows=%d dim=%d splits=%d", rows, dim, splits);
     ISPK_REQUIRE(!ln_out || (ln_gamma && ln_beta && ld_ln >= dim && ld_ln % 4 == 0), ISPK_E_NULL,
                  "ffn_combine_ln: LayerNorm output without gamma / beta");
-    ISPK_REQUIRE(ispk_aligned(x, 16) && ispk_aligned(parts, 16) && ispk_aligned(y, 16) && (!ln_out || ispk_aligned(ln_out, 8)),
+    ISPK_REQUIRE((!x || ispk_aligned(x, 16)) && ispk_aligned(parts, 16) && ispk_aligned(y, 16) && (!ln_out || ispk_aligned(ln_out, 8)),
                  ISPK_E_ALIGN, "ffn_combine_ln: 16-byte alignment required");
     if (rows == 0) return 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);

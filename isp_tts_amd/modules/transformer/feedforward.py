@@ -99,9 +99,11 @@ class FeedForward(nn.Module, Constructor):
                 and self.net[0].bias is None and self.net[3].bias is None and self.net[0].weight.shape[0] % 64 == 0
                 and not (self.training and self.dropout_p > 0))
 
-    def forward_prenorm_split(self, x: Tensor, norm, *, mask: Optional[Tensor] = None, next_norm: Optional[tuple] = None):
+    def forward_prenorm_split(self, x: Tensor, norm, *, mask: Optional[Tensor] = None, next_norm: Optional[tuple] = None,
+                              attn_proj: Optional[tuple] = None):
         """(y, LN_next(y) | None) for small batches: ispk_ffn_bf16_prenorm2_split + ispk_ffn_combine_ln_f32.  `next_norm` =
-        (weight, bias, eps, apply_mask, dtype) of the norm that consumes y."""
+        (weight, bias, eps, apply_mask, dtype) of the norm that consumes y.  `attn_proj` = (attention output before to_out,
+        Attention._chunked_wo()): x is the LAYER's input and the kernel applies to_out, mask and residual itself."""
         w1, _ = self._staged(torch.bfloat16)
         rows, chunks = x.numel() // x.shape[-1], w1.shape[0] // 32
         blocks = (rows + 127) // 128
@@ -110,7 +112,7 @@ class FeedForward(nn.Module, Constructor):
             if s <= self.max_splits and chunks % s == 0 and chunks // s >= 2 and blocks * s <= 256:
                 splits = s
         return runtime.ffn_prenorm2_split(x, norm.weight, norm.bias, w1, self._chunked_w2(), mask, splits, next_norm=next_norm,
-                                          norm_eps=norm.eps)
+                                          norm_eps=norm.eps, attn_proj=attn_proj)
 
     def prenorm_unfused_ok(self, x: Tensor, norm) -> bool:
         """Two-GEMM path (e.g. an activation the fused kernel lacks): can the first Linear's GEMM apply `norm` itself?

@@ -56,6 +56,11 @@ class TransformerLayer(nn.Module, Constructor):
     # to_out + residual + feed_forward_norm + feed-forward + residual as ONE kernel (ispk_attn_out_ffn_bf16; x1 never reaches
     # memory), bf16 path, dim 384 = heads * 64, decoder-sized batches:
     proj_ffn = True
+    # ... and in every workgroup of the split feed-forward (ispk_attn_out_ffn_split_bf16) - where that pays: with 2 splits (16,384
+    # decoder rows = 32 utterances per GPU: 1.512 -> 1.498 ms per step); with 4 - 8 splits per row block the repeated projection
+    # costs more than the to_out launch it saves (6,400 rows: 2.004 -> 2.012 ms; 8 utterances per GPU: 1.014 -> 1.066 ms)
+    proj_ffn_split = True
+    proj_ffn_split_min_rows = 8192
 
     def __init__(self, dim: int = 384, attention=None, feed_forward=None, pre_norm: bool = True,
                  adaptive_norm: bool = False, condition_dim: Optional[int] = None):
@@ -106,18 +111,24 @@ class TransformerLayer(nn.Module, Constructor):
         final = next_norm is not None and next_norm[4] != "stats"    # the stack's final norm: only the split path's combine serves it
         fuse = (cdt == torch.bfloat16 and self.proj_ffn and ada is None and context is None and attention_mask is None
                 and self.attention.out_dim == x.shape[-1] and self.feed_forward.proj_ok(x, self.feed_forward_norm))
+        # small batches: the same prologue in every workgroup of the split feed-forward (ispk_attn_out_ffn_split_bf16)
+        split_ok = (ada is None and (next_norm is None or next_norm[4] == "stats" or next_norm[4] in (cdt, torch.float32))
+                    and self.feed_forward.split_ok(x, self.feed_forward_norm))
+        fuse_split = (not fuse and split_ok and cdt == torch.bfloat16 and self.proj_ffn_split and context is None
+                      and attention_mask is None and self.attention.out_dim == x.shape[-1] == 384
+                      and x.numel() // x.shape[-1] >= self.proj_ffn_split_min_rows)
         if qkv_in:
-            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x, defer_out=fuse, qkv=normed)
+            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x, defer_out=fuse or fuse_split, qkv=normed)
         elif cdt == torch.bfloat16 and (handed or own):
             # attention_norm inside the q/kv GEMM, applied while it stages x: with the row statistics the previous layer's
             # feed-forward kernel handed over, or (first layer of a stack) computed by the GEMM's own waves
             an = self.attention_norm
-            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x, defer_out=fuse,
+            x1, inter, shared = self.attention(x, mask=mask, key_len=key_len, residual=x, defer_out=fuse or fuse_split,
                                                prenorm=(normed if handed else None, an.weight, an.bias, an.eps))
         else:
             h = normed if normed is not None else self.attention_norm(x, adaptive_condition, out_dtype=cdt, **kw1)
             x1, inter, shared = self.attention(h, mask=mask, context=context, context_mask=context_mask,
-                                               attention_mask=attention_mask, key_len=key_len, residual=x, defer_out=fuse)
+                                               attention_mask=attention_mask, key_len=key_len, residual=x, defer_out=fuse or fuse_split)
         hn = None
         if fuse:    # (x1 is the attention output before to_out)
             y, hn = self.feed_forward.forward_proj_prenorm(x, x1, self.attention._chunked_wo(), self.feed_forward_norm, mask=mask,
@@ -130,13 +141,16 @@ class TransformerLayer(nn.Module, Constructor):
             y, hn = self.feed_forward.forward_prenorm(x1, self.feed_forward_norm, mask=mask, next_norm=None if final else next_norm)
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                           shared_intermediates=shared, next_normed=hn)
-        if (ada is None and (next_norm is None or next_norm[4] == "stats" or next_norm[4] in (cdt, torch.float32))
-                and self.feed_forward.split_ok(x1, self.feed_forward_norm)):
+        if split_ok:
             # small batches: feed_forward_norm + feed-forward split over the inner dimension, then ONE pass that adds the
             # partial products, the residual and the mask and already applies the norm that consumes the result
             nn_ = None if next_norm is None else (next_norm[0], next_norm[1], next_norm[2], next_norm[3],
                                                   torch.float32 if next_norm[4] == torch.float32 else cdt)
-            y, hn = self.feed_forward.forward_prenorm_split(x1, self.feed_forward_norm, mask=mask, next_norm=nn_)
+            if fuse_split:    # (x1 is the attention output before to_out)
+                y, hn = self.feed_forward.forward_prenorm_split(x, self.feed_forward_norm, mask=mask, next_norm=nn_,
+                                                                attn_proj=(x1, self.attention._chunked_wo()))
+            else:
+                y, hn = self.feed_forward.forward_prenorm_split(x1, self.feed_forward_norm, mask=mask, next_norm=nn_)
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                           shared_intermediates=shared, next_normed=hn)
         if ada is None and self.feed_forward.prenorm_unfused_ok(x1, self.feed_forward_norm):

@@ -60,6 +60,7 @@ SIGNATURES = {
     "ispk_attn_out_ffn_qkv_bf16": [_P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32,
                                    _P, _P, _I64, _P],
     "ispk_chunk_k16_bf16": [_P, _I64, _I32, _I32, _P, _P],
+    "ispk_attn_out_ffn_split_bf16": [_P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _P, _P, _U32, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _F32, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
     "ispk_alibi_mqa_attn_f32": [_P, _I64, _P, _P, _I64, _P, _P, _P, _I64, _I32, _I32, _I32, _P],
@@ -480,21 +481,36 @@ def attn_out_ffn(x: Tensor, attn_out: Tensor, woc: Tensor, norm_weight: Tensor, 
 
 
 def ffn_prenorm2_split(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2c: Tensor, mask: Optional[Tensor],
-                       splits: int, next_norm: Optional[tuple] = None, norm_eps: float = 1e-5):
+                       splits: int, next_norm: Optional[tuple] = None, norm_eps: float = 1e-5, attn_proj: Optional[tuple] = None):
     """Small-batch form of `ffn_prenorm2` (ispk_ffn_bf16_prenorm2_split + ispk_ffn_combine_ln_f32): the inner dimension split
     over `splits` workgroups per row block, partial products added in split order with the residual and the mask, and -
     `next_norm` = (weight, bias, eps, apply_mask, dtype) - the LayerNorm that consumes the result from the same pass.
-    -> (y fp32, LN(y) | None)."""
+    -> (y fp32, LN(y) | None).
+    `attn_proj` = (attention output bf16 [..., D], `ffn_chunk_w2(Wo)`): x is the layer's INPUT and every split first forms
+    x1 = x + [mask] * (attn_out @ Wo^T) in its accumulators (ispk_attn_out_ffn_split_bf16; split 0's partial product carries x1,
+    the combine pass runs without a residual): y = [mask] * (x1 + feed_forward(LN(x1)))."""
     _dev(x, norm_weight, norm_bias, w1, w2c, mask)
     assert x.dtype == torch.float32 and w1.dtype == torch.bfloat16 and w2c.dtype == torch.bfloat16
     x2 = _rows2d(x)
     R, D = x2.shape
     Fi = w1.shape[0]
     parts = torch.empty((splits, R, D), dtype=torch.float32, device=x.device)   # per call: graph instances may run side by side
-    _launch("ffn2_bf16_kernel<20>", 4.0 * R * D * Fi, float(x2.numel() * 4 * splits + (w1.numel() + w2c.numel()) * 2
-                                                                           + splits * R * D * 4),
-            lib().ispk_ffn_bf16_prenorm2_split, x2.data_ptr(), x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(),
-            norm_eps, w1.data_ptr(), w2c.data_ptr(), parts.data_ptr(), R * D, splits, R, D, Fi, _stream())
+    if attn_proj is not None:
+        o, woc = attn_proj
+        _dev(o, woc)
+        o2 = _rows2d(o)
+        assert o.dtype == torch.bfloat16 and o2.shape == (R, D) and woc.dtype == torch.bfloat16 and woc.shape == (D // 32, D, 32)
+        mflat = mask.reshape(-1).contiguous() if mask is not None else None
+        _launch("ffn2_bf16_kernel<21>", (4.0 * R * D * Fi) + 2.0 * R * D * D * splits,
+                float((x2.numel() * 4 + o2.numel() * 2 + woc.numel() * 2) * splits + (w1.numel() + w2c.numel()) * 2 + splits * R * D * 4),
+                lib().ispk_attn_out_ffn_split_bf16, x2.data_ptr(), x2.stride(0), o2.data_ptr(), o2.stride(0), woc.data_ptr(),
+                norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w2c.data_ptr(), _ptr(mflat),
+                EP_MASK_ACC if mflat is not None else 0, parts.data_ptr(), R * D, splits, R, D, Fi, _stream())
+    else:
+        nbytes = x2.numel() * 4 * splits + (w1.numel() + w2c.numel()) * 2 + splits * R * D * 4
+        _launch("ffn2_bf16_kernel<20>", 4.0 * R * D * Fi, float(nbytes), lib().ispk_ffn_bf16_prenorm2_split, x2.data_ptr(),
+                x2.stride(0), norm_weight.data_ptr(), norm_bias.data_ptr(), norm_eps, w1.data_ptr(), w2c.data_ptr(),
+                parts.data_ptr(), R * D, splits, R, D, Fi, _stream())
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     if mask is not None:
         mask = mask.reshape(-1).contiguous()
@@ -506,7 +522,8 @@ def ffn_prenorm2_split(x: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Te
         ln = torch.empty(x.shape, dtype=ndtype, device=x.device)
         nmask, nbf16 = int(bool(apply_mask) and mask is not None), int(ndtype == torch.bfloat16)
     _launch("ffn_combine_ln_kernel", 0.0, float(R * D * 4 * (2 + splits) + (R * D * ln.element_size() if ln is not None else 0)),
-            lib().ispk_ffn_combine_ln_f32, x2.data_ptr(), x2.stride(0), parts.data_ptr(), R * D, splits, _ptr(mask), y.data_ptr(),
+            lib().ispk_ffn_combine_ln_f32, None if attn_proj is not None else x2.data_ptr(), x2.stride(0), parts.data_ptr(), R * D,
+            splits, _ptr(mask), y.data_ptr(),
             D, _ptr(nw), _ptr(nb), neps, nmask, _ptr(ln), D, nbf16, R, D, _stream())
     return y, ln
 

@@ -557,6 +557,49 @@ def test_split_ffn_for_small_batches(R, splits, masked):
     assert none is None and torch.equal(y3, y)
 
 
+@pytest.mark.parametrize("R,splits,masked", [(6400, 4, True), (800, 8, True), (130, 12, False)])
+def test_projection_in_the_split_ffn(R, splits, masked):
+    """ispk_attn_out_ffn_split_bf16 + ispk_ffn_combine_ln_f32 with x = NULL: every split forms x1 = x + mask * (o Wo^T) in its
+    accumulators, only split 0's partial product carries it - against the to_out GEMM followed by the plain split path, and
+    float64; NaN bit patterns in masked rows of the attention output do not leak; determinism."""
+    D, Fi = 384, 1536
+    x = synth._normal(f"t/pjs/x{R}", (R, D), 1.5, 0.4)
+    o = _bf(synth._normal(f"t/pjs/o{R}", (R, D), 1.0))
+    wo = _bf(synth._normal("t/pjs/wo", (D, D), D ** -0.5))
+    w1, w2 = _bf(synth._normal("t/pjs/w1", (Fi, D), D ** -0.5)), _bf(synth._normal("t/pjs/w2", (D, Fi), Fi ** -0.5))
+    g, b = synth._normal("t/pjs/g", (D,), 0.1, 1.0), synth._normal("t/pjs/b", (D,), 0.1)
+    ng, nb = synth._normal("t/pjs/ng", (D,), 0.1, 1.0), synth._normal("t/pjs/nb", (D,), 0.1)
+    mask = (torch.arange(R) % 7 != 3) if masked else None
+    d = lambda t: None if t is None else t.to(DEV)  # noqa: E731
+    woc, w2c = runtime.ffn_chunk_w2(d(wo)), runtime.ffn_chunk_w2(d(w2))
+    o_dev = d(o).clone()
+    if masked:
+        o_dev[~d(mask)] = float("nan")
+    nn_ = (d(ng), d(nb), 1e-5, False, torch.bfloat16)
+    y, hn = runtime.ffn_prenorm2_split(d(x), d(g), d(b), d(w1), w2c, d(mask), splits, next_norm=nn_, attn_proj=(o_dev, woc))
+    y2, hn2 = runtime.ffn_prenorm2_split(d(x), d(g), d(b), d(w1), w2c, d(mask), splits, next_norm=nn_, attn_proj=(o_dev, woc))
+    assert torch.equal(y, y2) and torch.equal(hn, hn2) and torch.isfinite(y).all() and torch.isfinite(hn.float()).all()
+    o_clean = d(o) if not masked else torch.where(d(mask)[:, None], d(o), torch.zeros_like(d(o)))
+    x1k = runtime.gemm(o_clean, d(wo), resid=d(x), mask=d(mask), flags=runtime.EP_MASK_ACC if masked else 0, out_dtype=torch.float32)
+    two, hn_two = runtime.ffn_prenorm2_split(x1k, d(g), d(b), d(w1), w2c, d(mask), splits, next_norm=nn_)
+    e2 = (y - two).abs()
+    print(f"split + projection R={R} x{splits}: vs to_out GEMM + split path max {e2.max().item():.3e}, rms {e2.pow(2).mean().sqrt().item():.3e}")
+    assert e2.max().item() <= 3e-2 and e2.pow(2).mean().sqrt().item() <= 2e-3
+    x64 = x.double()
+    pr = o.double() @ wo.double().t()
+    x1 = x64 + (pr * mask[:, None] if masked else pr)
+    h64 = (x1 - x1.mean(1, keepdim=True)) / torch.sqrt(x1.var(1, unbiased=False, keepdim=True) + 1e-5) * g.double() + b.double()
+    ref64 = x1 + F.gelu(h64 @ w1.double().t()) @ w2.double().t()
+    if masked:
+        ref64 = ref64 * mask[:, None]
+        assert y.cpu()[~mask].abs().max().item() == 0.0
+    err = (y.cpu().double() - ref64).abs()
+    assert err.max().item() <= 0.06 and err.pow(2).mean().sqrt().item() <= 6e-3
+    y64 = y.cpu().double()
+    ln64 = (y64 - y64.mean(1, keepdim=True)) / torch.sqrt(y64.var(1, unbiased=False, keepdim=True) + 1e-5) * ng.double() + nb.double()
+    assert (hn.cpu().double() - ln64).abs().max().item() <= 2.0 ** -7 * max(1.0, ln64.abs().max().item())   # bf16 rounding
+
+
 @pytest.mark.parametrize("R,D,Fi,masked", [(128 * 9 + 17, 384, 1536, True), (300, 256, 1024, True), (128 * 3, 384, 1536, False)])
 def test_fused_ffn_with_layernorm_prologue(R, D, Fi, masked):
     """ispk_ffn_bf16_prenorm == LayerNorm kernel (bf16 out, row mask) -> ispk_ffn_bf16 with the fp32 rows as residual:

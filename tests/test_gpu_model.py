@@ -716,6 +716,39 @@ def test_final_norm_from_the_split_feed_forward_combine_pass(gpu_model, out_dtyp
         enc.set_compute_dtype(torch.float32)
 
 
+@pytest.mark.parametrize("bsz,frames", [(64, 512), (32, 512), (12, 400)])
+def test_decoder_stack_with_the_layer_halves_in_one_kernel(gpu_model, bsz, frames):
+    """bf16 path: to_out + residual + feed_forward_norm + feed-forward + residual (+ the next layer's attention_norm and q/kv
+    projection) as ONE kernel per layer (`ispk_attn_out_ffn_bf16` / `_qkv_bf16`, decoder-sized batches; `_split_bf16` from 8,192
+    rows) against the same stack with those switches off (separate to_out GEMM, feed-forward kernel and q/kv GEMM): the same
+    bf16 products in another fp32 summation order - agreement far inside the bf16 path's own error; masked rows exactly zero."""
+    from isp_tts_amd.modules.transformer.feedforward import FeedForward
+    from isp_tts_amd.modules.transformer.transformer import TransformerLayer
+    x = synth._normal(f"t/halves/x{bsz}", (bsz, frames, 384)).to(DEV)
+    lens = torch.full((bsz,), frames, device=DEV)
+    lens[1::3] = frames // 2 + 3
+    mask = torch.arange(frames, device=DEV)[None] < lens[:, None]
+    dec = gpu_model.decoder
+    saved = (TransformerLayer.proj_ffn, TransformerLayer.proj_ffn_split, FeedForward.next_qkv)
+    try:
+        dec.set_compute_dtype(torch.bfloat16)
+        fused = dec(x, mask=mask, key_len=lens).out
+        assert torch.equal(fused, dec(x, mask=mask, key_len=lens).out)
+        TransformerLayer.proj_ffn = TransformerLayer.proj_ffn_split = FeedForward.next_qkv = False
+        plain = dec(x, mask=mask, key_len=lens).out
+        TransformerLayer.proj_ffn, TransformerLayer.proj_ffn_split = saved[0], saved[1]
+        no_qkv = dec(x, mask=mask, key_len=lens).out
+    finally:
+        TransformerLayer.proj_ffn, TransformerLayer.proj_ffn_split, FeedForward.next_qkv = saved
+        dec.set_compute_dtype(torch.float32)
+    scale = plain.abs().max().item()
+    for name, got in (("all in one", fused), ("without the q/kv epilogue", no_qkv)):
+        e = (got - plain).abs()
+        print(f"decoder stack {bsz} x {frames}, {name}: max |diff| {e.max().item():.3e}, rms {e.pow(2).mean().sqrt().item():.3e} (|out| <= {scale:.1f})")
+        assert e.max().item() <= 2e-2 * max(1.0, scale) and e.pow(2).mean().sqrt().item() <= 1e-3 * max(1.0, scale)
+        assert (got * ~mask[..., None]).abs().max() == 0
+
+
 def test_config2_encoder_decoder_scope_fp32(gpu_model, state_dict):
     """BASELINE config 2 (B = 32, TextEncoder + MelDecoder + to_mel on given activations, ragged masks, fp32) against the oracle."""
     bsz = 32                                          # BASELINE config 2's batch

@@ -19,7 +19,8 @@ O = os.environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/pmc_ffn"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(O + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = "ffn2" if "ffn2_bf16" in r["Kernel_Name"] else ("ffn1" if "ffn_bf16_kernel" in r["Kernel_Name"] else None)
+        n = r["Kernel_Name"]
+        k = ("ffn2" + n[n.index("ffn2_bf16_kernel") + 16:].split(">")[0] + ">") if "ffn2_bf16_kernel" in n else ("ffn1" if "ffn_bf16_kernel" in n else None)
         if k:
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(O + "/summary.txt", "w") as out:

@@ -96,14 +96,14 @@ class SegmentedForward:
     decoder.  Still ONE batch in flight: the next replay's front piece is ordered behind this replay's side piece."""
 
     def __init__(self, model, text: Tensor, text_len: Tensor, mel: Tensor, mel_len: Tensor, pitch: Tensor, energy: Tensor,
-                 flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None, warmup: int = 2):
+                 flow_noise: Optional[Tensor] = None, flow_time: Optional[Tensor] = None, warmup: int = 2, side_priority: int = 0):
         b, l = text.shape
         dev = text.device
         s = self.static = {"text": text.clone(), "text_len": text_len.clone(), "mel": mel.clone(), "mel_len": mel_len.clone(),
                            "pitch": pitch.clone(), "energy": energy.clone(),
                            "flow_noise": flow_noise.clone() if flow_noise is not None else torch.randn(b, l, 3, device=dev),
                            "flow_time": flow_time.clone() if flow_time is not None else torch.rand(b, device=dev)}
-        self.model, self.side = model, torch.cuda.Stream(device=dev)
+        self.model, self.side = model, torch.cuda.Stream(device=dev, priority=side_priority)
         frames = mel.shape[2]
         self.g_front = GraphedCall(lambda: model.forward_front(s["text"], s["text_len"], s["mel"], s["mel_len"], s["pitch"],
                                                                s["energy"]), warmup)

@@ -17,17 +17,19 @@ model = model.to("cuda").requires_grad_(False)
 model.set_compute_dtype(torch.bfloat16)
 d = {k: v.to("cuda") for k, v in synth.make_inputs(B, 100, 512).items()}
 obj = model
-if path[0] in ("TransformerLayer", "FeedForward"):      # a class attribute: every layer of every stack
-    from isp_tts_amd.modules.transformer import feedforward, transformer
-    obj = {"TransformerLayer": transformer.TransformerLayer, "FeedForward": feedforward.FeedForward}[path[0]]
+if path[0] in ("TransformerLayer", "FeedForward", "Attention"):      # a class attribute: every layer of every stack
+    from isp_tts_amd.modules.transformer import attention, feedforward, transformer
+    obj = {"TransformerLayer": transformer.TransformerLayer, "FeedForward": feedforward.FeedForward,
+           "Attention": attention.Attention}[path[0]]
     path = path[1:]
 for n in path[:-1]:
     obj = getattr(obj, n)
 graphs = {}
-for val in (True, False):
+VALS = [int(v) for v in os.environ["VALS"].split(",")] if os.environ.get("VALS") else [True, False]
+for val in VALS:
     setattr(obj, path[-1], val)
     graphs[val] = GraphedForward(model, d["text"], d["text_len"], d["mel"], d["mel_len"], d["pitch"], d["energy"], d["flow_x0"], d["flow_t"])
-res = {True: [], False: []}
+res = {v: [] for v in VALS}
 for rnd in range(6):
     for val, g in graphs.items():
         for _ in range(3):

@@ -229,6 +229,9 @@ def generate_soft_path(duration: Tensor, mask: Tensor) -> Tensor:
 
 
 class FlowTemporalAdaptor(nn.Module, Constructor):
+    # launch order with a predictor stream: the predictor's launches issued BEFORE the embedding stack's (True) or after (False)
+    predictor_first = False
+
     def __init__(self, encoder_dim: int = 384, predictor=None, embedding=None, pitch: bool = True, energy: bool = True,
                  soft_duration: bool = False):
         super().__init__()
@@ -288,8 +291,12 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
         pitch_target, energy_target = feats[..., 1:2], feats[..., 2:3]
         features = feats[..., 1:3]                   # = cat([pitch_target, energy_target], -1): a view, no copy
 
-        enc_out = self.embedding(features, mask=m3, key_len=enc_len, residual=enc_out)   # enc_out + embedding(...)
-        enc_out, dec_lens = self.length_regulator(enc_out, len_src, max_len=max_dec_len, alignment=alignment)
+        def decoder_input(enc_out_):
+            enc_out_ = self.embedding(features, mask=m3, key_len=enc_len, residual=enc_out_)   # enc_out + embedding(...)
+            return self.length_regulator(enc_out_, len_src, max_len=max_dec_len, alignment=alignment)
+
+        if not (side is not None and self.predictor_first):
+            enc_out, dec_lens = decoder_input(enc_out)
 
         def predict():
             tg = targets
@@ -304,6 +311,8 @@ class FlowTemporalAdaptor(nn.Module, Constructor):
                 pred, losses, duration_pred = predict()
             for t in (cond, feats, alignment, pitch_target_dense, energy_target_dense):
                 t.record_stream(side)
+            if self.predictor_first:
+                enc_out, dec_lens = decoder_input(enc_out)
         else:
             pred, losses, duration_pred = predict()
         log_duration_pred = pred[..., 0]

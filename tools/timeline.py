@@ -6,7 +6,8 @@ totals per kernel.  usage: timeline.py DIR [kernels per step]"""
 import csv, glob, os, re, sys, collections
 d = sys.argv[1]
 f = max(glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True), key=os.path.getmtime)
-rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), r.get("Stream_Id", "?"))
+        for r in csv.DictReader(open(f))]
 rows.sort()
 def short(n):
     n = re.sub(r"\(anonymous namespace\)::", "", n)
@@ -26,12 +27,13 @@ t0 = step[0][0]
 print(f"# one step: {len(step)} kernels, {(step[-1][1] - t0) / 1e3:.1f} us from the MAS kernel of one replay to the next")
 end_prev = t0
 busy = 0
-for s, e, n in step:
+QUEUES = os.environ.get("TIMELINE_QUEUES")      # also print the HSA queue / stream ids of every kernel
+for s, e, n, qid, sid in step:
     gap = (s - end_prev) / 1e3
-    print(f"{(s - t0) / 1e3:9.1f} us  {(e - s) / 1e3:7.1f} us  gap {gap:6.1f}  {short(n)}")
+    print(f"{(s - t0) / 1e3:9.1f} us  {(e - s) / 1e3:7.1f} us  gap {gap:6.1f}  {short(n)}" + (f"   [queue {qid} stream {sid}]" if QUEUES else ""))
     end_prev = max(end_prev, e)
 tot = collections.defaultdict(lambda: [0, 0.0])
-for s, e, n in step:
+for s, e, n, _q, _s in step:
     tot[short(n)][0] += 1
     tot[short(n)][1] += (e - s) / 1e3
 print("# totals per kernel")

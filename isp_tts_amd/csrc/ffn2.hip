@@ -30,6 +30,12 @@
 // wave takes its fragments.  Epilogue: 64 rows at a time through an fp32 LDS tile, so that whole rows come back out:
 // residual add (the fp32 rows are re-read: the file has no room to keep them), mask, the (mean, rstd) of the finished
 // rows for the next layer's q/kv GEMM, 16-byte coalesced stores.
+//
+// Instances (template argument): 0 the block above; 20 the split-inner form for small batches (a slice of the inner dimension per
+// workgroup, raw partial products, ispk_ffn_combine_ln_f32 adds them); 50 with the attention block's OUTPUT PROJECTION as the
+// prologue - x1 = x + mask * (o Woᵀ) is formed in product 2's accumulators and never reaches memory (transformer.py:91,
+// attention.py:172); 51 = 50 + the NEXT layer's attention_norm and q/kv projection as the epilogue (transformer.py:79-80,
+// attention.py:63-64); 21 = 20 with the projection prologue.  Everything else is an ablation / stamp variant of the experiments build.
 #include "common.h"
 
 namespace {

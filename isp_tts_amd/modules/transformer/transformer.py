@@ -9,6 +9,13 @@ Pre-norm layer, as launched here (7 kernels, activations make one HBM round trip
     f  = gelu(h2 · W1ᵀ)                                ispk_gemm, epilogue GELU
     y  = mask * (x1 + f · W2ᵀ)                         ispk_gemm, epilogue residual + MASK_OUT   (:105-110)
 The residual stream (x, x1, y) is always fp32; with compute_dtype = bf16 the GEMM/attention operands are bf16.
+
+bf16 path, decoder-sized batches (dim 384 = heads * 64, >= 16,385 rows): a layer is TWO launches -
+    o  = ALiBi-MQA(qkv)                                ispk_alibi_mqa_attn_bf16      (qkv comes from the previous layer's kernel)
+    y, qkv_next = ...                                  ispk_attn_out_ffn_qkv_bf16:   x1 = x + mask * (o · Woᵀ) in the accumulators,
+                                                       y = mask * (x1 + FFN(LN(x1))), qkv_next = LN_next(y) · [Wq;Wkv]_nextᵀ
+(first layer: q/kv by ispk_gemm_bf16_lnin; last layer: ispk_attn_out_ffn_bf16).  Small batches: LayerNorm folded into the split
+feed-forward's combine pass, see `FeedForward.forward_prenorm_split`.
 """
 from __future__ import annotations
 

@@ -230,6 +230,16 @@ int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uint16_t* attn
  * from the registers that store them (two-pass statistics, next_eps), kept as a bf16 tile in LDS, and multiplied with the weight
  * streamed as 24 k-step chunks: Wqkv_chunks = ispk_chunk_k16_bf16([Wq; Wkv]): [384/16][512][16].  qkv bf16 [rows][512]
  * (6 heads x 64 query features, then 64 key and 64 value features), ld_qkv elements between rows.  No row_stats. */
+/* ispk_attn_out_ffn_bf16 for the LAST layer of a stack: the stack's final LayerNorm (transformer.py:205-206, row-masked if ln_mask)
+ * of the finished rows as a second output from the same registers, ln_out bf16 (ln_bf16) or fp32 [rows][dim] at ld_ln - the separate
+ * LayerNorm launch and its re-read of the rows disappear; `out` may be NULL when only the normalised rows are consumed (the decoder:
+ * its output goes through `norm` into to_mel, model.py:168-171) and the fp32 rows are then not stored at all. */
+int32_t ispk_attn_out_ffn_norm_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                    const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta, float norm_eps,
+                                    const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask, float* out, int64_t ldo,
+                                    int32_t rows, int32_t dim, int32_t inner, uint32_t flags, const float* final_gamma,
+                                    const float* final_beta, float final_eps, int32_t ln_mask, void* ln_out, int64_t ld_ln,
+                                    int32_t ln_bf16, ispk_stream_t stream);
 /* The SMALL-batch form (text encoder) of the projection prologue: ispk_ffn_bf16_prenorm2_split whose every split first forms
  * x1 = x + [mask if ISPK_EP_MASK_ACC] * (attn_out Wo^T) in its accumulators (each needs LN(x1)); split 0's partial product keeps
  * x1, the others start from zero:  parts[0] = x1 + ffn_0(LN(x1)),  parts[s] = ffn_s(LN(x1)).  ispk_ffn_combine_ln_f32 then runs

@@ -92,6 +92,9 @@ struct Ffn2Params {
     const uint16_t* WqC = nullptr;   // ... its [to_q; to_kv] weight as 24 k-step chunks [384 / 16][512][16] ...
     uint16_t* qkv = nullptr;         // ... and the q/kv rows it produces, bf16 [rows][512]
     int64_t ld_qkv = 0;
+    void* ln_out = nullptr;          // projection mode, last layer of a stack: LN_final(out) rows (gamma2 / beta2 / eps2), bf16 or fp32 ...
+    int64_t ld_ln = 0;
+    int ln_bf16 = 0, ln_mask = 0;    // ... row-masked if ln_mask; p.out may then be NULL (the raw rows are not stored)
 };
 static_assert(kX2Off + 128 * kD * 2 <= kLds && 3 * kQChunk <= kX2Off && 128 * kOutRow <= kLds, "LDS carve-up of the q/kv epilogue");
 
@@ -989,9 +992,46 @@ __global__ __launch_bounds__(512, 2) void ffn2_bf16_kernel(Ffn2Params p) {
                 y[j] = a;
                 s += (a[0] + a[1]) + (a[2] + a[3]);
             }
-            if (live) {
+            if (live && (ABL != kProjMode || p.out)) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) *reinterpret_cast<f32x4*>(outp + (int64_t)r * p.ldo + 4 * (l31 + 32 * j)) = y[j];
+            }
+            if constexpr (ABL == kProjMode) {
+                if (p.ln_out) {      // the stack's final LayerNorm (transformer.py:205-206) from the same registers
+                    float sum = s;
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+                    const float mean = sum * (1.0f / kD);
+                    float q = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d = y[j][e] - mean;
+                            q = fmaf(d, d, q);
+                        }
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) q += __shfl_xor(q, off, 64);
+                    const float rstd = 1.0f / sqrtf(q * (1.0f / kD) + p.eps2), om = p.ln_mask ? mk : 1.0f;
+                    if (live) {
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const int c = 4 * (l31 + 32 * j);
+                            const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma2 + c), b4 = *reinterpret_cast<const f32x4*>(p.beta2 + c);
+                            float o[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = ((y[j][e] - mean) * rstd * g4[e] + b4[e]) * om;
+                            if (p.ln_bf16) {
+                                uint2 pk;
+                                pk.x = pack_bf16(o[0], o[1]);
+                                pk.y = pack_bf16(o[2], o[3]);
+                                *reinterpret_cast<uint2*>(static_cast<uint16_t*>(p.ln_out) + (int64_t)r * p.ld_ln + c) = pk;
+                            } else {
+                                *reinterpret_cast<f32x4*>(static_cast<float*>(p.ln_out) + (int64_t)r * p.ld_ln + c) = f32x4{o[0], o[1], o[2], o[3]};
+                            }
+                        }
+                    }
+                }
             }
             if (p.stats) {
 #pragma unroll
@@ -1273,6 +1313,44 @@ extern "C" int32_t ispk_attn_out_ffn_bf16(const float* x, int64_t ldx, const uin
                                           float* row_stats, float stats_eps, ispk_stream_t stream) {
     return attn_out_ffn_launch(x, ldx, attn_out, ld_attn, Wo_chunks, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, mask, out, ldo,
                                rows, dim, inner, flags, row_stats, stats_eps, nullptr, nullptr, 0.f, nullptr, nullptr, 0, false, stream);
+}
+
+// ... with the stack's FINAL LayerNorm as the epilogue's second output (last layer): ln_out = [mask if ln_mask] * LN_final(out), bf16 or
+// fp32; `out` may be NULL when only the normalised rows are consumed (the decoder feeding to_mel)
+extern "C" int32_t ispk_attn_out_ffn_norm_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,
+                                               const uint16_t* Wo_chunks, const float* norm_gamma, const float* norm_beta,
+                                               float norm_eps, const uint16_t* W1, const uint16_t* W2_chunks, const uint8_t* mask,
+                                               float* out, int64_t ldo, int32_t rows, int32_t dim, int32_t inner, uint32_t flags,
+                                               const float* final_gamma, const float* final_beta, float final_eps, int32_t ln_mask,
+                                               void* ln_out, int64_t ld_ln, int32_t ln_bf16, ispk_stream_t stream) {
+    ISPK_REQUIRE(x && attn_out && Wo_chunks && norm_gamma && norm_beta && W1 && W2_chunks && final_gamma && final_beta && ln_out,
+                 ISPK_E_NULL, "attn_out_ffn_norm: null pointer");
+    ISPK_REQUIRE(dim == kD, ISPK_E_UNSUPPORTED, "attn_out_ffn_norm: dim %d (built for 384 = heads * 64)", dim);
+    ISPK_REQUIRE(rows >= 0 && inner >= 64 && inner % 32 == 0, ISPK_E_SHAPE, "attn_out_ffn_norm: bad shape rows=%d inner=%d", rows, inner);
+    ISPK_REQUIRE((flags & ~(ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) == 0, ISPK_E_UNSUPPORTED, "attn_out_ffn_norm: unsupported flags");
+    ISPK_REQUIRE(!(((flags & (ISPK_EP_MASK_OUT | ISPK_EP_MASK_ACC)) || ln_mask) && !mask), ISPK_E_NULL,
+                 "attn_out_ffn_norm: mask flag without mask");
+    ISPK_REQUIRE(ldx % 4 == 0 && ld_attn % 8 == 0 && ldx >= dim && ld_attn >= dim && ld_ln >= dim && ld_ln % 4 == 0 &&
+                     (!out || (ldo % 4 == 0 && ldo >= dim && ispk_aligned(out, 16))) && ispk_aligned(x, 16) &&
+                     ispk_aligned(attn_out, 16) && ispk_aligned(Wo_chunks, 16) && ispk_aligned(W1, 16) && ispk_aligned(W2_chunks, 16) &&
+                     ispk_aligned(norm_gamma, 16) && ispk_aligned(norm_beta, 16) && ispk_aligned(final_gamma, 16) &&
+                     ispk_aligned(final_beta, 16) && ispk_aligned(ln_out, ln_bf16 ? 8 : 16),
+                 ISPK_E_ALIGN, "attn_out_ffn_norm: 16-byte alignment / strides that are multiples of 4 (fp32) and 8 (bf16) required");
+    if (rows == 0) return 0;
+    Ffn2Params p{x, ldx, norm_gamma, norm_beta, norm_eps, W1, W2_chunks, mask, out, ldo, rows, inner, flags, nullptr, 0.f};
+    p.o = attn_out;
+    p.ld_o = ld_attn;
+    p.WoC = Wo_chunks;
+    p.gamma2 = final_gamma;
+    p.beta2 = final_beta;
+    p.eps2 = final_eps;
+    p.ln_out = ln_out;
+    p.ld_ln = ld_ln;
+    p.ln_bf16 = ln_bf16;
+    p.ln_mask = ln_mask;
+    ISPK_RESERVE_LDS((&ffn2_bf16_kernel<kProjMode>), kLds, "attn_out_ffn_norm");
+    hipLaunchKernelGGL(ffn2_bf16_kernel<kProjMode>, dim3((rows + 127) / 128), dim3(512), kLds, reinterpret_cast<hipStream_t>(stream), p);
+    return ispk_launch_status();
 }
 
 extern "C" int32_t ispk_attn_out_ffn_qkv_bf16(const float* x, int64_t ldx, const uint16_t* attn_out, int64_t ld_attn,

@@ -153,12 +153,18 @@ class FeedForward(nn.Module, Constructor):
                 and self.net[0].weight.shape[0] % 32 == 0 and self.net[0].weight.shape[0] >= 64)
 
     def forward_proj_prenorm(self, x: Tensor, attn_out: Tensor, woc: Tensor, norm, *, mask: Optional[Tensor] = None,
-                             next_norm: Optional[tuple] = None):
+                             next_norm: Optional[tuple] = None, want_out: bool = True):
         """(y, stats | qkv | None) with x1 = x + [mask] * to_out(attn_out), y = [mask] * (x1 + feed_forward(norm(x1))) in one
         kernel (ispk_attn_out_ffn_bf16): x1 exists only in the kernel's accumulators.  `woc` = Attention._chunked_wo().
         `next_norm` = (weight, bias, eps, _, "stats"[, next layer's Attention]): with the Attention given and 6 heads the second
-        result is that layer's q/kv rows (bf16 [..., 512]) instead of the row statistics."""
+        result is that layer's q/kv rows (bf16 [..., 512]) instead of the row statistics.  `next_norm` = (weight, bias, eps,
+        apply_mask, torch dtype) - the STACK's final norm: the second result is LN_final(y) in that dtype, and with
+        `want_out=False` y itself is not stored (first result None)."""
         w1, _ = self._staged(torch.bfloat16)
+        if next_norm is not None and next_norm[4] in (torch.float32, torch.bfloat16):
+            # the stack's final LayerNorm from the same kernel: (y | None, LN_final(y)); y itself only if the caller wants it
+            return runtime.attn_out_ffn(x, attn_out, woc, norm.weight, norm.bias, w1, self._chunked_w2(), mask=mask, norm_eps=norm.eps,
+                                        final_norm=next_norm[:5], want_out=want_out)
         want = next_norm is not None and next_norm[4] == "stats"
         nxt_attn = next_norm[5] if want and len(next_norm) > 5 else None
         if nxt_attn is not None and self.next_qkv and nxt_attn.heads * 64 + 128 == 512 and nxt_attn.dim == x.shape[-1]:

@@ -63,6 +63,7 @@ class TransformerLayer(nn.Module, Constructor):
     # to_out + residual + feed_forward_norm + feed-forward + residual as ONE kernel (ispk_attn_out_ffn_bf16; x1 never reaches
     # memory), bf16 path, dim 384 = heads * 64, decoder-sized batches:
     proj_ffn = True
+    final_norm_fused = True    # the stack's final LayerNorm from the last layer's fused kernel (ispk_attn_out_ffn_norm_bf16)
     # ... and in every workgroup of the split feed-forward (ispk_attn_out_ffn_split_bf16) - where that pays: with 2 splits (16,384
     # decoder rows = 32 utterances per GPU: 1.512 -> 1.498 ms per step); with 4 - 8 splits per row block the repeated projection
     # costs more than the to_out launch it saves (6,400 rows: 2.004 -> 2.012 ms; 8 utterances per GPU: 1.014 -> 1.066 ms)
@@ -90,10 +91,13 @@ class TransformerLayer(nn.Module, Constructor):
                 context_mask: Optional[Tensor] = None, attention_mask: Optional[Tensor] = None,
                 adaptive_condition: Optional[Tensor] = None, cache: Optional[TransformerLayerIntermediates] = None,
                 shared_cache: Optional[AttentionSharedIntermediates] = None, *, key_len: Optional[Tensor] = None,
-                ada: Optional[tuple] = None, normed: Optional[Tensor] = None, next_norm: Optional[tuple] = None):
+                ada: Optional[tuple] = None, normed: Optional[Tensor] = None, next_norm: Optional[tuple] = None,
+                skip_out: bool = False):
         """`normed`: attention_norm(x) when the previous layer's feed-forward kernel already produced it; `next_norm`
         = (weight, bias, eps, apply_mask, dtype) of the norm that will consume this layer's output - if the fused
-        feed-forward kernel can emit it, the output carries it in `next_normed` (bf16 path, decoder-sized batches)."""
+        feed-forward kernel can emit it, the output carries it in `next_normed` (bf16 path, decoder-sized batches).
+        `skip_out`: the caller consumes only `next_normed` (the last layer of a stack whose output goes through the final norm) -
+        a kernel that produces the norm itself may then leave `out` unwritten (None)."""
         assert not self.adaptive_norm or adaptive_condition is not None or ada is not None, \
             "`adaptive_condition` should be provided for AdaptiveLayerNorm"
         if cache is not None:
@@ -138,8 +142,10 @@ class TransformerLayer(nn.Module, Constructor):
                                                attention_mask=attention_mask, key_len=key_len, residual=x, defer_out=fuse or fuse_split)
         hn = None
         if fuse:    # (x1 is the attention output before to_out)
+            fin = final and self.final_norm_fused and next_norm[0] is not None and next_norm[1] is not None
             y, hn = self.feed_forward.forward_proj_prenorm(x, x1, self.attention._chunked_wo(), self.feed_forward_norm, mask=mask,
-                                                           next_norm=None if final else next_norm)
+                                                           next_norm=next_norm if (fin or not final) else None,
+                                                           want_out=not (fin and skip_out))
             return TransformerLayerOutput(out=y, intermediates=TransformerLayerIntermediates(attention=inter),
                                           shared_intermediates=shared, next_normed=hn)
         if ada is None and self.feed_forward.prenorm_ok(x1, self.feed_forward_norm):
@@ -312,13 +318,14 @@ class Transformer(nn.Module, Constructor):
                     nxt = (nn_.weight, nn_.bias, nn_.eps, False, "stats", self.layers[li + 1].attention)
                 elif final_norm and out_dtype in (torch.float32, torch.bfloat16):
                     # last layer: the stack's own final norm (row-masked, transformer.py:205-206) - the split feed-forward's
-                    # combine pass applies it from the same read (small batches); the fused kernel cannot and ignores it
+                    # combine pass applies it from the same read (small batches), the fused layer kernel from the registers that
+                    # store the rows (decoder-sized batches, ispk_attn_out_ffn_norm_bf16); the plain fused kernel ignores it
                     nxt = (self.norm.weight, self.norm.bias, self.norm.eps, mask is not None, out_dtype)
                 if nxt is not None and (nxt[0] is None or nxt[1] is None):
                     nxt = None
             res = layer(out, mask=mask, context=context, context_mask=context_mask, attention_mask=attention_mask,
                         adaptive_condition=adaptive_condition, key_len=key_len, ada=None if ada is None else ada[li],
-                        normed=normed, next_norm=nxt)
+                        normed=normed, next_norm=nxt, skip_out=final_norm and li + 1 == len(self.layers))
             out, normed = res.out, res.next_normed
             if return_intermediates:
                 intermediates.append(res.intermediates)

@@ -60,6 +60,8 @@ SIGNATURES = {
     "ispk_attn_out_ffn_qkv_bf16": [_P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32,
                                    _P, _P, _I64, _P],
     "ispk_chunk_k16_bf16": [_P, _I64, _I32, _I32, _P, _P],
+    "ispk_attn_out_ffn_norm_bf16": [_P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _P, _P, _P, _I64, _I32, _I32, _I32, _U32, _P, _P, _F32,
+                                    _I32, _P, _I64, _I32, _P],
     "ispk_attn_out_ffn_split_bf16": [_P, _I64, _P, _I64, _P, _P, _P, _F32, _P, _P, _P, _U32, _P, _I64, _I32, _I32, _I32, _I32, _P],
     "ispk_gemm_bf16_lnin": [_P, _I64, _P, _P, _P, _F32, _P, _I64, _P, _I64, _P, _P, _I64, _P, _I32, _I32, _I32, _U32, _P],
     "ispk_linear_small_f32": [_P, _I64, _P, _I64, _P, _P, _I64, _P, _I64, _I32, _I32, _I32, _U32, _P],
@@ -441,13 +443,14 @@ def chunk_k16(w: Tensor) -> Tensor:
 
 def attn_out_ffn(x: Tensor, attn_out: Tensor, woc: Tensor, norm_weight: Tensor, norm_bias: Tensor, w1: Tensor, w2c: Tensor,
                  mask: Optional[Tensor] = None, norm_eps: float = 1e-5, want_stats: bool = False, stats_eps: float = 1e-5,
-                 next_qkv: Optional[tuple] = None):
+                 next_qkv: Optional[tuple] = None, final_norm: Optional[tuple] = None, want_out: bool = True):
     """ispk_attn_out_ffn_bf16 (dim 384 = heads * 64): the second half of a pre-norm layer in one kernel,
         x1 = x + [mask] * (attn_out @ Wo^T);  out = [mask] * (x1 + gelu(LN(x1) @ w1^T) @ w2^T)
     from the fp32 residual rows x and the bf16 attention output; woc = `ffn_chunk_w2(Wo)`, w2c = `ffn_chunk_w2(w2)`.  With
     `want_stats` also the (mean, rstd) of the output rows, fp32 [rows, 2].  With `next_qkv` = (norm weight, norm bias, eps,
     `chunk_k16([Wq; Wkv])`) of the NEXT layer (ispk_attn_out_ffn_qkv_bf16) also that layer's q/kv rows, bf16 [..., 512]:
-    -> (out, qkv)."""
+    -> (out, qkv).  With `final_norm` = (weight, bias, eps, apply_mask, dtype) of the STACK's final LayerNorm
+    (ispk_attn_out_ffn_norm_bf16) also LN_final(out) [* mask]: -> (out | None, ln); `want_out=False` does not store the raw rows."""
     _dev(x, attn_out, woc, norm_weight, norm_bias, w1, w2c, mask)
     assert x.dtype == torch.float32 and attn_out.dtype == torch.bfloat16 and w1.dtype == torch.bfloat16
     assert woc.dtype == torch.bfloat16 and w2c.dtype == torch.bfloat16
@@ -463,6 +466,19 @@ def attn_out_ffn(x: Tensor, attn_out: Tensor, woc: Tensor, norm_weight: Tensor, 
         mask = mask.reshape(-1).contiguous()
         flags = EP_MASK_ACC | EP_MASK_OUT
     nb = x2.numel() * 4 + o2.numel() * 2 + (woc.numel() + w1.numel() + w2c.numel()) * 2 + out.numel() * 4 + (R * 8 if want_stats else 0)
+    if final_norm is not None:
+        assert not want_stats and next_qkv is None
+        fw, fb, feps, fmask, fdtype = final_norm
+        _dev(fw, fb)
+        assert fdtype in (torch.float32, torch.bfloat16)
+        ln = torch.empty(x.shape, dtype=fdtype, device=x.device)
+        outp = out if want_out else None
+        _launch("ffn2_bf16_kernel<50>", 4.0 * R * D * Fi + 2.0 * R * D * D,
+                float(nb - (0 if want_out else out.numel() * 4) + ln.numel() * ln.element_size()), lib().ispk_attn_out_ffn_norm_bf16,
+                x2.data_ptr(), x2.stride(0), o2.data_ptr(), o2.stride(0), woc.data_ptr(), norm_weight.data_ptr(), norm_bias.data_ptr(),
+                norm_eps, w1.data_ptr(), w2c.data_ptr(), _ptr(mask), _ptr(outp), D, R, D, Fi, flags, fw.data_ptr(), fb.data_ptr(), feps,
+                int(bool(fmask) and mask is not None), ln.data_ptr(), D, int(fdtype == torch.bfloat16), _stream())
+        return outp, ln
     if next_qkv is not None:
         assert not want_stats
         ng, nbeta, neps, wqc = next_qkv

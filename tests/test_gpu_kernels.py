@@ -503,6 +503,17 @@ def test_projection_and_ffn_kernel(R, Fi, masked):
     assert (stats[:, 0].cpu().double() - o64.mean(1)).abs().max().item() <= 1e-6
     rstd = 1.0 / torch.sqrt(o64.var(1, unbiased=False) + 1e-5)
     assert ((stats[:, 1].cpu().double() - rstd) / rstd).abs().max().item() <= 1e-5
+    # ispk_attn_out_ffn_norm_bf16: the same rows and the stack's FINAL LayerNorm of them (row-masked), bf16 / fp32; rows not stored
+    fg, fb_ = synth._normal("t/pj/fg", (D,), 0.1, 1.0), synth._normal("t/pj/fb", (D,), 0.1)
+    for fdt, tol in ((torch.float32, 2e-5), (torch.bfloat16, 2.0 ** -7)):
+        out_f, ln = runtime.attn_out_ffn(d(x), o_dev, woc, d(g), d(b), d(w1), w2c, mask=d(mask), final_norm=(d(fg), d(fb_), 1e-5, True, fdt))
+        none, ln2 = runtime.attn_out_ffn(d(x), o_dev, woc, d(g), d(b), d(w1), w2c, mask=d(mask), final_norm=(d(fg), d(fb_), 1e-5, True, fdt),
+                                         want_out=False)
+        assert none is None and torch.equal(ln, ln2) and torch.equal(out_f.cpu(), out) and ln.dtype == fdt
+        sep = runtime.layernorm(out_f, d(fg), d(fb_), row_mask=d(mask), eps=1e-5, out_dtype=fdt)
+        assert (ln.float() - sep.float()).abs().max().item() <= tol * max(1.0, sep.float().abs().max().item())
+        if masked:
+            assert ln.cpu()[~mask].float().abs().max().item() == 0.0
     # ispk_attn_out_ffn_qkv_bf16: the same rows, and the NEXT layer's attention_norm + q/kv projection from the epilogue
     wq = _bf(synth._normal("t/pj/wq", (512, D), D ** -0.5))
     g2, b2 = synth._normal("t/pj/g2", (D,), 0.1, 1.0), synth._normal("t/pj/b2", (D,), 0.1)
